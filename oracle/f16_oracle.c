@@ -1,0 +1,802 @@
+/*
+ * oracle/f16_oracle.c — CPU restatement (plain C, scalar fp32) of the NeuralPlane F-16 env.step
+ * hot path.  TEST INFRASTRUCTURE ONLY — see f16_oracle.h.  Nothing under neuralplane_amd/ links,
+ * loads or calls this file.
+ *
+ * Every function cites the reference file:line it restates (paths relative to the reference
+ * root, xuecy22/NeuralPlane @ 2024-12-18).  The reference is eager PyTorch: each Python-level
+ * arithmetic operator is ONE fp32 rounding, Python float/int scalars are rounded to fp32 at the
+ * point of use, `c / tensor` is `tensor.reciprocal() * c` (torch/_tensor.py __rtruediv__), and
+ * `tensor ** 2` is `tensor * tensor`.  This file keeps that operation order literally — compile
+ * with -ffp-contract=off (the Makefile does) so the compiler adds no fused operations of its own.
+ *
+ * Where the reference's result depends on a library implementation rather than on IEEE-754
+ * (nn.Linear accumulation order; sin/cos/tan/pow), the oracle follows the numerics spec of
+ * DESIGN.md §Numerics, which the HIP kernel implements as well:
+ *   - Linear: acc = bias; acc = fmaf(W[j][k], x[k], acc) for k ascending.
+ *   - sin/cos/tan/pow: evaluated in fp64 by the fixed operation sequences below (fdlibm
+ *     kernels), rounded once to fp32.
+ * Parity of the whole against the reference is pinned by tests/golden (see the header).
+ */
+#include "f16_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* model blob                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    char name[24];
+    uint32_t input_mask, n_linear;
+    uint32_t dims[6];
+    double in_mean[3], in_std[3];
+    double out_mean, out_std;
+    uint32_t param_offset, n_params;
+} blob_rec; /* 128 bytes, little endian, see tools/export_weights.py */
+
+typedef struct {
+    int n_in, n_linear;
+    int dims[6];
+    int sel[3];           /* which of (alpha, beta, el) feeds input slot i */
+    float in_mean[3], in_std[3]; /* per input slot, rounded double->float like torch does */
+    float out_mean, out_std;
+    const float *w[4];
+    const float *b[4];
+} net_t;
+
+struct f16o_model {
+    net_t net[F16O_NUM_NETS];
+    float *params;
+};
+
+static int g_mode = 0;
+void f16o_set_mode(int mode) { g_mode = mode; }
+int f16o_get_mode(void) { return g_mode; }
+
+f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
+    const unsigned char *p = (const unsigned char *)blob;
+    if (nbytes < 16 || memcmp(p, "NPF16MLP", 8) != 0) return NULL;
+    uint32_t ver, nn;
+    memcpy(&ver, p + 8, 4);
+    memcpy(&nn, p + 12, 4);
+    if (ver != 1 || nn != F16O_NUM_NETS) return NULL;
+    size_t hdr = 16 + (size_t)nn * sizeof(blob_rec);
+    if (nbytes < hdr) return NULL;
+    f16o_model *m = (f16o_model *)calloc(1, sizeof(*m));
+    size_t pbytes = nbytes - hdr;
+    m->params = (float *)malloc(pbytes);
+    memcpy(m->params, p + hdr, pbytes);
+    for (uint32_t i = 0; i < nn; i++) {
+        blob_rec r;
+        memcpy(&r, p + 16 + (size_t)i * sizeof(blob_rec), sizeof(r));
+        net_t *t = &m->net[i];
+        t->n_linear = (int)r.n_linear;
+        if (t->n_linear < 2 || t->n_linear > 4) goto bad;
+        for (int k = 0; k < 6; k++) t->dims[k] = (int)r.dims[k];
+        t->n_in = t->dims[0];
+        int slot = 0;
+        for (int k = 0; k < 3; k++)
+            if (r.input_mask & (1u << k)) {
+                t->sel[slot] = k;
+                t->in_mean[slot] = (float)r.in_mean[k];
+                t->in_std[slot] = (float)r.in_std[k];
+                slot++;
+            }
+        if (slot != t->n_in) goto bad;
+        t->out_mean = (float)r.out_mean;
+        t->out_std = (float)r.out_std;
+        size_t off = r.param_offset, used = 0;
+        for (int l = 0; l < t->n_linear; l++) {
+            int in = t->dims[l], out = t->dims[l + 1];
+            if (in < 1 || in > 20 || out < 1 || out > 20) goto bad;
+            t->w[l] = m->params + off + used;
+            used += (size_t)in * out;
+            t->b[l] = m->params + off + used;
+            used += (size_t)out;
+        }
+        if (used != r.n_params || (off + used) * 4 > pbytes) goto bad;
+    }
+    return m;
+bad:
+    f16o_model_free(m);
+    return NULL;
+}
+
+void f16o_model_free(f16o_model *m) {
+    if (!m) return;
+    free(m->params);
+    free(m);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* numerics spec: elementary functions                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fdlibm (Sun Microsystems, freely redistributable) k_sin.c / k_cos.c / e_rem_pio2.c / e_log.c
+ * constants. */
+static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                    S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                    S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                    C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                    C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+static const double INVPIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
+                    PIO2_2 = 6.07710050630396597660e-11, PIO2_3 = 2.02226624871116645580e-21,
+                    PIO2_3T = 8.47842766036889956997e-32;
+static const double TWO_PI_D = 6.283185307179586476925;
+
+static void sincos_d(double x, double *sn, double *cs) {
+    if (!(fabs(x) < 1073741824.0)) x = fmod(x, TWO_PI_D); /* exact; inf/NaN -> NaN */
+    double k = rint(x * INVPIO2);
+    double r = fma(-k, PIO2_1, x);
+    r = fma(-k, PIO2_2, r);
+    r = fma(-k, PIO2_3, r);
+    r = fma(-k, PIO2_3T, r);
+    double z = r * r;
+    double p = fma(z, S6, S5);
+    p = fma(z, p, S4);
+    p = fma(z, p, S3);
+    p = fma(z, p, S2);
+    p = fma(z, p, S1);
+    double sr = fma(z * r, p, r);
+    double q = fma(z, C6, C5);
+    q = fma(z, q, C4);
+    q = fma(z, q, C3);
+    q = fma(z, q, C2);
+    q = fma(z, q, C1);
+    double cr = fma(z * z, q, fma(z, -0.5, 1.0));
+    int n = (int)k & 3; /* |k| < 2^30 here (NaN converts to an unspecified int; result is NaN anyway) */
+    if (k != k) n = 0;
+    double s_, c_;
+    switch (n) {
+    case 0: s_ = sr; c_ = cr; break;
+    case 1: s_ = cr; c_ = -sr; break;
+    case 2: s_ = -sr; c_ = -cr; break;
+    default: s_ = -cr; c_ = sr; break;
+    }
+    *sn = s_;
+    *cs = c_;
+}
+
+void f16o_sincos(float x, float *s, float *c) {
+    if (g_mode & F16O_MODE_LIBM) {
+        *s = sinf(x);
+        *c = cosf(x);
+        return;
+    }
+    double sd, cd;
+    sincos_d((double)x, &sd, &cd);
+    *s = (float)sd;
+    *c = (float)cd;
+}
+
+float f16o_tan(float x) {
+    if (g_mode & F16O_MODE_LIBM) return tanf(x);
+    double sd, cd;
+    sincos_d((double)x, &sd, &cd);
+    return (float)(sd / cd);
+}
+
+static const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
+                    LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
+                    LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+                    LG7 = 1.479819860511658591e-01;
+static const double INV_LN2 = 1.44269504088896338700e+00, LN2 = 6.93147180559945286227e-01;
+
+/* x^y for the atmosphere model: exp2(y*log2(x)) in fp64, fixed operation sequence. */
+static double pow_d(double x, double y) {
+    if (x != x || y != y) return NAN;
+    if (x < 0.0) return NAN; /* non-integer exponent */
+    if (x == 0.0) return y > 0.0 ? 0.0 : INFINITY;
+    if (x == INFINITY) return y > 0.0 ? INFINITY : 0.0;
+    /* x is a positive finite double (from a float: always a normal double) */
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+    double mant;
+    memcpy(&mant, &bits, 8);
+    if (mant > 1.4142135623730951) {
+        mant *= 0.5;
+        e += 1;
+    }
+    double f = mant - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * fma(w, fma(w, LG6, LG4), LG2);
+    double t2 = z * fma(w, fma(w, fma(w, LG7, LG5), LG3), LG1);
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double lnm = f - (hfsq - s * (hfsq + R));
+    double l2 = fma(lnm, INV_LN2, (double)e);
+    double P = y * l2;
+    if (P > 2000.0) P = 2000.0;
+    if (P < -2000.0) P = -2000.0;
+    double k = rint(P);
+    double t = (P - k) * LN2;
+    /* exp(t), |t| <= 0.347: Taylor to degree 13, Horner */
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, t, 1.0 / 479001600.0);
+    q = fma(q, t, 1.0 / 39916800.0);
+    q = fma(q, t, 1.0 / 3628800.0);
+    q = fma(q, t, 1.0 / 362880.0);
+    q = fma(q, t, 1.0 / 40320.0);
+    q = fma(q, t, 1.0 / 5040.0);
+    q = fma(q, t, 1.0 / 720.0);
+    q = fma(q, t, 1.0 / 120.0);
+    q = fma(q, t, 1.0 / 24.0);
+    q = fma(q, t, 1.0 / 6.0);
+    q = fma(q, t, 0.5);
+    q = fma(q, t, 1.0);
+    q = fma(q, t, 1.0);
+    return ldexp(q, (int)k);
+}
+
+float f16o_pow(float x, float y) {
+    if (g_mode & F16O_MODE_LIBM) return powf(x, y);
+    return (float)pow_d((double)x, (double)y);
+}
+
+/* envs/utils/utils.py:144-154  wrap_2PI / wrap_PI.  `angle % (2*pi)` is torch.remainder:
+ * fmod (exact) then `+ divisor` when the signs differ. */
+static const float TWO_PI_F = (float)(2.0 * 3.141592653589793);
+static const float PI_F = (float)3.141592653589793;
+
+float f16o_wrap_pi(float x) {
+    float res = fmodf(x, TWO_PI_F);
+    if (res != 0.0f && (res < 0.0f)) res = res + TWO_PI_F;
+    res = res + ((res < 0.0f) ? TWO_PI_F : 0.0f); /* res += 2*pi*mask1           :146-147 */
+    res = res - ((res > PI_F) ? TWO_PI_F : 0.0f); /* res -= 2*pi*mask1           :152-153 */
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* counter-based RNG of the numerics spec (production mode; the reference uses torch's global  */
+/* generator, whose stream is device-specific — parity tests inject the reference's draws).    */
+/* ------------------------------------------------------------------------------------------ */
+
+void f16o_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void rng_block(uint64_t seed, uint64_t call_idx, int64_t row, uint32_t blk, uint32_t out[4]) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t ctr[4] = {(uint32_t)(uint64_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)call_idx,
+                       (((uint32_t)(call_idx >> 32)) & 0x00FFFFFFu) | (blk << 24)};
+    f16o_philox4x32(ctr, key, out);
+}
+
+void f16o_rng_uniforms(uint64_t seed, uint64_t call_idx, int64_t row, float u8[8]) {
+    uint32_t w[4];
+    for (uint32_t b = 0; b < 2; b++) {
+        rng_block(seed, call_idx, row, b, w);
+        for (int i = 0; i < 4; i++) u8[4 * b + i] = (float)(w[i] >> 8) * 5.9604644775390625e-08f; /* 2^-24 */
+    }
+}
+
+static float logf_spec(float u) { /* u in (0,1), normal */
+    uint32_t bits;
+    memcpy(&bits, &u, 4);
+    int e = (int)(bits >> 23) - 127;
+    bits = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float m;
+    memcpy(&m, &bits, 4);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = fmaf(z, 0.111111111f, 0.142857143f);
+    p = fmaf(z, p, 0.2f);
+    p = fmaf(z, p, 0.333333333f);
+    p = fmaf(z, p, 1.0f);
+    return fmaf((float)e, 0.693147181f, (2.0f * s) * p);
+}
+
+static void sincos2pi_spec(float a, float *sn, float *cs) { /* a in [0,1) */
+    float q = rintf(a * 4.0f);
+    float f = fmaf(q, -0.25f, a);
+    float th = f * 6.28318531f;
+    float z = th * th;
+    float ps = fmaf(z, 2.75573192e-6f, -1.98412698e-4f);
+    ps = fmaf(z, ps, 8.33333333e-3f);
+    ps = fmaf(z, ps, -1.66666667e-1f);
+    ps = fmaf(z, ps, 1.0f);
+    float sr = th * ps;
+    float pc = fmaf(z, -2.75573192e-7f, 2.48015873e-5f);
+    pc = fmaf(z, pc, -1.38888889e-3f);
+    pc = fmaf(z, pc, 4.16666667e-2f);
+    pc = fmaf(z, pc, -0.5f);
+    float cr = fmaf(z, pc, 1.0f);
+    switch ((int)q & 3) {
+    case 0: *sn = sr; *cs = cr; break;
+    case 1: *sn = cr; *cs = -sr; break;
+    case 2: *sn = -sr; *cs = -cr; break;
+    default: *sn = -cr; *cs = sr; break;
+    }
+}
+
+void f16o_rng_normals(uint64_t seed, uint64_t call_idx, int64_t row, float z22[F16O_NOBS]) {
+    uint32_t w[4];
+    for (uint32_t b = 0; b < 6; b++) {
+        rng_block(seed, call_idx, row, 2 + b, w);
+        for (int h = 0; h < 2; h++) {
+            int pair = 2 * (int)b + h;
+            if (pair >= 11) break;
+            float u1 = ((float)(w[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-07f; /* 2^-23 */
+            float u2 = (float)(w[2 * h + 1] >> 8) * 5.9604644775390625e-08f;
+            float rad = sqrtf(-2.0f * logf_spec(u1));
+            float sn, cs;
+            sincos2pi_spec(u2, &sn, &cs);
+            z22[2 * pair] = rad * cs;
+            z22[2 * pair + 1] = rad * sn;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* hifi_F16: 43 MLP surrogates — envs/models/F16/hifi_F16_AeroData.py                          */
+/*   MLP.forward :25-29, normalize/unnormalize :32-37, per-net wrappers :149-746               */
+/* ------------------------------------------------------------------------------------------ */
+
+static float net_eval(const net_t *t, const float in3[3]) {
+    float x[20], y[20];
+    for (int i = 0; i < t->n_in; i++) x[i] = (in3[t->sel[i]] - t->in_mean[i]) / t->in_std[i]; /* normalize :32-33 */
+    if (g_mode & F16O_MODE_MLP_F64) {
+        double xd[20], yd[20];
+        for (int i = 0; i < t->n_in; i++) xd[i] = (double)x[i];
+        for (int l = 0; l < t->n_linear; l++) {
+            int in = t->dims[l], out = t->dims[l + 1];
+            for (int j = 0; j < out; j++) {
+                double acc = (double)t->b[l][j];
+                for (int k = 0; k < in; k++) acc += (double)t->w[l][j * in + k] * xd[k];
+                if (l + 1 < t->n_linear) acc = acc > 0.0 ? acc : 0.0;
+                yd[j] = acc;
+            }
+            for (int j = 0; j < out; j++) xd[j] = yd[j];
+        }
+        return (float)xd[0] * t->out_std + t->out_mean; /* unnormalize :36-37 */
+    }
+    for (int l = 0; l < t->n_linear; l++) {
+        int in = t->dims[l], out = t->dims[l + 1];
+        for (int j = 0; j < out; j++) {
+            float acc = t->b[l][j];
+            for (int k = 0; k < in; k++) acc = fmaf(t->w[l][j * in + k], x[k], acc);
+            if (l + 1 < t->n_linear) acc = acc > 0.0f ? acc : 0.0f; /* ReLU :19 */
+            y[j] = acc;
+        }
+        for (int j = 0; j < out; j++) x[j] = y[j];
+    }
+    return x[0] * t->out_std + t->out_mean; /* unnormalize :36-37 */
+}
+
+/* Non-finite inputs: torch propagates NaN through every Linear/ReLU; `acc > 0 ? acc : 0` does
+ * not.  The spec restores the reference's outcome for NaN inputs by poisoning all outputs when
+ * any of the three inputs is non-finite ("non-finite inputs"). */
+void f16o_aero(const f16o_model *m, float alpha_deg, float beta_deg, float el, float out[F16O_NUM_NETS]) {
+    float in3[3] = {alpha_deg, beta_deg, el};
+    float chk = (alpha_deg - alpha_deg) + (beta_deg - beta_deg) + (el - el); /* 0 or NaN */
+    for (int i = 0; i < F16O_NUM_NETS; i++) {
+        float v = net_eval(&m->net[i], in3);
+        out[i] = (chk == chk) ? v : NAN;
+    }
+}
+
+/* indices into the 43-vector = blob order = evaluation order in nlplant (F16_dynamics.py:140-195) */
+enum {
+    N_Cx, N_Cz, N_Cm, N_Cy, N_Cn, N_Cl,
+    N_Cxq, N_Cyr, N_Cyp, N_Czq, N_Clr, N_Clp, N_Cmq, N_Cnr, N_Cnp,
+    N_dCx_lef, N_dCz_lef, N_dCm_lef, N_dCy_lef, N_dCn_lef, N_dCl_lef,
+    N_dCxq_lef, N_dCyr_lef, N_dCyp_lef, N_dCzq_lef, N_dClr_lef, N_dClp_lef, N_dCmq_lef, N_dCnr_lef, N_dCnp_lef,
+    N_dCy_r30, N_dCn_r30, N_dCl_r30,
+    N_dCy_a20, N_dCy_a20_lef, N_dCn_a20, N_dCn_a20_lef, N_dCl_a20, N_dCl_a20_lef,
+    N_dCnbeta, N_dClbeta, N_dCm, N_eta_el
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* F16Dynamics.nlplant — envs/models/F16/F16_dynamics.py:37-228 (atmos :22-35)                  */
+/* ------------------------------------------------------------------------------------------ */
+
+static void nlplant_row(const f16o_model *m, const float x[17], float xd[12]) {
+    /* constants :61-76; Python-double expressions are folded in double and rounded once,
+     * exactly where the reference multiplies them into a tensor. */
+    const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
+    const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
+    const float xc = (float)(0.35 - 0.30);                             /* (xcgr - xcg)      :204 */
+    const float cbar_over_B = (float)(11.32 / 30.0);                   /* (cbar / B)        :212 */
+    const float r2d = (float)(180.0 / 3.141592653589793);              /* :76 */
+    const float c1 = (float)(63100.0 * (63100.0 - 55814.0) + 982.0 * 982.0); /* Jz*(Jz-Jy)+Jxz^2 :225 */
+    const float c2 = (float)(982.0 * (9496.0 - 55814.0 + 63100.0));    /* Jxz*(Jx-Jy+Jz)          */
+    const float c3 = (float)(63100.0 - 9496.0);                        /* (Jz - Jx)         :226 */
+    const float c4 = (float)(9496.0 * (9496.0 - 55814.0) + 982.0 * 982.0); /* Jx*(Jx-Jy)+Jxz^2 :227 */
+    const float denom = (float)(9496.0 * 63100.0 - 982.0 * 982.0);     /* :224 */
+
+    float alt = x[2], phi = x[3], theta = x[4], psi = x[5];
+    float vt = x[6];
+    float alpha = x[7] * r2d, beta = x[8] * r2d; /* degrees :85-86 */
+    float P = x[9], Q = x[10], R = x[11];
+    float sa, ca, sb, cb, st, ct, sphi, cphi, spsi, cpsi;
+    f16o_sincos(x[7], &sa, &ca);
+    f16o_sincos(x[8], &sb, &cb);
+    f16o_sincos(theta, &st, &ct);
+    float tt = f16o_tan(theta);
+    f16o_sincos(phi, &sphi, &cphi);
+    f16o_sincos(psi, &spsi, &cpsi);
+
+    vt = (float)(vt <= 0.01f) * 0.01f + (float)(vt > 0.01f) * vt; /* :104 */
+
+    float T = x[12], el = x[13], ail = x[14], rud = x[15];
+    /* lef = x[16] is identically 0 (F16_model.py:57): dlef = 1 - lef/25 = 1 and `* dlef` is exact */
+    float dail = ail / 21.5f, drud = rud / 30.0f; /* :114-115 */
+
+    /* atmos :22-35 (mach, ps are dead) */
+    float tfac = 1.0f - 0.703e-5f * alt;
+    float rho = 2.377e-3f * f16o_pow(tfac, 4.14f);
+    float qbar = (0.5f * rho) * (vt * vt);
+
+    float U = (vt * ca) * cb, V = vt * sb, W = (vt * sa) * cb; /* :129-131 */
+
+    xd[0] = (U * (ct * cpsi) + V * ((sphi * cpsi) * st - cphi * spsi)) + W * ((cphi * st) * cpsi + sphi * spsi);
+    xd[1] = (U * (ct * spsi) + V * ((sphi * spsi) * st + cphi * cpsi)) + W * ((cphi * st) * spsi - sphi * cpsi);
+    xd[2] = (U * st - V * (sphi * ct)) - W * (cphi * ct);
+    xd[3] = P + tt * (Q * sphi + R * cphi);
+    xd[4] = Q * cphi - R * sphi;
+    xd[5] = (Q * sphi + R * cphi) / ct;
+
+    float c[F16O_NUM_NETS];
+    f16o_aero(m, alpha, beta, el, c); /* :140-195 */
+
+    float inv2vt = 1.0f / (2.0f * vt);   /* (2*vt).reciprocal() */
+    float c2v = inv2vt * cbar;           /* cbar / (2 * vt)  :197 */
+    float b2v = inv2vt * B;              /* B / (2 * vt)     :206 */
+
+    float dXdQ = c2v * (c[N_Cxq] + c[N_dCxq_lef]);
+    float Cx_tot = (c[N_Cx] + c[N_dCx_lef]) + dXdQ * Q;
+    float dZdQ = c2v * (c[N_Czq] + c[N_dCz_lef]); /* reference uses delta_Cz_lef here (:199) */
+    float Cz_tot = (c[N_Cz] + c[N_dCz_lef]) + dZdQ * Q;
+    float dMdQ = c2v * (c[N_Cmq] + c[N_dCmq_lef]);
+    float Cm_tot = ((((c[N_Cm] * c[N_eta_el] + Cz_tot * xc) + c[N_dCm_lef]) + dMdQ * Q) + c[N_dCm]) + 0.0f;
+    float dYdail = c[N_dCy_a20] + c[N_dCy_a20_lef];
+    float dYdR = b2v * (c[N_Cyr] + c[N_dCyr_lef]);
+    float dYdP = b2v * (c[N_Cyp] + c[N_dCyp_lef]);
+    float Cy_tot = ((((c[N_Cy] + c[N_dCy_lef]) + dYdail * dail) + c[N_dCy_r30] * drud) + dYdR * R) + dYdP * P;
+    float dNdail = c[N_dCn_a20] + c[N_dCn_a20_lef];
+    float dNdR = b2v * (c[N_Cnr] + c[N_dCnr_lef]);
+    float dNdP = b2v * (c[N_Cnp] + c[N_dCnp_lef]);
+    float Cn_tot = ((((((c[N_Cn] + c[N_dCn_lef]) - (Cy_tot * xc) * cbar_over_B) + dNdail * dail) +
+                      c[N_dCn_r30] * drud) + dNdR * R) + dNdP * P) + c[N_dCnbeta] * beta;
+    float dLdail = c[N_dCl_a20] + c[N_dCl_a20_lef];
+    float dLdR = b2v * (c[N_Clr] + c[N_dClr_lef]);
+    float dLdP = b2v * (c[N_Clp] + c[N_dClp_lef]);
+    float Cl_tot = (((((c[N_Cl] + c[N_dCl_lef]) + dLdail * dail) + c[N_dCl_r30] * drud) + dLdR * R) + dLdP * P) +
+                   c[N_dClbeta] * beta;
+
+    float Udot = (((R * V - Q * W) - g * st) + ((qbar * S) * Cx_tot) / mass) + T / mass;
+    float Vdot = ((P * W - R * U) + (g * ct) * sphi) + ((qbar * S) * Cy_tot) / mass;
+    float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + ((qbar * S) * Cz_tot) / mass;
+    xd[6] = ((U * Udot + V * Vdot) + W * Wdot) / vt;
+    xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
+    xd[8] = (Vdot * vt - V * xd[6]) / ((vt * vt) * cb);
+    float L_tot = ((Cl_tot * qbar) * S) * B;
+    float M_tot = ((Cm_tot * qbar) * S) * cbar;
+    float N_tot = ((Cn_tot * qbar) * S) * B;
+    xd[9] = ((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng) / denom;
+    xd[10] = (((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng) / Jy;
+    xd[11] = ((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng) / denom;
+}
+
+void f16o_nlplant(const f16o_model *m, int64_t n, const float *x17, float *xdot12) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) nlplant_row(m, x17 + 17 * i, xdot12 + 12 * i);
+}
+
+static void xdot_su(const f16o_model *m, const float *s, const float *u, float xd[12]) {
+    float x[17];
+    memcpy(x, s, 12 * sizeof(float));
+    memcpy(x + 12, u, 5 * sizeof(float)); /* get_extended_state: hstack((s,u))  F16_model.py:47-49 */
+    nlplant_row(m, x, xd);
+}
+
+/* F16Model.get_acceleration — envs/models/F16_model.py:132-148 */
+static void acceleration_row(const f16o_model *m, const float *s, const float *u, float a[3]) {
+    float xd[12];
+    xdot_su(m, s, u, xd);
+    float sina, cosa, sinb, cosb;
+    f16o_sincos(s[7], &sina, &cosa);
+    f16o_sincos(s[8], &sinb, &cosb);
+    float vt = s[6];
+    float vel_u = (vt * cosb) * cosa, vel_v = vt * sinb, vel_w = (vt * cosb) * sina;
+    float u_dot = ((cosb * cosa) * xd[6] - ((vt * sinb) * cosa) * xd[8]) - ((vt * cosb) * sina) * xd[7];
+    float v_dot = sinb * xd[6] + (vt * cosb) * xd[8];
+    float w_dot = ((cosb * sina) * xd[6] - ((vt * sinb) * sina) * xd[8]) + ((vt * cosb) * cosa) * xd[7];
+    a[0] = (u_dot + s[10] * vel_w) - s[11] * vel_v;
+    a[1] = (v_dot + s[11] * vel_u) - s[9] * vel_w;
+    a[2] = (w_dot + s[9] * vel_v) - s[10] * vel_u;
+}
+
+void f16o_get_acceleration(const f16o_model *m, int64_t n, const float *s, const float *u, float *a3) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) acceleration_row(m, s + 12 * i, u + 5 * i, a3 + 3 * i);
+}
+
+/* F16Model.get_accels — envs/models/F16_model.py:164-181 (grav = 32.174 here, g = 32.17 in nlplant) */
+void f16o_get_accels(const f16o_model *m, int64_t n, const float *s, const float *u, float *n3) {
+    const float inv_grav = (float)(1.0 / 32.174), minv_grav = (float)(-1.0 / 32.174);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        float a[3];
+        acceleration_row(m, s + 12 * i, u + 5 * i, a); /* identical sub-expressions :166-178 */
+        float st, ct, sr, cr;
+        f16o_sincos(s[12 * i + 4], &st, &ct);
+        f16o_sincos(s[12 * i + 3], &sr, &cr);
+        n3[3 * i + 0] = inv_grav * a[0] + st;
+        n3[3 * i + 1] = inv_grav * a[1] - ct * sr;
+        n3[3 * i + 2] = minv_grav * a[2] + ct * cr;
+    }
+}
+
+/* F16Model.get_EAS2TAS — envs/models/F16_model.py:156-162 */
+static float eas2tas_row(float alt) {
+    float tfac = 1.0f - 0.703e-5f * alt;
+    float e = (1.0f / f16o_pow(tfac, 4.14f)) * 1.0f; /* 1 / t == t.reciprocal() * 1 */
+    return sqrtf(e);
+}
+
+void f16o_get_eas2tas(int64_t n, const float *s, float *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = eas2tas_row(s[12 * i + 2]);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* env: reset / update / obs / termination / reward                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* F16Model.reset :33-45 + {Heading,Control,Tracking}Task.reset + env_base.py:92 for ONE flagged row */
+static void reset_row(const f16o_cfg *cfg, float *s, float *u, float *tgt, int64_t *step_count, const float ru[5]) {
+    for (int k = 0; k < 12; k++) s[k] = 0.0f;
+    for (int k = 0; k < 5; k++) u[k] = 0.0f;
+    s[2] = ru[0] * (float)(cfg->max_altitude - cfg->min_altitude) + (float)cfg->min_altitude; /* :41 */
+    s[6] = ru[1] * (float)(cfg->max_vt - cfg->min_vt) + (float)cfg->min_vt;                   /* :42 */
+    u[0] = (float)cfg->init_T;                                                                /* :43 */
+    if (cfg->task == F16O_TASK_HEADING) { /* envs/tasks/heading_task.py:49-69 */
+        tgt[0] = s[2] + 1000.0f;
+        tgt[1] = f16o_wrap_pi(s[5] + (float)(2.0 * 3.141592653589793 / 3.0));
+        tgt[2] = s[6] + 0.0f;
+    } else if (cfg->task == F16O_TASK_CONTROL) { /* envs/tasks/control_task.py:49-68 */
+        float dp = (2.0f * (ru[2] - 0.5f)) * (float)cfg->max_pitch_increment;
+        float dh = (2.0f * (ru[3] - 0.5f)) * (float)cfg->max_heading_increment;
+        float dv = (2.0f * (ru[4] - 0.5f)) * (float)cfg->max_velocities_u_increment;
+        tgt[0] = f16o_wrap_pi(s[4] + dp);
+        tgt[1] = f16o_wrap_pi(s[5] + dh);
+        tgt[2] = s[6] + dv;
+    } else { /* envs/tasks/tracking_task.py:48-71 */
+        float dist = ru[2] * (float)(cfg->max_distance - cfg->min_distance) + (float)cfg->min_distance;
+        float th1 = (ru[3] * PI_F) / 3.0f - (float)(3.141592653589793 / 6.0);
+        float th2 = (ru[4] * PI_F) / 3.0f - (float)(3.141592653589793 / 6.0);
+        float s1, c1, s2, c2;
+        f16o_sincos(th1, &s1, &c1);
+        f16o_sincos(th2, &s2, &c2);
+        tgt[0] = s[0] + (dist * c1) * c2;
+        tgt[1] = s[1] + (dist * c1) * s2;
+        tgt[2] = s[2] + dist * s1;
+    }
+    *step_count = 0;
+}
+
+/* 22-float observation before noise: heading_task.py:71-152, control_task.py:70-152,
+ * tracking_task.py:73-155 (identical except slots 0..2) */
+static void obs_row(const f16o_cfg *cfg, const float *s, const float *u, const float *tgt, float *o) {
+    float alt = s[2], roll = s[3], pitch = s[4], heading = s[5], vt = s[6];
+    float eas2tas = eas2tas_row(alt);
+    float TAS = vt + (float)cfg->airspeed * 1.0f; /* get_TAS :96-97 */
+    float EAS = TAS / eas2tas;                    /* get_EAS :99-103 */
+    if (cfg->task == F16O_TASK_HEADING) {
+        o[0] = ((alt - tgt[0]) * 0.3048f) / 1000.0f;
+        o[1] = f16o_wrap_pi(heading - tgt[1]);
+        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+    } else if (cfg->task == F16O_TASK_CONTROL) {
+        o[0] = f16o_wrap_pi(pitch - tgt[0]);
+        o[1] = f16o_wrap_pi(heading - tgt[1]);
+        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+    } else {
+        o[0] = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
+        o[1] = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
+        o[2] = ((alt - tgt[2]) * 0.3048f) / 1000.0f;
+    }
+    o[3] = (alt * 0.3048f) / 5000.0f;
+    f16o_sincos(roll, &o[4], &o[5]);
+    f16o_sincos(pitch, &o[6], &o[7]);
+    o[8] = (EAS * 0.3048f) / 340.0f;
+    f16o_sincos(s[7], &o[9], &o[10]);
+    f16o_sincos(s[8], &o[11], &o[12]);
+    o[13] = s[9];
+    o[14] = s[10];
+    o[15] = s[11];
+    o[16] = ((u[0] / 0.225f) / 76300.0f) * 0.3048f;
+    o[17] = u[1] / 45.0f;
+    o[18] = u[2] / 45.0f;
+    o[19] = u[3] / 45.0f;
+    o[20] = u[4] / 45.0f;
+    o[21] = eas2tas;
+}
+
+static void add_noise(const f16o_cfg *cfg, float *o, const float *noise_row, uint64_t seed, uint64_t call_idx,
+                      int64_t grow) {
+    float scale = (float)cfg->noise_scale;
+    if (noise_row) { /* obs + randn_like(obs) * noise_scale */
+        for (int k = 0; k < F16O_NOBS; k++) o[k] = o[k] + noise_row[k] * scale;
+    } else if (scale != 0.0f) {
+        float z[F16O_NOBS];
+        f16o_rng_normals(seed, call_idx, grow, z);
+        for (int k = 0; k < F16O_NOBS; k++) o[k] = o[k] + z[k] * scale;
+    }
+}
+
+int f16o_reset(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+               int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *rand_u,
+               const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0, float *obs) {
+    (void)m;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        if (done[i] | bad[i] | timeout[i]) {
+            float ru[8];
+            if (rand_u) memcpy(ru, rand_u + 5 * i, 5 * sizeof(float));
+            else f16o_rng_uniforms(seed, call_idx, row0 + i, ru);
+            reset_row(cfg, s + 12 * i, u + 5 * i, tgt + 3 * i, step_count + i, ru);
+        }
+        done[i] = bad[i] = timeout[i] = 0; /* env_base.py:93-95 */
+        if (obs) {
+            obs_row(cfg, s + 12 * i, u + 5 * i, tgt + 3 * i, obs + F16O_NOBS * i);
+            add_noise(cfg, obs + F16O_NOBS * i, noise ? noise + F16O_NOBS * i : NULL, seed, call_idx, row0 + i);
+        }
+    }
+    return 0;
+}
+
+/* F16Model.update — envs/models/F16_model.py:51-67 (+ integrator, Appendix A.4 of SURVEY.md) */
+static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float *u, const float *a_in) {
+    float a[4];
+    for (int k = 0; k < 4; k++) { /* torch.clamp(action, -1, 1): NaN stays NaN */
+        float v = a_in[k];
+        v = v < -1.0f ? -1.0f : v;
+        v = v > 1.0f ? 1.0f : v;
+        a[k] = v;
+    }
+    float x[17];
+    memcpy(x, s, 12 * sizeof(float));
+    x[12] = 0.9f * u[0] + (((0.1f * a[0]) * 0.225f) * 76300.0f) / 0.3048f;
+    x[13] = 0.9f * u[1] + (0.1f * a[1]) * 45.0f;
+    x[14] = 0.9f * u[2] + (0.1f * a[2]) * 45.0f;
+    x[15] = 0.9f * u[3] + (0.1f * a[3]) * 45.0f;
+    x[16] = 0.0f;
+    const float dt = (float)cfg->dt - 0.0f; /* t = tensor([0., dt]); dt = t1 - t0 */
+    float k1[12];
+    nlplant_row(m, x, k1);
+    if (cfg->solver == F16O_SOLVER_EULER) {
+        for (int k = 0; k < 12; k++) s[k] = x[k] + dt * k1[k];
+    } else { /* torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule); parity UNPINNED (see header) */
+        const float third = (float)(1.0 / 3.0);
+        float y[17], k2[12], k3[12], k4[12];
+        memcpy(y, x, sizeof(y));
+        for (int k = 0; k < 12; k++) y[k] = x[k] + (dt * k1[k]) * third;
+        nlplant_row(m, y, k2);
+        for (int k = 0; k < 12; k++) y[k] = x[k] + dt * (k2[k] - k1[k] * third);
+        nlplant_row(m, y, k3);
+        for (int k = 0; k < 12; k++) y[k] = x[k] + dt * ((k1[k] - k2[k]) + k3[k]);
+        nlplant_row(m, y, k4);
+        for (int k = 0; k < 12; k++) s[k] = x[k] + (((k1[k] + 3.0f * (k2[k] + k3[k])) + k4[k]) * dt) * 0.125f;
+    }
+    for (int k = 0; k < 5; k++) u[k] = x[12 + k];
+}
+
+/* terminations (envs/termination_conditions/)) + rewards (envs/reward_functions/)) for one row */
+static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const float *s, const float *u,
+                            const float *tgt, int64_t step_count, uint8_t *done_o, uint8_t *bad_o,
+                            uint8_t *timeout_o, float *reward_o) {
+    /* Overload — overload.py:37-42 */
+    float a[3];
+    acceleration_row(m, s, u, a);
+    float acc = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+    int bad = (acc - (float)cfg->acceleration_limit) > 0.0f;
+    /* LowAltitude — low_altitude.py:29-30 */
+    bad |= (s[2] - (float)cfg->altitude_limit) < 0.0f;
+    /* HighSpeed / LowSpeed — high_speed.py:29-30, low_speed.py:29-30 */
+    float TAS = s[6] + (float)cfg->airspeed * 1.0f;
+    float vel = (TAS * 0.3048f) / 340.0f;
+    bad |= (vel - (float)cfg->max_velocity) >= 0.0f;
+    bad |= (vel - (float)cfg->min_velocity) <= 0.0f;
+    /* ExtremeState — extreme_state.py:32-36 */
+    float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
+    bad |= (alpha < (float)cfg->min_alpha) | (alpha > (float)cfg->max_alpha);
+    bad |= (beta < (float)cfg->min_beta) | (beta > (float)cfg->max_beta);
+    /* Unreach{Heading,Posture,Target} — unreach_heading.py:38-53, unreach_posture.py:40-55, unreach_target.py:38-47 */
+    const float pi36 = (float)(3.141592653589793 / 36.0);
+    int m1 = step_count >= cfg->max_check_interval, m2 = 1, m3, m4, m5;
+    float rew;
+    if (cfg->task == F16O_TASK_HEADING) {
+        m2 = step_count >= cfg->min_check_interval;
+        m3 = fabsf(f16o_wrap_pi(s[5] - tgt[1])) >= pi36;
+        m4 = fabsf(s[2] - tgt[0]) >= 100.0f;
+        m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
+        /* HeadingReward — heading_reward.py:26-36 */
+        float da = ((s[2] - tgt[0]) * 0.3048f) / 1000.0f;
+        float dh = f16o_wrap_pi(s[5] - tgt[1]) / PI_F;
+        float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        rew = (-(da * da) + -(dh * dh)) + -(dv * dv);
+    } else if (cfg->task == F16O_TASK_CONTROL) {
+        m3 = fabsf(f16o_wrap_pi(s[5] - tgt[1])) >= pi36;
+        m4 = fabsf(s[4] - tgt[0]) >= pi36;
+        m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
+        /* PostureReward — posture_reward.py:26-35 */
+        float dp = f16o_wrap_pi(s[4] - tgt[0]) / PI_F;
+        float dh = f16o_wrap_pi(s[5] - tgt[1]) / PI_F;
+        float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        rew = (-(dp * dp) + -(dh * dh)) + -(dv * dv);
+    } else {
+        m3 = fabsf(s[0] - tgt[0]) >= 100.0f;
+        m4 = fabsf(s[1] - tgt[1]) >= 100.0f;
+        m5 = fabsf(s[2] - tgt[2]) >= 100.0f;
+        /* PositionReward — position_reward.py:26-34 */
+        float dn = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
+        float de = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
+        float da = ((s[2] - tgt[2]) * 0.3048f) / 1000.0f;
+        rew = 0.1f * ((-(dn * dn) + -(de * de)) + -(da * da));
+    }
+    int off = (m3 | m4) | m5;
+    bad |= m1 & off;
+    int done = ((!off) & (!m1)) & m2;
+    *done_o = (uint8_t)done;
+    *bad_o = (uint8_t)bad;
+    *timeout_o = 0;
+    /* BaseTask.get_reward task_base.py:70-73: zeros += target reward; += EventDriven (int64 -> float)
+     * event_driven_reward.py:28 with the env's accumulated flags */
+    rew = 0.0f + rew;
+    rew = rew + (float)(-200 * bad + 200 * done);
+    *reward_o = rew;
+}
+
+int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+              int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+              int64_t act_stride, const float *rand_u, const float *noise, uint64_t seed, uint64_t call_idx,
+              int64_t row0, float *obs, float *reward) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        float *si = s + 12 * i, *ui = u + 5 * i, *ti = tgt + 3 * i;
+        if (done[i] | bad[i] | timeout[i]) { /* self.reset()  env_base.py:100 */
+            float ru[8];
+            if (rand_u) memcpy(ru, rand_u + 5 * i, 5 * sizeof(float));
+            else f16o_rng_uniforms(seed, call_idx, row0 + i, ru);
+            reset_row(cfg, si, ui, ti, step_count + i, ru);
+        }
+        update_row(m, cfg, si, ui, action + act_stride * i); /* :101 */
+        step_count[i] += 1;                                  /* :102 */
+        obs_row(cfg, si, ui, ti, obs + F16O_NOBS * i);       /* :103 */
+        add_noise(cfg, obs + F16O_NOBS * i, noise ? noise + F16O_NOBS * i : NULL, seed, call_idx, row0 + i);
+        done_reward_row(m, cfg, si, ui, ti, step_count[i], done + i, bad + i, timeout + i, reward + i); /* :105-106 */
+    }
+    return 0;
+}
+
+int f16o_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,109 @@
+/*
+ * oracle/f16_oracle.h — CPU restatement of the NeuralPlane F-16 env.step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle: a plain-C, scalar, fp32 restatement of the
+ * reference's algorithm (xuecy22/NeuralPlane @ 2024-12-18; file:line citations are in f16_oracle.c
+ * next to each function).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it; the product (neuralplane_amd/) never does and has no CPU fallback.
+ *
+ * Parity pin: tests/golden/ (.npz) are produced by importing the reference itself in the build
+ * container (tools/gen_golden.py); tests/test_oracle_vs_golden.py checks this file against them,
+ * including a "pin mode" in which everything except the fp32 operation order is made
+ * implementation-independent so the comparison is bit-exact.
+ *
+ * Layout here is the REFERENCE's (array-of-structs, row-major [n][k]) on purpose: the oracle
+ * restates the reference, not the HIP kernel's SoA layout.
+ */
+#ifndef F16_ORACLE_H
+#define F16_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F16O_NUM_NETS 43
+#define F16O_NS 12 /* states   */
+#define F16O_NU 5  /* controls */
+#define F16O_NOBS 22
+
+enum { F16O_TASK_HEADING = 0, F16O_TASK_CONTROL = 1, F16O_TASK_TRACKING = 2 };
+enum { F16O_SOLVER_EULER = 0, F16O_SOLVER_RK4 = 1 };
+
+/* YAML values exactly as Python holds them (doubles); rounded to fp32 where the reference's
+ * tensor arithmetic rounds them (envs/configs/ YAML, read via getattr(config, key, default)). */
+typedef struct f16o_cfg {
+    int32_t task;   /* F16O_TASK_*   */
+    int32_t solver; /* F16O_SOLVER_* */
+    double dt, airspeed, noise_scale;
+    double altitude_limit, acceleration_limit, max_velocity, min_velocity;
+    double min_alpha, max_alpha, min_beta, max_beta;
+    int64_t max_check_interval, min_check_interval;
+    double init_T, max_altitude, min_altitude, max_vt, min_vt;
+    double max_heading_increment, max_pitch_increment, max_velocities_u_increment; /* control */
+    double max_distance, min_distance;                                              /* tracking */
+} f16o_cfg;
+
+typedef struct f16o_model f16o_model;
+
+/* Parse the NPF16MLP v1 blob (tools/export_weights.py).  Returns NULL on malformed input. */
+f16o_model *f16o_model_load(const void *blob, size_t nbytes);
+void f16o_model_free(f16o_model *m);
+
+/* mode bits (f16o_set_mode): default 0 = the shipped numerics spec. */
+#define F16O_MODE_MLP_F64 1  /* pin mode: MLPs evaluated in fp64 from fp32 inputs, rounded once */
+#define F16O_MODE_LIBM 2     /* transcendental functions from the host libm (sinf/cosf/tanf/powf) */
+void f16o_set_mode(int mode);
+int f16o_get_mode(void);
+
+/* 43 aero coefficients for one (alpha_deg, beta_deg, el_deg); order = blob order. */
+void f16o_aero(const f16o_model *m, float alpha_deg, float beta_deg, float el, float out[F16O_NUM_NETS]);
+
+/* xdot[n][12] = F16Dynamics.nlplant(x[n][17])[:, :12] */
+void f16o_nlplant(const f16o_model *m, int64_t n, const float *x17, float *xdot12);
+
+/* getters of F16Model that need the dynamics (s[n][12], u[n][5]) */
+void f16o_get_acceleration(const f16o_model *m, int64_t n, const float *s, const float *u, float *a3);
+void f16o_get_accels(const f16o_model *m, int64_t n, const float *s, const float *u, float *n3);
+void f16o_get_eas2tas(int64_t n, const float *s, float *out);
+
+/* Elementary functions of the numerics spec, exposed for unit tests. */
+void f16o_sincos(float x, float *s, float *c);
+float f16o_tan(float x);
+float f16o_pow(float x, float y);
+float f16o_wrap_pi(float x);
+void f16o_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* reset uniforms u[8] and 22 standard normals for (seed, call_idx, global_row) */
+void f16o_rng_uniforms(uint64_t seed, uint64_t call_idx, int64_t row, float u8[8]);
+void f16o_rng_normals(uint64_t seed, uint64_t call_idx, int64_t row, float z22[F16O_NOBS]);
+
+/*
+ * One BaseEnv.reset() (env_base.py:83-97).
+ *   flags in/out: done/bad/timeout uint8[n]; rows with any flag set are re-initialised, then ALL
+ *   flags are cleared.  rand_u: NULL -> counter-based RNG (seed, call_idx, row0+i); else
+ *   float[n][5] = (U_alt, U_vt, U_task0, U_task1, U_task2) consumed for flagged rows only.
+ *   noise: NULL -> counter-based RNG (skipped entirely when noise_scale==0); else float[n][22]
+ *   standard normals (obs + noise*noise_scale, as the reference writes it).
+ */
+int f16o_reset(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+               int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *rand_u,
+               const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0, float *obs);
+
+/*
+ * One BaseEnv.step(action) (env_base.py:99-109): auto-reset -> control lag + integrator ->
+ * step_count+=1 -> obs -> terminations -> reward.  action: float[n][act_stride], columns 0..3 used.
+ * On return done/bad/timeout hold the new flags; obs float[n][22]; reward float[n].
+ */
+int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+              int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+              int64_t act_stride, const float *rand_u, const float *noise, uint64_t seed, uint64_t call_idx,
+              int64_t row0, float *obs, float *reward);
+
+int f16o_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

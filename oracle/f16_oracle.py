@@ -1,0 +1,235 @@
+"""ctypes/numpy front-end of the CPU parity oracle (oracle/f16_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, `__graft_entry__.smoke()` and bench.py's
+`cpu_baseline` leg — never by `neuralplane_amd`.  Arrays use the REFERENCE's layout
+(`s[n,12]`, `u[n,5]`, `tgt[n,3]`, `obs[n,22]`, row-major), see f16_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import yaml
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, '_build', 'libf16oracle.so')
+DEFAULT_BLOB = os.path.join(_REPO, 'neuralplane_amd', 'assets', 'f16_aero_mlp.bin')
+CONFIG_DIR = os.path.join(_REPO, 'neuralplane_amd', 'envs', 'configs')
+
+TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
+SOLVERS = {'euler': 0, 'rk4': 1}
+MODE_MLP_F64 = 1
+MODE_LIBM = 2
+
+
+class Cfg(C.Structure):
+    _fields_ = [('task', C.c_int32), ('solver', C.c_int32),
+                ('dt', C.c_double), ('airspeed', C.c_double), ('noise_scale', C.c_double),
+                ('altitude_limit', C.c_double), ('acceleration_limit', C.c_double),
+                ('max_velocity', C.c_double), ('min_velocity', C.c_double),
+                ('min_alpha', C.c_double), ('max_alpha', C.c_double),
+                ('min_beta', C.c_double), ('max_beta', C.c_double),
+                ('max_check_interval', C.c_int64), ('min_check_interval', C.c_int64),
+                ('init_T', C.c_double), ('max_altitude', C.c_double), ('min_altitude', C.c_double),
+                ('max_vt', C.c_double), ('min_vt', C.c_double),
+                ('max_heading_increment', C.c_double), ('max_pitch_increment', C.c_double),
+                ('max_velocities_u_increment', C.c_double),
+                ('max_distance', C.c_double), ('min_distance', C.c_double)]
+
+
+def build(force=False):
+    """Compile oracle/_build/libf16oracle.so with gcc (Makefile)."""
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_oracle.h', 'Makefile'))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
+        subprocess.run(['make', '-C', _HERE], check=True, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def load_cfg(task, solver=None, overrides=None):
+    """Scenario YAML -> Cfg, using the same defaults as the reference's getattr() calls."""
+    with open(os.path.join(CONFIG_DIR, f'{task}.yaml')) as f:
+        y = yaml.safe_load(f)
+    y.update(overrides or {})
+    g = y.get
+    c = Cfg()
+    c.task = TASKS[task]
+    c.solver = SOLVERS[solver or g('solver', 'euler')]
+    c.dt = g('dt', 0.02)
+    c.airspeed = g('airspeed', 0)
+    c.noise_scale = g('noise_scale', 0.01)
+    c.altitude_limit = g('altitude_limit', 2500.0)
+    c.acceleration_limit = g('acceleration_limit', 300.0)
+    c.max_velocity = g('max_velocity', 3)
+    c.min_velocity = g('min_velocity', 0.01)
+    c.min_alpha, c.max_alpha = g('min_alpha', -20), g('max_alpha', 45)
+    c.min_beta, c.max_beta = g('min_beta', -30), g('max_beta', 30)
+    c.max_check_interval = g('max_check_interval', 1500)
+    c.min_check_interval = g('min_check_interval', 300)
+    c.init_T = y['init_state']['init_T']
+    c.max_altitude, c.min_altitude = g('max_altitude', 20000), g('min_altitude', 19000)
+    c.max_vt, c.min_vt = g('max_vt', 1200), g('min_vt', 1000)
+    c.max_heading_increment = g('max_heading_increment', 0.3)
+    c.max_pitch_increment = g('max_pitch_increment', 0.3)
+    c.max_velocities_u_increment = g('max_velocities_u_increment', 100)
+    c.max_distance, c.min_distance = g('max_distance', 2000), g('min_distance', 2000)
+    return c
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class Oracle:
+    """One loaded model + scenario config.  State lives in the caller's numpy arrays."""
+
+    def __init__(self, task='heading', solver=None, overrides=None, blob_path=DEFAULT_BLOB, mode=0):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.f16o_model_load.restype = C.c_void_p
+        L.f16o_model_load.argtypes = [C.c_char_p, C.c_size_t]
+        L.f16o_model_free.argtypes = [C.c_void_p]
+        L.f16o_tan.restype = C.c_float
+        L.f16o_tan.argtypes = [C.c_float]
+        L.f16o_pow.restype = C.c_float
+        L.f16o_pow.argtypes = [C.c_float, C.c_float]
+        L.f16o_wrap_pi.restype = C.c_float
+        L.f16o_wrap_pi.argtypes = [C.c_float]
+        L.f16o_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.f16o_aero.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        with open(blob_path, 'rb') as f:
+            blob = f.read()
+        self.model = L.f16o_model_load(blob, len(blob))
+        if not self.model:
+            raise RuntimeError('f16o_model_load failed')
+        self.task = task
+        self.cfg = load_cfg(task, solver, overrides)
+        self.mode = mode
+        self.threads = L.f16o_num_threads()
+
+    def __del__(self):
+        try:
+            self.lib.f16o_model_free(self.model)
+        except Exception:
+            pass
+
+    def _set_mode(self):
+        self.lib.f16o_set_mode(self.mode)
+
+    # ---- elementary pieces -------------------------------------------------------------
+    def sincos(self, x):
+        self._set_mode()
+        x = _f32(x).reshape(-1)
+        s = np.empty_like(x)
+        c = np.empty_like(x)
+        a, b = C.c_float(), C.c_float()
+        for i, v in enumerate(x):
+            self.lib.f16o_sincos(C.c_float(v), C.byref(a), C.byref(b))
+            s[i], c[i] = a.value, b.value
+        return s, c
+
+    def tan(self, x):
+        self._set_mode()
+        return np.array([self.lib.f16o_tan(C.c_float(v)) for v in _f32(x).reshape(-1)], dtype=np.float32)
+
+    def pow(self, x, y):
+        self._set_mode()
+        return np.array([self.lib.f16o_pow(C.c_float(v), C.c_float(y)) for v in _f32(x).reshape(-1)], dtype=np.float32)
+
+    def wrap_pi(self, x):
+        return np.array([self.lib.f16o_wrap_pi(C.c_float(v)) for v in _f32(x).reshape(-1)], dtype=np.float32)
+
+    def philox(self, ctr, key):
+        out = (C.c_uint32 * 4)()
+        self.lib.f16o_philox4x32((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        return list(out)
+
+    def rng_uniforms(self, seed, call_idx, row):
+        out = (C.c_float * 8)()
+        self.lib.f16o_rng_uniforms(C.c_uint64(seed), C.c_uint64(call_idx), C.c_int64(row), out)
+        return np.array(out, dtype=np.float32)
+
+    def rng_normals(self, seed, call_idx, row):
+        out = (C.c_float * 22)()
+        self.lib.f16o_rng_normals(C.c_uint64(seed), C.c_uint64(call_idx), C.c_int64(row), out)
+        return np.array(out, dtype=np.float32)
+
+    def aero(self, alpha_deg, beta_deg, el):
+        self._set_mode()
+        a, b, e = (_f32(v).reshape(-1) for v in (alpha_deg, beta_deg, el))
+        out = np.empty((a.size, 43), dtype=np.float32)
+        row = (C.c_float * 43)()
+        for i in range(a.size):
+            self.lib.f16o_aero(C.c_void_p(self.model), C.c_float(a[i]), C.c_float(b[i]), C.c_float(e[i]), row)
+            out[i] = row
+        return out
+
+    def nlplant(self, x17):
+        self._set_mode()
+        x = _f32(x17)
+        out = np.empty((x.shape[0], 12), dtype=np.float32)
+        self.lib.f16o_nlplant(C.c_void_p(self.model), C.c_int64(x.shape[0]), _p(x), _p(out))
+        return out
+
+    def get_acceleration(self, s, u):
+        self._set_mode()
+        s, u = _f32(s), _f32(u)
+        out = np.empty((s.shape[0], 3), dtype=np.float32)
+        self.lib.f16o_get_acceleration(C.c_void_p(self.model), C.c_int64(s.shape[0]), _p(s), _p(u), _p(out))
+        return out
+
+    def get_accels(self, s, u):
+        self._set_mode()
+        s, u = _f32(s), _f32(u)
+        out = np.empty((s.shape[0], 3), dtype=np.float32)
+        self.lib.f16o_get_accels(C.c_void_p(self.model), C.c_int64(s.shape[0]), _p(s), _p(u), _p(out))
+        return out
+
+    def get_eas2tas(self, s):
+        self._set_mode()
+        s = _f32(s)
+        out = np.empty(s.shape[0], dtype=np.float32)
+        self.lib.f16o_get_eas2tas(C.c_int64(s.shape[0]), _p(s), _p(out))
+        return out
+
+    # ---- env level -----------------------------------------------------------------------
+    @staticmethod
+    def new_state(n):
+        """Arrays as BaseEnv.__init__ leaves them: zeros, all three flags set (env_base.py:28-33)."""
+        return dict(s=np.zeros((n, 12), np.float32), u=np.zeros((n, 5), np.float32),
+                    tgt=np.zeros((n, 3), np.float32), step_count=np.zeros(n, np.int64),
+                    done=np.ones(n, np.uint8), bad=np.ones(n, np.uint8), timeout=np.ones(n, np.uint8))
+
+    def reset(self, st, rand_u=None, noise=None, seed=0, call_idx=0, row0=0, want_obs=True):
+        self._set_mode()
+        n = st['s'].shape[0]
+        obs = np.empty((n, 22), np.float32) if want_obs else None
+        ru = None if rand_u is None else _f32(rand_u)
+        nz = None if noise is None else _f32(noise)
+        rc = self.lib.f16o_reset(C.c_void_p(self.model), C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']),
+                                 _p(st['tgt']), _p(st['step_count'], C.c_int64), _p(st['done'], C.c_uint8),
+                                 _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(ru), _p(nz),
+                                 C.c_uint64(seed), C.c_uint64(call_idx), C.c_int64(row0), _p(obs))
+        assert rc == 0
+        return obs
+
+    def step(self, st, action, rand_u=None, noise=None, seed=0, call_idx=0, row0=0):
+        self._set_mode()
+        n = st['s'].shape[0]
+        a = _f32(action)
+        assert a.ndim == 2 and a.shape[0] == n and a.shape[1] >= 4
+        obs = np.empty((n, 22), np.float32)
+        rew = np.empty(n, np.float32)
+        ru = None if rand_u is None else _f32(rand_u)
+        nz = None if noise is None else _f32(noise)
+        rc = self.lib.f16o_step(C.c_void_p(self.model), C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']),
+                                _p(st['tgt']), _p(st['step_count'], C.c_int64), _p(st['done'], C.c_uint8),
+                                _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(a),
+                                C.c_int64(a.shape[1]), _p(ru), _p(nz), C.c_uint64(seed), C.c_uint64(call_idx),
+                                C.c_int64(row0), _p(obs), _p(rew))
+        assert rc == 0
+        return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()

@@ -1,0 +1,467 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+    python tools/gen_golden.py            # writes every fixture under tests/golden/
+
+The reference (`/root/reference`, pure Python/PyTorch) is imported unmodified on device='cpu'
+through the two import shims in tools/oracle_shims/ (torchdiffeq, gym).  Fixtures are DATA only:
+inputs and the reference's outputs.  Nothing of the reference travels to the GPU box.
+
+Two flavours are recorded for the floating-point fixtures:
+  * plain      — the reference exactly as it runs (ATen sgemm for nn.Linear, SLEEF sin/cos/pow);
+                 the oracle / HIP path must agree within tolerance (tests state it).
+  * `_pin`     — "pin mode": the only implementation-defined pieces are made implementation-
+                 independent by monkey-patching the *libraries the reference calls* (never its
+                 files): nn.Linear stacks are evaluated in fp64 and rounded once, sin/cos/tan/pow/sqrt
+                 are evaluated in fp64 and rounded once (ATen's fp32 sqrt goes through MKL VML and is
+                 not correctly rounded).  What remains is the reference's own
+                 fp32 operation order, which the oracle must then reproduce BIT-EXACTLY.
+
+Randomness: the reference draws from torch's global generator; the draws are recorded here by
+wrapping torch.rand / rand_like / randn_like and stored in the fixtures (`rand_u`, `noise`) so the
+consumers can inject them.
+"""
+import contextlib
+import io
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, 'oracle_shims'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, '/root/reference/envs')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+torch.set_num_threads(1)
+
+TGT_ATTRS = {'heading': ('target_altitude', 'target_heading', 'target_vt'),
+             'control': ('target_pitch', 'target_heading', 'target_vt'),
+             'tracking': ('target_npos', 'target_epos', 'target_altitude')}
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+# ------------------------------------------------------------------------------------------------
+# library patches
+# ------------------------------------------------------------------------------------------------
+class Recorder:
+    """Wraps torch.rand / rand_like / randn_like to log every draw the reference makes."""
+
+    def __init__(self):
+        self.log = []
+        self._orig = (torch.rand, torch.rand_like, torch.randn_like)
+
+    def __enter__(self):
+        o_rand, o_rand_like, o_randn_like = self._orig
+
+        def rand(*a, **k):
+            r = o_rand(*a, **k)
+            self.log.append(('rand', r.clone()))
+            return r
+
+        def rand_like(*a, **k):
+            r = o_rand_like(*a, **k)
+            self.log.append(('rand', r.clone()))
+            return r
+
+        def randn_like(*a, **k):
+            r = o_randn_like(*a, **k)
+            self.log.append(('randn', r.clone()))
+            return r
+
+        torch.rand, torch.rand_like, torch.randn_like = rand, rand_like, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.rand_like, torch.randn_like = self._orig
+
+    def take(self):
+        out, self.log = self.log, []
+        return out
+
+
+@contextlib.contextmanager
+def pin_mode(mlp_cls):
+    """fp64-and-round-once versions of the library calls whose fp32 result is implementation-defined."""
+    o_sin, o_cos, o_tan, o_pow, o_tpow, o_fwd = torch.sin, torch.cos, torch.tan, torch.pow, torch.Tensor.__pow__, mlp_cls.forward
+    o_sqrt = torch.sqrt
+
+    def pw(x, e):
+        if isinstance(e, (int, float)) and e == 2:
+            return x * x  # ATen's own special case (pow_tensor_scalar): exact fp32 product
+        assert isinstance(e, float)
+        return o_pow(x.double(), float(np.float32(e))).float()  # ATen rounds the exponent to fp32
+
+    def fwd(self, x):
+        h = x.to(torch.float32).double()
+        for layer in self.layers:
+            h = F.linear(h, layer.weight.double(), layer.bias.double()) if isinstance(layer, nn.Linear) else torch.relu(h)
+        return h.float().reshape(-1)
+
+    torch.sin = lambda x: o_sin(x.double()).float()
+    torch.cos = lambda x: o_cos(x.double()).float()
+    torch.tan = lambda x: o_tan(x.double()).float()
+    # ATen CPU routes sqrt through MKL VML (<1 ulp, not correctly rounded): make it the IEEE sqrt
+    torch.sqrt = lambda x: o_sqrt(x.double()).float()
+    torch.pow = pw
+    torch.Tensor.__pow__ = pw
+    mlp_cls.forward = fwd
+    try:
+        yield
+    finally:
+        torch.sin, torch.cos, torch.tan, torch.pow = o_sin, o_cos, o_tan, o_pow
+        torch.sqrt = o_sqrt
+        torch.Tensor.__pow__ = o_tpow
+        mlp_cls.forward = o_fwd
+
+
+@contextlib.contextmanager
+def maybe_pin(pin, mlp_cls):
+    if pin:
+        with pin_mode(mlp_cls):
+            yield
+    else:
+        yield
+
+
+def make_env(task, n, seed=0, solver=None):
+    from envs.control_env import ControlEnv
+    with quiet():
+        env = ControlEnv(num_envs=n, config=task, model='F16', random_seed=seed, device='cpu')
+    if solver:
+        env.model.solver = solver
+    return env
+
+
+def mlp_class(env):
+    return type(env.model.dynamics.hifi_F16.Cx_model)
+
+
+# ------------------------------------------------------------------------------------------------
+# fixture builders
+# ------------------------------------------------------------------------------------------------
+def aero_inputs(rng, n):
+    a = rng.uniform(-20, 90, n)
+    b = rng.uniform(-30, 30, n)
+    e = rng.uniform(-25, 25, n)
+    # edge rows: exact zeros (every reset aircraft), far extrapolation, signed values
+    a[:6] = [0, 0, 45, -20, 170, -90]
+    b[:6] = [0, 30, -30, 0, 80, -60]
+    e[:6] = [0, 0, 25, -25, 45, -45]
+    return [np.asarray(v, np.float32) for v in (a, b, e)]
+
+
+def aero_eval(hifi, a, b, e):
+    a, b, e = (torch.from_numpy(v) for v in (a, b, e))
+    groups = [hifi.hifi_C(a, b, e), hifi.hifi_damping(a), hifi.hifi_C_lef(a, b), hifi.hifi_damping_lef(a),
+              hifi.hifi_rudder(a, b), hifi.hifi_ailerons(a, b), hifi.hifi_other_coeffs(a, e)[:4]]
+    return torch.stack([t for g in groups for t in g], dim=1).numpy()
+
+
+def gen_aero(env):
+    rng = np.random.RandomState(11)
+    a, b, e = aero_inputs(rng, 384)
+    hifi = env.model.dynamics.hifi_F16
+    out = aero_eval(hifi, a, b, e)
+    with pin_mode(mlp_class(env)):
+        out_pin = aero_eval(hifi, a, b, e)
+    assert out.shape == (384, 43)
+    np.savez_compressed(os.path.join(OUT, 'aero_kat.npz'), alpha_deg=a, beta_deg=b, el=e, coef=out, coef_pin=out_pin)
+
+
+def random_flight_states(rng, n):
+    s = np.zeros((n, 12), np.float32)
+    s[:, 0] = rng.uniform(-5e4, 5e4, n)
+    s[:, 1] = rng.uniform(-5e4, 5e4, n)
+    s[:, 2] = rng.uniform(1000, 45000, n)
+    s[:, 3] = rng.uniform(-3.2, 3.2, n)
+    s[:, 4] = rng.uniform(-1.4, 1.4, n)
+    s[:, 5] = rng.uniform(-7, 7, n)
+    s[:, 6] = rng.uniform(150, 1500, n)
+    s[:, 7] = rng.uniform(-0.4, 0.9, n)
+    s[:, 8] = rng.uniform(-0.5, 0.5, n)
+    s[:, 9:12] = rng.uniform(-2, 2, (n, 3))
+    u = np.zeros((n, 5), np.float32)
+    u[:, 0] = rng.uniform(-2000, 60000, n)
+    u[:, 1:4] = rng.uniform(-45, 45, (n, 3))
+    return s, u
+
+
+def gen_nlplant(env):
+    rng = np.random.RandomState(12)
+    s, u = random_flight_states(rng, 512)
+    # edge rows
+    s[0] = 0; s[0, 2] = 19500; s[0, 6] = 1100; u[0] = [2000, 0, 0, 0, 0]  # a freshly reset aircraft
+    s[1, 6] = 0.005          # vt below the 0.01 clamp
+    s[2, 6] = -3.0           # negative vt
+    s[3, 2] = 36000.0        # above the tropopause switch
+    s[4, 4] = 1.5707         # pitch close to pi/2
+    s[5, 5] = 50.0; s[5, 3] = -40.0  # many turns of yaw / roll
+    s[6, 7] = 0.0; s[6, 8] = 0.0
+    x = np.hstack([s, u]).astype(np.float32)
+    dyn = env.model.dynamics
+    xd = dyn.nlplant(torch.from_numpy(x)).numpy()[:, :12]
+    with pin_mode(mlp_class(env)):
+        xd_pin = dyn.nlplant(torch.from_numpy(x)).numpy()[:, :12]
+    np.savez_compressed(os.path.join(OUT, 'nlplant_kat.npz'), x17=x, xdot=xd, xdot_pin=xd_pin)
+
+
+def gen_getters(env_unused):
+    rng = np.random.RandomState(13)
+    n = 256
+    s, u = random_flight_states(rng, n)
+    env = make_env('heading', n)
+    out = {}
+    for pin in (False, True):
+        with maybe_pin(pin, mlp_class(env)):
+            env.model.s = torch.from_numpy(s.copy())
+            env.model.u = torch.from_numpy(u.copy())
+            m = env.model
+            sfx = '_pin' if pin else ''
+            out['accel' + sfx] = torch.stack(m.get_acceleration(), 1).numpy()
+            out['accels' + sfx] = torch.stack(m.get_accels(), 1).numpy()
+            out['G' + sfx] = m.get_G().numpy()
+            out['eas2tas' + sfx] = m.get_EAS2TAS().numpy()
+            out['eas' + sfx] = m.get_EAS().numpy()
+            out['xdot' + sfx] = m.get_extended_state().numpy()[:, :12]
+    np.savez_compressed(os.path.join(OUT, 'getters_kat.npz'), s=s, u=u, **out)
+
+
+def get_tgt(env, task):
+    return torch.stack([getattr(env.task, a) for a in TGT_ATTRS[task]], 1).numpy().copy()
+
+
+def set_tgt(env, task, tgt):
+    for k, a in enumerate(TGT_ATTRS[task]):
+        setattr(env.task, a, torch.from_numpy(tgt[:, k].copy()))
+
+
+def force_state(env, task, st):
+    env.model.s = torch.from_numpy(st['s'].copy())
+    env.model.u = torch.from_numpy(st['u'].copy())
+    env.model.recent_s = env.model.s.clone()
+    env.model.recent_u = env.model.u.clone()
+    set_tgt(env, task, st['tgt'])
+    env.step_count = torch.from_numpy(st['step_count'].copy())
+    env.is_done = torch.from_numpy(st['done'].astype(bool))
+    env.bad_done = torch.from_numpy(st['bad'].astype(bool))
+    env.exceed_time_limit = torch.from_numpy(st['timeout'].astype(bool))
+
+
+def read_state(env, task):
+    return dict(s=env.model.s.numpy().copy(), u=env.model.u.numpy().copy(), tgt=get_tgt(env, task),
+                step_count=env.step_count.numpy().copy())
+
+
+def draws_to_arrays(log, reset_mask, n, n_task_draws, which_randn):
+    """Map the recorded draws of one reset()/step() call onto per-row arrays."""
+    rand = [t.numpy() for k, t in log if k == 'rand']
+    randn = [t.numpy() for k, t in log if k == 'randn']
+    rand_u = np.zeros((n, 5), np.float32)
+    assert len(rand) == 2 + n_task_draws, (len(rand), n_task_draws)
+    for c, r in enumerate(rand):
+        assert r.shape == (int(reset_mask.sum()),)
+        rand_u[reset_mask, c] = r
+    noise = randn[which_randn].astype(np.float32)
+    assert noise.shape == (n, 22)
+    return rand_u, noise
+
+
+def ref_step(env, task, st, action, pin):
+    """One teacher-forced env.step from state `st`; returns outputs + the randomness consumed."""
+    n = st['s'].shape[0]
+    force_state(env, task, st)
+    reset_mask = (st['done'] | st['bad'] | st['timeout']).astype(bool)
+    with maybe_pin(pin, mlp_class(env)), Recorder() as rec, quiet():
+        obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(action.copy()))
+        log = rec.take()
+    rand_u, noise = draws_to_arrays(log, reset_mask, n, 0 if task == 'heading' else 3, which_randn=1)
+    out = read_state(env, task)
+    out.update(obs=obs.numpy().copy(), reward=rew.numpy().copy(), done=done.numpy().astype(np.uint8),
+               bad=bad.numpy().astype(np.uint8), timeout=tmo.numpy().astype(np.uint8))
+    return out, rand_u, noise
+
+
+def build_step_inputs(task, n, rng):
+    """Input states for the teacher-forced step KAT: a mix of fresh rows (all flags set, as after
+    construction), mid-flight rows, rows at the step_count gates and rows sitting on their target."""
+    s, u = random_flight_states(rng, n)
+    # keep most rows inside the envelope so that not everything terminates
+    s[:, 2] = rng.uniform(3000, 30000, n)
+    s[:, 3] = rng.uniform(-1.0, 1.0, n)
+    s[:, 4] = rng.uniform(-0.5, 0.5, n)
+    s[:, 6] = rng.uniform(400, 1300, n)
+    s[:, 7] = rng.uniform(-0.1, 0.4, n)
+    s[:, 8] = rng.uniform(-0.1, 0.1, n)
+    s[:, 9:12] = rng.uniform(-0.5, 0.5, (n, 3))
+    u[:, 0] = rng.uniform(0, 30000, n)
+    u[:, 1:4] = rng.uniform(-10, 10, (n, 3))
+    tgt = np.zeros((n, 3), np.float32)
+    if task == 'heading':
+        tgt[:, 0] = s[:, 2] + rng.uniform(-1500, 1500, n)
+        tgt[:, 1] = rng.uniform(-3.1, 3.1, n)
+        tgt[:, 2] = s[:, 6] + rng.uniform(-100, 100, n)
+    elif task == 'control':
+        tgt[:, 0] = rng.uniform(-1.0, 1.0, n)
+        tgt[:, 1] = rng.uniform(-3.1, 3.1, n)
+        tgt[:, 2] = s[:, 6] + rng.uniform(-100, 100, n)
+    else:
+        tgt[:, 0] = s[:, 0] + rng.uniform(-3000, 3000, n)
+        tgt[:, 1] = s[:, 1] + rng.uniform(-3000, 3000, n)
+        tgt[:, 2] = s[:, 2] + rng.uniform(-1500, 1500, n)
+    step_count = rng.randint(0, 2600, n).astype(np.int64)
+    gates = [298, 299, 300, 301, 2498, 2499, 2500, 2501]
+    step_count[:32] = np.tile(gates, 4)
+    # rows 0..63: sitting (almost) on the target so that `done` can fire / just miss
+    k = 64
+    if task == 'heading':
+        tgt[:k, 0] = s[:k, 2] + rng.uniform(-120, 120, k)
+        tgt[:k, 1] = s[:k, 5] + rng.uniform(-0.1, 0.1, k)
+        tgt[:k, 2] = s[:k, 6] + rng.uniform(-25, 25, k)
+    elif task == 'control':
+        tgt[:k, 0] = s[:k, 4] + rng.uniform(-0.1, 0.1, k)
+        tgt[:k, 1] = s[:k, 5] + rng.uniform(-0.1, 0.1, k)
+        tgt[:k, 2] = s[:k, 6] + rng.uniform(-25, 25, k)
+    else:
+        tgt[:k] = s[:k, :3] + rng.uniform(-120, 120, (k, 3))
+    # hazard rows: low altitude, slow, fast, extreme alpha/beta, violent rates (overload)
+    s[64, 2] = 2500.5; s[65, 2] = 2499.0; s[66, 6] = 3400.0; s[67, 6] = 9.0
+    s[68, 7] = 0.79; s[69, 7] = -0.36; s[70, 8] = 0.53; s[71, 8] = -0.53
+    s[72, 9:12] = [6.0, -5.0, 4.0]; s[73, 10] = 9.0; u[74, 1] = 45.0; s[75, 6] = 0.004
+    done = np.zeros(n, np.uint8)
+    bad = np.zeros(n, np.uint8)
+    tmo = np.zeros(n, np.uint8)
+    # rows 96..159 arrive flagged (different flag combinations) and get re-initialised first
+    done[96:128] = 1
+    bad[112:144] = 1
+    tmo[140:160] = 1
+    action = rng.uniform(-1.3, 1.3, (n, 4)).astype(np.float32)  # beyond [-1,1] on purpose: clamp
+    action[0] = [1, 0, 0, 0]
+    return dict(s=s.astype(np.float32), u=u.astype(np.float32), tgt=tgt.astype(np.float32),
+                step_count=step_count, done=done, bad=bad, timeout=tmo), action
+
+
+def gen_step_kat(task, solver=None, n=256, tag=None):
+    rng = np.random.RandomState({'heading': 21, 'control': 22, 'tracking': 23}[task] + (100 if solver else 0))
+    env = make_env(task, n, solver=solver)
+    st, action = build_step_inputs(task, n, rng)
+    data = {('in_' + k): v for k, v in st.items()}
+    data['action'] = action
+    for pin in (False, True):
+        torch.manual_seed(1234)
+        out, rand_u, noise = ref_step(env, task, st, action, pin)
+        sfx = '_pin' if pin else ''
+        for k, v in out.items():
+            data['out_' + k + sfx] = v
+        data['rand_u'] = rand_u  # same seed -> same draws in both flavours
+        data['noise'] = noise
+    # the very first step of a fresh env: every row flagged (env_base.py:31-33)
+    env2 = make_env(task, n, solver=solver)
+    st0 = dict(s=np.zeros((n, 12), np.float32), u=np.zeros((n, 5), np.float32), tgt=np.zeros((n, 3), np.float32),
+               step_count=np.zeros(n, np.int64), done=np.ones(n, np.uint8), bad=np.ones(n, np.uint8),
+               timeout=np.ones(n, np.uint8))
+    for pin in (False, True):
+        torch.manual_seed(4321)
+        out, rand_u, noise = ref_step(env2, task, st0, action, pin)
+        sfx = '_pin' if pin else ''
+        for k, v in out.items():
+            data['first_out_' + k + sfx] = v
+        data['first_rand_u'] = rand_u
+        data['first_noise'] = noise
+    name = tag or f'step_kat_{task}'
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
+
+
+def traj_actions(T, n, seed=123):
+    """Deterministic action sequence shared with tests/ (numpy RandomState is version-stable)."""
+    rng = np.random.RandomState(seed)
+    t = np.arange(T, dtype=np.float64)[:, None, None]
+    phase = rng.uniform(0, 2 * np.pi, (1, n, 4))
+    freq = rng.uniform(0.002, 0.02, (1, n, 4))
+    a = 0.3 * np.sin(2 * np.pi * freq * t + phase) + rng.uniform(-1, 1, (T, n, 4)) * np.array([1.0, 0.3, 0.3, 0.3])
+    a[..., 0] = 0.5 + 0.5 * a[..., 0]
+    return np.clip(a, -1, 1).astype(np.float32)
+
+
+def gen_traj(task='heading', n=128, T=1000):
+    env = make_env(task, n, seed=0)
+    env.task.noise_scale = 0  # keeps the fixture small; noise parity is covered by step_kat
+    acts = traj_actions(T, n)
+    states, obs_l, rew_l = [], [], []
+    flags = np.zeros((T, n, 3), np.uint8)
+    rand_u = np.zeros((T, n, 5), np.float32)
+    tgts = []
+    n_task = 0 if task == 'heading' else 3
+    for t in range(T):
+        prev = (env.is_done | env.bad_done | env.exceed_time_limit).numpy().astype(bool)
+        with Recorder() as rec, quiet():
+            obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(acts[t]))
+            log = rec.take()
+        ru, _ = draws_to_arrays(log, prev, n, n_task, which_randn=1)
+        rand_u[t] = ru
+        flags[t, :, 0] = done.numpy()
+        flags[t, :, 1] = bad.numpy()
+        flags[t, :, 2] = tmo.numpy()
+        if (t + 1) % 10 == 0 or t < 3:
+            states.append(np.hstack([env.model.s.numpy(), env.model.u.numpy()[:, :4], get_tgt(env, task)]))
+            obs_l.append(obs.numpy().copy())
+            rew_l.append(rew.numpy().copy())
+    rec_steps = np.array([t for t in range(T) if (t + 1) % 10 == 0 or t < 3], np.int64)
+    np.savez_compressed(os.path.join(OUT, f'traj_{task}_N{n}_T{T}.npz'), action_seed=np.int64(123),
+                        rec_steps=rec_steps, state=np.stack(states).astype(np.float32),
+                        obs=np.stack(obs_l).astype(np.float32), reward=np.stack(rew_l).astype(np.float32),
+                        flags=flags, rand_u=rand_u, step_count_final=env.step_count.numpy())
+    print(f'traj {task}: done={int(flags[:, :, 0].sum())} bad={int(flags[:, :, 1].sum())}')
+
+
+def gen_recorded_episode():
+    """Rows 0..426 of the authors' CUDA recording renders/result/*.npy (render_ppo.py:157-175)."""
+    d = '/root/reference/renders/result'
+    cols = ['npos', 'epos', 'altitude', 'roll', 'pitch', 'yaw', 'vt', 'alpha', 'beta', 'G', 'T', 'el', 'ail', 'rud']
+    arr = np.stack([np.load(os.path.join(d, c + '.npy')).reshape(-1)[:427] for c in cols], 1).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'recorded_episode0.npz'), columns=np.array(cols), rows=arr)
+    # sanity: replay with the reference dynamics
+    from envs.models.F16.F16_dynamics import F16Dynamics
+    with quiet():
+        dyn = F16Dynamics('cpu')
+    s = torch.zeros(1, 12)
+    s[0, 2] = float(arr[0, 2]); s[0, 6] = float(arr[0, 6])
+    worst = 0.0
+    for t in range(426):
+        u = torch.tensor([[arr[t + 1, 10], arr[t + 1, 11], arr[t + 1, 12], arr[t + 1, 13], 0.0]])
+        x = torch.hstack((s, u))
+        s = (x + torch.tensor(0.02) * dyn.nlplant(x))[:, :12]
+        ref = arr[t + 1, :9]
+        worst = max(worst, float(np.max(np.abs(s[0, :9].numpy() - ref) / np.maximum(np.abs(ref), 1e-3))))
+    print('recorded episode replay with reference dynamics: worst rel err', worst)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    env = make_env('heading', 4)
+    gen_aero(env)
+    gen_nlplant(env)
+    gen_getters(env)
+    for task in ('heading', 'control', 'tracking'):
+        gen_step_kat(task)
+    gen_step_kat('heading', solver='rk4', tag='step_kat_heading_rk4')
+    gen_traj('heading', 128, 1000)
+    gen_traj('control', 64, 300)
+    gen_traj('tracking', 64, 300)
+    gen_recorded_episode()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+    main()
