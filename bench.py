@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — aircraft-steps/sec of the fused F-16 Heading env.step on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n AIRCRAFT_PER_GPU] [--task heading]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: F-16 Heading, N = 1e6 aircraft per GPU (weak scaling: the
+batch shards embarrassingly, no data-path collective), envs/configs/heading.yaml constants
+(Euler, dt = 0.02, noise_scale = 0.01), per-step uniform random actions from a fixed seed so that
+terminations / auto-resets occur at a realistic rate.  A "step" is one `ControlEnv.step(action)`
+= one fused HIP kernel launch; inputs (state, actions) are resident in HBM before the timed region.
+Protocol follows the reference's own benchmark (envs/measure_env.py:65-78: back-to-back env.step,
+500 steps) with a warm-up and device synchronisation added.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for the roofline arithmetic).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic work per aircraft-step, F-16 Heading, Euler
+ALGO_BYTES = 278.0      # HBM: read s48+u20+tgt12+step_count8+flags3+action16, write s48+u20+step_count8+obs88+reward4+flags3
+ALGO_FLOP = 33.8e3      # aero eval 23 770 + force-side re-evaluation 9 160 + ~900 non-MLP (FMA = 2)
+PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak == fp32 (f32-input) MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(task, budget_s=15.0):
+    """The CPU oracle (oracle/, the C restatement of the reference path) timed on this box's host
+    cores on a bounded sample of the same workload.  A reported baseline, never the thing shipped."""
+    import numpy as np
+    from oracle.f16_oracle import Oracle
+    o = Oracle(task)
+    n = 20000
+    st = Oracle.new_state(n)
+    rng = np.random.RandomState(0)
+    acts = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(4)]
+    o.reset(st, seed=0, call_idx=0)
+    o.step(st, acts[0], seed=0, call_idx=1)  # warm
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        o.step(st, acts[steps % 4], seed=0, call_idx=2 + steps)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 2000:
+            break
+    return {'value': n * steps / el, 'unit': 'aircraft-steps/s', 'cores': int(o.threads), 'kind': 'port',
+            'sample': f'F-16 {task}, N={n} aircraft x {steps} steps, oracle/f16_oracle.c (OpenMP, fp32 scalar, '
+                      f'same numerics spec), {el:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--n', type=int, default=1_000_000, help='aircraft per GPU')
+    ap.add_argument('--task', default='heading', choices=['heading', 'control', 'tracking'])
+    ap.add_argument('--actions', default='random', choices=['random', 'constant'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with '
+                             f'python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...')
+        raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)  # RCCL; used for the timing barrier only
+
+    from neuralplane_amd.envs.control_env import ControlEnv
+    n = args.n
+    env = ControlEnv(num_envs=n, config=args.task, model='F16', random_seed=0, device=str(dev), row0=rank * n)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    if args.actions == 'random':
+        pool = [torch.rand((n, 4), generator=g, device=dev) * 2 - 1 for _ in range(8)]
+    else:  # the reference benchmark's clamped constant action (measure_env.py:12-16,68-72)
+        pool = [torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(n, 1)]
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    env.reset()
+    for i in range(args.warmup):
+        env.step(pool[i % len(pool)])
+    env._batch.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step(pool[i % len(pool)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_cnt = env._batch.get_timing()
+    env._batch.set_timing(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # sanity of the timed region: states finite for live rows, counters advanced
+    fin = bool(torch.isfinite(env.model.s).all().item())
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        kern_s = kern_ms * 1e-3
+        ach_tflops = n * ALGO_FLOP / kern_s / 1e12 if kern_s > 0 else 0.0
+        ach_gbs = n * ALGO_BYTES / kern_s / 1e9 if kern_s > 0 else 0.0
+        out = {
+            'metric': 'aircraft-steps/sec at N=1e6 F-16 Heading; 1/2/4/8 MI355X scaling',
+            'value': value, 'unit': 'aircraft-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'F-16 {args.task}, N={n} aircraft per GPU, euler dt=0.02, noise_scale per YAML, '
+                                   f'{args.actions} actions, one fused HIP kernel per env.step',
+                       'aircraft_per_gpu': n, 'sharding': f'rows split over {world} GPU(s), no data-path collective'},
+            'roofline': {'bound': 'mfma', 'achieved': ach_tflops, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach_tflops / PEAK_FP32_TFLOPS, 'traffic': None,
+                         'kernel': 'f16_env_kernel<task,solver,STEP>', 'kernel_avg_ms': kern_ms, 'launches_timed': kern_cnt,
+                         'note': 'fp32 VECTOR (VALU) roof: 157.3 TFLOP/s is both the fp32 vector peak and the '
+                                 'f32-input MFMA peak on gfx950; the kernel issues no MFMA. achieved = 33.8 KFLOP x N / '
+                                 'avg launch duration (HIP events on the launch stream)'},
+            'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                             'frac': ach_gbs / PEAK_HBM_GBS, 'note': '278 algorithmic B per aircraft-step; not the binding roof'},
+            'state_finite': fin,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.task)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

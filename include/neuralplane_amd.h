@@ -1,0 +1,121 @@
+/*
+ * neuralplane_amd.h — C ABI of the MI355X-native NeuralPlane F-16 env.step hot path.
+ *
+ * The reference (xuecy22/NeuralPlane @ 2024-12-18) is 100 % Python/PyTorch and has NO native or
+ * FFI layer; its boundary for this path is the duck-typed Python env surface.  This header is the
+ * native boundary a replacement must export underneath that surface: each entry point names the
+ * reference Python interface it replaces (paths relative to the reference root).  The Python
+ * mirror of the surface (neuralplane_amd/envs/) binds these symbols with ctypes; INTEGRATION.md
+ * shows the stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures (the stream is a
+ *     `void*` holding a hipStream_t, NULL = default stream).
+ *   - All buffers are DEVICE pointers owned by the caller; the library never allocates per call
+ *     and never frees caller memory.  Kernels are enqueued asynchronously on `stream`.
+ *   - Every function returns 0 on success, non-zero on failure; np_last_error() gives the
+ *     thread-local message.  No exceptions cross the ABI.  There is NO CPU fallback: without a
+ *     gfx950 device every compute entry point fails.
+ *   - State is structure-of-arrays: component k of aircraft i is at base[k*ld + i].
+ */
+#ifndef NEURALPLANE_AMD_H
+#define NEURALPLANE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NP_ABI_VERSION 1
+
+#define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
+#define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
+#define NP_NUM_TARGETS 3   /* task targets (heading: alt,heading,vt | control: pitch,heading,vt | tracking: n,e,alt) */
+#define NP_NUM_OBS 22      /* envs/tasks/heading_task.py:71-152                                                   */
+#define NP_NUM_DERIVED 20  /* rows written by np_f16_derived()                                                    */
+
+enum { NP_TASK_HEADING = 0, NP_TASK_CONTROL = 1, NP_TASK_TRACKING = 2 }; /* envs/control_env.py:28-35 */
+enum { NP_SOLVER_EULER = 0, NP_SOLVER_RK4 = 1 };                          /* envs/models/F16_model.py:16,64-67 */
+
+/* Scenario constants = the keys of envs/configs/{heading,control,tracking}.yaml, with the
+ * defaults of the reference's getattr(config, key, default) calls.  Values are passed as Python
+ * holds them (double / int); the library rounds them to fp32 where the reference's tensor
+ * arithmetic does. */
+typedef struct np_f16_cfg {
+    int32_t task;   /* NP_TASK_*   */
+    int32_t solver; /* NP_SOLVER_* */
+    double dt, airspeed, noise_scale;                               /* F16_model.py:15-17, heading_task.py:32 */
+    double altitude_limit, acceleration_limit, max_velocity, min_velocity; /* termination_conditions/ __init__ */
+    double min_alpha, max_alpha, min_beta, max_beta;                /* extreme_state.py:13-16 */
+    int64_t max_check_interval, min_check_interval;                 /* unreach_heading.py:16-17 */
+    double init_T, max_altitude, min_altitude, max_vt, min_vt;      /* F16_model.py:25-29 */
+    double max_heading_increment, max_pitch_increment, max_velocities_u_increment; /* control_task.py:30-32 */
+    double max_distance, min_distance;                              /* tracking_task.py:30-31 */
+} np_f16_cfg;
+
+/* Buffers of one reset()/step() call.  n aircraft, global row index of local row i = row0 + i
+ * (used only to key the counter-based RNG, so that a batch sharded over several GPUs draws the
+ * same numbers as the unsharded batch). */
+typedef struct np_f16_io {
+    float *s;              /* [12][ld]  F16Model.s            (F16_model.py:19)  in/out */
+    float *u;              /* [5][ld]   F16Model.u            (F16_model.py:21)  in/out (row 4 = lef stays 0) */
+    float *tgt;            /* [3][ld]   task.target_*         (heading_task.py:26-28) in/out */
+    int64_t ld;            /* leading dimension of s/u/tgt (>= n) */
+    int64_t *step_count;   /* [n]       BaseEnv.step_count    (env_base.py:28) in/out */
+    const uint8_t *done_in, *bad_in, *timeout_in;   /* [n] flags left by the previous step (env_base.py:31-33) */
+    uint8_t *done_out, *bad_out, *timeout_out;      /* [n] new flags; may NOT alias the *_in buffers */
+    const float *action;   /* [n][act_stride] row-major, columns 0..3 read (F16_model.py:52-56); NULL for reset */
+    int64_t act_stride;
+    float *obs;            /* [n][22] row-major (what the policy consumes); may be NULL for reset */
+    float *reward;         /* [n]; unused by reset */
+    /* Parity hooks (normally NULL -> in-kernel counter-based RNG keyed by seed/call_idx/row):   */
+    const float *rand_u;   /* [n][5] uniforms (alt, vt, task0, task1, task2) consumed by flagged rows */
+    const float *noise;    /* [n][22] standard normals added as obs + noise*noise_scale */
+    uint64_t seed;         /* RNG key */
+    uint64_t call_idx;     /* RNG counter word: the caller increments it once per reset()/step() call */
+    int64_t row0;
+} np_f16_io;
+
+typedef struct np_f16_ctx np_f16_ctx;
+
+int np_abi_version(void);
+const char *np_last_error(void);
+
+/* Upload the 43-MLP asset blob (NPF16MLP v1, neuralplane_amd/assets/f16_aero_mlp.bin) and the
+ * scenario constants to `device`.  Replaces F16Dynamics/hifi_F16 construction
+ * (envs/models/F16/hifi_F16_AeroData.py:40-129) + parse_config (envs/utils/utils.py:12-27). */
+int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg *cfg, int device, np_f16_ctx **out);
+void np_f16_ctx_destroy(np_f16_ctx *ctx);
+
+/* BaseEnv.reset() — envs/env_base.py:83-97 (F16Model.reset F16_model.py:33-45, task.reset
+ * heading_task.py:49-69 / control_task.py:49-68 / tracking_task.py:48-71, then obs()).
+ * Rows with any *_in flag set are re-initialised; all *_out flags are written as 0. */
+int np_f16_reset(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream);
+
+/* BaseEnv.step(action) — envs/env_base.py:99-109: auto-reset, F16Model.update
+ * (F16_model.py:51-67, one integrator step of F16Dynamics.nlplant F16_dynamics.py:37-228),
+ * step_count += 1, task.get_obs, the six termination conditions (task_base.py:75-96) and the
+ * reward (task_base.py:60-73), fused into ONE kernel launch. */
+int np_f16_step(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream);
+
+/* Derived quantities behind F16Model's getters (F16_model.py:47-49, 132-181), SoA out[20][ld_out]:
+ *   rows 0..11  get_extended_state()[:, :12]  (xdot)
+ *   rows 12..14 get_acceleration()            (ax, ay, az)
+ *   rows 15..17 get_accels()                  (nx_cg, ny_cg, nz_cg)
+ *   row  18     get_EAS2TAS()
+ *   row  19     get_EAS()                                                                  */
+int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, int64_t ld, float *out,
+                   int64_t ld_out, void *stream);
+
+/* Average duration in ms of the `count` most recent np_f16_step launches on this context,
+ * measured with HIP events recorded on the launch stream around each launch (0 disables;
+ * enable with np_f16_set_timing(ctx, 1)).  Synchronises on the recorded events. */
+int np_f16_set_timing(np_f16_ctx *ctx, int enable);
+int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

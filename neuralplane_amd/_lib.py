@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/neuralplane_amd.h (libneuralplane_hip.so).
+
+PyTorch is imported first on purpose: the extension's DT_NEEDED `libamdhip64.so.7` then resolves to
+the HIP runtime PyTorch-ROCm already loaded (same SONAME), so tensors and kernels share one runtime.
+There is no CPU fallback: if the extension is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+from . import build as _build
+
+TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
+SOLVERS = {'euler': 0, 'rk4': 1}
+ABI_VERSION = 1
+
+
+class NpF16Cfg(C.Structure):
+    _fields_ = [('task', C.c_int32), ('solver', C.c_int32),
+                ('dt', C.c_double), ('airspeed', C.c_double), ('noise_scale', C.c_double),
+                ('altitude_limit', C.c_double), ('acceleration_limit', C.c_double),
+                ('max_velocity', C.c_double), ('min_velocity', C.c_double),
+                ('min_alpha', C.c_double), ('max_alpha', C.c_double),
+                ('min_beta', C.c_double), ('max_beta', C.c_double),
+                ('max_check_interval', C.c_int64), ('min_check_interval', C.c_int64),
+                ('init_T', C.c_double), ('max_altitude', C.c_double), ('min_altitude', C.c_double),
+                ('max_vt', C.c_double), ('min_vt', C.c_double),
+                ('max_heading_increment', C.c_double), ('max_pitch_increment', C.c_double),
+                ('max_velocities_u_increment', C.c_double),
+                ('max_distance', C.c_double), ('min_distance', C.c_double)]
+
+
+class NpF16Io(C.Structure):
+    _fields_ = [('s', C.c_void_p), ('u', C.c_void_p), ('tgt', C.c_void_p), ('ld', C.c_int64),
+                ('step_count', C.c_void_p),
+                ('done_in', C.c_void_p), ('bad_in', C.c_void_p), ('timeout_in', C.c_void_p),
+                ('done_out', C.c_void_p), ('bad_out', C.c_void_p), ('timeout_out', C.c_void_p),
+                ('action', C.c_void_p), ('act_stride', C.c_int64),
+                ('obs', C.c_void_p), ('reward', C.c_void_p),
+                ('rand_u', C.c_void_p), ('noise', C.c_void_p),
+                ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64)]
+
+
+EXPORTS = ('np_abi_version', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
+           'np_f16_step', 'np_f16_derived', 'np_f16_set_timing', 'np_f16_get_timing')
+
+_lib = None
+
+
+def so_path():
+    return _build.SO
+
+
+def load():
+    """dlopen the extension (built in-tree by neuralplane_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = so_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f'{path} is missing: run `python -m neuralplane_amd.build` (hipcc, gfx950). '
+                           'neuralplane_amd has no CPU fallback.')
+    lib = C.CDLL(path)
+    lib.np_abi_version.restype = C.c_int
+    lib.np_last_error.restype = C.c_char_p
+    lib.np_f16_ctx_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(NpF16Cfg), C.c_int, C.POINTER(C.c_void_p)]
+    lib.np_f16_ctx_destroy.argtypes = [C.c_void_p]
+    lib.np_f16_ctx_destroy.restype = None
+    lib.np_f16_reset.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16Io), C.c_void_p]
+    lib.np_f16_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16Io), C.c_void_p]
+    lib.np_f16_derived.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                   C.c_void_p]
+    lib.np_f16_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.np_f16_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    if lib.np_abi_version() != ABI_VERSION:
+        raise RuntimeError('libneuralplane_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('neuralplane_amd: ' + load().np_last_error().decode())

@@ -1,0 +1,172 @@
+"""F16Batch — device-resident state of N F-16 aircraft and the fused reset/step launches.
+
+This is the thin host layer between the reference-shaped Python env surface (neuralplane_amd/envs)
+and the C ABI (include/neuralplane_amd.h).  PyTorch-ROCm is used for what it is good at — device
+memory, streams, the caching allocator — and nothing else: every number is produced by the HIP
+kernels in csrc/.  State is structure-of-arrays (`s[12,n]`, `u[5,n]`, `tgt[3,n]`); the `[n,k]`
+tensors the reference exposes (`model.s`, `model.u`) are transposed *views* of these buffers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+
+ASSET_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'f16_aero_mlp.bin')
+NUM_DERIVED = 20
+
+
+def cfg_from_config(config, task, solver=None):
+    """Scenario attribute bag (parse_config) -> np_f16_cfg, with the reference's getattr defaults."""
+    g = lambda k, d: getattr(config, k, d)  # noqa: E731
+    c = _lib.NpF16Cfg()
+    c.task = _lib.TASKS[task]
+    sol = solver or g('solver', 'euler')
+    if sol not in _lib.SOLVERS:
+        raise NotImplementedError(f"solver '{sol}' (supported: euler, rk4)")
+    c.solver = _lib.SOLVERS[sol]
+    c.dt = g('dt', 0.02)                                    # F16_model.py:15
+    c.airspeed = g('airspeed', 0)                           # F16_model.py:17
+    c.noise_scale = g('noise_scale', 0.01)                  # heading_task.py:32
+    c.altitude_limit = g('altitude_limit', 2500.0)          # low_altitude.py:13
+    c.acceleration_limit = g('acceleration_limit', 300.0)   # overload.py:13
+    c.max_velocity = g('max_velocity', 3)                   # high_speed.py:13
+    c.min_velocity = g('min_velocity', 0.01)                # low_speed.py:13
+    c.min_alpha, c.max_alpha = g('min_alpha', -20), g('max_alpha', 45)   # extreme_state.py:13-16
+    c.min_beta, c.max_beta = g('min_beta', -30), g('max_beta', 30)
+    c.max_check_interval = g('max_check_interval', 1500)    # unreach_heading.py:16
+    c.min_check_interval = g('min_check_interval', 300)     # unreach_heading.py:17
+    c.init_T = config.init_state['init_T']                  # F16_model.py:43
+    c.max_altitude, c.min_altitude = g('max_altitude', 20000), g('min_altitude', 19000)  # F16_model.py:25-26
+    c.max_vt, c.min_vt = g('max_vt', 1200), g('min_vt', 1000)                           # F16_model.py:27-28
+    c.max_heading_increment = g('max_heading_increment', 0.3)          # control_task.py:31
+    c.max_pitch_increment = g('max_pitch_increment', 0.3)              # control_task.py:30
+    c.max_velocities_u_increment = g('max_velocities_u_increment', 100)  # control_task.py:32
+    c.max_distance, c.min_distance = g('max_distance', 2000), g('min_distance', 2000)  # tracking_task.py:30-31
+    return c
+
+
+class F16Batch:
+    """N aircraft on one GPU.  `row0` is the global index of local row 0 (sharded batches)."""
+
+    def __init__(self, n, config, task, device, seed=0, solver=None, row0=0, blob_path=ASSET_BLOB):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError(f"neuralplane_amd runs on MI355X (torch device 'cuda:N'), not on '{device}': "
+                               'there is no CPU fallback')
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.n = int(n)
+        self.task = task
+        self.cfg = cfg_from_config(config, task, solver)
+        self.noise_scale = float(self.cfg.noise_scale)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.row0 = int(row0)
+        self.call_idx = 0
+        with open(blob_path, 'rb') as f:
+            blob = f.read()
+        ctx = C.c_void_p()
+        _lib.check(self.lib.np_f16_ctx_create(blob, len(blob), C.byref(self.cfg), self.device.index, C.byref(ctx)))
+        self._ctx = ctx
+        d = self.device
+        n = self.n
+        self.s = torch.zeros((12, n), dtype=torch.float32, device=d)
+        self.u = torch.zeros((5, n), dtype=torch.float32, device=d)
+        self.tgt = torch.zeros((3, n), dtype=torch.float32, device=d)
+        self.step_count = torch.zeros(n, dtype=torch.int64, device=d)
+        # BaseEnv.__init__ leaves all three flags set so that the first reset()/step() initialises
+        # every row (env_base.py:31-33)
+        self.flags = torch.ones((3, n), dtype=torch.uint8, device=d)
+        self._derived = None
+        self._derived_key = None
+        self._version = 0
+
+    def __del__(self):
+        ctx = getattr(self, '_ctx', None)
+        if ctx:
+            try:
+                self.lib.np_f16_ctx_destroy(ctx)
+            except Exception:
+                pass
+            self._ctx = None
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _io(self, new_flags, action, obs, reward, rand_u, noise):
+        io = _lib.NpF16Io()
+        io.s, io.u, io.tgt, io.ld = self.s.data_ptr(), self.u.data_ptr(), self.tgt.data_ptr(), self.n
+        io.step_count = self.step_count.data_ptr()
+        f, g = self.flags, new_flags
+        io.done_in, io.bad_in, io.timeout_in = f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr()
+        io.done_out, io.bad_out, io.timeout_out = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
+        if action is not None:
+            io.action, io.act_stride = action.data_ptr(), action.stride(0)
+        io.obs = obs.data_ptr() if obs is not None else None
+        io.reward = reward.data_ptr() if reward is not None else None
+        io.rand_u = rand_u.data_ptr() if rand_u is not None else None
+        io.noise = noise.data_ptr() if noise is not None else None
+        io.seed, io.call_idx, io.row0 = self.seed, self.call_idx, self.row0
+        return io
+
+    def _inject(self, t, cols):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, dtype=torch.float32, device=self.device).contiguous()
+        if tuple(t.shape) != (self.n, cols):
+            raise ValueError(f'expected shape ({self.n}, {cols}), got {tuple(t.shape)}')
+        return t
+
+    # -- launches ------------------------------------------------------------------------------
+    def reset(self, rand_u=None, noise=None):
+        """BaseEnv.reset(): re-initialise flagged rows, clear all flags, return obs[n,22]."""
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
+        io = self._io(new_flags, None, obs, None, rand_u, noise)
+        _lib.check(self.lib.np_f16_reset(self._ctx, self.n, C.byref(io), self._stream()))
+        self.flags = new_flags
+        self.call_idx += 1
+        self._version += 1
+        return obs
+
+    def step(self, action, rand_u=None, noise=None):
+        """BaseEnv.step(action): ONE kernel launch.  Returns obs, reward, flags[3,n] (uint8)."""
+        if action.device != self.device or action.dtype != torch.float32:
+            action = action.to(device=self.device, dtype=torch.float32)
+        if action.dim() != 2 or action.shape[0] != self.n or action.shape[1] < 4:
+            raise ValueError(f'action must be [n={self.n}, >=4], got {tuple(action.shape)}')
+        if action.stride(1) != 1:
+            action = action.contiguous()
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
+        io = self._io(new_flags, action, obs, reward, rand_u, noise)
+        _lib.check(self.lib.np_f16_step(self._ctx, self.n, C.byref(io), self._stream()))
+        self.flags = new_flags
+        self.call_idx += 1
+        self._version += 1
+        return obs, reward, new_flags
+
+    def derived(self):
+        """[20,n] derived quantities at the current (s,u) (np_f16_derived), cached per state version."""
+        key = (self._version, self.s.data_ptr(), self.u.data_ptr(), self.s._version, self.u._version)
+        if self._derived is None or self._derived_key != key:
+            out = torch.empty((NUM_DERIVED, self.n), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.np_f16_derived(self._ctx, self.n, self.s.data_ptr(), self.u.data_ptr(), self.n,
+                                               out.data_ptr(), self.n, self._stream()))
+            self._derived, self._derived_key = out, key
+        return self._derived
+
+    # -- kernel timing (bench.py) ---------------------------------------------------------------
+    def set_timing(self, enable):
+        _lib.check(self.lib.np_f16_set_timing(self._ctx, int(bool(enable))))
+
+    def get_timing(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

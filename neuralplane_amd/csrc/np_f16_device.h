@@ -1,0 +1,477 @@
+// np_f16_device.h — per-aircraft device functions of the fused F-16 env.step kernel (gfx950).
+//
+// One lane = one aircraft.  All MLP weights are wave-uniform and live in __constant__ memory in
+// the order the FMA chains consume them, so the compiler feeds them through s_load_dwordxN and
+// the FMAs are `v_fmac_f32 v_acc, s_weight, v_x` — no VGPR and no LDS spent on weights.
+//
+// Arithmetic follows the reference operator by operator (see the citations) and
+// the numerics spec of DESIGN.md for the implementation-defined pieces.  Build with
+// -ffp-contract=off: the only fused operations are the explicit fmaf() chains of the Linear layers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "np_math.h"
+#include "np_nets.h"
+
+namespace npf16 {
+
+__constant__ float c_kblob[KBLOB_FLOATS];
+
+// Scenario constants, pre-rounded on the host exactly where the reference rounds them.
+struct DevCfg {
+    float dt, airspeed, noise_scale;
+    float altitude_limit, acceleration_limit, max_velocity, min_velocity;
+    float min_alpha, max_alpha, min_beta, max_beta;
+    long long max_check_interval, min_check_interval;
+    float init_T, alt_span, min_altitude, vt_span, min_vt;
+    float max_heading_increment, max_pitch_increment, max_velocities_u_increment;
+    float dist_span, min_distance;
+};
+
+// ---------------------------------------------------------------------------------------------
+// MLP evaluation — hifi_F16_AeroData.py:12-37 (MLP.forward, normalize, unnormalize)
+//   Linear: acc = bias; acc = fmaf(W[j][k], x[k], acc), k ascending (numerics spec)
+// ---------------------------------------------------------------------------------------------
+// Weight stream of one net: the KBLOB record is consumed strictly front to back, one weight per
+// FMA.  Weights are wave-uniform, so they travel through the scalar unit: a CHUNK of 16 weights is
+// one `s_load_dwordx16` into 16 SGPRs and each FMA names its weight as an SGPR operand
+// (`v_fmac_f32 v_acc, s_w, v_x` / `v_pk_fma_f32`).  Two chunks ahead are kept in flight.  Left to
+// itself hipcc hoists dozens of these loads, overflows the 102 SGPRs and spills them lane-by-lane
+// into VGPRs (thousands of v_readlane/v_writelane); the empty asm "pins" below tie the stream
+// pointer to each consumed chunk so that at most NBUF chunks are ever live.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef f32x16 f32x16_u __attribute__((aligned(4)));
+
+template <int NBUF, int LEN>  // LEN = floats in the record
+struct WStream {
+    int off;  // KBLOB offset of the record, wave-uniform
+    f32x16 buf[NBUF];
+    int p;  // position in the record; a compile-time constant after full unrolling
+
+    __device__ __forceinline__ void start(int base) {
+        off = base;
+        p = 0;
+#pragma unroll
+        for (int b = 0; b < NBUF; b++)
+            if (16 * b < LEN) buf[b] = *(const f32x16_u *)(c_kblob + off + 16 * b);
+    }
+    __device__ __forceinline__ float next() {
+        const int c = p / 16, l = p % 16;
+        if (l == 0) {
+            // chunk c is about to be consumed: it must have landed, and nothing issued after this
+            // point may be scheduled above it (the later loads depend on the pinned offset).
+            // Two statements, 32-bit offset: hipcc treats a multi-output asm, and a 64-bit pointer
+            // that went through asm, as divergent values (-> vector loads, "illegal VGPR to SGPR copy").
+            asm volatile("" : "+s"(buf[c % NBUF]));
+            asm volatile("" : "+s"(off));
+            if (c > 0 && 16 * (c - 1 + NBUF) < LEN)
+                buf[(c - 1) % NBUF] = *(const f32x16_u *)(c_kblob + off + 16 * (c - 1 + NBUF));
+        }
+        p++;
+        return buf[c % NBUF][l];
+    }
+};
+
+// One Linear(+ReLU) layer fed from the weight stream: bias[out] then W^T[in][out] (k-major).
+template <int IN, int OUT, bool RELU, class WS>
+__device__ __forceinline__ void dense(WS &ws, const float (&x)[IN], float (&y)[OUT]) {
+#pragma unroll
+    for (int j = 0; j < OUT; j++) y[j] = ws.next();
+#pragma unroll
+    for (int k = 0; k < IN; k++) {
+#pragma unroll
+        for (int j = 0; j < OUT; j++) y[j] = fmaf(ws.next(), x[k], y[j]);
+    }
+    if (RELU) {
+#pragma unroll
+        for (int j = 0; j < OUT; j++) y[j] = y[j] > 0.0f ? y[j] : 0.0f;
+    }
+}
+
+constexpr int WS_NBUF = 3;
+
+template <int IN, int H1, int H2, int H3>
+__device__ __forceinline__ float mlp_body(int w, const float (&x)[IN]) {
+    constexpr int LEN = IN * H1 + H1 + H1 * H2 + H2 + (H3 > 0 ? H2 * H3 + H3 + H3 + 1 : H2 + 1) + 2;
+    WStream<WS_NBUF, LEN> ws;
+    ws.start(w);
+    float h1[H1], h2[H2];
+    dense<IN, H1, true>(ws, x, h1);
+    dense<H1, H2, true>(ws, h1, h2);
+    float y[1];
+    if constexpr (H3 > 0) {
+        float h3[H3];
+        dense<H2, H3, true>(ws, h2, h3);
+        dense<H3, 1, false>(ws, h3, y);
+    } else {
+        dense<H2, 1, false>(ws, h2, y);
+    }
+    const float out_std = ws.next();
+    const float out_mean = ws.next();
+    return y[0] * out_std + out_mean;  // unnormalize: X * std + mean
+}
+
+// All nets of one class (np_nets.h): same shape, same inputs, KBLOB records back to back.  ONE
+// compact loop body per class keeps the instruction footprint of a full aero evaluation at a few
+// KB (it stays in the instruction cache) where straight-line code for 42 nets would be ~100 KB.
+// Each net's output goes to this lane's column of the LDS scratch: out[slot*LD] (ds_write_b32,
+// consecutive lanes -> consecutive banks), from where the coefficient build-up reads it back.
+template <int CL, bool FORCE_ONLY, int LD>
+__device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
+    constexpr NetClass c = CLASSES[CL];
+    constexpr int n = FORCE_ONLY ? c.n_force : c.count;
+    if constexpr (n > 0) {
+        float x[c.n_in];
+#pragma unroll
+        for (int i = 0; i < c.n_in; i++) x[i] = xn[c.grp[i]];
+        int w = class_base(CL);
+        float *__restrict__ o = out + class_slot(CL) * LD;
+#pragma nounroll
+        for (int i = 0; i < n; i++) {
+            *o = mlp_body<c.n_in, c.h1, c.h2, c.h3>(w, x);
+            w += class_stride(CL);
+            o += LD;
+        }
+    }
+}
+
+template <bool FORCE_ONLY, int LD>
+__device__ __forceinline__ void eval_aero(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
+    eval_class<CL_DAMP, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_DLEF, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_C, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_D_RUD, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_D_LEF, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_E_LEF, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_E_RUD, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_F, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_ETA, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_YPLEF, FORCE_ONLY, LD>(xn, out);
+    eval_class<CL_YA20, FORCE_ONLY, LD>(xn, out);
+}
+
+// The 9 distinct input normalisations (X - mean) / std of mean_std.csv.
+__device__ __forceinline__ void normalise_inputs(float alpha_deg, float beta_deg, float el, float (&xn)[NUM_NORM_GROUPS]) {
+#pragma unroll
+    for (int g = 0; g < NUM_NORM_GROUPS; g++) {
+        const float v = (g <= G_A_RUD) ? alpha_deg : (g <= G_B_O ? beta_deg : el);
+        xn[g] = (v - c_kblob[2 * g]) / c_kblob[2 * g + 1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F16Dynamics.nlplant — envs/models/F16/F16_dynamics.py:37-228 (atmos :22-35)
+// ---------------------------------------------------------------------------------------------
+struct Trig {  // sines/cosines of the attitude and flow angles of one state
+    float sa, ca, sb, cb, st, ct, sphi, cphi;
+};
+
+// Aerodynamic force/moment coefficients -> xdot[6..11] (+ xdot[0..5] when FULL).
+// FULL=false evaluates only the 16 force-side nets needed for xdot[6..8] (the Overload check,
+// overload.py:37-42 -> F16_model.py:132-148): identical arithmetic for those three outputs.
+template <bool FULL, int LD>
+__device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
+                                        float cpsi, float *__restrict__ coef, float (&xd)[12]) {
+    const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
+    const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
+    const float xc = (float)(0.35 - 0.30);
+    const float cbar_over_B = (float)(11.32 / 30.0);
+    const float r2d = (float)(180.0 / 3.141592653589793);
+    const float c1 = (float)(63100.0 * (63100.0 - 55814.0) + 982.0 * 982.0);
+    const float c2 = (float)(982.0 * (9496.0 - 55814.0 + 63100.0));
+    const float c3 = (float)(63100.0 - 9496.0);
+    const float c4 = (float)(9496.0 * (9496.0 - 55814.0) + 982.0 * 982.0);
+    const float denom = (float)(9496.0 * 63100.0 - 982.0 * 982.0);
+
+    const float alt = s[2];
+    float vt = s[6];
+    const float alpha = s[7] * r2d, beta = s[8] * r2d;
+    const float P = s[9], Q = s[10], R = s[11];
+    const float sa = tr.sa, ca = tr.ca, sb = tr.sb, cb = tr.cb, st = tr.st, ct = tr.ct, sphi = tr.sphi, cphi = tr.cphi;
+
+    vt = (vt <= 0.01f ? 1.0f : 0.0f) * 0.01f + (vt > 0.01f ? 1.0f : 0.0f) * vt;  // :104
+
+    const float T = u[0], el = u[1], ail = u[2], rud = u[3];
+    const float dail = ail / 21.5f, drud = rud / 30.0f;  // lef == 0 -> dlef == 1 (exact)
+
+    const float tfac = 1.0f - 0.703e-5f * alt;
+    const float rho = 2.377e-3f * np_pow(tfac, 4.14f);
+    const float qbar = (0.5f * rho) * (vt * vt);
+
+    const float U = (vt * ca) * cb, V = vt * sb, W = (vt * sa) * cb;
+
+    if (FULL) {
+        xd[0] = (U * (ct * cpsi) + V * ((sphi * cpsi) * st - cphi * spsi)) + W * ((cphi * st) * cpsi + sphi * spsi);
+        xd[1] = (U * (ct * spsi) + V * ((sphi * spsi) * st + cphi * cpsi)) + W * ((cphi * st) * spsi - sphi * cpsi);
+        xd[2] = (U * st - V * (sphi * ct)) - W * (cphi * ct);
+        xd[3] = P + tt * (Q * sphi + R * cphi);
+        xd[4] = Q * cphi - R * sphi;
+        xd[5] = (Q * sphi + R * cphi) / ct;
+    }
+
+    float xn[NUM_NORM_GROUPS];
+    normalise_inputs(alpha, beta, el, xn);
+    // non-finite inputs poison every coefficient (numerics spec, "non-finite inputs")
+    const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
+    const bool ok = (chk == chk);
+    const float qnan = __builtin_nanf("");
+    eval_aero<!FULL, LD>(xn, coef);
+#define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
+
+    const float inv2vt = 1.0f / (2.0f * vt);
+    const float c2v = inv2vt * cbar;
+    const float b2v = inv2vt * B;
+
+    // --- X / Z force ---------------------------------------------------------------------
+    const float dCx_lef = NPF16_NET(N_dCx_lef);
+    const float dXdQ = c2v * (NPF16_NET(N_Cxq) + NPF16_NET(N_dCxq_lef));
+    const float Cx_tot = (NPF16_NET(N_Cx) + dCx_lef) + dXdQ * Q;
+    const float dCz_lef = NPF16_NET(N_dCz_lef);
+    const float dZdQ = c2v * (NPF16_NET(N_Czq) + dCz_lef);  // reference uses delta_Cz_lef here (:199)
+    const float Cz_tot = (NPF16_NET(N_Cz) + dCz_lef) + dZdQ * Q;
+    // --- Y force ---------------------------------------------------------------------------
+    const float dYdail = NPF16_NET(N_dCy_a20) + NPF16_NET(N_dCy_a20_lef);
+    const float dYdR = b2v * (NPF16_NET(N_Cyr) + NPF16_NET(N_dCyr_lef));
+    const float dYdP = b2v * (NPF16_NET(N_Cyp) + NPF16_NET(N_dCyp_lef));
+    const float Cy_tot =
+        ((((NPF16_NET(N_Cy) + NPF16_NET(N_dCy_lef)) + dYdail * dail) + NPF16_NET(N_dCy_r30) * drud) + dYdR * R) + dYdP * P;
+
+    const float Udot = (((R * V - Q * W) - g * st) + ((qbar * S) * Cx_tot) / mass) + T / mass;
+    const float Vdot = ((P * W - R * U) + (g * ct) * sphi) + ((qbar * S) * Cy_tot) / mass;
+    const float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + ((qbar * S) * Cz_tot) / mass;
+    xd[6] = ((U * Udot + V * Vdot) + W * Wdot) / vt;
+    xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
+    xd[8] = (Vdot * vt - V * xd[6]) / ((vt * vt) * cb);
+
+    if (FULL) {
+        // --- pitching moment ----------------------------------------------------------------
+        const float dMdQ = c2v * (NPF16_NET(N_Cmq) + NPF16_NET(N_dCmq_lef));
+        const float Cm_tot =
+            ((((NPF16_NET(N_Cm) * NPF16_NET(N_eta_el) + Cz_tot * xc) + NPF16_NET(N_dCm_lef)) + dMdQ * Q) + NPF16_NET(N_dCm)) +
+            0.0f;
+        // --- yawing moment ------------------------------------------------------------------
+        const float dNdail = NPF16_NET(N_dCn_a20) + NPF16_NET(N_dCn_a20_lef);
+        const float dNdR = b2v * (NPF16_NET(N_Cnr) + NPF16_NET(N_dCnr_lef));
+        const float dNdP = b2v * (NPF16_NET(N_Cnp) + NPF16_NET(N_dCnp_lef));
+        const float Cn_tot = ((((((NPF16_NET(N_Cn) + NPF16_NET(N_dCn_lef)) - (Cy_tot * xc) * cbar_over_B) + dNdail * dail) +
+                                NPF16_NET(N_dCn_r30) * drud) + dNdR * R) + dNdP * P) + NPF16_NET(N_dCnbeta) * beta;
+        // --- rolling moment -----------------------------------------------------------------
+        const float dLdail = NPF16_NET(N_dCl_a20) + NPF16_NET(N_dCl_a20_lef);
+        const float dLdR = b2v * (NPF16_NET(N_Clr) + NPF16_NET(N_dClr_lef));
+        const float dLdP = b2v * (NPF16_NET(N_Clp) + NPF16_NET(N_dClp_lef));
+        const float Cl_tot = (((((NPF16_NET(N_Cl) + NPF16_NET(N_dCl_lef)) + dLdail * dail) + NPF16_NET(N_dCl_r30) * drud) +
+                               dLdR * R) + dLdP * P) + NPF16_NET(N_dClbeta) * beta;
+
+        const float L_tot = ((Cl_tot * qbar) * S) * B;
+        const float M_tot = ((Cm_tot * qbar) * S) * cbar;
+        const float N_tot = ((Cn_tot * qbar) * S) * B;
+        xd[9] = ((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng) / denom;
+        xd[10] = (((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng) / Jy;
+        xd[11] = ((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng) / denom;
+    }
+#undef NPF16_NET
+}
+
+__device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &tt) {
+    np_sincos(s[7], tr.sa, tr.ca);
+    np_sincos(s[8], tr.sb, tr.cb);
+    np_sincostan(s[4], tr.st, tr.ct, tt);
+    np_sincos(s[3], tr.sphi, tr.cphi);
+}
+
+// full derivative at (s,u) including the heading terms
+template <int LD>
+__device__ __forceinline__ void xdot_full(const float (&s)[12], const float (&u)[4], float *__restrict__ coef, float (&xd)[12]) {
+    Trig tr;
+    float tt, spsi, cpsi;
+    trig_of(s, tr, tt);
+    np_sincos(s[5], spsi, cpsi);
+    nlplant<true, LD>(s, u, tr, tt, spsi, cpsi, coef, xd);
+}
+
+// F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)
+__device__ __forceinline__ void body_acceleration(const float (&s)[12], const Trig &tr, const float (&xd)[12], float (&a)[3]) {
+    const float sina = tr.sa, cosa = tr.ca, sinb = tr.sb, cosb = tr.cb;
+    const float vt = s[6];
+    const float vel_u = (vt * cosb) * cosa, vel_v = vt * sinb, vel_w = (vt * cosb) * sina;
+    const float u_dot = ((cosb * cosa) * xd[6] - ((vt * sinb) * cosa) * xd[8]) - ((vt * cosb) * sina) * xd[7];
+    const float v_dot = sinb * xd[6] + (vt * cosb) * xd[8];
+    const float w_dot = ((cosb * sina) * xd[6] - ((vt * sinb) * sina) * xd[8]) + ((vt * cosb) * cosa) * xd[7];
+    a[0] = (u_dot + s[10] * vel_w) - s[11] * vel_v;
+    a[1] = (v_dot + s[11] * vel_u) - s[9] * vel_w;
+    a[2] = (w_dot + s[9] * vel_v) - s[10] * vel_u;
+}
+
+// F16Model.get_EAS2TAS — F16_model.py:156-162
+__device__ __forceinline__ float eas2tas_of(float alt) {
+    const float tfac = 1.0f - 0.703e-5f * alt;
+    const float e = (1.0f / np_pow(tfac, 4.14f)) * 1.0f;
+    return sqrtf(e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// reset of one flagged aircraft — F16_model.py:33-45 + task.reset + env_base.py:92
+// ---------------------------------------------------------------------------------------------
+template <int TASK>
+__device__ __forceinline__ void reset_row(const DevCfg &cfg, const float (&ru)[5], float (&s)[12], float (&u)[4],
+                                          float (&tgt)[3], long long &step_count) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0.0f;
+    u[1] = u[2] = u[3] = 0.0f;
+    s[2] = ru[0] * cfg.alt_span + cfg.min_altitude;
+    s[6] = ru[1] * cfg.vt_span + cfg.min_vt;
+    u[0] = cfg.init_T;
+    if (TASK == 0) {  // heading_task.py:49-69
+        tgt[0] = s[2] + 1000.0f;
+        tgt[1] = np_wrap_pi(s[5] + (float)(2.0 * 3.141592653589793 / 3.0));
+        tgt[2] = s[6] + 0.0f;
+    } else if (TASK == 1) {  // control_task.py:49-68
+        const float dp = (2.0f * (ru[2] - 0.5f)) * cfg.max_pitch_increment;
+        const float dh = (2.0f * (ru[3] - 0.5f)) * cfg.max_heading_increment;
+        const float dv = (2.0f * (ru[4] - 0.5f)) * cfg.max_velocities_u_increment;
+        tgt[0] = np_wrap_pi(s[4] + dp);
+        tgt[1] = np_wrap_pi(s[5] + dh);
+        tgt[2] = s[6] + dv;
+    } else {  // tracking_task.py:48-71
+        const float PI_F = 3.14159265358979323846f;
+        const float dist = ru[2] * cfg.dist_span + cfg.min_distance;
+        const float th1 = (ru[3] * PI_F) / 3.0f - (float)(3.141592653589793 / 6.0);
+        const float th2 = (ru[4] * PI_F) / 3.0f - (float)(3.141592653589793 / 6.0);
+        float s1, c1, s2, c2;
+        np_sincos(th1, s1, c1);
+        np_sincos(th2, s2, c2);
+        tgt[0] = s[0] + (dist * c1) * c2;
+        tgt[1] = s[1] + (dist * c1) * s2;
+        tgt[2] = s[2] + dist * s1;
+    }
+    step_count = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// observation (before noise) — heading_task.py:71-152 / control_task.py:70-152 / tracking_task.py:73-155
+// ---------------------------------------------------------------------------------------------
+template <int TASK>
+__device__ __forceinline__ void observe(const DevCfg &cfg, const float (&s)[12], const float (&u)[4], const float (&tgt)[3],
+                                        const Trig &tr, float (&o)[22]) {
+    const float alt = s[2], pitch = s[4], heading = s[5], vt = s[6];
+    const float eas2tas = eas2tas_of(alt);
+    const float TAS = vt + cfg.airspeed * 1.0f;
+    const float EAS = TAS / eas2tas;
+    if (TASK == 0) {
+        o[0] = ((alt - tgt[0]) * 0.3048f) / 1000.0f;
+        o[1] = np_wrap_pi(heading - tgt[1]);
+        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+    } else if (TASK == 1) {
+        o[0] = np_wrap_pi(pitch - tgt[0]);
+        o[1] = np_wrap_pi(heading - tgt[1]);
+        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+    } else {
+        o[0] = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
+        o[1] = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
+        o[2] = ((alt - tgt[2]) * 0.3048f) / 1000.0f;
+    }
+    o[3] = (alt * 0.3048f) / 5000.0f;
+    o[4] = tr.sphi;
+    o[5] = tr.cphi;
+    o[6] = tr.st;
+    o[7] = tr.ct;
+    o[8] = (EAS * 0.3048f) / 340.0f;
+    o[9] = tr.sa;
+    o[10] = tr.ca;
+    o[11] = tr.sb;
+    o[12] = tr.cb;
+    o[13] = s[9];
+    o[14] = s[10];
+    o[15] = s[11];
+    o[16] = ((u[0] / 0.225f) / 76300.0f) * 0.3048f;
+    o[17] = u[1] / 45.0f;
+    o[18] = u[2] / 45.0f;
+    o[19] = u[3] / 45.0f;
+    o[20] = 0.0f / 45.0f;  // lef
+    o[21] = eas2tas;
+}
+
+// 22 standard normals of (seed, call_idx, row): Philox blocks 2..7, Box-Muller per pair
+__device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, int64_t row, float scale, float (&o)[22]) {
+#pragma unroll
+    for (uint32_t b = 0; b < 6; b++) {
+        uint32_t w[4];
+        rng_block(seed, call_idx, row, 2 + b, w);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int pair = 2 * (int)b + h;
+            if (pair < 11) {
+                const float u1 = ((float)(w[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                const float u2 = (float)(w[2 * h + 1] >> 8) * 5.9604644775390625e-08f;
+                const float rad = sqrtf(-2.0f * logf_spec(u1));
+                float sn, cs;
+                sincos2pi_spec(u2, sn, cs);
+                o[2 * pair] = o[2 * pair] + (rad * cs) * scale;
+                o[2 * pair + 1] = o[2 * pair + 1] + (rad * sn) * scale;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// terminations + reward at the new state — termination_conditions/*.py, reward_functions/*.py,
+// task_base.py:60-96, env_base.py:70-75
+// ---------------------------------------------------------------------------------------------
+template <int TASK>
+__device__ __forceinline__ void done_and_reward(const DevCfg &cfg, const float (&s)[12], const float (&tgt)[3],
+                                                const float (&acc3)[3], long long step_count, bool &done, bool &bad,
+                                                float &reward) {
+    const float PI_F = 3.14159265358979323846f;
+    const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
+    bool b = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
+    b |= (s[2] - cfg.altitude_limit) < 0.0f;               // low_altitude.py:29-30
+    const float TAS = s[6] + cfg.airspeed * 1.0f;
+    const float vel = (TAS * 0.3048f) / 340.0f;
+    b |= (vel - cfg.max_velocity) >= 0.0f;                 // high_speed.py:29-30
+    b |= (vel - cfg.min_velocity) <= 0.0f;                 // low_speed.py:29-30
+    const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
+    b |= (alpha < cfg.min_alpha) | (alpha > cfg.max_alpha);  // extreme_state.py:32-36
+    b |= (beta < cfg.min_beta) | (beta > cfg.max_beta);
+    const float pi36 = (float)(3.141592653589793 / 36.0);
+    const bool m1 = step_count >= cfg.max_check_interval;
+    bool m2 = true, m3, m4, m5;
+    float rew;
+    if (TASK == 0) {  // unreach_heading.py:38-53, heading_reward.py:26-36
+        m2 = step_count >= cfg.min_check_interval;
+        const float dpsi = np_wrap_pi(s[5] - tgt[1]);
+        m3 = fabsf(dpsi) >= pi36;
+        m4 = fabsf(s[2] - tgt[0]) >= 100.0f;
+        m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
+        const float da = ((s[2] - tgt[0]) * 0.3048f) / 1000.0f;
+        const float dh = dpsi / PI_F;
+        const float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        rew = (-(da * da) + -(dh * dh)) + -(dv * dv);
+    } else if (TASK == 1) {  // unreach_posture.py:40-55, posture_reward.py:26-35
+        const float dpsi = np_wrap_pi(s[5] - tgt[1]);
+        m3 = fabsf(dpsi) >= pi36;
+        m4 = fabsf(s[4] - tgt[0]) >= pi36;
+        m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
+        const float dp = np_wrap_pi(s[4] - tgt[0]) / PI_F;
+        const float dh = dpsi / PI_F;
+        const float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        rew = (-(dp * dp) + -(dh * dh)) + -(dv * dv);
+    } else {  // unreach_target.py:38-47, position_reward.py:26-34
+        m3 = fabsf(s[0] - tgt[0]) >= 100.0f;
+        m4 = fabsf(s[1] - tgt[1]) >= 100.0f;
+        m5 = fabsf(s[2] - tgt[2]) >= 100.0f;
+        const float dn = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
+        const float de = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
+        const float da = ((s[2] - tgt[2]) * 0.3048f) / 1000.0f;
+        rew = 0.1f * ((-(dn * dn) + -(de * de)) + -(da * da));
+    }
+    const bool off = (m3 | m4) | m5;
+    b |= m1 & off;
+    const bool d = ((!off) & (!m1)) & m2;
+    rew = 0.0f + rew;                                            // task_base.py:70-72
+    rew = rew + (float)(-200 * (int)b + 200 * (int)d);           // event_driven_reward.py:28
+    done = d;
+    bad = b;
+    reward = rew;
+}
+
+}  // namespace npf16

@@ -1,0 +1,550 @@
+// np_f16_kernels.hip — fused F-16 env.step / env.reset kernels for gfx950 and the C ABI around them
+// (include/neuralplane_amd.h).  One kernel launch per BaseEnv.step (reference: envs/env_base.py:99-109).
+//
+// Mapping: one lane per aircraft, 256-thread workgroups (one wave per SIMD), SoA state in HBM so
+// every state load/store is a coalesced dword access; actions are read as one 16-byte load per
+// lane; the [n][22] observation rows are transposed through LDS and stored as coalesced dwords.
+// The MLP weights are wave-uniform __constant__ data (scalar loads -> SGPR operands of v_fmac).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see neuralplane_amd/build.py).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/neuralplane_amd.h"
+#include "np_f16_device.h"
+
+namespace npf16 {
+
+constexpr int BLOCK = 256;
+constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
+// LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
+// (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
+constexpr int LDS_FLOATS = (NUM_LIVE_NETS * BLOCK > BLOCK * OBS_LD) ? NUM_LIVE_NETS * BLOCK : BLOCK * OBS_LD;
+
+struct KArgs {
+    float *s, *u, *tgt;
+    long long ld;
+    long long *step_count;
+    const uint8_t *fin0, *fin1, *fin2;
+    uint8_t *fout0, *fout1, *fout2;
+    const float *action;
+    long long act_stride;
+    float *obs, *reward;
+    const float *rand_u, *noise;
+    uint64_t seed, call_idx;
+    long long row0, n;
+    DevCfg cfg;
+};
+
+// STEP=true : BaseEnv.step  (env_base.py:99-109)
+// STEP=false: BaseEnv.reset (env_base.py:83-97)
+template <int TASK, int SOLVER, bool STEP>
+__global__ __launch_bounds__(BLOCK) void f16_env_kernel(const KArgs a) {
+    __shared__ float lds[LDS_FLOATS];
+    float *obs_tile = lds;
+    const int t = threadIdx.x;
+    float *coef = lds + t;  // this lane's coefficient column, stride BLOCK
+    const long long i0 = (long long)blockIdx.x * BLOCK;
+    const long long i = i0 + t;
+    const bool valid = i < a.n;
+    const long long ic = valid ? i : a.n - 1;  // tail lanes shadow the last row; their stores are masked
+    const DevCfg &cfg = a.cfg;
+
+    float s[12], u[4], tgt[3];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = a.s[k * a.ld + ic];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = a.u[k * a.ld + ic];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tgt[k] = a.tgt[k * a.ld + ic];
+    long long sc = a.step_count[ic];
+    const bool flagged = (a.fin0[ic] | a.fin1[ic] | a.fin2[ic]) != 0;
+
+    // ---- self.reset(): re-initialise rows flagged by the previous step (env_base.py:83-95) ----
+    if (flagged) {
+        float ru[5];
+        if (a.rand_u) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) ru[k] = a.rand_u[ic * 5 + k];
+        } else {
+            uint32_t w0[4], w1[4];
+            rng_block(a.seed, a.call_idx, a.row0 + ic, 0, w0);
+            rng_block(a.seed, a.call_idx, a.row0 + ic, 1, w1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ru[k] = (float)(w0[k] >> 8) * 5.9604644775390625e-08f;
+            ru[4] = (float)(w1[0] >> 8) * 5.9604644775390625e-08f;
+        }
+        reset_row<TASK>(cfg, ru, s, u, tgt, sc);
+    }
+
+    if (STEP) {
+        // ---- F16Model.update (F16_model.py:51-67) ----
+        float act[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float v = a.action[ic * a.act_stride + k];
+            v = v < -1.0f ? -1.0f : v;  // torch.clamp(action, -1, 1); NaN stays NaN
+            v = v > 1.0f ? 1.0f : v;
+            act[k] = v;
+        }
+        u[0] = 0.9f * u[0] + (((0.1f * act[0]) * 0.225f) * 76300.0f) / 0.3048f;
+        u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
+        u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
+        u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
+        const float dt = cfg.dt;
+        if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
+            float k1[12];
+            xdot_full<BLOCK>(s, u, coef, k1);
+#pragma unroll
+            for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
+        } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
+            const float third = (float)(1.0 / 3.0);
+            float y[12], k1[12], k2[12], k3[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) y[k] = s[k];
+#pragma nounroll
+            for (int stage = 0; stage < 4; stage++) {
+                float kk[12];
+                xdot_full<BLOCK>(y, u, coef, kk);
+                if (stage == 0) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        k1[k] = kk[k];
+                        y[k] = s[k] + (dt * k1[k]) * third;
+                    }
+                } else if (stage == 1) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        k2[k] = kk[k];
+                        y[k] = s[k] + dt * (k2[k] - k1[k] * third);
+                    }
+                } else if (stage == 2) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        k3[k] = kk[k];
+                        y[k] = s[k] + dt * ((k1[k] - k2[k]) + k3[k]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) y[k] = s[k] + (((k1[k] + 3.0f * (k2[k] + k3[k])) + kk[k]) * dt) * 0.125f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) s[k] = y[k];
+        }
+        sc += 1;  // env_base.py:102
+    }
+
+    // ---- observation at the new state (task.get_obs) ----
+    Trig tr;
+    float tt_unused;
+    trig_of(s, tr, tt_unused);
+    float o[22];
+    observe<TASK>(cfg, s, u, tgt, tr, o);
+    if (a.noise) {  // obs + randn_like(obs) * noise_scale
+#pragma unroll
+        for (int k = 0; k < 22; k++) o[k] = o[k] + a.noise[ic * 22 + k] * cfg.noise_scale;
+    } else if (cfg.noise_scale != 0.0f) {
+        add_rng_noise(a.seed, a.call_idx, a.row0 + ic, cfg.noise_scale, o);
+    }
+
+    bool done = false, bad = false;
+    float reward = 0.0f;
+    if (STEP) {
+        // Overload needs xdot[6..8] at the NEW (s,u): force-side nets only (overload.py:37-42)
+        float xd[12];
+        nlplant<false, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, xd);
+        float acc3[3];
+        body_acceleration(s, tr, xd, acc3);
+        done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done, bad, reward);
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) a.s[k * a.ld + i] = s[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.u[k * a.ld + i] = u[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) a.tgt[k * a.ld + i] = tgt[k];
+        a.step_count[i] = sc;
+        a.fout0[i] = done ? 1 : 0;
+        a.fout1[i] = bad ? 1 : 0;
+        a.fout2[i] = 0;
+        if (STEP) a.reward[i] = reward;
+    }
+
+    // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
+    if (a.obs) {
+        __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
+#pragma unroll
+        for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
+        __syncthreads();
+        const long long rows = (a.n - i0) < BLOCK ? (a.n - i0) : BLOCK;
+        const int total = (int)rows * 22;
+        float *dst = a.obs + i0 * 22;
+#pragma unroll
+        for (int it = 0; it < 22; it++) {
+            const int L = it * BLOCK + t;
+            if (L < total) {
+                const int r = L / 22, c = L - r * 22;
+                dst[L] = obs_tile[r * OBS_LD + c];
+            }
+        }
+    }
+}
+
+// F16Model getters that need the dynamics (F16_model.py:47-49, 132-181): out[20][ld_out]
+__global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restrict__ sp, const float *__restrict__ up,
+                                                            long long ld, float *__restrict__ out, long long ld_out,
+                                                            long long n, float airspeed) {
+    __shared__ float lds[NUM_LIVE_NETS * BLOCK];
+    float *coef = lds + threadIdx.x;
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;  // keep control flow wave-uniform (weights stay in SGPRs)
+    float s[12], u[4];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = sp[k * ld + ic];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = up[k * ld + ic];
+    Trig tr;
+    float tt, spsi, cpsi;
+    trig_of(s, tr, tt);
+    np_sincos(s[5], spsi, cpsi);
+    float xd[12];
+    nlplant<true, BLOCK>(s, u, tr, tt, spsi, cpsi, coef, xd);
+    float a3[3];
+    body_acceleration(s, tr, xd, a3);
+    const float inv_grav = (float)(1.0 / 32.174), minv_grav = (float)(-1.0 / 32.174);  // F16_model.py:166,176-178
+    const float nx = inv_grav * a3[0] + tr.st;
+    const float ny = inv_grav * a3[1] - tr.ct * tr.sphi;
+    const float nz = minv_grav * a3[2] + tr.ct * tr.cphi;
+    const float e2t = eas2tas_of(s[2]);
+    const float eas = (s[6] + airspeed * 1.0f) / e2t;
+    if (!valid) return;
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[k * ld_out + i] = xd[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[(12 + k) * ld_out + i] = a3[k];
+    out[15 * ld_out + i] = nx;
+    out[16 * ld_out + i] = ny;
+    out[17 * ld_out + i] = nz;
+    out[18 * ld_out + i] = e2t;
+    out[19 * ld_out + i] = eas;
+}
+
+}  // namespace npf16
+
+// =================================================================================================
+// host side: C ABI
+// =================================================================================================
+using namespace npf16;
+
+static thread_local std::string g_err;
+static int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+#define NP_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+struct np_f16_ctx {
+    int device;
+    int task, solver;
+    DevCfg cfg;
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double t_sum_ms;
+    int64_t t_count;
+};
+
+namespace {
+
+#pragma pack(push, 1)
+struct BlobRec {  // NPF16MLP v1 record (tools/export_weights.py)
+    char name[24];
+    uint32_t input_mask, n_linear;
+    uint32_t dims[6];
+    double in_mean[3], in_std[3];
+    double out_mean, out_std;
+    uint32_t param_offset, n_params;
+};
+#pragma pack(pop)
+static_assert(sizeof(BlobRec) == 128, "blob record is 128 bytes");
+
+// asset blob (torch layout W[out][in]) -> kernel-order blob (np_nets.h)
+int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb) {
+    const unsigned char *p = (const unsigned char *)blob;
+    if (!p || nbytes < 16 || std::memcmp(p, "NPF16MLP", 8) != 0) return fail("weights blob: bad magic");
+    uint32_t ver, nn;
+    std::memcpy(&ver, p + 8, 4);
+    std::memcpy(&nn, p + 12, 4);
+    if (ver != 1 || nn != NUM_NETS) return fail("weights blob: unsupported version / net count");
+    const size_t hdr = 16 + (size_t)nn * sizeof(BlobRec);
+    if (nbytes < hdr) return fail("weights blob: truncated header");
+    const size_t pfloats = (nbytes - hdr) / 4;
+    std::vector<float> par(pfloats);
+    std::memcpy(par.data(), p + hdr, pfloats * 4);
+    kb.assign(KBLOB_FLOATS, 0.0f);
+    bool grp_set[NUM_NORM_GROUPS] = {};
+    for (int cl = 0; cl < NUM_CLASSES; cl++) {
+        const NetClass c = CLASSES[cl];
+        const int hid[3] = {c.h1, c.h2, c.h3};
+        const int n_hidden = c.h3 > 0 ? 3 : 2;
+        for (int m = 0; m < c.count; m++) {
+            const int net = c.nets[m];
+            BlobRec r;
+            std::memcpy(&r, p + 16 + (size_t)net * sizeof(BlobRec), sizeof(r));
+            const std::string nm(r.name, strnlen(r.name, sizeof(r.name)));
+            if ((int)r.n_linear != n_hidden + 1 || (int)r.dims[0] != c.n_in) return fail("weights blob: shape of net " + nm + " does not match its class");
+            for (int l = 0; l < n_hidden; l++)
+                if ((int)r.dims[l + 1] != hid[l]) return fail("weights blob: hidden widths of net " + nm + " do not match its class");
+            if ((int)r.n_params != class_params(c)) return fail("weights blob: parameter count of net " + nm);
+            if ((size_t)r.param_offset + r.n_params > pfloats) return fail("weights blob: truncated parameters");
+            // input slot k of the net <- k-th set bit of input_mask (bit0 alpha, bit1 beta, bit2 el)
+            int slot = 0;
+            for (int k = 0; k < 3; k++) {
+                if (!(r.input_mask & (1u << k))) continue;
+                if (slot >= c.n_in) return fail("weights blob: input mask of net " + nm);
+                const int g = c.grp[slot++];
+                const bool kind_ok = (k == 0 && g >= G_A_C && g <= G_A_RUD) || (k == 1 && (g == G_B_C || g == G_B_O)) ||
+                                     (k == 2 && (g == G_E_C || g == G_E_ETA));
+                if (!kind_ok) return fail("weights blob: input kind of net " + nm + " does not match its class");
+                const float mean = (float)r.in_mean[k], sd = (float)r.in_std[k];  // torch rounds the CSV doubles to fp32
+                if (!grp_set[g]) {
+                    kb[2 * g] = mean;
+                    kb[2 * g + 1] = sd;
+                    grp_set[g] = true;
+                } else if (kb[2 * g] != mean || kb[2 * g + 1] != sd) {
+                    return fail("weights blob: normalisation of net " + nm + " differs from its class");
+                }
+            }
+            if (slot != c.n_in) return fail("weights blob: input mask of net " + nm);
+            const float *src = par.data() + r.param_offset;
+            float *dst = kb.data() + class_base(cl) + (size_t)m * class_stride(cl);
+            int in = c.n_in;
+            for (int l = 0; l <= n_hidden; l++) {
+                const int out = (l < n_hidden) ? hid[l] : 1;
+                const float *W = src, *bias = src + (size_t)in * out;
+                for (int j = 0; j < out; j++) dst[j] = bias[j];
+                for (int k = 0; k < in; k++)
+                    for (int j = 0; j < out; j++) dst[out + k * out + j] = W[j * in + k];
+                src += (size_t)in * out + out;
+                dst += (size_t)in * out + out;
+                in = out;
+            }
+            dst[0] = (float)r.out_std;
+            dst[1] = (float)r.out_mean;
+        }
+    }
+    for (int g = 0; g < NUM_NORM_GROUPS; g++)
+        if (!grp_set[g]) return fail("weights blob: a normalisation group is unused");
+    return 0;
+}
+
+DevCfg make_devcfg(const np_f16_cfg &c) {
+    DevCfg d;
+    d.dt = (float)c.dt - 0.0f;  // t = tensor([0., dt]); dt = t1 - t0   (F16_model.py:66)
+    d.airspeed = (float)c.airspeed;
+    d.noise_scale = (float)c.noise_scale;
+    d.altitude_limit = (float)c.altitude_limit;
+    d.acceleration_limit = (float)c.acceleration_limit;
+    d.max_velocity = (float)c.max_velocity;
+    d.min_velocity = (float)c.min_velocity;
+    d.min_alpha = (float)c.min_alpha;
+    d.max_alpha = (float)c.max_alpha;
+    d.min_beta = (float)c.min_beta;
+    d.max_beta = (float)c.max_beta;
+    d.max_check_interval = c.max_check_interval;
+    d.min_check_interval = c.min_check_interval;
+    d.init_T = (float)c.init_T;
+    d.alt_span = (float)(c.max_altitude - c.min_altitude);  // Python arithmetic first, then one rounding
+    d.min_altitude = (float)c.min_altitude;
+    d.vt_span = (float)(c.max_vt - c.min_vt);
+    d.min_vt = (float)c.min_vt;
+    d.max_heading_increment = (float)c.max_heading_increment;
+    d.max_pitch_increment = (float)c.max_pitch_increment;
+    d.max_velocities_u_increment = (float)c.max_velocities_u_increment;
+    d.dist_span = (float)(c.max_distance - c.min_distance);
+    d.min_distance = (float)c.min_distance;
+    return d;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            switched = (e == hipSuccess);
+        }
+        return e;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+template <bool STEP>
+int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
+    if (!ctx || !io) return fail("null ctx/io");
+    if (n <= 0) return 0;
+    if (!io->s || !io->u || !io->tgt || !io->step_count || !io->done_in || !io->bad_in || !io->timeout_in ||
+        !io->done_out || !io->bad_out || !io->timeout_out)
+        return fail("null state/flag buffer");
+    if (io->ld < n) return fail("ld < n");
+    if (STEP && (!io->action || !io->obs || !io->reward || io->act_stride < 4))
+        return fail("step needs action (>=4 columns), obs and reward buffers");
+    if (io->done_out == io->done_in || io->bad_out == io->bad_in || io->timeout_out == io->timeout_in)
+        return fail("flag outputs may not alias flag inputs");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    KArgs a;
+    a.s = io->s; a.u = io->u; a.tgt = io->tgt; a.ld = io->ld; a.step_count = (long long *)io->step_count;
+    a.fin0 = io->done_in; a.fin1 = io->bad_in; a.fin2 = io->timeout_in;
+    a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
+    a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward;
+    a.rand_u = io->rand_u; a.noise = io->noise; a.seed = io->seed; a.call_idx = io->call_idx;
+    a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = STEP && ctx->timing;
+    if (timed) {
+        if (!ctx->pool.empty()) {
+            ev = ctx->pool.back();
+            ctx->pool.pop_back();
+        } else {
+            NP_HIP(hipEventCreate(&ev.first));
+            NP_HIP(hipEventCreate(&ev.second));
+        }
+        NP_HIP(hipEventRecord(ev.first, st));
+    }
+#define NP_LAUNCH(T, S) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP>), grid, block, 0, st, a)
+    const int key = ctx->task * 2 + (STEP ? ctx->solver : 0);
+    switch (key) {
+    case 0: NP_LAUNCH(0, 0); break;
+    case 1: NP_LAUNCH(0, 1); break;
+    case 2: NP_LAUNCH(1, 0); break;
+    case 3: NP_LAUNCH(1, 1); break;
+    case 4: NP_LAUNCH(2, 0); break;
+    case 5: NP_LAUNCH(2, 1); break;
+    default: return fail("bad task/solver");
+    }
+#undef NP_LAUNCH
+    NP_HIP(hipGetLastError());
+    if (timed) {
+        NP_HIP(hipEventRecord(ev.second, st));
+        ctx->events.push_back(ev);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int np_abi_version(void) { return NP_ABI_VERSION; }
+const char *np_last_error(void) { return g_err.c_str(); }
+
+int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg *cfg, int device, np_f16_ctx **out) {
+    if (!out || !cfg) return fail("null argument");
+    *out = nullptr;
+    if (cfg->task < 0 || cfg->task > 2) return fail("cfg.task must be NP_TASK_HEADING/CONTROL/TRACKING");
+    if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
+    std::vector<float> kb;
+    if (pack_kblob(weights_blob, nbytes, kb)) return 1;
+    int ndev = 0;
+    NP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(device));
+    hipDeviceProp_t prop;
+    NP_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(std::string("device arch ") + prop.gcnArchName + " is not gfx950 (MI355X)");
+    NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_kblob), kb.data(), sizeof(float) * KBLOB_FLOATS));
+    np_f16_ctx *ctx = new np_f16_ctx();
+    ctx->device = device;
+    ctx->task = cfg->task;
+    ctx->solver = cfg->solver;
+    ctx->cfg = make_devcfg(*cfg);
+    ctx->timing = false;
+    ctx->t_sum_ms = 0.0;
+    ctx->t_count = 0;
+    *out = ctx;
+    return 0;
+}
+
+void np_f16_ctx_destroy(np_f16_ctx *ctx) {
+    if (!ctx) return;
+    for (auto &e : ctx->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (auto &e : ctx->pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete ctx;
+}
+
+int np_f16_reset(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) { return launch_env<false>(ctx, n, io, stream); }
+
+int np_f16_step(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) { return launch_env<true>(ctx, n, io, stream); }
+
+int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, int64_t ld, float *out, int64_t ld_out,
+                   void *stream) {
+    if (!ctx || !s || !u || !out) return fail("null argument");
+    if (n <= 0) return 0;
+    if (ld < n || ld_out < n) return fail("leading dimension < n");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipLaunchKernelGGL(f16_derived_kernel, grid, block, 0, (hipStream_t)stream, s, u, (long long)ld, out, (long long)ld_out,
+                       (long long)n, ctx->cfg.airspeed);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_f16_set_timing(np_f16_ctx *ctx, int enable) {
+    if (!ctx) return fail("null ctx");
+    ctx->timing = enable != 0;
+    ctx->t_sum_ms = 0.0;
+    ctx->t_count = 0;
+    for (auto &e : ctx->events) ctx->pool.push_back(e);
+    ctx->events.clear();
+    return 0;
+}
+
+int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count) {
+    if (!ctx) return fail("null ctx");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    for (auto &e : ctx->events) {
+        NP_HIP(hipEventSynchronize(e.second));
+        float ms = 0.0f;
+        NP_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        ctx->t_sum_ms += ms;
+        ctx->t_count += 1;
+        ctx->pool.push_back(e);
+    }
+    ctx->events.clear();
+    if (avg_ms) *avg_ms = ctx->t_count ? ctx->t_sum_ms / (double)ctx->t_count : 0.0;
+    if (count) *count = ctx->t_count;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+// np_math.h — device-side elementary functions of the numerics spec.
+//
+// The reference evaluates sin/cos/tan/pow through ATen (SLEEF / MKL-VML on CPU, CUDA libdevice on
+// GPU): implementation-defined to ~1 ulp.  To make trajectories reproducible bit-for-bit across
+// devices and against the CPU oracle, this framework fixes them as explicit fp64 operation
+// sequences (fdlibm kernels), rounded ONCE to fp32.  IEEE-754 fma/div/sqrt/rint are correctly
+// rounded on gfx950 and on the host, so the sequences give identical bits everywhere.
+// Compile with -ffp-contract=off: every fused operation is spelled out here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace npf16 {
+
+// fdlibm k_sin.c / k_cos.c / e_rem_pio2.c / e_log.c constants (Sun Microsystems, freely redistributable)
+#define NPM_S1 (-1.66666666666666324348e-01)
+#define NPM_S2 (8.33333333332248946124e-03)
+#define NPM_S3 (-1.98412698298579493134e-04)
+#define NPM_S4 (2.75573137070700676789e-06)
+#define NPM_S5 (-2.50507602534068634195e-08)
+#define NPM_S6 (1.58969099521155010221e-10)
+#define NPM_C1 (4.16666666666666019037e-02)
+#define NPM_C2 (-1.38888888888741095749e-03)
+#define NPM_C3 (2.48015872894767294178e-05)
+#define NPM_C4 (-2.75573143513906633035e-07)
+#define NPM_C5 (2.08757232129817482790e-09)
+#define NPM_C6 (-1.13596475577881948265e-11)
+#define NPM_INVPIO2 (6.36619772367581382433e-01)
+#define NPM_PIO2_1 (1.57079632673412561417e+00)
+#define NPM_PIO2_2 (6.07710050630396597660e-11)
+#define NPM_PIO2_3 (2.02226624871116645580e-21)
+#define NPM_PIO2_3T (8.47842766036889956997e-32)
+#define NPM_TWO_PI (6.283185307179586476925)
+
+__device__ __forceinline__ void sincos_d(double x, double &sn, double &cs) {
+    if (!(fabs(x) < 1073741824.0)) x = fmod(x, NPM_TWO_PI);  // exact remainder; inf/NaN -> NaN (cold path)
+    const double k = rint(x * NPM_INVPIO2);
+    double r = fma(-k, NPM_PIO2_1, x);
+    r = fma(-k, NPM_PIO2_2, r);
+    r = fma(-k, NPM_PIO2_3, r);
+    r = fma(-k, NPM_PIO2_3T, r);
+    const double z = r * r;
+    double p = fma(z, NPM_S6, NPM_S5);
+    p = fma(z, p, NPM_S4);
+    p = fma(z, p, NPM_S3);
+    p = fma(z, p, NPM_S2);
+    p = fma(z, p, NPM_S1);
+    const double sr = fma(z * r, p, r);
+    double q = fma(z, NPM_C6, NPM_C5);
+    q = fma(z, q, NPM_C4);
+    q = fma(z, q, NPM_C3);
+    q = fma(z, q, NPM_C2);
+    q = fma(z, q, NPM_C1);
+    const double cr = fma(z * z, q, fma(z, -0.5, 1.0));
+    int n = (k == k) ? ((int)k & 3) : 0;
+    const bool swap = n & 1;
+    double s_ = swap ? cr : sr;
+    double c_ = swap ? sr : cr;
+    // n: 0 (s,c) 1 (c,-s) 2 (-s,-c) 3 (-c,s)
+    sn = (n & 2) ? -s_ : s_;
+    cs = ((n + 1) & 2) ? -c_ : c_;
+}
+
+__device__ __forceinline__ void np_sincos(float x, float &s, float &c) {
+    double sd, cd;
+    sincos_d((double)x, sd, cd);
+    s = (float)sd;
+    c = (float)cd;
+}
+
+// sin, cos and tan of the same angle (tan = sin/cos in fp64, rounded once)
+__device__ __forceinline__ void np_sincostan(float x, float &s, float &c, float &t) {
+    double sd, cd;
+    sincos_d((double)x, sd, cd);
+    s = (float)sd;
+    c = (float)cd;
+    t = (float)(sd / cd);
+}
+
+#define NPM_LG1 (6.666666666666735130e-01)
+#define NPM_LG2 (3.999999999940941908e-01)
+#define NPM_LG3 (2.857142874366239149e-01)
+#define NPM_LG4 (2.222219843214978396e-01)
+#define NPM_LG5 (1.818357216161805012e-01)
+#define NPM_LG6 (1.531383769920937332e-01)
+#define NPM_LG7 (1.479819860511658591e-01)
+#define NPM_INV_LN2 (1.44269504088896338700e+00)
+#define NPM_LN2 (6.93147180559945286227e-01)
+
+// x^y = exp2(y*log2 x) in fp64, fixed operation sequence (only caller: the atmosphere model's tfac^4.14)
+__device__ __forceinline__ float np_pow(float xf, float yf) {
+    const double x = (double)xf, y = (double)yf;
+    if (x != x || y != y) return __builtin_nanf("");
+    if (x < 0.0) return __builtin_nanf("");
+    if (x == 0.0) return y > 0.0 ? 0.0f : __builtin_inff();
+    if (x == (double)__builtin_inff()) return y > 0.0 ? __builtin_inff() : 0.0f;
+    uint64_t bits = (uint64_t)__double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+    double mant = __longlong_as_double((long long)bits);
+    if (mant > 1.4142135623730951) {
+        mant *= 0.5;
+        e += 1;
+    }
+    const double f = mant - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, NPM_LG6, NPM_LG4), NPM_LG2);
+    const double t2 = z * fma(w, fma(w, fma(w, NPM_LG7, NPM_LG5), NPM_LG3), NPM_LG1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double lnm = f - (hfsq - s * (hfsq + R));
+    const double l2 = fma(lnm, NPM_INV_LN2, (double)e);
+    double P = y * l2;
+    if (P > 2000.0) P = 2000.0;
+    if (P < -2000.0) P = -2000.0;
+    const double k = rint(P);
+    const double t = (P - k) * NPM_LN2;
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, t, 1.0 / 479001600.0);
+    q = fma(q, t, 1.0 / 39916800.0);
+    q = fma(q, t, 1.0 / 3628800.0);
+    q = fma(q, t, 1.0 / 362880.0);
+    q = fma(q, t, 1.0 / 40320.0);
+    q = fma(q, t, 1.0 / 5040.0);
+    q = fma(q, t, 1.0 / 720.0);
+    q = fma(q, t, 1.0 / 120.0);
+    q = fma(q, t, 1.0 / 24.0);
+    q = fma(q, t, 1.0 / 6.0);
+    q = fma(q, t, 0.5);
+    q = fma(q, t, 1.0);
+    q = fma(q, t, 1.0);
+    return (float)ldexp(q, (int)k);
+}
+
+// envs/utils/utils.py:144-154 wrap_PI: torch.remainder (exact fmod, then +divisor on sign mismatch),
+// `res += 2*pi*(res<0)`, `res -= 2*pi*(res>pi)`; 2*pi and pi rounded to fp32 at use.
+__device__ __forceinline__ float np_wrap_pi(float x) {
+    const float TWO_PI_F = 6.28318530717958647692f;
+    const float PI_F = 3.14159265358979323846f;
+    float res = fmodf(x, TWO_PI_F);
+    if (res != 0.0f && res < 0.0f) res = res + TWO_PI_F;
+    res = res + ((res < 0.0f) ? TWO_PI_F : 0.0f);
+    res = res - ((res > PI_F) ? TWO_PI_F : 0.0f);
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG of the spec: Philox4x32-10, key = seed, counter = (row, call_idx | block<<56)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__device__ __forceinline__ void rng_block(uint64_t seed, uint64_t call_idx, int64_t row, uint32_t blk,
+                                          uint32_t (&out)[4]) {
+    philox4x32_10((uint32_t)(uint64_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)call_idx,
+                  (((uint32_t)(call_idx >> 32)) & 0x00FFFFFFu) | (blk << 24), (uint32_t)seed, (uint32_t)(seed >> 32),
+                  out);
+}
+
+// fp32 log of u in (0,1) and sin/cos of 2*pi*a, a in [0,1): only feed the observation noise
+// (Box-Muller); explicit fmaf sequences so that host and device agree bit-for-bit.
+__device__ __forceinline__ float logf_spec(float u) {
+    uint32_t bits = __float_as_uint(u);
+    int e = (int)(bits >> 23) - 127;
+    bits = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float m = __uint_as_float(bits);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = fmaf(z, 0.111111111f, 0.142857143f);
+    p = fmaf(z, p, 0.2f);
+    p = fmaf(z, p, 0.333333333f);
+    p = fmaf(z, p, 1.0f);
+    return fmaf((float)e, 0.693147181f, (2.0f * s) * p);
+}
+
+__device__ __forceinline__ void sincos2pi_spec(float a, float &sn, float &cs) {
+    const float q = rintf(a * 4.0f);
+    const float f = fmaf(q, -0.25f, a);
+    const float th = f * 6.28318531f;
+    const float z = th * th;
+    float ps = fmaf(z, 2.75573192e-6f, -1.98412698e-4f);
+    ps = fmaf(z, ps, 8.33333333e-3f);
+    ps = fmaf(z, ps, -1.66666667e-1f);
+    ps = fmaf(z, ps, 1.0f);
+    const float sr = th * ps;
+    float pc = fmaf(z, -2.75573192e-7f, 2.48015873e-5f);
+    pc = fmaf(z, pc, -1.38888889e-3f);
+    pc = fmaf(z, pc, 4.16666667e-2f);
+    pc = fmaf(z, pc, -0.5f);
+    const float cr = fmaf(z, pc, 1.0f);
+    const int n = (int)q & 3;
+    const bool swap = n & 1;
+    const float s_ = swap ? cr : sr;
+    const float c_ = swap ? sr : cr;
+    sn = (n & 2) ? -s_ : s_;
+    cs = ((n + 1) & 2) ? -c_ : c_;
+}
+
+}  // namespace npf16

@@ -1,0 +1,121 @@
+// np_nets.h — static description of the F-16 aero-coefficient MLPs and of the kernel-order weight
+// blob ("KBLOB") that lives in __constant__ memory.
+//
+// Reference: envs/models/F16/hifi_F16_AeroData.py:40-129 (shapes), :149-746 (which inputs and which
+// normalisation row each net uses), model/mean_std.csv (the constants).  NetId order = evaluation
+// order in F16Dynamics.nlplant (F16_dynamics.py:140-195) = order of the NPF16MLP v1 asset blob.
+//
+// The 43 nets have only 7 distinct shapes.  The kernel evaluates them class by class: a class is a
+// run of nets with the SAME shape and the SAME (normalised) inputs, stored back to back in the
+// KBLOB with a constant stride, so one compact loop body per class serves all its nets (weights
+// come in through scalar loads at `class_base + i*stride`).  Within a class the nets needed for the
+// body forces (xdot[6..8], i.e. the Overload re-evaluation) come first, so the force-only
+// evaluation is the same loops with smaller trip counts.  `delta_Czq_lef` is evaluated by the
+// reference but its value is never used (F16_dynamics.py:167-175 skips temp[3]); it is not stored.
+//
+// KBLOB layout (floats):
+//   [0 .. 2*NUM_NORM_GROUPS)   (mean, std) of the 9 distinct input normalisations
+//   per class, per net:        per Linear layer: bias[out] then W^T[in][out] (k-major: the order
+//                              the FMA chains consume them), then out_std, out_mean
+// np_pack_kblob (np_f16_kernels.hip) also verifies that every net of a class has the fp32
+// normalisation constants of the class, so this static grouping cannot silently disagree with the
+// data.
+#pragma once
+#include <cstdint>
+
+namespace npf16 {
+
+constexpr int NUM_NETS = 43;
+
+enum NetId : int {
+    N_Cx, N_Cz, N_Cm, N_Cy, N_Cn, N_Cl,
+    N_Cxq, N_Cyr, N_Cyp, N_Czq, N_Clr, N_Clp, N_Cmq, N_Cnr, N_Cnp,
+    N_dCx_lef, N_dCz_lef, N_dCm_lef, N_dCy_lef, N_dCn_lef, N_dCl_lef,
+    N_dCxq_lef, N_dCyr_lef, N_dCyp_lef, N_dCzq_lef, N_dClr_lef, N_dClp_lef, N_dCmq_lef, N_dCnr_lef, N_dCnp_lef,
+    N_dCy_r30, N_dCn_r30, N_dCl_r30,
+    N_dCy_a20, N_dCy_a20_lef, N_dCn_a20, N_dCn_a20_lef, N_dCl_a20, N_dCl_a20_lef,
+    N_dCnbeta, N_dClbeta, N_dCm, N_eta_el
+};
+
+// distinct (input, mean, std) normalisations in mean_std.csv
+enum NormGroup : int {
+    G_A_C = 0,     // alpha: mean 35,   std 32.83  (Cx Cz Cm Cn Cl)
+    G_A_DAMP = 1,  // alpha: mean 35,   std 31.77  (damping, delta_Cnbeta, delta_Clbeta, delta_Cm)
+    G_A_LEF = 2,   // alpha: mean 12.5, std 18.89  (delta_C*_lef, delta_C*_a20_lef)
+    G_A_DLEF = 3,  // alpha: mean 12.5, std 18.77  (damping _lef)
+    G_A_RUD = 4,   // alpha: mean 35,   std 31.97  (rudder, Cy, a20)
+    G_B_C = 5,     // beta : std 17.91             (Cx Cz Cm Cn Cl)
+    G_B_O = 6,     // beta : std 17.44             (all other beta nets)
+    G_E_C = 7,     // el   : std 14.92             (Cx Cz Cm Cn Cl)
+    G_E_ETA = 8,   // el   : std 14.44             (eta_el)
+    NUM_NORM_GROUPS = 9,
+    G_NONE = -1
+};
+
+constexpr int MAX_CLASS_NETS = 12;
+
+struct NetClass {
+    int n_in;                  // 1..3 inputs
+    int h1, h2, h3;            // hidden widths (h3 == 0: two hidden layers)
+    int grp[3];                // normalisation group of each input slot
+    int count;                 // nets in the class
+    int n_force;               // the first n_force nets feed xdot[6..8]
+    int nets[MAX_CLASS_NETS];  // NetId of each member, force-side first
+};
+
+enum ClassId : int { CL_DAMP, CL_DLEF, CL_C, CL_D_RUD, CL_D_LEF, CL_E_LEF, CL_E_RUD, CL_F, CL_ETA, CL_YPLEF, CL_YA20, NUM_CLASSES };
+
+constexpr NetClass CLASSES[NUM_CLASSES] = {
+    /* CL_DAMP  */ {1, 20, 10, 0, {G_A_DAMP, G_NONE, G_NONE}, 12, 4,
+                    {N_Cxq, N_Cyr, N_Cyp, N_Czq, N_Clr, N_Clp, N_Cmq, N_Cnr, N_Cnp, N_dCnbeta, N_dClbeta, N_dCm}},
+    /* CL_DLEF  */ {1, 20, 10, 0, {G_A_DLEF, G_NONE, G_NONE}, 7, 2,
+                    {N_dCxq_lef, N_dCyr_lef, N_dClr_lef, N_dClp_lef, N_dCmq_lef, N_dCnr_lef, N_dCnp_lef}},
+    /* CL_C     */ {3, 20, 10, 0, {G_A_C, G_B_C, G_E_C}, 5, 2, {N_Cx, N_Cz, N_Cm, N_Cn, N_Cl}},
+    /* CL_D_RUD */ {2, 20, 10, 0, {G_A_RUD, G_B_O, G_NONE}, 2, 1, {N_Cy, N_dCl_a20}},
+    /* CL_D_LEF */ {2, 20, 10, 0, {G_A_LEF, G_B_O, G_NONE}, 2, 1, {N_dCx_lef, N_dCl_lef}},
+    /* CL_E_LEF */ {2, 20, 10, 5, {G_A_LEF, G_B_O, G_NONE}, 4, 2, {N_dCz_lef, N_dCy_lef, N_dCm_lef, N_dCn_lef}},
+    /* CL_E_RUD */ {2, 20, 10, 5, {G_A_RUD, G_B_O, G_NONE}, 4, 1, {N_dCy_r30, N_dCn_r30, N_dCl_r30, N_dCn_a20}},
+    /* CL_F     */ {2, 20, 20, 10, {G_A_LEF, G_B_O, G_NONE}, 3, 1, {N_dCy_a20_lef, N_dCn_a20_lef, N_dCl_a20_lef}},
+    /* CL_ETA   */ {1, 20, 10, 0, {G_E_ETA, G_NONE, G_NONE}, 1, 0, {N_eta_el}},
+    /* CL_YPLEF */ {1, 20, 10, 5, {G_A_DLEF, G_NONE, G_NONE}, 1, 1, {N_dCyp_lef}},
+    /* CL_YA20  */ {2, 20, 10, 10, {G_A_RUD, G_B_O, G_NONE}, 1, 1, {N_dCy_a20}},
+};
+
+constexpr int NUM_LIVE_NETS = 42;  // 43 minus the dead delta_Czq_lef
+
+// parameters (weights + biases) of one net of a class, as in the asset blob
+constexpr int class_params(const NetClass &c) {
+    int tot = c.n_in * c.h1 + c.h1 + c.h1 * c.h2 + c.h2;
+    if (c.h3 > 0) return tot + c.h2 * c.h3 + c.h3 + c.h3 + 1;
+    return tot + c.h2 + 1;
+}
+// KBLOB stride of one net of a class: parameters + (out_std, out_mean)
+constexpr int class_stride(int cl) { return class_params(CLASSES[cl]) + 2; }
+
+constexpr int KBLOB_HEADER = 2 * NUM_NORM_GROUPS;
+
+constexpr int class_base(int cl) {  // KBLOB offset of the first net of class cl
+    int off = KBLOB_HEADER;
+    for (int k = 0; k < cl; k++) off += CLASSES[k].count * class_stride(k);
+    return off;
+}
+constexpr int class_slot(int cl) {  // output slot of the first net of class cl
+    int s = 0;
+    for (int k = 0; k < cl; k++) s += CLASSES[k].count;
+    return s;
+}
+// + one chunk of padding: the weight stream reads whole 16-float chunks
+constexpr int KBLOB_FLOATS = class_base(NUM_CLASSES) + 16;
+static_assert(class_slot(NUM_CLASSES) == NUM_LIVE_NETS, "every live net belongs to exactly one class");
+
+// output slot (position in class order) of a net; -1 for the dead net
+constexpr int slot_of(int net) {
+    int s = 0;
+    for (int cl = 0; cl < NUM_CLASSES; cl++)
+        for (int i = 0; i < CLASSES[cl].count; i++, s++)
+            if (CLASSES[cl].nets[i] == net) return s;
+    return -1;
+}
+static_assert(slot_of(N_dCzq_lef) == -1 && slot_of(N_Cx) >= 0 && slot_of(N_eta_el) >= 0, "slot table");
+
+}  // namespace npf16

@@ -1,0 +1,94 @@
+"""BaseEnv — the gym-style reset()/step() surface of the reference (envs/env_base.py:12-109).
+
+Same constructor, attributes and return values; the body of reset()/step() is ONE HIP kernel
+launch each (np_f16_reset / np_f16_step) on the current PyTorch-ROCm stream, so callers never
+need an explicit synchronisation and nothing in the step forces a device->host sync (the
+reference syncs >= 8 times per step through torch.any()/print and torch.sum() sizes).
+"""
+import torch
+
+from ..core import F16Batch
+from .spaces import Env
+from .utils.utils import parse_config
+
+
+class BaseEnv(Env):
+    def __init__(self, num_envs=10, config='heading', model='F16', random_seed=None, device='cuda:0', row0=0):
+        super().__init__()
+        self.config = parse_config(config)
+        self.num_envs = num_envs
+        self.num_agents = getattr(self.config, 'num_agents', 100)
+        self.n = self.num_agents * self.num_envs
+        self.device = torch.device(device)
+        self.create_records = False
+        self._row0 = row0
+        self.load(random_seed, config, model)
+
+    def load(self, random_seed, config, model):
+        raise NotImplementedError
+
+    def _make_batch(self, task, random_seed):
+        # random_seed=None: the reference leaves torch's global generator unseeded; here the
+        # counter-based RNG simply needs a key
+        seed = 0 if random_seed is None else int(random_seed)
+        self._batch = F16Batch(self.n, self.config, task, self.device, seed=seed, row0=self._row0)
+        self.device = self._batch.device
+        return self._batch
+
+    # -- flags / counters as the reference exposes them ------------------------------------------
+    @property
+    def step_count(self):
+        return self._batch.step_count
+
+    @property
+    def is_done(self):
+        return self._batch.flags[0].view(torch.bool)
+
+    @property
+    def bad_done(self):
+        return self._batch.flags[1].view(torch.bool)
+
+    @property
+    def exceed_time_limit(self):
+        return self._batch.flags[2].view(torch.bool)
+
+    @property
+    def observation_space(self):
+        return self.task.observation_space
+
+    @property
+    def action_space(self):
+        return self.task.action_space
+
+    @property
+    def num_observation(self):
+        return self.task.num_observation
+
+    @property
+    def num_actions(self):
+        return self.task.num_actions
+
+    def info(self):
+        return {}
+
+    def get_number_of_agents(self):
+        return self.n
+
+    def seed(self, random_seed):
+        self._batch.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
+
+    # -- the hot path ------------------------------------------------------------------------------
+    def reset(self, rand_u=None, noise=None):
+        """Re-initialise flagged rows, clear the flags, return obs[n,22] (env_base.py:83-97)."""
+        return self._batch.reset(rand_u=rand_u, noise=noise)
+
+    def step(self, action, render=False, count=0, rand_u=None, noise=None):
+        """(obs, reward, done, bad_done, exceed_time_limit, info) — env_base.py:99-109.
+
+        `rand_u` / `noise` are parity hooks (inject the reference's random draws); normally None.
+        """
+        obs, reward, flags = self._batch.step(action, rand_u=rand_u, noise=noise)
+        if render:
+            raise NotImplementedError('TacView rendering is outside the accelerated path (SURVEY.md §8f N4)')
+        f = flags.view(torch.bool)
+        return obs, reward, f[0], f[1], f[2], self.info()

@@ -1,0 +1,59 @@
+"""Task objects of the env surface (reference: envs/tasks/task_base.py and the three task files).
+
+A task here only carries what callers read: spaces, `num_observation/num_actions`, `noise_scale`
+and the three per-aircraft target tensors (views into the SoA target buffer).  Target re-draw,
+observation, reward and termination are fused into the HIP step/reset kernels
+(heading_task.py:49-152, control_task.py:49-152, tracking_task.py:48-155, task_base.py:60-96).
+"""
+import numpy as np
+
+from ..spaces import Box
+
+
+class BaseTask:
+    target_names = ()
+
+    def __init__(self, config, n, device, random_seed, batch):
+        self.config = config
+        self.n = n
+        self.device = device
+        self._b = batch
+        self.num_observation = getattr(config, 'num_observation', 12)
+        self.num_actions = getattr(config, 'num_actions', 5)
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.num_observation,))
+        self.action_space = Box(low=-np.inf, high=np.inf, shape=(self.num_actions,))
+
+    @property
+    def noise_scale(self):
+        return self._b.noise_scale
+
+    def _target(self, k):
+        return self._b.tgt[k]
+
+    def _set_target(self, k, value):
+        self._b.tgt[k].copy_(value)
+
+
+def _target_property(k):
+    return property(lambda self: self._target(k), lambda self, v: self._set_target(k, v))
+
+
+class HeadingTask(BaseTask):
+    """targets: altitude [ft], heading [rad], vt [ft/s]  (heading_task.py:26-28)"""
+    target_altitude = _target_property(0)
+    target_heading = _target_property(1)
+    target_vt = _target_property(2)
+
+
+class ControlTask(BaseTask):
+    """targets: pitch [rad], heading [rad], vt [ft/s]  (control_task.py:27-29)"""
+    target_pitch = _target_property(0)
+    target_heading = _target_property(1)
+    target_vt = _target_property(2)
+
+
+class TrackingTask(BaseTask):
+    """targets: npos, epos, altitude [ft]  (tracking_task.py:27-29)"""
+    target_npos = _target_property(0)
+    target_epos = _target_property(1)
+    target_altitude = _target_property(2)
