@@ -69,9 +69,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    from neuralplane_amd import sharding
+    rank, local_rank, world = sharding.env_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with '
@@ -81,14 +80,13 @@ def main():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)  # RCCL; used for the timing barrier only
+    dist = sharding.init_distributed('nccl', dev)  # RCCL; used for the timing barrier / max only
 
     from neuralplane_amd.envs.control_env import ControlEnv
-    n = args.n
-    env = ControlEnv(num_envs=n, config=args.task, model='F16', random_seed=0, device=str(dev), row0=rank * n)
+    n = args.n  # weak scaling: every GPU simulates args.n aircraft, global rows [rank*n, (rank+1)*n)
+    row0, n_local = sharding.shard_rows(world * n, world, rank)
+    assert n_local == n
+    env = ControlEnv(num_envs=n, config=args.task, model='F16', random_seed=0, device=str(dev), row0=row0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     if args.actions == 'random':
@@ -115,10 +113,7 @@ def main():
     kern_ms, kern_cnt = env._batch.get_timing()
     env._batch.set_timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
     # sanity of the timed region: states finite for live rows, counters advanced
     fin = bool(torch.isfinite(env.model.s).all().item())
 

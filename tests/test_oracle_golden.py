@@ -1,0 +1,258 @@
+"""CPU tests: the oracle (oracle/f16_oracle.c) against the golden vectors recorded from the
+REFERENCE itself (tools/gen_golden.py) — this is what pins the oracle before it is trusted as the
+checker of the HIP path.
+
+* pin mode  (`*_pin` arrays): MLPs in fp64-and-round-once, sin/cos/tan/pow/sqrt in fp64-and-round-
+  once on both sides -> what remains is the reference's fp32 operation order, which the oracle
+  must reproduce BIT-EXACTLY (states, targets, obs incl. injected noise, reward, masks, counters).
+* plain mode: the reference as it runs (ATen sgemm, SLEEF/VML) vs the shipped numerics spec:
+  <= 1e-4 relative with the per-state scale floors of SURVEY.md §8(d); masks exact in
+  teacher-forced single steps.
+"""
+import numpy as np
+import pytest
+
+from oracle.f16_oracle import MODE_LIBM, MODE_MLP_F64, Oracle
+
+STATE_FLOORS = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1, .1, .1, .1], np.float32)
+XDOT_FLOORS = np.array([10, 10, 10, .1, .1, .1, 1, .1, .1, 1, 1, 1], np.float32)
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def relerr(a, ref, floor):
+    e = np.abs(a - ref) / np.maximum(np.abs(ref), floor)
+    return float(np.nanmax(e))
+
+
+# ---------------------------------------------------------------------------------------------------
+# elementary functions of the numerics spec
+# ---------------------------------------------------------------------------------------------------
+def test_philox_known_answers():
+    """Random123 Philox4x32-10 known-answer vectors."""
+    o = Oracle('heading')
+    assert o.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert o.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert o.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_sincos_tan_pow_are_correctly_rounded_fp64_evaluations():
+    o = Oracle('heading')
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(-10, 10, 4000), rng.uniform(-600, 600, 2000), [0.0, -0.0, 1e-30, 3.0e9, -7.5e12]]).astype(np.float32)
+    s, c = o.sincos(x)
+    xd = x.astype(np.float64)
+    # fp64 libm rounded to fp32 == the spec, up to double-rounding ties (never seen in 6000 samples)
+    big = np.abs(xd) >= 2 ** 30
+    assert np.array_equal(s[~big], np.sin(xd[~big]).astype(np.float32))
+    assert np.array_equal(c[~big], np.cos(xd[~big]).astype(np.float32))
+    assert np.all(np.abs(s[big]) <= 1) and np.all(np.abs(c[big]) <= 1)  # huge angles: reduced mod fp64(2*pi), still finite
+    t = o.tan(x[~big][:2000])
+    assert np.array_equal(t, np.tan(xd[~big][:2000]).astype(np.float32))
+    for v in (np.inf, -np.inf, np.nan):
+        s1, c1 = o.sincos(np.float32(v))
+        assert np.isnan(s1[0]) and np.isnan(c1[0])
+    base = rng.uniform(0.05, 1.3, 3000).astype(np.float32)
+    p = o.pow(base, np.float32(4.14))
+    ref = np.power(base.astype(np.float64), np.float64(np.float32(4.14))).astype(np.float32)
+    assert np.array_equal(p, ref)
+    assert np.isnan(o.pow(np.float32(-0.5), np.float32(4.14))[0]) and o.pow(np.float32(0), np.float32(4.14))[0] == 0
+    assert np.isinf(o.pow(np.float32(np.inf), np.float32(4.14))[0]) and np.isnan(o.pow(np.float32(np.nan), np.float32(4.14))[0])
+
+
+def test_wrap_pi_matches_torch_remainder_semantics():
+    import torch
+    o = Oracle('heading')
+    x = np.concatenate([np.random.RandomState(1).uniform(-50, 50, 2000), [0, -0.0, np.pi, -np.pi, 2 * np.pi, 7.0, -7.0]]).astype(np.float32)
+    t = torch.from_numpy(x.copy())
+    res = t % (2 * torch.pi)
+    res += 2 * torch.pi * (res < 0)
+    res -= 2 * torch.pi * (res > torch.pi)
+    assert np.array_equal(o.wrap_pi(x), res.numpy())
+
+
+def test_rng_streams_are_keyed_by_seed_call_and_global_row():
+    o = Oracle('heading')
+    u = o.rng_uniforms(5, 3, 10)
+    assert np.all((u >= 0) & (u < 1)) and len(set(u.tolist())) == 8
+    assert not np.array_equal(u, o.rng_uniforms(5, 4, 10)) and not np.array_equal(u, o.rng_uniforms(6, 3, 10))
+    assert not np.array_equal(u, o.rng_uniforms(5, 3, 11))
+    z = np.stack([o.rng_normals(1, 0, r) for r in range(4000)])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and np.all(np.isfinite(z))
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------
+# aero MLPs, nlplant, getters
+# ---------------------------------------------------------------------------------------------------
+def test_aero_mlps(golden_dir):
+    g = np.load(f'{golden_dir}/aero_kat.npz')
+    o = Oracle('heading', mode=MODE_MLP_F64)
+    assert same(o.aero(g['alpha_deg'], g['beta_deg'], g['el']), g['coef_pin'])
+    o = Oracle('heading')
+    c = o.aero(g['alpha_deg'], g['beta_deg'], g['el'])
+    import json
+    import os
+    man = json.load(open(os.path.join(os.path.dirname(golden_dir), '..', 'neuralplane_amd', 'assets', 'f16_aero_mlp.json')))
+    std = np.array([n['out_std'] for n in man['nets']], np.float32)
+    err = np.abs(c - g['coef']) / np.maximum(np.abs(g['coef']), std[None, :])
+    assert err.max() < 2e-5  # same size as the reference's own fp32-vs-fp64 noise (5e-6 measured)
+    # non-finite inputs poison every coefficient (torch propagates NaN through Linear/ReLU)
+    assert np.all(np.isnan(o.aero(np.float32(np.nan), np.float32(0), np.float32(0))))
+    assert np.all(np.isnan(o.aero(np.float32(1), np.float32(np.inf), np.float32(0))))
+
+
+def test_nlplant(golden_dir):
+    g = np.load(f'{golden_dir}/nlplant_kat.npz')
+    assert same(Oracle('heading', mode=MODE_MLP_F64).nlplant(g['x17']), g['xdot_pin'])
+    xd = Oracle('heading').nlplant(g['x17'])
+    assert relerr(xd, g['xdot'], XDOT_FLOORS) < 1e-4
+    # the host-libm flavour of the oracle (sinf/cosf/powf from glibc) stays within the same band
+    assert relerr(Oracle('heading', mode=MODE_LIBM).nlplant(g['x17']), g['xdot'], XDOT_FLOORS) < 1e-4
+
+
+def test_model_getters(golden_dir):
+    g = np.load(f'{golden_dir}/getters_kat.npz')
+    o = Oracle('heading', mode=MODE_MLP_F64)
+    assert same(o.get_acceleration(g['s'], g['u']), g['accel_pin'])
+    assert same(o.get_accels(g['s'], g['u']), g['accels_pin'])
+    assert same(o.get_eas2tas(g['s']), g['eas2tas_pin'])
+    o = Oracle('heading')
+    assert relerr(o.get_acceleration(g['s'], g['u']), g['accel'], 1.0) < 1e-4
+    assert relerr(o.get_accels(g['s'], g['u']), g['accels'], 0.1) < 1e-4
+    assert relerr(o.get_eas2tas(g['s']), g['eas2tas'], 1.0) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# env.step: teacher-forced single steps
+# ---------------------------------------------------------------------------------------------------
+STEP_FIXTURES = [('heading', 'step_kat_heading', None), ('control', 'step_kat_control', None),
+                 ('tracking', 'step_kat_tracking', None), ('heading', 'step_kat_heading_rk4', 'rk4')]
+
+
+def _run_step(task, solver, g, pre, mode):
+    n = g['action'].shape[0]
+    o = Oracle(task, solver=solver, mode=mode)
+    if pre == '':
+        st = {k: g['in_' + k].copy() for k in ['s', 'u', 'tgt', 'step_count', 'done', 'bad', 'timeout']}
+        ru, nz = g['rand_u'], g['noise']
+    else:
+        st = Oracle.new_state(n)
+        ru, nz = g['first_rand_u'], g['first_noise']
+    obs, rew, d, b, t = o.step(st, g['action'], rand_u=ru, noise=nz)
+    return st, obs, rew, d, b, t
+
+
+@pytest.mark.parametrize('task,fixture,solver', STEP_FIXTURES)
+@pytest.mark.parametrize('pre', ['', 'first_'])
+def test_step_pin_mode_is_bit_exact(task, fixture, solver, pre, golden_dir):
+    """rk4 note: the rk4 goldens come from the restated torchdiffeq tableau (tools/oracle_shims) —
+    they pin the oracle to the shim, not to torchdiffeq itself (parity UNPINNED)."""
+    g = np.load(f'{golden_dir}/{fixture}.npz')
+    st, obs, rew, d, b, t = _run_step(task, solver, g, pre, MODE_MLP_F64)
+    k = pre + 'out_'
+    for name, val in [('s', st['s']), ('u', st['u']), ('tgt', st['tgt']), ('obs', obs), ('reward', rew)]:
+        assert same(val, g[k + name + '_pin']), f'{fixture}/{pre}: {name}'
+    assert np.array_equal(st['step_count'], g[k + 'step_count_pin'])
+    assert np.array_equal(d, g[k + 'done_pin']) and np.array_equal(b, g[k + 'bad_pin']) and np.array_equal(t, g[k + 'timeout_pin'])
+    if pre == '':
+        assert g[k + 'done_pin'].sum() > 10 and g[k + 'bad_pin'].sum() > 10  # the fixture really exercises the masks
+
+
+@pytest.mark.parametrize('task,fixture,solver', STEP_FIXTURES)
+@pytest.mark.parametrize('pre', ['', 'first_'])
+def test_step_plain_mode_within_tolerance_masks_exact(task, fixture, solver, pre, golden_dir):
+    g = np.load(f'{golden_dir}/{fixture}.npz')
+    st, obs, rew, d, b, t = _run_step(task, solver, g, pre, 0)
+    k = pre + 'out_'
+    tol = 2e-4 if solver == 'rk4' else 1e-4
+    assert relerr(st['s'], g[k + 's'], STATE_FLOORS) < tol
+    assert same(st['u'], g[k + 'u'])  # control lag has no implementation-defined piece
+    assert relerr(st['tgt'], g[k + 'tgt'], 1.0) < 1e-6
+    assert relerr(obs, g[k + 'obs'], 0.1) < 1e-4
+    assert relerr(rew, g[k + 'reward'], 1.0) < 1e-4
+    assert np.array_equal(st['step_count'], g[k + 'step_count'])
+    assert np.array_equal(d, g[k + 'done']) and np.array_equal(b, g[k + 'bad']) and np.array_equal(t, g[k + 'timeout'])
+
+
+# ---------------------------------------------------------------------------------------------------
+# free-running trajectories and the authors' recorded episode
+# ---------------------------------------------------------------------------------------------------
+def _traj_actions(T, n, seed=123):
+    """Same formula as tools/gen_golden.py:traj_actions (numpy RandomState is version-stable)."""
+    rng = np.random.RandomState(seed)
+    t = np.arange(T, dtype=np.float64)[:, None, None]
+    phase = rng.uniform(0, 2 * np.pi, (1, n, 4))
+    freq = rng.uniform(0.002, 0.02, (1, n, 4))
+    a = 0.3 * np.sin(2 * np.pi * freq * t + phase) + rng.uniform(-1, 1, (T, n, 4)) * np.array([1.0, 0.3, 0.3, 0.3])
+    a[..., 0] = 0.5 + 0.5 * a[..., 0]
+    return np.clip(a, -1, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('task,n,T', [('heading', 128, 1000), ('control', 64, 300), ('tracking', 64, 300)])
+def test_free_running_trajectory_vs_reference(task, n, T, golden_dir):
+    """Free-running env.step from a fresh env for T steps with the reference's reset draws injected.
+    fp32 trajectories separate chaotically (the reference's own fp32-vs-fp64 noise is p99 3e-4 after
+    1000 steps), so: the bulk (median / p90) must stay within 1e-4, and a mask may
+    differ from the reference only on a row that has already drifted or sits within 1e-3 of a
+    threshold — never on a row that still tracks the reference."""
+    g = np.load(f'{golden_dir}/traj_{task}_N{n}_T{T}.npz')
+    acts = _traj_actions(T, n)
+    o = Oracle(task, overrides={'noise_scale': 0})
+    st = Oracle.new_state(n)
+    rec = {int(t): i for i, t in enumerate(g['rec_steps'])}
+    diverged = np.zeros(n, bool)   # rows whose episode boundary differed from the reference once
+    errs = []
+    n_mask_diff = 0
+    for t in range(T):
+        obs, rew, d, b, tm = o.step(st, acts[t], rand_u=g['rand_u'][t])
+        fl = g['flags'][t]
+        diff = (d != fl[:, 0]) | (b != fl[:, 1]) | (tm != fl[:, 2])
+        n_mask_diff += int((diff & ~diverged).sum())
+        diverged |= diff
+        if t in rec:
+            ref = g['state'][rec[t]]
+            e = np.abs(st['s'] - ref[:, :12]) / np.maximum(np.abs(ref[:, :12]), STATE_FLOORS)
+            errs.append((t, np.nanmax(e, axis=1)))
+    ok_rows = ~diverged
+    assert ok_rows.mean() > 0.9, 'more than 10% of the rows left the reference episode schedule'
+    assert n_mask_diff <= max(2, n // 32), f'{n_mask_diff} first-time mask differences'
+    for t, e in errs:
+        e = e[ok_rows]
+        if t < 100:
+            assert np.max(e) < 1e-4, (t, np.max(e))
+        assert np.median(e) < 1e-4 and np.percentile(e, 90) < 5e-4, (t, np.median(e), np.percentile(e, 90))
+
+
+def test_recorded_cuda_episode_replay(golden_dir):
+    """Independent cross-check: the authors' own CUDA recording (renders/result/*.npy, first episode,
+    427 rows) replayed through the oracle's nlplant + Euler with the recorded controls."""
+    g = np.load(f'{golden_dir}/recorded_episode0.npz')
+    rows = g['rows']
+    cols = list(g['columns'])
+    ix = {c: cols.index(c) for c in cols}
+    o = Oracle('heading')
+    s = np.zeros((1, 12), np.float32)
+    s[0, 2], s[0, 6] = rows[0, ix['altitude']], rows[0, ix['vt']]
+    dt = np.float32(0.02)
+    floors = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1], np.float32)
+    worst, worst200 = 0.0, 0.0
+    for t in range(426):
+        u = np.array([[rows[t + 1, ix['T']], rows[t + 1, ix['el']], rows[t + 1, ix['ail']], rows[t + 1, ix['rud']], 0]], np.float32)
+        x = np.hstack([s, u]).astype(np.float32)
+        s = (x[:, :12] + dt * o.nlplant(x)).astype(np.float32)
+        ref = rows[t + 1, :9]
+        e = float(np.max(np.abs(s[0, :9] - ref) / np.maximum(np.abs(ref), floors)))
+        worst = max(worst, e)
+        if t < 200:
+            worst200 = max(worst200, e)
+    # the episode ends in a departure (terminated at row 426): the CUDA-vs-CPU difference grows
+    # exponentially over the last ~150 steps (measured 5e-6 @200, 9e-5 @400, 1.9e-4 @426)
+    assert worst200 < 1e-5, worst200
+    assert worst < 1e-3, worst
+    G = np.sqrt((o.get_accels(s, u) ** 2).sum())
+    assert abs(G - rows[426, ix['G']]) / rows[426, ix['G']] < 1e-3
