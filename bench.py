@@ -33,6 +33,21 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak == fp32 (f32-input) MFMA pea
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(n, task):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json;
+    bench.py cannot collect PMC counters itself).  None unless the profile matches this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if int(d.get('n', -1)) == int(n) and task == 'heading':
+            best = float(d['traffic_bytes_per_launch'])
+    return best
+
+
 def cpu_baseline(task, budget_s=15.0):
     """The CPU oracle (oracle/, the C restatement of the reference path) timed on this box's host
     cores on a bounded sample of the same workload.  A reported baseline, never the thing shipped."""
@@ -131,7 +146,8 @@ def main():
                                    f'{args.actions} actions, one fused HIP kernel per env.step',
                        'aircraft_per_gpu': n, 'sharding': f'rows split over {world} GPU(s), no data-path collective'},
             'roofline': {'bound': 'mfma', 'achieved': ach_tflops, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach_tflops / PEAK_FP32_TFLOPS, 'traffic': None,
+                         'frac': ach_tflops / PEAK_FP32_TFLOPS, 'traffic': pmc_traffic(n, args.task),
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)', 'algorithmic_bytes_per_launch': n * ALGO_BYTES,
                          'kernel': 'f16_env_kernel<task,solver,STEP>', 'kernel_avg_ms': kern_ms, 'launches_timed': kern_cnt,
                          'note': 'fp32 VECTOR (VALU) roof: 157.3 TFLOP/s is both the fp32 vector peak and the '
                                  'f32-input MFMA peak on gfx950; the kernel issues no MFMA. achieved = 33.8 KFLOP x N / '
