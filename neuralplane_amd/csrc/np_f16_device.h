@@ -77,10 +77,12 @@ template <int IN, int OUT, bool RELU, class WS>
 __device__ __forceinline__ void dense(WS &ws, const float (&x)[IN], float (&y)[OUT]) {
 #pragma unroll
     for (int j = 0; j < OUT; j++) y[j] = ws.next();
+    if (OUT & 1) (void)ws.next();  // rows are padded to an even length (np_nets.h::asm_record_len)
 #pragma unroll
     for (int k = 0; k < IN; k++) {
 #pragma unroll
         for (int j = 0; j < OUT; j++) y[j] = fmaf(ws.next(), x[k], y[j]);
+        if (OUT & 1) (void)ws.next();
     }
     if (RELU) {
 #pragma unroll
@@ -92,24 +94,35 @@ constexpr int WS_NBUF = 3;
 
 template <int IN, int H1, int H2, int H3>
 __device__ __forceinline__ float mlp_body(int w, const float (&x)[IN]) {
-    constexpr int LEN = IN * H1 + H1 + H1 * H2 + H2 + (H3 > 0 ? H2 * H3 + H3 + H3 + 1 : H2 + 1) + 2;
+    constexpr int LEN = asm_record_len(IN, H1, H2, H3);
     WStream<WS_NBUF, LEN> ws;
     ws.start(w);
     float h1[H1], h2[H2];
     dense<IN, H1, true>(ws, x, h1);
     dense<H1, H2, true>(ws, h1, h2);
-    float y[1];
+    float y;
     if constexpr (H3 > 0) {
         float h3[H3];
         dense<H2, H3, true>(ws, h2, h3);
-        dense<H3, 1, false>(ws, h3, y);
+        y = ws.next();  // final layer: bias, W[0][0..H3), padded to even
+#pragma unroll
+        for (int k = 0; k < H3; k++) y = fmaf(ws.next(), h3[k], y);
+        if (((1 + H3) & 1) != 0) (void)ws.next();
     } else {
-        dense<H2, 1, false>(ws, h2, y);
+        y = ws.next();
+#pragma unroll
+        for (int k = 0; k < H2; k++) y = fmaf(ws.next(), h2[k], y);
+        if (((1 + H2) & 1) != 0) (void)ws.next();
     }
     const float out_std = ws.next();
     const float out_mean = ws.next();
-    return y[0] * out_std + out_mean;  // unnormalize: X * std + mean
+    return y * out_std + out_mean;  // unnormalize: X * std + mean
 }
+
+#ifndef NPF16_ASM_MLP
+#define NPF16_ASM_MLP 1  // 1: hand-scheduled asm class bodies (np_mlp_asm.inc); 0: the C++ bodies above (A/B + reference)
+#endif
+#include "np_mlp_asm.inc"
 
 // All nets of one class (np_nets.h): same shape, same inputs, KBLOB records back to back.  ONE
 // compact loop body per class keeps the instruction footprint of a full aero evaluation at a few
@@ -120,6 +133,17 @@ template <int CL, bool FORCE_ONLY, int LD>
 __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
     constexpr NetClass c = CLASSES[CL];
     constexpr int n = FORCE_ONLY ? c.n_force : c.count;
+#if NPF16_ASM_MLP
+    if constexpr (n > 0) {
+        // one asm statement for the whole class; `out` points into LDS: the low 32 bits of the flat
+        // address are the LDS byte offset ds_write_b32 wants
+        const unsigned lds_addr = (unsigned)(unsigned long long)(out + class_slot(CL) * LD);
+        const float x0 = xn[c.grp[0]];
+        const float x1 = c.n_in > 1 ? xn[c.grp[c.n_in > 1 ? 1 : 0]] : 0.0f;
+        const float x2 = c.n_in > 2 ? xn[c.grp[c.n_in > 2 ? 2 : 0]] : 0.0f;
+        mlp_class_asm<c.n_in, c.h1, c.h2, c.h3>(c_kblob + class_base(CL), n, lds_addr, (unsigned)(LD * sizeof(float)), x0, x1, x2);
+    }
+#else
     if constexpr (n > 0) {
         float x[c.n_in];
 #pragma unroll
@@ -133,6 +157,7 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
             o += LD;
         }
     }
+#endif
 }
 
 template <bool FORCE_ONLY, int LD>

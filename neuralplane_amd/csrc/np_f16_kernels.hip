@@ -333,15 +333,21 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb) {
             const float *src = par.data() + r.param_offset;
             float *dst = kb.data() + class_base(cl) + (size_t)m * class_stride(cl);
             int in = c.n_in;
-            for (int l = 0; l <= n_hidden; l++) {
-                const int out = (l < n_hidden) ? hid[l] : 1;
+            for (int l = 0; l < n_hidden; l++) {  // hidden layers: bias row + `in` weight rows, rows padded to even
+                const int out = hid[l], row = pad2(out);
                 const float *W = src, *bias = src + (size_t)in * out;
                 for (int j = 0; j < out; j++) dst[j] = bias[j];
                 for (int k = 0; k < in; k++)
-                    for (int j = 0; j < out; j++) dst[out + k * out + j] = W[j * in + k];
+                    for (int j = 0; j < out; j++) dst[row * (k + 1) + j] = W[j * in + k];
                 src += (size_t)in * out + out;
-                dst += (size_t)in * out + out;
+                dst += (size_t)row * (in + 1);
                 in = out;
+            }
+            {  // final layer in -> 1: bias, W[0][0..in), padded to even
+                const float *W = src, *bias = src + in;
+                dst[0] = bias[0];
+                for (int k = 0; k < in; k++) dst[1 + k] = W[k];
+                dst += pad2(1 + in);
             }
             dst[0] = (float)r.out_std;
             dst[1] = (float)r.out_mean;

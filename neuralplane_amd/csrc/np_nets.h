@@ -16,7 +16,8 @@
 // KBLOB layout (floats):
 //   [0 .. 2*NUM_NORM_GROUPS)   (mean, std) of the 9 distinct input normalisations
 //   per class, per net:        per Linear layer: bias[out] then W^T[in][out] (k-major: the order
-//                              the FMA chains consume them), then out_std, out_mean
+//                              the FMA chains consume them; every row padded to an even length),
+//                              then out_std, out_mean, zero padding to a multiple of 32 floats
 // np_pack_kblob (np_f16_kernels.hip) also verifies that every net of a class has the fp32
 // normalisation constants of the class, so this static grouping cannot silently disagree with the
 // data.
@@ -89,8 +90,19 @@ constexpr int class_params(const NetClass &c) {
     if (c.h3 > 0) return tot + c.h2 * c.h3 + c.h3 + c.h3 + 1;
     return tot + c.h2 + 1;
 }
-// KBLOB stride of one net of a class: parameters + (out_std, out_mean)
-constexpr int class_stride(int cl) { return class_params(CLASSES[cl]) + 2; }
+// KBLOB record of one net (floats), laid out for the asm bodies (tools/gen_mlp_asm.py): rows padded
+// to an even length so that every (neuron j, j+1) weight pair is an even-aligned SGPR pair, the
+// record padded to whole groups of 32 floats.
+constexpr int pad2(int n) { return n + (n & 1); }
+constexpr int asm_record_len(int n_in, int h1, int h2, int h3) {
+    int n = pad2(h1) + n_in * pad2(h1) + pad2(h2) + h1 * pad2(h2);
+    if (h3 > 0) n += pad2(h3) + h2 * pad2(h3) + pad2(1 + h3);
+    else n += pad2(1 + h2);
+    n += 2;  // out_std, out_mean
+    return (n + 31) / 32 * 32;
+}
+// KBLOB stride of one net of a class
+constexpr int class_stride(int cl) { return asm_record_len(CLASSES[cl].n_in, CLASSES[cl].h1, CLASSES[cl].h2, CLASSES[cl].h3); }
 
 constexpr int KBLOB_HEADER = 2 * NUM_NORM_GROUPS;
 
@@ -104,8 +116,8 @@ constexpr int class_slot(int cl) {  // output slot of the first net of class cl
     for (int k = 0; k < cl; k++) s += CLASSES[k].count;
     return s;
 }
-// + one chunk of padding: the weight stream reads whole 16-float chunks
-constexpr int KBLOB_FLOATS = class_base(NUM_CLASSES) + 16;
+// + padding: the weight stream prefetches one group (32 floats) past the last record it evaluates
+constexpr int KBLOB_FLOATS = class_base(NUM_CLASSES) + 64;
 static_assert(class_slot(NUM_CLASSES) == NUM_LIVE_NETS, "every live net belongs to exactly one class");
 
 // output slot (position in class order) of a net; -1 for the dead net

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Generate neuralplane_amd/csrc/np_mlp_asm.inc — the hand-scheduled gfx950 bodies of the aero MLPs.
+
+One `asm volatile` statement evaluates ALL nets of a class (same shape, same inputs, KBLOB records
+back to back): weights stream through the scalar unit in 16-dword chunks, double-buffered in groups
+of two chunks (4 x 16 fixed SGPRs), each group's `s_load_dwordx16` pair issued one group (32 FMAs)
+ahead of its single `s_waitcnt lgkmcnt(0)` — also across net boundaries, the records being
+contiguous.  FMAs are `v_pk_fma_f32 acc[2], s[2], x(broadcast)`: two neurons of a layer per
+instruction, the weight pair an SGPR operand (130 TFLOP/s issue ceiling on MI355X,
+tools/microbench/fma_rates.hip).  Every accumulator keeps the spec's order
+`acc = bias; acc = fma(W[j][k], x[k], acc)`, k ascending, so results are bit-identical to the C++
+path and to the oracle.
+
+Why asm: hipcc cannot be steered into this schedule (it either spills SGPRs lane-by-lane into VGPRs
+or sinks every load next to its use), and asm loads whose destinations the compiler can see are
+unsafe (it spills / re-uses SGPRs of in-flight loads; tools/audit_smem_asm.py).  Inside ONE
+statement nothing is visible to the compiler: temporaries are fixed registers declared as clobbers.
+
+Record layout of one net (floats) — must match np_nets.h::asm_record_len / pack_kblob:
+  per hidden layer (in -> out):  bias[out] (+pad to even), then for k < in: W[.][k] as a row of
+                                 `out` weights (+pad to even)            [pairs are even-aligned]
+  final layer (in -> 1):         bias, W[0][0..in) (+pad to even)
+  out_std, out_mean, then zero padding to a multiple of 32 floats (whole groups)
+"""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_mlp_asm.inc')
+
+SHAPES = [(1, 20, 10, 0), (3, 20, 10, 0), (2, 20, 10, 0), (2, 20, 10, 5), (2, 20, 20, 10), (1, 20, 10, 5), (2, 20, 10, 10)]
+
+# fixed registers (declared as clobbers of every statement)
+S_BASE = 32      # s[32:33] record pointer
+S_CNT = 35       # remaining nets
+S_W0 = 36        # s[36:99] four 16-dword weight buffers
+V_H = [100, 120, 140]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
+V_X = 150        # v150,v152,v154: the (normalised) inputs, even registers
+V_Y = 156        # net output
+V_ADDR = 157     # LDS byte address of the output slot
+V_CLOBBER = list(range(100, 158))
+S_CLOBBER = list(range(32, 100))
+
+
+def pad2(n):
+    return n + (n & 1)
+
+
+def record_len(IN, H1, H2, H3):
+    hid = [H1, H2] + ([H3] if H3 else [])
+    n, prev = 0, IN
+    for h in hid:
+        n += pad2(h) + prev * pad2(h)
+        prev = h
+    n += pad2(1 + prev) + 2
+    return (n + 31) // 32 * 32
+
+
+class Body:
+    """Instruction list of one net evaluation, given the buffer parity of its first group."""
+
+    def __init__(self, shape, parity):
+        self.IN, self.H1, self.H2, self.H3 = shape
+        self.len = record_len(*shape)
+        self.nch = self.len // 16
+        self.parity = parity  # 0: first group in buffers 0,1 ; 1: in buffers 2,3
+        self.ins = []
+        self.pos = 0
+        self.cur_group = -1
+
+    def sreg(self, pos):
+        c, l = divmod(pos, 16)
+        b = (c + 2 * self.parity) % 4
+        return S_W0 + 16 * b + l
+
+    def buf_of_chunk(self, c):
+        return S_W0 + 16 * ((c + 2 * self.parity) % 4)
+
+    def touch(self, pos):
+        """Called before an instruction that reads record position `pos`: emits the group boundary
+        (wait for this group, issue the loads of the next one) when a new group starts."""
+        g = pos // 32
+        while self.cur_group < g:
+            self.cur_group += 1
+            c = 2 * self.cur_group
+            self.ins.append('s_waitcnt lgkmcnt(0)')
+            for cc in (c + 2, c + 3):  # next group (runs into the next record when cc >= nch: contiguous)
+                self.ins.append(f's_load_dwordx16 s[{self.buf_of_chunk(cc)}:{self.buf_of_chunk(cc) + 15}], '
+                                f's[{S_BASE}:{S_BASE + 1}], 0x{cc * 64:x}')
+
+    def spair(self, pos):
+        assert pos % 2 == 0
+        self.touch(pos)
+        r = self.sreg(pos)
+        assert r % 2 == 0
+        return f's[{r}:{r + 1}]'
+
+    def s1(self, pos):
+        self.touch(pos)
+        return f's{self.sreg(pos)}'
+
+    @staticmethod
+    def vpair(r):
+        assert r % 2 == 0
+        return f'v[{r}:{r + 1}]'
+
+    def dense(self, n_in, n_out, in_regs, out_base):
+        """hidden layer with ReLU: bias row then n_in weight rows, pairs via v_pk_fma_f32."""
+        row = pad2(n_out)
+        p0 = self.pos
+        for j in range(0, n_out - 1, 2):
+            sp = self.spair(p0 + j)
+            self.ins.append(f'v_pk_mov_b32 {self.vpair(out_base + j)}, {sp}, {sp} op_sel:[0,1]')
+        if n_out & 1:
+            self.ins.append(f'v_mov_b32 v{out_base + n_out - 1}, {self.s1(p0 + n_out - 1)}')
+        for k in range(n_in):
+            pk = p0 + row * (k + 1)
+            xr = in_regs[k]
+            e = xr & 1
+            xp = self.vpair(xr - e)
+            for j in range(0, n_out - 1, 2):
+                sp = self.spair(pk + j)
+                acc = self.vpair(out_base + j)
+                self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {xp}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]')
+            if n_out & 1:
+                j = n_out - 1
+                self.ins.append(f'v_fmac_f32 v{out_base + j}, {self.s1(pk + j)}, v{xr}')
+        for j in range(n_out):
+            self.ins.append(f'v_max_f32 v{out_base + j}, 0, v{out_base + j}')
+        self.pos = p0 + row * (n_in + 1)
+
+    def final(self, n_in, in_regs):
+        p0 = self.pos
+        self.ins.append(f'v_mov_b32 v{V_Y}, {self.s1(p0)}')
+        for k in range(n_in):
+            self.ins.append(f'v_fmac_f32 v{V_Y}, {self.s1(p0 + 1 + k)}, v{in_regs[k]}')
+        self.pos = p0 + pad2(1 + n_in)
+        # unnormalize: X * std + mean, two roundings (hifi_F16_AeroData.py:36-37)
+        self.ins.append(f'v_mul_f32 v{V_Y}, {self.s1(self.pos)}, v{V_Y}')
+        self.ins.append(f'v_add_f32 v{V_Y}, {self.s1(self.pos + 1)}, v{V_Y}')
+        self.pos += 2
+
+    def build(self):
+        x_regs = [V_X, V_X + 2, V_X + 4][:self.IN]
+        self.dense(self.IN, self.H1, x_regs, V_H[0])
+        h1 = [V_H[0] + i for i in range(self.H1)]
+        self.dense(self.H1, self.H2, h1, V_H[1])
+        h2 = [V_H[1] + i for i in range(self.H2)]
+        if self.H3:
+            self.dense(self.H2, self.H3, h2, V_H[2])
+            self.final(self.H3, [V_H[2] + i for i in range(self.H3)])
+        else:
+            self.final(self.H2, h2)
+        assert self.pos <= self.len, (self.pos, self.len)
+        # make sure every group of the record passed its boundary (padding groups included), so that
+        # the stream position is exactly one record further when the next net starts
+        self.touch(self.len - 1)
+        assert self.cur_group == self.len // 32 - 1
+        return self.ins
+
+
+def gen_function(shape):
+    IN, H1, H2, H3 = shape
+    ln = record_len(*shape)
+    ngroups = ln // 32
+    two_parities = ngroups % 2 == 1
+    name = f'mlp_class_asm_{IN}_{H1}_{H2}_{H3}'
+    lines = []
+    A = lines.append
+    A(f'// shape {IN}-{H1}-{H2}' + (f'-{H3}' if H3 else '') + f'-1: record {ln} floats = {ngroups} groups'
+      + (' (odd: two buffer parities)' if two_parities else ''))
+    A(f'__device__ __forceinline__ void {name}(const float *w, int count, unsigned lds_addr, unsigned lds_step, '
+      'float x0, float x1, float x2) {')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
+    emit(f's_mov_b32 s{S_CNT}, %[cnt]')
+    emit(f'v_mov_b32 v{V_X}, %[x0]')
+    if IN > 1:
+        emit(f'v_mov_b32 v{V_X + 2}, %[x1]')
+    if IN > 2:
+        emit(f'v_mov_b32 v{V_X + 4}, %[x2]')
+    emit(f'v_mov_b32 v{V_ADDR}, %[addr]')
+    # prologue: first group of the first net into buffers 0,1
+    emit(f's_load_dwordx16 s[{S_W0}:{S_W0 + 15}], s[{S_BASE}:{S_BASE + 1}], 0x0')
+    emit(f's_load_dwordx16 s[{S_W0 + 16}:{S_W0 + 31}], s[{S_BASE}:{S_BASE + 1}], 0x40')
+    emit('.LNP_LOOP_%=:')
+    for parity in ([0, 1] if two_parities else [0]):
+        for ins in Body(shape, parity).build():
+            emit(ins)
+        emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
+        emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
+        emit(f's_add_u32 s{S_BASE}, s{S_BASE}, 0x{ln * 4:x}')
+        emit(f's_addc_u32 s{S_BASE + 1}, s{S_BASE + 1}, 0')
+        emit(f's_sub_u32 s{S_CNT}, s{S_CNT}, 1')
+        emit(f's_cmp_lg_u32 s{S_CNT}, 0')
+        if two_parities and parity == 0:
+            emit('s_cbranch_scc0 .LNP_DONE_%=')
+        else:
+            emit('s_cbranch_scc1 .LNP_LOOP_%=')
+    emit('.LNP_DONE_%=:')
+    emit('s_waitcnt lgkmcnt(0)')  # retire the dangling prefetch of the record after the last one
+    A('        :')
+    A('        : [w] "s"(w), [cnt] "s"(count), [addr] "v"(lds_addr), [step] "s"(lds_step), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2)')
+    clob = ', '.join([f'"v{r}"' for r in V_CLOBBER] + [f'"s{r}"' for r in S_CLOBBER] + ['"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+    A('')
+    return lines, name
+
+
+def main():
+    out = ['// GENERATED by tools/gen_mlp_asm.py — do not edit.  See that file for the design notes.',
+           '// One asm statement per net class: double-buffered scalar weight stream + v_pk_fma_f32 chains.',
+           '#pragma once', '']
+    for shape in SHAPES:
+        lines, _ = gen_function(shape)
+        out += lines
+    out.append('// record lengths the generator assumed (checked against np_nets.h::asm_record_len)')
+    for shape in SHAPES:
+        IN, H1, H2, H3 = shape
+        out.append(f'static_assert(asm_record_len({IN}, {H1}, {H2}, {H3}) == {record_len(*shape)}, "KBLOB record layout");')
+    out.append('')
+    out.append('template <int IN, int H1, int H2, int H3>')
+    out.append('__device__ __forceinline__ void mlp_class_asm(const float *w, int count, unsigned lds_addr, unsigned lds_step, '
+               'float x0, float x1, float x2) {')
+    first = True
+    for shape in SHAPES:
+        IN, H1, H2, H3 = shape
+        kw = 'if' if first else 'else if'
+        out.append(f'    {kw} constexpr (IN == {IN} && H1 == {H1} && H2 == {H2} && H3 == {H3}) '
+                   f'mlp_class_asm_{IN}_{H1}_{H2}_{H3}(w, count, lds_addr, lds_step, x0, x1, x2);')
+        first = False
+    out.append('    else static_assert(IN < 0, "no asm body for this MLP shape");')
+    out.append('}')
+    with open(OUT, 'w') as f:
+        f.write('\n'.join(out) + '\n')
+    print('wrote', OUT, sum(len(l) for l in out), 'bytes')
+    for shape in SHAPES:
+        print(shape, 'record', record_len(*shape), 'groups', record_len(*shape) // 32)
+
+
+if __name__ == '__main__':
+    main()
