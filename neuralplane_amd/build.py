@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libneuralplane_hip.so')
 SOURCES = ['np_f16_kernels.hip']
-HEADERS = ['np_f16_device.h', 'np_math.h', 'np_nets.h', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
+HEADERS = ['np_f16_device.h', 'np_math.h', 'np_nets.h', 'np_mlp_asm.inc', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared']
 
 
@@ -36,7 +36,8 @@ def build_hip(force=False, verbose=False):
     """Compile every HIP source for gfx950 into libneuralplane_hip.so.  Returns the path."""
     if not force and not is_stale():
         return SO
-    cmd = [_hipcc()] + FLAGS + ['-o', SO] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get('NPF16_EXTRA_FLAGS', '').split()  # tuning experiments only (e.g. -DNPF16_BLOCK=64)
+    cmd = [_hipcc()] + FLAGS + extra + ['-o', SO] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -21,7 +21,13 @@
 
 namespace npf16 {
 
-constexpr int BLOCK = 256;
+#ifndef NPF16_BLOCK
+#define NPF16_BLOCK 128
+#endif
+#ifndef NPF16_MINWAVES
+#define NPF16_MINWAVES 3  // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int BLOCK = NPF16_BLOCK;
 constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
 // LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
 // (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
@@ -45,7 +51,7 @@ struct KArgs {
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
 // STEP=false: BaseEnv.reset (env_base.py:83-97)
 template <int TASK, int SOLVER, bool STEP>
-__global__ __launch_bounds__(BLOCK) void f16_env_kernel(const KArgs a) {
+__global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KArgs a) {
     __shared__ float lds[LDS_FLOATS];
     float *obs_tile = lds;
     const int t = threadIdx.x;

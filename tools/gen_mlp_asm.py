@@ -33,11 +33,11 @@ SHAPES = [(1, 20, 10, 0), (3, 20, 10, 0), (2, 20, 10, 0), (2, 20, 10, 5), (2, 20
 S_BASE = 32      # s[32:33] record pointer
 S_CNT = 35       # remaining nets
 S_W0 = 36        # s[36:99] four 16-dword weight buffers
-V_H = [100, 120, 140]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
-V_X = 150        # v150,v152,v154: the (normalised) inputs, even registers
-V_Y = 156        # net output
-V_ADDR = 157     # LDS byte address of the output slot
-V_CLOBBER = list(range(100, 158))
+V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
+V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
+V_Y = 126        # net output
+V_ADDR = 127     # LDS byte address of the output slot
+V_CLOBBER = list(range(70, 128))
 S_CLOBBER = list(range(32, 100))
 
 
