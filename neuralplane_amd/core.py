@@ -15,6 +15,7 @@ from . import _lib
 
 ASSET_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'f16_aero_mlp.bin')
 NUM_DERIVED = 20
+NUM_CACHED = 14
 
 
 def cfg_from_config(config, task, solver=None):
@@ -79,6 +80,12 @@ class F16Batch:
         # BaseEnv.__init__ leaves all three flags set so that the first reset()/step() initialises
         # every row (env_base.py:31-33)
         self.flags = torch.ones((3, n), dtype=torch.uint8, device=d)
+        # cross-step cache of the 14 force-side (alpha, beta)-only aero coefficients (np_f16_io.coef_cache).  It is
+        # valid only while nobody but the kernels wrote `s`: torch bumps `s._version` on every in-place
+        # write through a tensor (model.s[mask] = ...), raw-pointer kernel writes do not.
+        self.coef_cache = torch.empty(int(self.lib.np_f16_cache_floats(n)), dtype=torch.float32, device=d)
+        self._cache_valid = False
+        self._s_version = self.s._version
         self._derived = None
         self._derived_key = None
         self._version = 0
@@ -109,6 +116,11 @@ class F16Batch:
         io.reward = reward.data_ptr() if reward is not None else None
         io.rand_u = rand_u.data_ptr() if rand_u is not None else None
         io.noise = noise.data_ptr() if noise is not None else None
+        if self.s._version != self._s_version:  # the caller edited the state: cached coefficients are stale
+            self._cache_valid = False
+            self._s_version = self.s._version
+        io.coef_cache = self.coef_cache.data_ptr()
+        io.cache_valid = 1 if (self._cache_valid and not os.environ.get('NPF16_NO_CACHE')) else 0
         io.seed, io.call_idx, io.row0 = self.seed, self.call_idx, self.row0
         return io
 
@@ -147,6 +159,7 @@ class F16Batch:
         rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
         io = self._io(new_flags, action, obs, reward, rand_u, noise)
         _lib.check(self.lib.np_f16_step(self._ctx, self.n, C.byref(io), self._stream()))
+        self._cache_valid = True  # every row's coefficients were just rewritten for its new state
         self.flags = new_flags
         self.call_idx += 1
         self._version += 1

@@ -16,6 +16,9 @@
 namespace npf16 {
 
 __constant__ float c_kblob[KBLOB_FLOATS];
+// the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once per
+// context by the same device code (f16_reset_coef_kernel) so that they are bit-identical to an in-line evaluation
+__constant__ float c_reset_coef[NUM_CACHED];
 
 // Scenario constants, pre-rounded on the host exactly where the reference rounds them.
 struct DevCfg {
@@ -129,27 +132,28 @@ __device__ __forceinline__ float mlp_body(int w, const float (&x)[IN]) {
 // KB (it stays in the instruction cache) where straight-line code for 42 nets would be ~100 KB.
 // Each net's output goes to this lane's column of the LDS scratch: out[slot*LD] (ds_write_b32,
 // consecutive lanes -> consecutive banks), from where the coefficient build-up reads it back.
-template <int CL, bool FORCE_ONLY, int LD>
+template <int CL, int COUNT, int LD, int FIRST = 0>  // nets [FIRST, FIRST+COUNT) of class CL
 __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
     constexpr NetClass c = CLASSES[CL];
-    constexpr int n = FORCE_ONLY ? c.n_force : c.count;
+    constexpr int n = COUNT;
+    static_assert(COUNT >= 0 && FIRST >= 0 && FIRST + COUNT <= c.count, "class range");
 #if NPF16_ASM_MLP
     if constexpr (n > 0) {
         // one asm statement for the whole class; `out` points into LDS: the low 32 bits of the flat
         // address are the LDS byte offset ds_write_b32 wants
-        const unsigned lds_addr = (unsigned)(unsigned long long)(out + class_slot(CL) * LD);
+        const unsigned lds_addr = (unsigned)(unsigned long long)(out + (class_slot(CL) + FIRST) * LD);
         const float x0 = xn[c.grp[0]];
         const float x1 = c.n_in > 1 ? xn[c.grp[c.n_in > 1 ? 1 : 0]] : 0.0f;
         const float x2 = c.n_in > 2 ? xn[c.grp[c.n_in > 2 ? 2 : 0]] : 0.0f;
-        mlp_class_asm<c.n_in, c.h1, c.h2, c.h3>(c_kblob + class_base(CL), n, lds_addr, (unsigned)(LD * sizeof(float)), x0, x1, x2);
+        mlp_class_asm<c.n_in, c.h1, c.h2, c.h3, n, (int)(LD * sizeof(float))>(c_kblob + class_base(CL) + FIRST * class_stride(CL), lds_addr, x0, x1, x2);
     }
 #else
     if constexpr (n > 0) {
         float x[c.n_in];
 #pragma unroll
         for (int i = 0; i < c.n_in; i++) x[i] = xn[c.grp[i]];
-        int w = class_base(CL);
-        float *__restrict__ o = out + class_slot(CL) * LD;
+        int w = class_base(CL) + FIRST * class_stride(CL);
+        float *__restrict__ o = out + (class_slot(CL) + FIRST) * LD;
 #pragma nounroll
         for (int i = 0; i < n; i++) {
             *o = mlp_body<c.n_in, c.h1, c.h2, c.h3>(w, x);
@@ -160,19 +164,30 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
 #endif
 }
 
-template <bool FORCE_ONLY, int LD>
-__device__ __forceinline__ void eval_aero(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
-    eval_class<CL_DAMP, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_DLEF, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_C, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_D_RUD, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_D_LEF, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_E_LEF, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_E_RUD, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_F, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_ETA, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_YPLEF, FORCE_ONLY, LD>(xn, out);
-    eval_class<CL_YA20, FORCE_ONLY, LD>(xn, out);
+// the 36 nets that depend on (alpha, beta) only -> slots 0..35.  Within every class the nets that feed
+// xdot[6..8] (force side, 14 in total) come first.
+enum AbPart : int { AB_ALL = 0, AB_FORCE = 1, AB_REST = 2 };
+template <int LD, int PART>
+__device__ __forceinline__ void eval_ab(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
+#define NPF16_CLS(cl)                                                                                      \
+    eval_class<cl, (PART == AB_ALL ? CLASSES[cl].count : PART == AB_FORCE ? CLASSES[cl].n_force : CLASSES[cl].count - CLASSES[cl].n_force), \
+               LD, (PART == AB_REST ? CLASSES[cl].n_force : 0)>(xn, out)
+    NPF16_CLS(CL_DAMP);
+    NPF16_CLS(CL_DLEF);
+    NPF16_CLS(CL_D_RUD);
+    NPF16_CLS(CL_D_LEF);
+    NPF16_CLS(CL_E_LEF);
+    NPF16_CLS(CL_E_RUD);
+    NPF16_CLS(CL_F);
+    NPF16_CLS(CL_YPLEF);
+    NPF16_CLS(CL_YA20);
+#undef NPF16_CLS
+}
+// the el-dependent nets: the first N_C of (Cx Cz Cm Cn Cl) and eta_el -> slots 36..41
+template <int N_C, int N_ETA, int LD>
+__device__ __forceinline__ void eval_el(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
+    eval_class<CL_C, N_C, LD>(xn, out);
+    eval_class<CL_ETA, N_ETA, LD>(xn, out);
 }
 
 // The 9 distinct input normalisations (X - mean) / std of mean_std.csv.
@@ -192,9 +207,12 @@ struct Trig {  // sines/cosines of the attitude and flow angles of one state
 };
 
 // Aerodynamic force/moment coefficients -> xdot[6..11] (+ xdot[0..5] when FULL).
-// FULL=false evaluates only the 16 force-side nets needed for xdot[6..8] (the Overload check,
-// overload.py:37-42 -> F16_model.py:132-148): identical arithmetic for those three outputs.
-template <bool FULL, int LD>
+// FULL=false builds only xdot[6..8] (the Overload check, overload.py:37-42 -> F16_model.py:132-148)
+// from the 16 force-side coefficients: identical arithmetic for those three outputs.
+// PART: which alpha/beta-only nets are evaluated here — AB_ALL, AB_FORCE (FULL=false), or AB_REST
+// when the 14 force-side slots of `coef` already hold the values of THIS state (carried over from
+// the Overload evaluation of the previous step).
+template <bool FULL, int PART, int LD>
 __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
                                         float cpsi, float *__restrict__ coef, float (&xd)[12]) {
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
@@ -240,7 +258,8 @@ __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4
     const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
     const bool ok = (chk == chk);
     const float qnan = __builtin_nanf("");
-    eval_aero<!FULL, LD>(xn, coef);
+    eval_ab<LD, PART>(xn, coef);
+    eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, coef);
 #define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
 
     const float inv2vt = 1.0f / (2.0f * vt);
@@ -305,13 +324,13 @@ __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &t
 }
 
 // full derivative at (s,u) including the heading terms
-template <int LD>
+template <int PART, int LD>
 __device__ __forceinline__ void xdot_full(const float (&s)[12], const float (&u)[4], float *__restrict__ coef, float (&xd)[12]) {
     Trig tr;
     float tt, spsi, cpsi;
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
-    nlplant<true, LD>(s, u, tr, tt, spsi, cpsi, coef, xd);
+    nlplant<true, PART, LD>(s, u, tr, tt, spsi, cpsi, coef, xd);
 }
 
 // F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)

@@ -27,7 +27,12 @@ namespace npf16 {
 #ifndef NPF16_MINWAVES
 #define NPF16_MINWAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef NPF16_STAGGER_CYCLES
+#define NPF16_STAGGER_CYCLES 20000  // ~10 us at 2 GHz per phase step; 0 disables the de-phasing
+#endif
 constexpr int BLOCK = NPF16_BLOCK;
+// workgroups resident at once: 256 CUs x 4 SIMDs x NPF16_MINWAVES wave slots / waves per workgroup
+constexpr int FIRST_GENERATION = 256 * 4 * NPF16_MINWAVES / (BLOCK / 64);
 constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
 // LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
 // (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
@@ -43,6 +48,7 @@ struct KArgs {
     long long act_stride;
     float *obs, *reward;
     const float *rand_u, *noise;
+    float *cache;  // [workgroup][14][BLOCK] force-side alpha/beta-only coefficients at the current state (may be null)
     uint64_t seed, call_idx;
     long long row0, n;
     DevCfg cfg;
@@ -50,7 +56,9 @@ struct KArgs {
 
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
 // STEP=false: BaseEnv.reset (env_base.py:83-97)
-template <int TASK, int SOLVER, bool STEP>
+// CACHED    : a.cache holds, for every row, the 14 force-side alpha/beta-only coefficients of its CURRENT
+//             state (written by the previous step's Overload evaluation) -> the integrator skips them.
+template <int TASK, int SOLVER, bool STEP, bool CACHED>
 __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KArgs a) {
     __shared__ float lds[LDS_FLOATS];
     float *obs_tile = lds;
@@ -61,6 +69,22 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     const bool valid = i < a.n;
     const long long ic = valid ? i : a.n - 1;  // tail lanes shadow the last row; their stores are masked
     const DevCfg &cfg = a.cfg;
+
+    // ---- de-phasing -----------------------------------------------------------------------------------
+    // Every workgroup does identical work: load state (HBM) -> ~45 K VALU cycles -> store.  Launched
+    // together, the 3 waves that share a SIMD stay in lock-step, so the chip alternates between "everybody
+    // waits for HBM" and "everybody computes" and the memory time ADDS to the compute time (measured 0.50 ms
+    // vs 0.43 ms per step at N = 1e6, A/B in one session).  Delaying the workgroups of the first generation by
+    // (blockIdx % 3) x ~10 us spreads the phases (co-resident waves come from workgroups whose indices differ
+    // by a power of two, so % 3 separates them; keying on the SIMD wave-slot id of HW_REG_HW_ID measured
+    // worse: 0.45 ms); later workgroups inherit the phase of the workgroup whose slot they take.  Only done
+    // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
+    // assumption that affects speed only, never results.
+    if (STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
+        const long long wait = (long long)(blockIdx.x % 3) * NPF16_STAGGER_CYCLES;
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
 
     float s[12], u[4], tgt[3];
 #pragma unroll
@@ -89,6 +113,20 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         reset_row<TASK>(cfg, ru, s, u, tgt, sc);
     }
 
+    // cache tile of this workgroup: 14 rows of BLOCK floats, contiguous
+    float *cache_blk = a.cache ? a.cache + ((long long)blockIdx.x * NUM_CACHED) * BLOCK + t : nullptr;
+    if (STEP && CACHED) {  // coefficient columns <- cache (a reset aircraft sits at alpha = beta = 0)
+#pragma unroll
+        for (int k = 0; k < NUM_CACHED; k++) {
+            const float c = cache_blk[k * BLOCK];
+            coef[cached_slot(k) * BLOCK] = flagged ? c_reset_coef[k] : c;
+        }
+    }
+    if (!STEP && a.cache && flagged && valid) {  // reset(): keep the cache consistent for re-initialised rows
+#pragma unroll
+        for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = c_reset_coef[k];
+    }
+
     if (STEP) {
         // ---- F16Model.update (F16_model.py:51-67) ----
         float act[4];
@@ -106,7 +144,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         const float dt = cfg.dt;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
-            xdot_full<BLOCK>(s, u, coef, k1);
+            xdot_full<(CACHED ? AB_REST : AB_ALL), BLOCK>(s, u, coef, k1);
 #pragma unroll
             for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
         } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
@@ -117,7 +155,8 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma nounroll
             for (int stage = 0; stage < 4; stage++) {
                 float kk[12];
-                xdot_full<BLOCK>(y, u, coef, kk);
+                if (CACHED && stage == 0) xdot_full<AB_REST, BLOCK>(y, u, coef, kk);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, BLOCK>(y, u, coef, kk);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -163,9 +202,10 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     bool done = false, bad = false;
     float reward = 0.0f;
     if (STEP) {
-        // Overload needs xdot[6..8] at the NEW (s,u): force-side nets only (overload.py:37-42)
+        // Overload needs xdot[6..8] at the NEW (s,u) (overload.py:37-42): the 14 force-side alpha/beta-only
+        // nets (kept for the next step's integrator -> cache) plus the force-side Cx, Cz
         float xd[12];
-        nlplant<false, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, xd);
+        nlplant<false, AB_FORCE, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, xd);
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
         done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done, bad, reward);
@@ -183,6 +223,10 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         a.fout1[i] = bad ? 1 : 0;
         a.fout2[i] = 0;
         if (STEP) a.reward[i] = reward;
+        if (STEP && a.cache) {
+#pragma unroll
+            for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = coef[cached_slot(k) * BLOCK];
+        }
     }
 
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
@@ -224,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
     float xd[12];
-    nlplant<true, BLOCK>(s, u, tr, tt, spsi, cpsi, coef, xd);
+    nlplant<true, AB_ALL, BLOCK>(s, u, tr, tt, spsi, cpsi, coef, xd);
     float a3[3];
     body_acceleration(s, tr, xd, a3);
     const float inv_grav = (float)(1.0 / 32.174), minv_grav = (float)(-1.0 / 32.174);  // F16_model.py:166,176-178
@@ -243,6 +287,20 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     out[17 * ld_out + i] = nz;
     out[18 * ld_out + i] = e2t;
     out[19 * ld_out + i] = eas;
+}
+
+// cached coefficients of a reset aircraft (alpha = beta = 0) -> out[14]; run once per context
+__global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out) {
+    __shared__ float lds[NUM_LIVE_NETS * BLOCK];
+    float *coef = lds + threadIdx.x;
+    float xn[NUM_NORM_GROUPS];
+    const float r2d = (float)(180.0 / 3.141592653589793);
+    normalise_inputs(0.0f * r2d, 0.0f * r2d, 0.0f, xn);
+    eval_ab<BLOCK, AB_FORCE>(xn, coef);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NUM_CACHED; k++) out[k] = coef[cached_slot(k) * BLOCK];
+    }
 }
 
 }  // namespace npf16
@@ -428,7 +486,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.fin0 = io->done_in; a.fin1 = io->bad_in; a.fin2 = io->timeout_in;
     a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward;
-    a.rand_u = io->rand_u; a.noise = io->noise; a.seed = io->seed; a.call_idx = io->call_idx;
+    a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t st = (hipStream_t)stream;
@@ -444,7 +502,13 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         }
         NP_HIP(hipEventRecord(ev.first, st));
     }
-#define NP_LAUNCH(T, S) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP>), grid, block, 0, st, a)
+    const bool cached = STEP && io->coef_cache && io->cache_valid;
+    if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
+#define NP_LAUNCH(T, S)                                                                                   \
+    do {                                                                                                  \
+        if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP>), grid, block, 0, st, a);        \
+        else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false>), grid, block, 0, st, a);              \
+    } while (0)
     const int key = ctx->task * 2 + (STEP ? ctx->solver : 0);
     switch (key) {
     case 0: NP_LAUNCH(0, 0); break;
@@ -469,6 +533,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
 extern "C" {
 
 int np_abi_version(void) { return NP_ABI_VERSION; }
+int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHED; }
 const char *np_last_error(void) { return g_err.c_str(); }
 
 int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg *cfg, int device, np_f16_ctx **out) {
@@ -488,6 +553,18 @@ int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg 
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("device arch ") + prop.gcnArchName + " is not gfx950 (MI355X)");
     NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_kblob), kb.data(), sizeof(float) * KBLOB_FLOATS));
+    {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
+        float *d_rc = nullptr;
+        NP_HIP(hipMalloc(&d_rc, sizeof(float) * NUM_CACHED));
+        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc);
+        hipError_t e1 = hipGetLastError();
+        hipError_t e2 = hipDeviceSynchronize();
+        hipError_t e3 = hipMemcpyToSymbol(HIP_SYMBOL(c_reset_coef), d_rc, sizeof(float) * NUM_CACHED, 0, hipMemcpyDeviceToDevice);
+        (void)hipFree(d_rc);
+        NP_HIP(e1);
+        NP_HIP(e2);
+        NP_HIP(e3);
+    }
     np_f16_ctx *ctx = new np_f16_ctx();
     ctx->device = device;
     ctx->task = cfg->task;

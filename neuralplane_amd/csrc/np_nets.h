@@ -64,22 +64,31 @@ struct NetClass {
     int nets[MAX_CLASS_NETS];  // NetId of each member, force-side first
 };
 
-enum ClassId : int { CL_DAMP, CL_DLEF, CL_C, CL_D_RUD, CL_D_LEF, CL_E_LEF, CL_E_RUD, CL_F, CL_ETA, CL_YPLEF, CL_YA20, NUM_CLASSES };
+// Classes are ordered so that the 36 nets whose inputs are (alpha, beta) only come first (output
+// slots 0..35).  The Overload check at the END of step t evaluates the 14 force-side ones among them
+// at the new state; those values are exactly what the integrator needs at the START of step t+1
+// (same alpha, beta; only `el` changes with the new action), so they are carried across steps in a
+// per-aircraft cache instead of being re-evaluated.  The two el-dependent classes
+// (Cx Cz Cm Cn Cl, eta_el) follow (slots 36..41).
+enum ClassId : int { CL_DAMP, CL_DLEF, CL_D_RUD, CL_D_LEF, CL_E_LEF, CL_E_RUD, CL_F, CL_YPLEF, CL_YA20, CL_C, CL_ETA, NUM_CLASSES };
+constexpr int NUM_AB_CLASSES = 9;  // CL_DAMP .. CL_YA20
+constexpr int NUM_AB_NETS = 36;    // output slots 0..35
+constexpr int NUM_CACHED = 14;     // force-side alpha/beta-only nets: the first n_force of every AB class
 
 constexpr NetClass CLASSES[NUM_CLASSES] = {
     /* CL_DAMP  */ {1, 20, 10, 0, {G_A_DAMP, G_NONE, G_NONE}, 12, 4,
                     {N_Cxq, N_Cyr, N_Cyp, N_Czq, N_Clr, N_Clp, N_Cmq, N_Cnr, N_Cnp, N_dCnbeta, N_dClbeta, N_dCm}},
     /* CL_DLEF  */ {1, 20, 10, 0, {G_A_DLEF, G_NONE, G_NONE}, 7, 2,
                     {N_dCxq_lef, N_dCyr_lef, N_dClr_lef, N_dClp_lef, N_dCmq_lef, N_dCnr_lef, N_dCnp_lef}},
-    /* CL_C     */ {3, 20, 10, 0, {G_A_C, G_B_C, G_E_C}, 5, 2, {N_Cx, N_Cz, N_Cm, N_Cn, N_Cl}},
     /* CL_D_RUD */ {2, 20, 10, 0, {G_A_RUD, G_B_O, G_NONE}, 2, 1, {N_Cy, N_dCl_a20}},
     /* CL_D_LEF */ {2, 20, 10, 0, {G_A_LEF, G_B_O, G_NONE}, 2, 1, {N_dCx_lef, N_dCl_lef}},
     /* CL_E_LEF */ {2, 20, 10, 5, {G_A_LEF, G_B_O, G_NONE}, 4, 2, {N_dCz_lef, N_dCy_lef, N_dCm_lef, N_dCn_lef}},
     /* CL_E_RUD */ {2, 20, 10, 5, {G_A_RUD, G_B_O, G_NONE}, 4, 1, {N_dCy_r30, N_dCn_r30, N_dCl_r30, N_dCn_a20}},
     /* CL_F     */ {2, 20, 20, 10, {G_A_LEF, G_B_O, G_NONE}, 3, 1, {N_dCy_a20_lef, N_dCn_a20_lef, N_dCl_a20_lef}},
-    /* CL_ETA   */ {1, 20, 10, 0, {G_E_ETA, G_NONE, G_NONE}, 1, 0, {N_eta_el}},
     /* CL_YPLEF */ {1, 20, 10, 5, {G_A_DLEF, G_NONE, G_NONE}, 1, 1, {N_dCyp_lef}},
     /* CL_YA20  */ {2, 20, 10, 10, {G_A_RUD, G_B_O, G_NONE}, 1, 1, {N_dCy_a20}},
+    /* CL_C     */ {3, 20, 10, 0, {G_A_C, G_B_C, G_E_C}, 5, 2, {N_Cx, N_Cz, N_Cm, N_Cn, N_Cl}},
+    /* CL_ETA   */ {1, 20, 10, 0, {G_E_ETA, G_NONE, G_NONE}, 1, 0, {N_eta_el}},
 };
 
 constexpr int NUM_LIVE_NETS = 42;  // 43 minus the dead delta_Czq_lef
@@ -92,14 +101,15 @@ constexpr int class_params(const NetClass &c) {
 }
 // KBLOB record of one net (floats), laid out for the asm bodies (tools/gen_mlp_asm.py): rows padded
 // to an even length so that every (neuron j, j+1) weight pair is an even-aligned SGPR pair, the
-// record padded to whole groups of 32 floats.
+// record padded to whole weight-stream groups (ASM_GROUP floats).
+constexpr int ASM_GROUP = 48;  // floats per weight-stream group (3 x s_load_dwordx16), see tools/gen_mlp_asm.py
 constexpr int pad2(int n) { return n + (n & 1); }
 constexpr int asm_record_len(int n_in, int h1, int h2, int h3) {
     int n = pad2(h1) + n_in * pad2(h1) + pad2(h2) + h1 * pad2(h2);
     if (h3 > 0) n += pad2(h3) + h2 * pad2(h3) + pad2(1 + h3);
     else n += pad2(1 + h2);
     n += 2;  // out_std, out_mean
-    return (n + 31) / 32 * 32;
+    return (n + ASM_GROUP - 1) / ASM_GROUP * ASM_GROUP;
 }
 // KBLOB stride of one net of a class
 constexpr int class_stride(int cl) { return asm_record_len(CLASSES[cl].n_in, CLASSES[cl].h1, CLASSES[cl].h2, CLASSES[cl].h3); }
@@ -117,8 +127,23 @@ constexpr int class_slot(int cl) {  // output slot of the first net of class cl
     return s;
 }
 // + padding: the weight stream prefetches one group (32 floats) past the last record it evaluates
-constexpr int KBLOB_FLOATS = class_base(NUM_CLASSES) + 64;
+constexpr int KBLOB_FLOATS = class_base(NUM_CLASSES) + 2 * ASM_GROUP;
 static_assert(class_slot(NUM_CLASSES) == NUM_LIVE_NETS, "every live net belongs to exactly one class");
+static_assert(class_slot(NUM_AB_CLASSES) == NUM_AB_NETS, "alpha/beta-only nets occupy slots 0..35");
+constexpr int num_force_ab() {
+    int n = 0;
+    for (int cl = 0; cl < NUM_AB_CLASSES; cl++) n += CLASSES[cl].n_force;
+    return n;
+}
+static_assert(num_force_ab() == NUM_CACHED, "cached nets = force-side alpha/beta-only nets");
+// cache row r (0..13) <-> output slot: the r-th force-side AB net in class order
+constexpr int cached_slot(int r) {
+    for (int cl = 0; cl < NUM_AB_CLASSES; cl++) {
+        if (r < CLASSES[cl].n_force) return class_slot(cl) + r;
+        r -= CLASSES[cl].n_force;
+    }
+    return -1;
+}
 
 // output slot (position in class order) of a net; -1 for the dead net
 constexpr int slot_of(int net) {

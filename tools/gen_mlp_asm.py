@@ -30,15 +30,18 @@ OUT = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_mlp_asm
 SHAPES = [(1, 20, 10, 0), (3, 20, 10, 0), (2, 20, 10, 0), (2, 20, 10, 5), (2, 20, 20, 10), (1, 20, 10, 5), (2, 20, 10, 10)]
 
 # fixed registers (declared as clobbers of every statement)
-S_BASE = 32      # s[32:33] record pointer
-S_CNT = 35       # remaining nets
-S_W0 = 36        # s[36:99] four 16-dword weight buffers
+CPG = 3          # 16-dword chunks per group (a group is retired by ONE s_waitcnt lgkmcnt(0))
+NBUF = 2 * CPG   # double-buffered groups
+GROUP = 16 * CPG # floats per group
+S_W0 = 4         # s[4:99] six 16-dword weight buffers
+S_BASE = 100     # s[100:101] record pointer
+S_CNT = 'vcc_lo' # remaining nets
 V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
 V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
 V_Y = 126        # net output
 V_ADDR = 127     # LDS byte address of the output slot
 V_CLOBBER = list(range(70, 128))
-S_CLOBBER = list(range(32, 100))
+S_CLOBBER = list(range(S_W0, S_W0 + 16 * NBUF)) + [S_BASE, S_BASE + 1]
 
 
 def pad2(n):
@@ -52,7 +55,7 @@ def record_len(IN, H1, H2, H3):
         n += pad2(h) + prev * pad2(h)
         prev = h
     n += pad2(1 + prev) + 2
-    return (n + 31) // 32 * 32
+    return (n + GROUP - 1) // GROUP * GROUP
 
 
 class Body:
@@ -62,28 +65,28 @@ class Body:
         self.IN, self.H1, self.H2, self.H3 = shape
         self.len = record_len(*shape)
         self.nch = self.len // 16
-        self.parity = parity  # 0: first group in buffers 0,1 ; 1: in buffers 2,3
+        self.parity = parity  # 0: first group in the first CPG buffers ; 1: in the other CPG buffers
         self.ins = []
         self.pos = 0
         self.cur_group = -1
 
     def sreg(self, pos):
         c, l = divmod(pos, 16)
-        b = (c + 2 * self.parity) % 4
+        b = (c + CPG * self.parity) % NBUF
         return S_W0 + 16 * b + l
 
     def buf_of_chunk(self, c):
-        return S_W0 + 16 * ((c + 2 * self.parity) % 4)
+        return S_W0 + 16 * ((c + CPG * self.parity) % NBUF)
 
     def touch(self, pos):
         """Called before an instruction that reads record position `pos`: emits the group boundary
         (wait for this group, issue the loads of the next one) when a new group starts."""
-        g = pos // 32
+        g = pos // GROUP
         while self.cur_group < g:
             self.cur_group += 1
-            c = 2 * self.cur_group
+            c = CPG * self.cur_group
             self.ins.append('s_waitcnt lgkmcnt(0)')
-            for cc in (c + 2, c + 3):  # next group (runs into the next record when cc >= nch: contiguous)
+            for cc in range(c + CPG, c + 2 * CPG):  # next group (runs into the next record when cc >= nch: contiguous)
                 self.ins.append(f's_load_dwordx16 s[{self.buf_of_chunk(cc)}:{self.buf_of_chunk(cc) + 15}], '
                                 f's[{S_BASE}:{S_BASE + 1}], 0x{cc * 64:x}')
 
@@ -154,38 +157,38 @@ class Body:
         # make sure every group of the record passed its boundary (padding groups included), so that
         # the stream position is exactly one record further when the next net starts
         self.touch(self.len - 1)
-        assert self.cur_group == self.len // 32 - 1
+        assert self.cur_group == self.len // GROUP - 1
         return self.ins
 
 
 def gen_function(shape):
     IN, H1, H2, H3 = shape
     ln = record_len(*shape)
-    ngroups = ln // 32
+    ngroups = ln // GROUP
     two_parities = ngroups % 2 == 1
     name = f'mlp_class_asm_{IN}_{H1}_{H2}_{H3}'
     lines = []
     A = lines.append
     A(f'// shape {IN}-{H1}-{H2}' + (f'-{H3}' if H3 else '') + f'-1: record {ln} floats = {ngroups} groups'
       + (' (odd: two buffer parities)' if two_parities else ''))
-    A(f'__device__ __forceinline__ void {name}(const float *w, int count, unsigned lds_addr, unsigned lds_step, '
-      'float x0, float x1, float x2) {')
+    A('template <int COUNT, int LDS_STEP>')
+    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_addr, float x0, float x1, float x2) {{')
     A('    asm volatile(')
 
     def emit(s):
         A(f'        "{s}\\n\\t"')
 
     emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
-    emit(f's_mov_b32 s{S_CNT}, %[cnt]')
+    emit(f's_mov_b32 {S_CNT}, %[cnt]')
     emit(f'v_mov_b32 v{V_X}, %[x0]')
     if IN > 1:
         emit(f'v_mov_b32 v{V_X + 2}, %[x1]')
     if IN > 2:
         emit(f'v_mov_b32 v{V_X + 4}, %[x2]')
     emit(f'v_mov_b32 v{V_ADDR}, %[addr]')
-    # prologue: first group of the first net into buffers 0,1
-    emit(f's_load_dwordx16 s[{S_W0}:{S_W0 + 15}], s[{S_BASE}:{S_BASE + 1}], 0x0')
-    emit(f's_load_dwordx16 s[{S_W0 + 16}:{S_W0 + 31}], s[{S_BASE}:{S_BASE + 1}], 0x40')
+    # prologue: first group of the first net into the first CPG buffers
+    for c in range(CPG):
+        emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
     emit('.LNP_LOOP_%=:')
     for parity in ([0, 1] if two_parities else [0]):
         for ins in Body(shape, parity).build():
@@ -194,8 +197,8 @@ def gen_function(shape):
         emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
         emit(f's_add_u32 s{S_BASE}, s{S_BASE}, 0x{ln * 4:x}')
         emit(f's_addc_u32 s{S_BASE + 1}, s{S_BASE + 1}, 0')
-        emit(f's_sub_u32 s{S_CNT}, s{S_CNT}, 1')
-        emit(f's_cmp_lg_u32 s{S_CNT}, 0')
+        emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
+        emit(f's_cmp_lg_u32 {S_CNT}, 0')
         if two_parities and parity == 0:
             emit('s_cbranch_scc0 .LNP_DONE_%=')
         else:
@@ -203,8 +206,8 @@ def gen_function(shape):
     emit('.LNP_DONE_%=:')
     emit('s_waitcnt lgkmcnt(0)')  # retire the dangling prefetch of the record after the last one
     A('        :')
-    A('        : [w] "s"(w), [cnt] "s"(count), [addr] "v"(lds_addr), [step] "s"(lds_step), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2)')
-    clob = ', '.join([f'"v{r}"' for r in V_CLOBBER] + [f'"s{r}"' for r in S_CLOBBER] + ['"scc"', '"memory"'])
+    A('        : [w] "s"(w), [cnt] "n"(COUNT), [addr] "v"(lds_addr), [step] "n"(LDS_STEP), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2)')
+    clob = ', '.join([f'"v{r}"' for r in V_CLOBBER] + [f'"s{r}"' for r in S_CLOBBER] + ['"vcc"', '"scc"', '"memory"'])
     A(f'        : {clob});')
     A('}')
     A('')
@@ -223,15 +226,14 @@ def main():
         IN, H1, H2, H3 = shape
         out.append(f'static_assert(asm_record_len({IN}, {H1}, {H2}, {H3}) == {record_len(*shape)}, "KBLOB record layout");')
     out.append('')
-    out.append('template <int IN, int H1, int H2, int H3>')
-    out.append('__device__ __forceinline__ void mlp_class_asm(const float *w, int count, unsigned lds_addr, unsigned lds_step, '
-               'float x0, float x1, float x2) {')
+    out.append('template <int IN, int H1, int H2, int H3, int COUNT, int LDS_STEP>')
+    out.append('__device__ __forceinline__ void mlp_class_asm(const float *w, unsigned lds_addr, float x0, float x1, float x2) {')
     first = True
     for shape in SHAPES:
         IN, H1, H2, H3 = shape
         kw = 'if' if first else 'else if'
         out.append(f'    {kw} constexpr (IN == {IN} && H1 == {H1} && H2 == {H2} && H3 == {H3}) '
-                   f'mlp_class_asm_{IN}_{H1}_{H2}_{H3}(w, count, lds_addr, lds_step, x0, x1, x2);')
+                   f'mlp_class_asm_{IN}_{H1}_{H2}_{H3}<COUNT, LDS_STEP>(w, lds_addr, x0, x1, x2);')
         first = False
     out.append('    else static_assert(IN < 0, "no asm body for this MLP shape");')
     out.append('}')
@@ -239,7 +241,7 @@ def main():
         f.write('\n'.join(out) + '\n')
     print('wrote', OUT, sum(len(l) for l in out), 'bytes')
     for shape in SHAPES:
-        print(shape, 'record', record_len(*shape), 'groups', record_len(*shape) // 32)
+        print(shape, 'record', record_len(*shape), 'groups', record_len(*shape) // GROUP)
 
 
 if __name__ == '__main__':
