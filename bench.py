@@ -51,10 +51,20 @@ def pmc_traffic(n, task):
 def cpu_baseline(task, budget_s=15.0):
     """The CPU oracle (oracle/, the C restatement of the reference path) timed on this box's host
     cores on a bounded sample of the same workload.  A reported baseline, never the thing shipped."""
+    import math
     import numpy as np
+    # threads = CPUs this process may really use (affinity mask, capped by the cgroup CPU quota): libgomp's
+    # default is the machine's CPU count, which oversubscribes a container limited to a few cores
+    cpus = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            cpus = max(1, min(cpus, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
     from oracle.f16_oracle import Oracle
-    o = Oracle(task)
-    n = 20000
+    o = Oracle(task, threads=cpus)  # (OMP_NUM_THREADS is too late here: torch already initialised libgomp)
+    n = 4096 * max(4, cpus)
     st = Oracle.new_state(n)
     rng = np.random.RandomState(0)
     acts = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(4)]

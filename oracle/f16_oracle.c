@@ -793,6 +793,14 @@ int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, flo
     return 0;
 }
 
+void f16o_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int f16o_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

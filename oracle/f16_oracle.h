@@ -102,6 +102,7 @@ int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, flo
               int64_t row0, float *obs, float *reward);
 
 int f16o_num_threads(void);
+void f16o_set_threads(int n); /* OpenMP threads used by the batched entry points */
 
 #ifdef __cplusplus
 }

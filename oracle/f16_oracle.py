@@ -87,7 +87,7 @@ def _p(a, t=C.c_float):
 class Oracle:
     """One loaded model + scenario config.  State lives in the caller's numpy arrays."""
 
-    def __init__(self, task='heading', solver=None, overrides=None, blob_path=DEFAULT_BLOB, mode=0):
+    def __init__(self, task='heading', solver=None, overrides=None, blob_path=DEFAULT_BLOB, mode=0, threads=None):
         self.lib = C.CDLL(build())
         L = self.lib
         L.f16o_model_load.restype = C.c_void_p
@@ -109,6 +109,8 @@ class Oracle:
         self.task = task
         self.cfg = load_cfg(task, solver, overrides)
         self.mode = mode
+        if threads:
+            L.f16o_set_threads(int(threads))
         self.threads = L.f16o_num_threads()
 
     def __del__(self):

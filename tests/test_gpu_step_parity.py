@@ -118,3 +118,64 @@ def test_derived_getters_bit_exact_vs_oracle(golden_dir):
     err = np.abs(d[12:15].T - g['accel']) / np.maximum(np.abs(g['accel']), 1.0)
     assert err.max() < 1e-4
     assert np.abs(d[18] - g['eas2tas']).max() < 1e-6 and np.abs(d[19] - g['eas']).max() / 1000 < 1e-6
+
+
+def test_cross_step_cache_is_invalidated_by_external_state_edits():
+    """The 14 cached aero coefficients are valid only while nobody but the kernels wrote `s`.  Editing the
+    state through the reference-style views (`model.s[rows] = ...`, planning_env.py:166) between steps must
+    fall back to the un-cached kernel for that step; results stay bit-identical to the oracle either way."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    n, seed = 700, 3
+    env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=seed, device='cuda:0')
+    o = Oracle('heading')
+    st = Oracle.new_state(n)
+    rng = np.random.RandomState(9)
+    env.reset()
+    o.reset(st, seed=seed, call_idx=0)
+    b = env._batch
+    used_cached = []
+    for t in range(12):
+        if t in (4, 9):  # push some aircraft to another attitude / speed behind the kernels' back
+            rows = torch.arange(0, n, 7, device='cuda')
+            s_view = env.model.s
+            s_view[rows, 7] = 0.21          # alpha
+            s_view[rows, 8] = -0.05         # beta
+            s_view[rows, 6] = 640.0         # vt
+            st['s'][::7, 7], st['s'][::7, 8], st['s'][::7, 6] = 0.21, -0.05, 640.0
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        valid_before = b._cache_valid and b.s._version == b._s_version
+        used_cached.append(bool(valid_before))
+        obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, o_done, o_bad, _ = o.step(st, a, seed=seed, call_idx=t + 1)
+        assert _same(env.model.s.cpu().numpy(), st['s']), f'state differs at step {t}'
+        assert _same(obs.cpu().numpy(), o_obs) and _same(rew.cpu().numpy(), o_rew), f'obs/reward differ at step {t}'
+        assert np.array_equal(bad.cpu().numpy(), o_bad.astype(bool)) and np.array_equal(done.cpu().numpy(), o_done.astype(bool))
+    assert used_cached[0] is False and used_cached[4] is False and used_cached[9] is False
+    assert all(used_cached[i] for i in (1, 2, 3, 5, 6, 7, 8, 10, 11))
+
+
+def test_env_surface_matches_reference_contract():
+    """Shapes, dtypes, attributes and getters of the ControlEnv / GPUVecEnv surface."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import GPUVecEnv
+    n = 130
+    venv = GPUVecEnv([lambda: ControlEnv(num_envs=n, config='control', model='F16', random_seed=1, device='cuda:0')])
+    env = venv.env
+    assert (env.n, env.num_agents, env.num_observation, env.num_actions) == (n, 1, 22, 4)
+    assert env.observation_space.shape == (22,) and env.action_space.shape == (4,)
+    assert env.is_done.dtype == torch.bool and bool(env.is_done.all()) and env.step_count.dtype == torch.int64
+    obs = venv.reset()
+    assert obs.shape == (n, 1, 22) and obs.dtype == np.float32 and not env.is_done.any()
+    o, r, d, b, t, info = venv.step(np.zeros((n, 1, 4), np.float32))
+    assert o.shape == (n, 1, 22) and r.shape == (n, 1, 1) and d.shape == b.shape == t.shape == (n, 1, 1) and info == {}
+    assert d.dtype == np.bool_ and r.dtype == np.float32 and int(env.step_count[0]) == 1
+    m = env.model
+    assert m.s.shape == (n, 12) and m.u.shape == (n, 5) and m.dt == 0.02
+    assert all(x.shape == (n,) for x in m.get_position() + m.get_posture() + m.get_angular_velocity() + m.get_acceleration())
+    assert m.get_G().shape == (n,) and m.get_EAS().shape == (n,) and m.get_extended_state().shape == (n, 17)
+    assert torch.allclose(m.get_TAS(), m.get_vt()) and env.task.target_pitch.shape == (n,) and env.task.noise_scale == 0.01
+    # flags returned by step are fresh tensors: the next step does not mutate them
+    d_prev = env.is_done.clone()
+    keep = env.is_done
+    venv.step(np.ones((n, 1, 4), np.float32))
+    assert torch.equal(keep, d_prev)
