@@ -175,6 +175,24 @@ class F16Batch:
             self._derived, self._derived_key = out, key
         return self._derived
 
+    # -- checkpoint / resume (the reference never checkpoints env state) ------------
+    def state_dict(self):
+        """Everything needed to continue the trajectories bit for bit: state, targets, counters, the flags
+        left by the last step and the RNG counter (the RNG is counter-based: no generator state)."""
+        return {'s': self.s.clone(), 'u': self.u.clone(), 'tgt': self.tgt.clone(), 'step_count': self.step_count.clone(),
+                'flags': self.flags.clone(), 'call_idx': int(self.call_idx), 'seed': int(self.seed), 'row0': int(self.row0),
+                'task': self.task, 'n': self.n}
+
+    def load_state_dict(self, sd):
+        if sd['n'] != self.n or sd['task'] != self.task:
+            raise ValueError(f"checkpoint is for n={sd['n']}, task={sd['task']}; this batch is n={self.n}, task={self.task}")
+        for k in ('s', 'u', 'tgt', 'step_count'):
+            getattr(self, k).copy_(sd[k].to(self.device))
+        self.flags = sd['flags'].to(self.device).clone()
+        self.call_idx, self.seed, self.row0 = int(sd['call_idx']), int(sd['seed']), int(sd['row0'])
+        self._cache_valid = False  # cached coefficients belong to the state that was just overwritten
+        self._version += 1
+
     # -- kernel timing (bench.py) ---------------------------------------------------------------
     def set_timing(self, enable):
         _lib.check(self.lib.np_f16_set_timing(self._ctx, int(bool(enable))))

@@ -77,6 +77,13 @@ class BaseEnv(Env):
     def seed(self, random_seed):
         self._batch.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
 
+    def state_dict(self):
+        """Env-state checkpoint (tensors on the env device); see F16Batch.state_dict."""
+        return self._batch.state_dict()
+
+    def load_state_dict(self, sd):
+        self._batch.load_state_dict(sd)
+
     # -- the hot path ------------------------------------------------------------------------------
     def reset(self, rand_u=None, noise=None):
         """Re-initialise flagged rows, clear the flags, return obs[n,22] (env_base.py:83-97)."""

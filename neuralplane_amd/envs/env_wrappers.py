@@ -34,3 +34,20 @@ class GPUVecEnv:
 
     def close(self):
         pass
+
+
+class DeviceVecEnv(GPUVecEnv):
+    """GPUVecEnv with the same `[E, A, ...]` shapes but torch tensors that never leave the GPU
+    (SURVEY.md §8f N1): GPUVecEnv pays 1 H2D + 5 D2H copies per step (~126 B per aircraft, ~2 ms at
+    N = 1e6 over PCIe Gen5 — five times the fused kernel); a device-resident policy / rollout buffer
+    does not need them."""
+
+    def reset(self):
+        obs = self.env.reset()
+        return self._shape(obs, obs.shape[-1])
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(self.n, -1)
+        obs, reward, done, bad_done, exceed_time_limit, info = self.env.step(a)
+        return (self._shape(obs, obs.shape[-1]), self._shape(reward, 1), self._shape(done, 1),
+                self._shape(bad_done, 1), self._shape(exceed_time_limit, 1), info)

@@ -179,3 +179,29 @@ def test_env_surface_matches_reference_contract():
     keep = env.is_done
     venv.step(np.ones((n, 1, 4), np.float32))
     assert torch.equal(keep, d_prev)
+
+
+def test_checkpoint_resume_is_bit_exact_and_device_vec_env_keeps_tensors_on_gpu(tmp_path):
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+    n = 900
+    mk = lambda: DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='tracking', model='F16', random_seed=4, device='cuda:0')])  # noqa: E731
+    g = torch.Generator(device='cuda')
+    g.manual_seed(0)
+    acts = [torch.rand((n, 1, 4), generator=g, device='cuda') * 2.4 - 1.2 for _ in range(40)]
+    a_env = mk()
+    obs = a_env.reset()
+    assert obs.is_cuda and obs.shape == (n, 1, 22)
+    for a in acts[:25]:
+        out = a_env.step(a)
+    assert all(t.is_cuda for t in out[:5]) and out[1].shape == (n, 1, 1) and out[2].dtype == torch.bool
+    torch.save(a_env.env.state_dict(), tmp_path / 'env.pt')
+    ref = [a_env.step(a) for a in acts[25:]]
+    b_env = mk()
+    b_env.env.load_state_dict(torch.load(tmp_path / 'env.pt'))
+    for a, r in zip(acts[25:], ref):
+        out = b_env.step(a)
+        for x, y in zip(out[:5], r[:5]):
+            assert torch.equal(x, y)
+    assert torch.equal(b_env.env.model.s, a_env.env.model.s) and torch.equal(b_env.env.step_count, a_env.env.step_count)
+    assert bool(ref[-1][3].any()) or bool(a_env.env.step_count.min() < 40)   # the resumed stretch really contained resets
