@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 2
+#define NP_ABI_VERSION 3
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -82,7 +82,11 @@ typedef struct np_f16_io {
      * whenever it modified `s` behind the library's back since the last np_f16_step on these buffers. */
     float *coef_cache;
     int32_t cache_valid;
-    int32_t reserved_;
+    /* inner_step != 0 selects the semantics of ONE of the 50 low-level iterations inside PlanningEnv.step
+     * (envs/planning_env.py:153-176): no auto-reset, rows whose *_in flags are already set keep their state
+     * (`s[reset] = recent_s[reset]`, controls still advance), step_count += 1 for every row, and the *_out
+     * flags ACCUMULATE (out = in | new), as BaseEnv.done does between two reset() calls (env_base.py:70-75). */
+    int32_t inner_step;
     uint64_t seed;         /* RNG key */
     uint64_t call_idx;     /* RNG counter word: the caller increments it once per reset()/step() call */
     int64_t row0;
@@ -120,6 +124,12 @@ int np_f16_step(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream);
  *   row  19     get_EAS()                                                                  */
 int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, int64_t ld, float *out,
                    int64_t ld_out, void *stream);
+
+/* PlanningEnv.low_level_obs(target_pitch, target_heading, target_vt) — envs/planning_env.py:60-142: the 22-float
+ * observation of the low-level controller (same layout as ControlTask.get_obs, no noise) for caller-supplied
+ * targets tgt3[3][ld].  obs: [n][22] row-major. */
+int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, const float *tgt3, int64_t ld,
+                        float *obs, void *stream);
 
 /* Average duration in ms of the `count` most recent np_f16_step launches on this context,
  * measured with HIP events recorded on the launch stream around each launch (0 disables;

@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NpF16Cfg(C.Structure):
@@ -39,12 +39,12 @@ class NpF16Io(C.Structure):
                 ('action', C.c_void_p), ('act_stride', C.c_int64),
                 ('obs', C.c_void_p), ('reward', C.c_void_p),
                 ('rand_u', C.c_void_p), ('noise', C.c_void_p),
-                ('coef_cache', C.c_void_p), ('cache_valid', C.c_int32), ('reserved_', C.c_int32),
+                ('coef_cache', C.c_void_p), ('cache_valid', C.c_int32), ('inner_step', C.c_int32),
                 ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64)]
 
 
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
-           'np_f16_step', 'np_f16_derived', 'np_f16_set_timing', 'np_f16_get_timing')
+           'np_f16_step', 'np_f16_derived', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing')
 
 _lib = None
 
@@ -74,6 +74,7 @@ def load():
     lib.np_f16_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16Io), C.c_void_p]
     lib.np_f16_derived.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                    C.c_void_p]
+    lib.np_f16_lowlevel_obs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.np_f16_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.np_f16_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if lib.np_abi_version() != ABI_VERSION:

@@ -103,7 +103,7 @@ class F16Batch:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _io(self, new_flags, action, obs, reward, rand_u, noise):
+    def _io(self, new_flags, action, obs, reward, rand_u, noise, inner=False):
         io = _lib.NpF16Io()
         io.s, io.u, io.tgt, io.ld = self.s.data_ptr(), self.u.data_ptr(), self.tgt.data_ptr(), self.n
         io.step_count = self.step_count.data_ptr()
@@ -121,6 +121,7 @@ class F16Batch:
             self._s_version = self.s._version
         io.coef_cache = self.coef_cache.data_ptr()
         io.cache_valid = 1 if (self._cache_valid and not os.environ.get('NPF16_NO_CACHE')) else 0
+        io.inner_step = 1 if inner else 0
         io.seed, io.call_idx, io.row0 = self.seed, self.call_idx, self.row0
         return io
 
@@ -133,9 +134,9 @@ class F16Batch:
         return t
 
     # -- launches ------------------------------------------------------------------------------
-    def reset(self, rand_u=None, noise=None):
+    def reset(self, rand_u=None, noise=None, want_obs=True):
         """BaseEnv.reset(): re-initialise flagged rows, clear all flags, return obs[n,22]."""
-        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device) if want_obs else None
         new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
         rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
         io = self._io(new_flags, None, obs, None, rand_u, noise)
@@ -145,8 +146,9 @@ class F16Batch:
         self._version += 1
         return obs
 
-    def step(self, action, rand_u=None, noise=None):
-        """BaseEnv.step(action): ONE kernel launch.  Returns obs, reward, flags[3,n] (uint8)."""
+    def step(self, action, rand_u=None, noise=None, inner=False):
+        """BaseEnv.step(action): ONE kernel launch.  Returns obs, reward, flags[3,n] (uint8).
+        inner=True: one low-level iteration of PlanningEnv.step (np_f16_io.inner_step)."""
         if action.device != self.device or action.dtype != torch.float32:
             action = action.to(device=self.device, dtype=torch.float32)
         if action.dim() != 2 or action.shape[0] != self.n or action.shape[1] < 4:
@@ -157,13 +159,23 @@ class F16Batch:
         reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
         new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
         rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
-        io = self._io(new_flags, action, obs, reward, rand_u, noise)
+        io = self._io(new_flags, action, obs, reward, rand_u, noise, inner=inner)
         _lib.check(self.lib.np_f16_step(self._ctx, self.n, C.byref(io), self._stream()))
         self._cache_valid = True  # every row's coefficients were just rewritten for its new state
         self.flags = new_flags
         self.call_idx += 1
         self._version += 1
         return obs, reward, new_flags
+
+    def lowlevel_obs(self, tgt3):
+        """PlanningEnv.low_level_obs for targets tgt3[3,n] (pitch, heading, vt) -> obs[n,22]."""
+        tgt3 = torch.as_tensor(tgt3, dtype=torch.float32, device=self.device).contiguous()
+        if tuple(tgt3.shape) != (3, self.n):
+            raise ValueError(f'tgt3 must be [3, {self.n}]')
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.np_f16_lowlevel_obs(self._ctx, self.n, self.s.data_ptr(), self.u.data_ptr(), tgt3.data_ptr(), self.n,
+                                                obs.data_ptr(), self._stream()))
+        return obs
 
     def derived(self):
         """[20,n] derived quantities at the current (s,u) (np_f16_derived), cached per state version."""

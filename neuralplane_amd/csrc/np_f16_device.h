@@ -463,8 +463,8 @@ __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, 
 // ---------------------------------------------------------------------------------------------
 template <int TASK>
 __device__ __forceinline__ void done_and_reward(const DevCfg &cfg, const float (&s)[12], const float (&tgt)[3],
-                                                const float (&acc3)[3], long long step_count, bool &done, bool &bad,
-                                                float &reward) {
+                                                const float (&acc3)[3], long long step_count, bool done_prev, bool bad_prev,
+                                                bool &done, bool &bad, float &reward) {
     const float PI_F = 3.14159265358979323846f;
     const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
     bool b = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
@@ -510,7 +510,8 @@ __device__ __forceinline__ void done_and_reward(const DevCfg &cfg, const float (
     }
     const bool off = (m3 | m4) | m5;
     b |= m1 & off;
-    const bool d = ((!off) & (!m1)) & m2;
+    b |= bad_prev;                                               // env_base.py:72-74: flags accumulate until the next reset()
+    const bool d = (((!off) & (!m1)) & m2) | done_prev;
     rew = 0.0f + rew;                                            // task_base.py:70-72
     rew = rew + (float)(-200 * (int)b + 200 * (int)d);           // event_driven_reward.py:28
     done = d;

@@ -48,6 +48,7 @@ struct KArgs {
     long long act_stride;
     float *obs, *reward;
     const float *rand_u, *noise;
+    int inner;     // one low-level iteration of PlanningEnv.step: no auto-reset, flagged rows frozen, flags accumulate
     float *cache;  // [workgroup][14][BLOCK] force-side alpha/beta-only coefficients at the current state (may be null)
     uint64_t seed, call_idx;
     long long row0, n;
@@ -96,8 +97,9 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     long long sc = a.step_count[ic];
     const bool flagged = (a.fin0[ic] | a.fin1[ic] | a.fin2[ic]) != 0;
 
+    const bool frozen = a.inner && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
     // ---- self.reset(): re-initialise rows flagged by the previous step (env_base.py:83-95) ----
-    if (flagged) {
+    if (flagged && !a.inner) {
         float ru[5];
         if (a.rand_u) {
 #pragma unroll
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) {
             const float c = cache_blk[k * BLOCK];
-            coef[cached_slot(k) * BLOCK] = flagged ? c_reset_coef[k] : c;
+            coef[cached_slot(k) * BLOCK] = (flagged && !a.inner) ? c_reset_coef[k] : c;
         }
     }
-    if (!STEP && a.cache && flagged && valid) {  // reset(): keep the cache consistent for re-initialised rows
+    if (!STEP && a.cache && flagged && valid && !a.inner) {  // reset(): keep the cache consistent for re-initialised rows
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = c_reset_coef[k];
     }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
             float k1[12];
             xdot_full<(CACHED ? AB_REST : AB_ALL), BLOCK>(s, u, coef, k1);
 #pragma unroll
-            for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
+            for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
         } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
             const float third = (float)(1.0 / 3.0);
             float y[12], k1[12], k2[12], k3[12];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 12; k++) s[k] = y[k];
+            for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : y[k];
         }
         sc += 1;  // env_base.py:102
     }
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         nlplant<false, AB_FORCE, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, xd);
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
-        done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done, bad, reward);
+        // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
+        const bool done_prev = a.inner && a.fin0[ic] != 0, bad_prev = a.inner && a.fin1[ic] != 0;
+        done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward);
     }
 
     if (valid) {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         a.step_count[i] = sc;
         a.fout0[i] = done ? 1 : 0;
         a.fout1[i] = bad ? 1 : 0;
-        a.fout2[i] = 0;
+        a.fout2[i] = (a.inner && a.fin2[ic] != 0) ? 1 : 0;
         if (STEP) a.reward[i] = reward;
         if (STEP && a.cache) {
 #pragma unroll
@@ -287,6 +291,42 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     out[17 * ld_out + i] = nz;
     out[18 * ld_out + i] = e2t;
     out[19 * ld_out + i] = eas;
+}
+
+// PlanningEnv.low_level_obs (planning_env.py:60-142): ControlTask-style observation for caller-supplied targets, no noise
+__global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__restrict__ sp, const float *__restrict__ up,
+                                                                 const float *__restrict__ tp, long long ld, float *__restrict__ obs,
+                                                                 long long n, DevCfg cfg) {
+    __shared__ float tile[BLOCK * OBS_LD];
+    const int t = threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * BLOCK, i = i0 + t;
+    const long long ic = i < n ? i : n - 1;
+    float s[12], u[4], tgt[3];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = sp[k * ld + ic];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = up[k * ld + ic];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tgt[k] = tp[k * ld + ic];
+    Trig tr;
+    float tt;
+    trig_of(s, tr, tt);
+    float o[22];
+    observe<1>(cfg, s, u, tgt, tr, o);
+#pragma unroll
+    for (int k = 0; k < 22; k++) tile[t * OBS_LD + k] = o[k];
+    __syncthreads();
+    const long long rows = (n - i0) < BLOCK ? (n - i0) : BLOCK;
+    const int total = (int)rows * 22;
+    float *dst = obs + i0 * 22;
+#pragma unroll
+    for (int it = 0; it < 22; it++) {
+        const int L = it * BLOCK + t;
+        if (L < total) {
+            const int r = L / 22, c = L - r * 22;
+            dst[L] = tile[r * OBS_LD + c];
+        }
+    }
 }
 
 // cached coefficients of a reset aircraft (alpha = beta = 0) -> out[14]; run once per context
@@ -486,6 +526,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.fin0 = io->done_in; a.fin1 = io->bad_in; a.fin2 = io->timeout_in;
     a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward;
+    a.inner = io->inner_step ? 1 : 0;
     a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
@@ -604,6 +645,20 @@ int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, i
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipLaunchKernelGGL(f16_derived_kernel, grid, block, 0, (hipStream_t)stream, s, u, (long long)ld, out, (long long)ld_out,
                        (long long)n, ctx->cfg.airspeed);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, const float *tgt3, int64_t ld, float *obs,
+                        void *stream) {
+    if (!ctx || !s || !u || !tgt3 || !obs) return fail("null argument");
+    if (n <= 0) return 0;
+    if (ld < n) return fail("leading dimension < n");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipLaunchKernelGGL(f16_lowlevel_obs_kernel, grid, block, 0, (hipStream_t)stream, s, u, tgt3, (long long)ld, obs, (long long)n,
+                       ctx->cfg);
     NP_HIP(hipGetLastError());
     return 0;
 }

@@ -707,8 +707,8 @@ static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float
 
 /* terminations (envs/termination_conditions/)) + rewards (envs/reward_functions/)) for one row */
 static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const float *s, const float *u,
-                            const float *tgt, int64_t step_count, uint8_t *done_o, uint8_t *bad_o,
-                            uint8_t *timeout_o, float *reward_o) {
+                            const float *tgt, int64_t step_count, int done_prev, int bad_prev, int timeout_prev,
+                            uint8_t *done_o, uint8_t *bad_o, uint8_t *timeout_o, float *reward_o) {
     /* Overload — overload.py:37-42 */
     float a[3];
     acceleration_row(m, s, u, a);
@@ -761,9 +761,14 @@ static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const floa
     int off = (m3 | m4) | m5;
     bad |= m1 & off;
     int done = ((!off) & (!m1)) & m2;
+    /* BaseEnv.done (env_base.py:70-75): self.is_done = self.is_done + done, ... — the env flags accumulate
+     * until the next reset(); inside BaseEnv.step they were just cleared, inside PlanningEnv.step's 50
+     * iterations (planning_env.py:153-176) they are not */
+    done |= done_prev;
+    bad |= bad_prev;
     *done_o = (uint8_t)done;
     *bad_o = (uint8_t)bad;
-    *timeout_o = 0;
+    *timeout_o = (uint8_t)(timeout_prev != 0);
     /* BaseTask.get_reward task_base.py:70-73: zeros += target reward; += EventDriven (int64 -> float)
      * event_driven_reward.py:28 with the env's accumulated flags */
     rew = 0.0f + rew;
@@ -771,26 +776,55 @@ static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const floa
     *reward_o = rew;
 }
 
-int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
-              int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
-              int64_t act_stride, const float *rand_u, const float *noise, uint64_t seed, uint64_t call_idx,
-              int64_t row0, float *obs, float *reward) {
+static int step_impl(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+                     int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+                     int64_t act_stride, const float *rand_u, const float *noise, uint64_t seed, uint64_t call_idx,
+                     int64_t row0, float *obs, float *reward, int inner) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) {
         float *si = s + 12 * i, *ui = u + 5 * i, *ti = tgt + 3 * i;
-        if (done[i] | bad[i] | timeout[i]) { /* self.reset()  env_base.py:100 */
+        const int flagged = done[i] | bad[i] | timeout[i];
+        const int dp = inner ? done[i] : 0, bp = inner ? bad[i] : 0, tp = inner ? timeout[i] : 0;
+        if (flagged && !inner) { /* self.reset()  env_base.py:100 */
             float ru[8];
             if (rand_u) memcpy(ru, rand_u + 5 * i, 5 * sizeof(float));
             else f16o_rng_uniforms(seed, call_idx, row0 + i, ru);
             reset_row(cfg, si, ui, ti, step_count + i, ru);
         }
+        float keep[12];
+        memcpy(keep, si, sizeof(keep));
         update_row(m, cfg, si, ui, action + act_stride * i); /* :101 */
+        if (inner && flagged) memcpy(si, keep, sizeof(keep)); /* planning_env.py:162-166: s[reset] = recent_s[reset] */
         step_count[i] += 1;                                  /* :102 */
         obs_row(cfg, si, ui, ti, obs + F16O_NOBS * i);       /* :103 */
         add_noise(cfg, obs + F16O_NOBS * i, noise ? noise + F16O_NOBS * i : NULL, seed, call_idx, row0 + i);
-        done_reward_row(m, cfg, si, ui, ti, step_count[i], done + i, bad + i, timeout + i, reward + i); /* :105-106 */
+        done_reward_row(m, cfg, si, ui, ti, step_count[i], dp, bp, tp, done + i, bad + i, timeout + i, reward + i); /* :105-106 */
     }
     return 0;
+}
+
+int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+              int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+              int64_t act_stride, const float *rand_u, const float *noise, uint64_t seed, uint64_t call_idx,
+              int64_t row0, float *obs, float *reward) {
+    return step_impl(m, cfg, n, s, u, tgt, step_count, done, bad, timeout, action, act_stride, rand_u, noise, seed, call_idx,
+                     row0, obs, reward, 0);
+}
+
+/* one of the 50 low-level iterations of PlanningEnv.step — envs/planning_env.py:153-176 */
+int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+                    int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+                    int64_t act_stride, const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0,
+                    float *obs, float *reward) {
+    return step_impl(m, cfg, n, s, u, tgt, step_count, done, bad, timeout, action, act_stride, NULL, noise, seed, call_idx,
+                     row0, obs, reward, 1);
+}
+
+/* PlanningEnv.low_level_obs — envs/planning_env.py:60-142: ControlTask-style observation, caller's targets, no noise */
+void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs) {
+    f16o_cfg c = *cfg;
+    c.task = F16O_TASK_CONTROL;
+    for (int64_t i = 0; i < n; i++) obs_row(&c, s + 12 * i, u + 5 * i, tgt3 + 3 * i, obs + F16O_NOBS * i);
 }
 
 void f16o_set_threads(int n) {

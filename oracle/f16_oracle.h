@@ -101,6 +101,15 @@ int f16o_step(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, flo
               int64_t act_stride, const float *rand_u, const float *noise, uint64_t seed, uint64_t call_idx,
               int64_t row0, float *obs, float *reward);
 
+/* One of the 50 low-level iterations inside PlanningEnv.step (envs/planning_env.py:153-176): no auto-reset,
+ * rows whose flags are already set keep their state (controls still advance), flags accumulate. */
+int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
+                    int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+                    int64_t act_stride, const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0,
+                    float *obs, float *reward);
+/* PlanningEnv.low_level_obs (envs/planning_env.py:60-142); tgt3[n][3] = (target_pitch, target_heading, target_vt) */
+void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs);
+
 int f16o_num_threads(void);
 void f16o_set_threads(int n); /* OpenMP threads used by the batched entry points */
 

@@ -219,6 +219,30 @@ class Oracle:
         assert rc == 0
         return obs
 
+    def lowlevel_obs(self, st, tgt3):
+        """PlanningEnv.low_level_obs for tgt3[n,3] = (target_pitch, target_heading, target_vt)."""
+        self._set_mode()
+        t = _f32(tgt3)
+        n = st['s'].shape[0]
+        obs = np.empty((n, 22), np.float32)
+        self.lib.f16o_lowlevel_obs(C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']), _p(t), _p(obs))
+        return obs
+
+    def step_inner(self, st, action, noise=None, seed=0, call_idx=0, row0=0):
+        """One low-level iteration of PlanningEnv.step (no auto-reset, flagged rows frozen, flags accumulate)."""
+        self._set_mode()
+        n = st['s'].shape[0]
+        a = _f32(action)
+        obs = np.empty((n, 22), np.float32)
+        rew = np.empty(n, np.float32)
+        nz = None if noise is None else _f32(noise)
+        rc = self.lib.f16o_step_inner(C.c_void_p(self.model), C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']),
+                                      _p(st['tgt']), _p(st['step_count'], C.c_int64), _p(st['done'], C.c_uint8),
+                                      _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(a), C.c_int64(a.shape[1]),
+                                      _p(nz), C.c_uint64(seed), C.c_uint64(call_idx), C.c_int64(row0), _p(obs), _p(rew))
+        assert rc == 0
+        return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()
+
     def step(self, st, action, rand_u=None, noise=None, seed=0, call_idx=0, row0=0):
         self._set_mode()
         n = st['s'].shape[0]

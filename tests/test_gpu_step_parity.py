@@ -205,3 +205,50 @@ def test_checkpoint_resume_is_bit_exact_and_device_vec_env_keeps_tensors_on_gpu(
             assert torch.equal(x, y)
     assert torch.equal(b_env.env.model.s, a_env.env.model.s) and torch.equal(b_env.env.step_count, a_env.env.step_count)
     assert bool(ref[-1][3].any()) or bool(a_env.env.step_count.min() < 40)   # the resumed stretch really contained resets
+
+
+def test_planning_env_bit_exact_vs_oracle_and_close_to_reference(golden_dir):
+    """PlanningEnv mirror (reset + 50 x {low-level obs kernel, controller, inner fused step}) with the reference's
+    recorded low-level actions replayed as the controller: == oracle bit for bit, masks == reference."""
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    g = np.load(f'{golden_dir}/planning_kat.npz')
+    hi = g['hi_actions']
+    n = hi.shape[1]
+
+    class Replay:
+        def __init__(self):
+            self.k, self.i, self.obs_seen = 0, 0, []
+
+        def __call__(self, obs, rnn, masks, deterministic=True):
+            a = torch.from_numpy(g[f'll_act_{self.k}'][self.i]).cuda()
+            self.obs_seen.append(obs)
+            self.i += 1
+            return a, None, rnn
+
+    ctrl = Replay()
+    env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cuda:0', controller=ctrl)
+    o = Oracle('tracking')
+    st = Oracle.new_state(n)
+    for k in range(hi.shape[0]):
+        ctrl.k, ctrl.i, ctrl.obs_seen = k, 0, []
+        # inject the reference's reset draws: PlanningEnv.step begins with self.reset()
+        env._batch.reset(rand_u=g[f'rand_u_{k}'], want_obs=False)
+        obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(hi[k]).cuda())
+        o.reset(st, rand_u=g[f'rand_u_{k}'], want_obs=False)
+        a = np.clip(hi[k], -1, 1).astype(np.float32)
+        tgt3 = np.stack([st['s'][:, 4] + a[:, 0] * np.float32(0.3), st['s'][:, 5] + a[:, 1] * np.float32(0.3),
+                         st['s'][:, 6] + a[:, 2] * np.float32(30)], 1).astype(np.float32)
+        for i in range(50):
+            ll = o.lowlevel_obs(st, tgt3)
+            assert _same(ctrl.obs_seen[i].cpu().numpy(), ll), f'low-level obs differs (outer {k}, inner {i})'
+            o_obs, o_rew, o_d, o_b, o_t = o.step_inner(st, g[f'll_act_{k}'][i])
+        assert _same(env.model.s.cpu().numpy(), st['s']) and _same(env.model.u.cpu().numpy(), st['u'])
+        assert _same(obs.cpu().numpy(), o_obs) and _same(rew.cpu().numpy(), o_rew)
+        assert np.array_equal(env.step_count.cpu().numpy(), st['step_count'])
+        fl = g[f'flags_{k}']
+        for got, orc, ref in ((done, o_d, fl[0]), (bad, o_b, fl[1]), (tmo, o_t, fl[2])):
+            assert np.array_equal(got.cpu().numpy(), orc.astype(bool)) and np.array_equal(orc, ref)
+    with pytest.raises(RuntimeError):
+        PlanningEnv(num_envs=4, config='tracking', model='F16', random_seed=0, device='cuda:0')   # no controller, no checkpoint
+    with pytest.raises(NotImplementedError):
+        PlanningEnv(num_envs=4, config='heading', model='F16', random_seed=0, device='cuda:0', controller=ctrl)

@@ -256,3 +256,43 @@ def test_recorded_cuda_episode_replay(golden_dir):
     assert worst < 1e-3, worst
     G = np.sqrt((o.get_accels(s, u) ** 2).sum())
     assert abs(G - rows[426, ix['G']]) / rows[426, ix['G']] < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# PlanningEnv: 50 low-level iterations per high-level step
+# ---------------------------------------------------------------------------------------------------
+def planning_targets(st, hi_action):
+    """planning_env.py:146-152 in fp32: clamp, then pitch + a0*0.3, yaw + a1*0.3, vt + a2*30."""
+    a = np.clip(hi_action, -1, 1).astype(np.float32)
+    s = st['s']
+    return np.stack([s[:, 4] + a[:, 0] * np.float32(0.3), s[:, 5] + a[:, 1] * np.float32(0.3),
+                     s[:, 6] + a[:, 2] * np.float32(30)], 1).astype(np.float32)
+
+
+def test_planning_env_replay_vs_reference(golden_dir):
+    """The reference's PlanningEnv.step driven by a seeded random-init low-level actor (its checkpoint is not in
+    the snapshot); the recorded low-level actions are replayed through the oracle's reset / low_level_obs /
+    inner-step restatement.  Plain-mode tolerance (the reference ran ATen arithmetic); masks must agree."""
+    g = np.load(f'{golden_dir}/planning_kat.npz')
+    hi = g['hi_actions']
+    n = hi.shape[1]
+    o = Oracle('tracking')
+    st = Oracle.new_state(n)
+    total_bad = 0
+    for k in range(hi.shape[0]):
+        o.reset(st, rand_u=g[f'rand_u_{k}'], want_obs=False)
+        tgt3 = planning_targets(st, hi[k])
+        for i in range(50):
+            ll = o.lowlevel_obs(st, tgt3)
+            assert relerr(ll, g[f'll_obs_{k}'][i], 0.1) < 2e-4, (k, i)
+            obs, rew, d, b, t = o.step_inner(st, g[f'll_act_{k}'][i])
+        fl = g[f'flags_{k}']
+        assert np.array_equal(d, fl[0]) and np.array_equal(b, fl[1]) and np.array_equal(t, fl[2]), f'outer {k}: masks'
+        assert np.array_equal(st['step_count'], g[f'step_count_{k}'])
+        live = ~(fl[1].astype(bool))      # terminated rows were frozen mid-way: compare them too, same tolerance
+        assert relerr(st['s'], g[f's_{k}'], STATE_FLOORS) < 5e-4
+        assert relerr(st['s'][live], g[f's_{k}'][live], STATE_FLOORS) < 2e-4
+        assert relerr(st['u'], g[f'u_{k}'], 1.0) < 1e-6 and relerr(st['tgt'], g[f'tgt_{k}'], 1.0) < 1e-6
+        assert relerr(obs, g[f'obs_{k}'], 0.1) < 5e-4 and relerr(rew, g[f'reward_{k}'], 1.0) < 5e-4
+        total_bad += int(fl[1].sum())
+    assert 0 < total_bad < 3 * n, 'fixture should mix terminated (frozen) and surviving rows'

@@ -446,8 +446,75 @@ def gen_recorded_episode():
     print('recorded episode replay with reference dynamics: worst rel err', worst)
 
 
+def gen_planning(n=48, outer=3):
+    """PlanningEnv.step (envs/planning_env.py:144-177) with a seeded RANDOM-INIT low-level PPOActor (the trained
+    checkpoint is not part of the reference snapshot).  Records the 50 low-level actions of every outer step so
+    that consumers can replay them instead of re-running the GRU (whose GEMMs are implementation-defined)."""
+    if not hasattr(np, 'product'):
+        np.product = np.prod  # the reference targets numpy 1.x (algorithms/utils/flatten.py:83)
+    import envs.planning_env as pe
+    o_load = torch.load
+    sentinel = object()
+    torch.load = lambda f, *a, **k: sentinel if str(f).endswith('actor_latest.pt') else o_load(f, *a, **k)
+    actor_cls = pe.PPOActor
+    o_lsd = actor_cls.load_state_dict
+    # the ACTOR keeps its seeded random initialisation (its checkpoint is not shipped); the aero MLPs load normally
+    actor_cls.load_state_dict = lambda self, sd, *a, **k: None if sd is sentinel else o_lsd(self, sd, *a, **k)
+    try:
+        with quiet():
+            env = pe.PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cpu')
+    finally:
+        torch.load = o_load
+        actor_cls.load_state_dict = o_lsd
+    # amplify the (gain=0.01) random actor so that the low-level actions actually move the aircraft
+    scale = 25.0
+    real = env.controller
+
+    class Rec:
+        def __init__(self):
+            self.log = []
+
+        def __call__(self, obs, rnn, masks, deterministic=True):
+            a, lp, rnn = real(obs, rnn, masks, deterministic=deterministic)
+            a = a * scale
+            self.log.append((obs.numpy().copy(), a.numpy().copy()))
+            return a, lp, rnn
+
+    rec = Rec()
+    env.controller = rec
+    rng = np.random.RandomState(31)
+    data = {}
+    hi_actions = rng.uniform(-1.2, 1.2, (outer, n, 3)).astype(np.float32)
+    for k in range(outer):
+        rec.log = []
+        prev = (env.is_done | env.bad_done | env.exceed_time_limit).numpy().astype(bool)
+        with Recorder() as r, quiet():
+            obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(hi_actions[k]))
+            log = r.take()
+        rand = [t.numpy() for kind, t in log if kind == 'rand']
+        rand_u = np.zeros((n, 5), np.float32)
+        assert len(rand) == 5
+        for c, x in enumerate(rand):
+            rand_u[prev, c] = x
+        data[f'rand_u_{k}'] = rand_u
+        data[f'll_obs_{k}'] = np.stack([o for o, _ in rec.log])
+        data[f'll_act_{k}'] = np.stack([a for _, a in rec.log])
+        data[f's_{k}'] = env.model.s.numpy().copy()
+        data[f'u_{k}'] = env.model.u.numpy().copy()
+        data[f'tgt_{k}'] = get_tgt(env, 'tracking')
+        data[f'step_count_{k}'] = env.step_count.numpy().copy()
+        data[f'obs_{k}'] = obs.numpy().copy()
+        data[f'reward_{k}'] = rew.numpy().copy()
+        data[f'flags_{k}'] = np.stack([done.numpy(), bad.numpy(), tmo.numpy()]).astype(np.uint8)
+        print('planning outer', k, 'done', int(done.sum()), 'bad', int(bad.sum()))
+    np.savez_compressed(os.path.join(OUT, 'planning_kat.npz'), hi_actions=hi_actions, **data)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'planning':
+        gen_planning()
+        return
     env = make_env('heading', 4)
     gen_aero(env)
     gen_nlplant(env)
@@ -459,6 +526,7 @@ def main():
     gen_traj('control', 64, 300)
     gen_traj('tracking', 64, 300)
     gen_recorded_episode()
+    gen_planning()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

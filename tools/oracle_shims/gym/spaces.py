@@ -24,3 +24,7 @@ class MultiBinary:
 
 class Tuple:
     pass
+
+
+class Dict:
+    pass
