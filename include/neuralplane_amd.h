@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 3
+#define NP_ABI_VERSION 4
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -54,6 +54,12 @@ typedef struct np_f16_cfg {
     double init_T, max_altitude, min_altitude, max_vt, min_vt;      /* F16_model.py:25-29 */
     double max_heading_increment, max_pitch_increment, max_velocities_u_increment; /* control_task.py:30-32 */
     double max_distance, min_distance;                              /* tracking_task.py:30-31 */
+    /* Numerics option (not a reference key): evaluate the 22 single-input aero nets through their exact
+     * piecewise-linear tables (PWL section of the version-2 weights blob) instead of the MLP FMA chains.
+     * Same functions (a ReLU MLP of one input IS piecewise linear), 0.4 ppm from their fp64 value; results
+     * differ from the default by ~1e-5 relative per coefficient, i.e. by the fp32 noise of the MLP itself. */
+    int32_t aero_1d_tables;
+    int32_t reserved_cfg_;
 } np_f16_cfg;
 
 /* Buffers of one reset()/step() call.  n aircraft, global row index of local row i = row0 + i

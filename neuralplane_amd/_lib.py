@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NpF16Cfg(C.Structure):
@@ -28,7 +28,8 @@ class NpF16Cfg(C.Structure):
                 ('max_vt', C.c_double), ('min_vt', C.c_double),
                 ('max_heading_increment', C.c_double), ('max_pitch_increment', C.c_double),
                 ('max_velocities_u_increment', C.c_double),
-                ('max_distance', C.c_double), ('min_distance', C.c_double)]
+                ('max_distance', C.c_double), ('min_distance', C.c_double),
+                ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32)]
 
 
 class NpF16Io(C.Structure):

@@ -18,7 +18,7 @@ NUM_DERIVED = 20
 NUM_CACHED = 14
 
 
-def cfg_from_config(config, task, solver=None):
+def cfg_from_config(config, task, solver=None, aero_1d_tables=None):
     """Scenario attribute bag (parse_config) -> np_f16_cfg, with the reference's getattr defaults."""
     g = lambda k, d: getattr(config, k, d)  # noqa: E731
     c = _lib.NpF16Cfg()
@@ -45,13 +45,17 @@ def cfg_from_config(config, task, solver=None):
     c.max_pitch_increment = g('max_pitch_increment', 0.3)              # control_task.py:30
     c.max_velocities_u_increment = g('max_velocities_u_increment', 100)  # control_task.py:32
     c.max_distance, c.min_distance = g('max_distance', 2000), g('min_distance', 2000)  # tracking_task.py:30-31
+    # numerics option of this framework: scenario key `aero_1d_tables`, else env NPF16_AERO_1D_TABLES
+    if aero_1d_tables is None:
+        aero_1d_tables = g('aero_1d_tables', int(os.environ.get('NPF16_AERO_1D_TABLES', '0')))
+    c.aero_1d_tables = 1 if aero_1d_tables else 0
     return c
 
 
 class F16Batch:
     """N aircraft on one GPU.  `row0` is the global index of local row 0 (sharded batches)."""
 
-    def __init__(self, n, config, task, device, seed=0, solver=None, row0=0, blob_path=ASSET_BLOB):
+    def __init__(self, n, config, task, device, seed=0, solver=None, row0=0, blob_path=ASSET_BLOB, aero_1d_tables=None):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -61,7 +65,8 @@ class F16Batch:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.n = int(n)
         self.task = task
-        self.cfg = cfg_from_config(config, task, solver)
+        self.cfg = cfg_from_config(config, task, solver, aero_1d_tables)
+        self.aero_1d_tables = bool(self.cfg.aero_1d_tables)
         self.noise_scale = float(self.cfg.noise_scale)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.row0 = int(row0)

@@ -19,6 +19,9 @@ __constant__ float c_kblob[KBLOB_FLOATS];
 // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once per
 // context by the same device code (f16_reset_coef_kernel) so that they are bit-identical to an in-line evaluation
 __constant__ float c_reset_coef[NUM_CACHED];
+// numerics-spec option "aero_1d_tables": exact piecewise-linear tables of the 22 single-input nets + (out_std, out_mean)
+__constant__ float c_pwl[NUM_PWL_TABLES * PWL_TABLE_FLOATS];
+__constant__ float c_pwl_unnorm[NUM_PWL_TABLES * 2];
 
 // Scenario constants, pre-rounded on the host exactly where the reference rounds them.
 struct DevCfg {
@@ -29,6 +32,7 @@ struct DevCfg {
     float init_T, alt_span, min_altitude, vt_span, min_vt;
     float max_heading_increment, max_pitch_increment, max_velocities_u_increment;
     float dist_span, min_distance;
+    int aero_1d_tables;  // single-input nets through their piecewise-linear tables instead of the MLP bodies
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -132,11 +136,43 @@ __device__ __forceinline__ float mlp_body(int w, const float (&x)[IN]) {
 // KB (it stays in the instruction cache) where straight-line code for 42 nets would be ~100 KB.
 // Each net's output goes to this lane's column of the LDS scratch: out[slot*LD] (ds_write_b32,
 // consecutive lanes -> consecutive banks), from where the coefficient build-up reads it back.
+// Single-input nets as table lookups (spec option aero_1d_tables): per net a 6-step binary search over 63 sorted
+// breakpoints, then one fma on the segment's line.  The searches of all nets of the class are interleaved so
+// that their dependent gathers (per-lane addresses into __constant__ tables, served by the vector L1) overlap.
+template <int CL, int COUNT, int LD, int FIRST>
+__device__ __forceinline__ void eval_class_pwl(float x, float *__restrict__ out) {
+    constexpr NetClass c = CLASSES[CL];
+    int idx[COUNT > 0 ? COUNT : 1];
+#pragma unroll
+    for (int m = 0; m < COUNT; m++) idx[m] = 0;
+#pragma unroll
+    for (int h = PWL_SEG / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int m = 0; m < COUNT; m++) {
+            const int tb = pwl_index(c.nets[FIRST + m]) * PWL_TABLE_FLOATS;
+            idx[m] += (x >= c_pwl[tb + idx[m] + h - 1]) ? h : 0;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < COUNT; m++) {
+        const int ti = pwl_index(c.nets[FIRST + m]);
+        const int tb = ti * PWL_TABLE_FLOATS;
+        const float yn = fmaf(c_pwl[tb + PWL_SEG + idx[m]], x - c_pwl[tb + 2 * PWL_SEG + idx[m]], c_pwl[tb + 3 * PWL_SEG + idx[m]]);
+        out[(class_slot(CL) + FIRST + m) * LD] = yn * c_pwl_unnorm[2 * ti] + c_pwl_unnorm[2 * ti + 1];
+    }
+}
+
 template <int CL, int COUNT, int LD, int FIRST = 0>  // nets [FIRST, FIRST+COUNT) of class CL
-__device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
+__device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
     constexpr NetClass c = CLASSES[CL];
     constexpr int n = COUNT;
     static_assert(COUNT >= 0 && FIRST >= 0 && FIRST + COUNT <= c.count, "class range");
+    if constexpr (c.n_in == 1 && n > 0) {
+        if (tables) {  // wave-uniform
+            eval_class_pwl<CL, COUNT, LD, FIRST>(xn[c.grp[0]], out);
+            return;
+        }
+    }
 #if NPF16_ASM_MLP
     if constexpr (n > 0) {
         // one asm statement for the whole class; `out` points into LDS: the low 32 bits of the flat
@@ -168,10 +204,10 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
 // xdot[6..8] (force side, 14 in total) come first.
 enum AbPart : int { AB_ALL = 0, AB_FORCE = 1, AB_REST = 2 };
 template <int LD, int PART>
-__device__ __forceinline__ void eval_ab(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
+__device__ __forceinline__ void eval_ab(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
 #define NPF16_CLS(cl)                                                                                      \
     eval_class<cl, (PART == AB_ALL ? CLASSES[cl].count : PART == AB_FORCE ? CLASSES[cl].n_force : CLASSES[cl].count - CLASSES[cl].n_force), \
-               LD, (PART == AB_REST ? CLASSES[cl].n_force : 0)>(xn, out)
+               LD, (PART == AB_REST ? CLASSES[cl].n_force : 0)>(xn, out, tables)
     NPF16_CLS(CL_DAMP);
     NPF16_CLS(CL_DLEF);
     NPF16_CLS(CL_D_RUD);
@@ -185,9 +221,9 @@ __device__ __forceinline__ void eval_ab(const float (&xn)[NUM_NORM_GROUPS], floa
 }
 // the el-dependent nets: the first N_C of (Cx Cz Cm Cn Cl) and eta_el -> slots 36..41
 template <int N_C, int N_ETA, int LD>
-__device__ __forceinline__ void eval_el(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out) {
-    eval_class<CL_C, N_C, LD>(xn, out);
-    eval_class<CL_ETA, N_ETA, LD>(xn, out);
+__device__ __forceinline__ void eval_el(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+    eval_class<CL_C, N_C, LD>(xn, out, tables);
+    eval_class<CL_ETA, N_ETA, LD>(xn, out, tables);
 }
 
 // The 9 distinct input normalisations (X - mean) / std of mean_std.csv.
@@ -214,7 +250,7 @@ struct Trig {  // sines/cosines of the attitude and flow angles of one state
 // the Overload evaluation of the previous step).
 template <bool FULL, int PART, int LD>
 __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
-                                        float cpsi, float *__restrict__ coef, float (&xd)[12]) {
+                                        float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12]) {
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
     const float xc = (float)(0.35 - 0.30);
@@ -258,8 +294,8 @@ __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4
     const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
     const bool ok = (chk == chk);
     const float qnan = __builtin_nanf("");
-    eval_ab<LD, PART>(xn, coef);
-    eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, coef);
+    eval_ab<LD, PART>(xn, coef, tables);
+    eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, coef, tables);
 #define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
 
     const float inv2vt = 1.0f / (2.0f * vt);
@@ -325,12 +361,13 @@ __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &t
 
 // full derivative at (s,u) including the heading terms
 template <int PART, int LD>
-__device__ __forceinline__ void xdot_full(const float (&s)[12], const float (&u)[4], float *__restrict__ coef, float (&xd)[12]) {
+__device__ __forceinline__ void xdot_full(const float (&s)[12], const float (&u)[4], float *__restrict__ coef, bool tables,
+                                          float (&xd)[12]) {
     Trig tr;
     float tt, spsi, cpsi;
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
-    nlplant<true, PART, LD>(s, u, tr, tt, spsi, cpsi, coef, xd);
+    nlplant<true, PART, LD>(s, u, tr, tt, spsi, cpsi, coef, tables, xd);
 }
 
 // F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)

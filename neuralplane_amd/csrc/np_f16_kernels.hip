@@ -9,6 +9,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see neuralplane_amd/build.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     const bool valid = i < a.n;
     const long long ic = valid ? i : a.n - 1;  // tail lanes shadow the last row; their stores are masked
     const DevCfg &cfg = a.cfg;
+    const bool tables = cfg.aero_1d_tables != 0;
 
     // ---- de-phasing -----------------------------------------------------------------------------------
     // Every workgroup does identical work: load state (HBM) -> ~45 K VALU cycles -> store.  Launched
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         const float dt = cfg.dt;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
-            xdot_full<(CACHED ? AB_REST : AB_ALL), BLOCK>(s, u, coef, k1);
+            xdot_full<(CACHED ? AB_REST : AB_ALL), BLOCK>(s, u, coef, tables, k1);
 #pragma unroll
             for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
         } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma nounroll
             for (int stage = 0; stage < 4; stage++) {
                 float kk[12];
-                if (CACHED && stage == 0) xdot_full<AB_REST, BLOCK>(y, u, coef, kk);  // y == s: cached coefficients apply
-                else xdot_full<AB_ALL, BLOCK>(y, u, coef, kk);
+                if (CACHED && stage == 0) xdot_full<AB_REST, BLOCK>(y, u, coef, tables, kk);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, BLOCK>(y, u, coef, tables, kk);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         // Overload needs xdot[6..8] at the NEW (s,u) (overload.py:37-42): the 14 force-side alpha/beta-only
         // nets (kept for the next step's integrator -> cache) plus the force-side Cx, Cz
         float xd[12];
-        nlplant<false, AB_FORCE, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, xd);
+        nlplant<false, AB_FORCE, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd);
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
         // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 // F16Model getters that need the dynamics (F16_model.py:47-49, 132-181): out[20][ld_out]
 __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                             long long ld, float *__restrict__ out, long long ld_out,
-                                                            long long n, float airspeed) {
+                                                            long long n, float airspeed, int tables) {
     __shared__ float lds[NUM_LIVE_NETS * BLOCK];
     float *coef = lds + threadIdx.x;
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
     float xd[12];
-    nlplant<true, AB_ALL, BLOCK>(s, u, tr, tt, spsi, cpsi, coef, xd);
+    nlplant<true, AB_ALL, BLOCK>(s, u, tr, tt, spsi, cpsi, coef, tables != 0, xd);
     float a3[3];
     body_acceleration(s, tr, xd, a3);
     const float inv_grav = (float)(1.0 / 32.174), minv_grav = (float)(-1.0 / 32.174);  // F16_model.py:166,176-178
@@ -330,13 +332,13 @@ __global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__
 }
 
 // cached coefficients of a reset aircraft (alpha = beta = 0) -> out[14]; run once per context
-__global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out) {
+__global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out, int tables) {
     __shared__ float lds[NUM_LIVE_NETS * BLOCK];
     float *coef = lds + threadIdx.x;
     float xn[NUM_NORM_GROUPS];
     const float r2d = (float)(180.0 / 3.141592653589793);
     normalise_inputs(0.0f * r2d, 0.0f * r2d, 0.0f, xn);
-    eval_ab<BLOCK, AB_FORCE>(xn, coef);
+    eval_ab<BLOCK, AB_FORCE>(xn, coef, tables != 0);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) out[k] = coef[cached_slot(k) * BLOCK];
@@ -387,13 +389,13 @@ struct BlobRec {  // NPF16MLP v1 record (tools/export_weights.py)
 static_assert(sizeof(BlobRec) == 128, "blob record is 128 bytes");
 
 // asset blob (torch layout W[out][in]) -> kernel-order blob (np_nets.h)
-int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb) {
+int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vector<float> &pwl, std::vector<float> &pwl_unnorm) {
     const unsigned char *p = (const unsigned char *)blob;
     if (!p || nbytes < 16 || std::memcmp(p, "NPF16MLP", 8) != 0) return fail("weights blob: bad magic");
     uint32_t ver, nn;
     std::memcpy(&ver, p + 8, 4);
     std::memcpy(&nn, p + 12, 4);
-    if (ver != 1 || nn != NUM_NETS) return fail("weights blob: unsupported version / net count");
+    if ((ver != 1 && ver != 2) || nn != NUM_NETS) return fail("weights blob: unsupported version / net count");
     const size_t hdr = 16 + (size_t)nn * sizeof(BlobRec);
     if (nbytes < hdr) return fail("weights blob: truncated header");
     const size_t pfloats = (nbytes - hdr) / 4;
@@ -459,6 +461,40 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb) {
     }
     for (int g = 0; g < NUM_NORM_GROUPS; g++)
         if (!grp_set[g]) return fail("weights blob: a normalisation group is unused");
+    // PWL section (blob v2): "PWL1", n_tables, seg_cap, then {net_index, n_segments, t[64], a[64], x0[64], c[64]}
+    pwl.clear();
+    pwl_unnorm.clear();
+    if (ver >= 2) {
+        size_t n_par = 0;
+        for (int i = 0; i < NUM_NETS; i++) {
+            BlobRec r;
+            std::memcpy(&r, p + 16 + (size_t)i * sizeof(BlobRec), sizeof(r));
+            n_par = std::max(n_par, (size_t)r.param_offset + r.n_params);
+        }
+        const unsigned char *q = p + hdr + n_par * 4, *end = p + nbytes;
+        uint32_t nt, cap;
+        if (q + 12 > end || std::memcmp(q, "PWL1", 4) != 0) return fail("weights blob: PWL section missing");
+        std::memcpy(&nt, q + 4, 4);
+        std::memcpy(&cap, q + 8, 4);
+        if (nt != NUM_PWL_TABLES || cap != PWL_SEG) return fail("weights blob: PWL section shape");
+        q += 12;
+        pwl.assign((size_t)NUM_PWL_TABLES * PWL_TABLE_FLOATS, 0.0f);
+        pwl_unnorm.assign((size_t)NUM_PWL_TABLES * 2, 0.0f);
+        for (uint32_t k = 0; k < nt; k++) {
+            uint32_t idx, nseg;
+            if (q + 8 + PWL_TABLE_FLOATS * 4 > end) return fail("weights blob: truncated PWL section");
+            std::memcpy(&idx, q, 4);
+            std::memcpy(&nseg, q + 4, 4);
+            if (idx >= (uint32_t)NUM_NETS || pwl_index((int)idx) != (int)k || nseg < 1 || nseg > (uint32_t)PWL_SEG)
+                return fail("weights blob: PWL table order does not match the kernel's");
+            std::memcpy(pwl.data() + (size_t)k * PWL_TABLE_FLOATS, q + 8, PWL_TABLE_FLOATS * 4);
+            BlobRec r;
+            std::memcpy(&r, p + 16 + (size_t)idx * sizeof(BlobRec), sizeof(r));
+            pwl_unnorm[2 * k] = (float)r.out_std;
+            pwl_unnorm[2 * k + 1] = (float)r.out_mean;
+            q += 8 + PWL_TABLE_FLOATS * 4;
+        }
+    }
     return 0;
 }
 
@@ -487,6 +523,7 @@ DevCfg make_devcfg(const np_f16_cfg &c) {
     d.max_velocities_u_increment = (float)c.max_velocities_u_increment;
     d.dist_span = (float)(c.max_distance - c.min_distance);
     d.min_distance = (float)c.min_distance;
+    d.aero_1d_tables = c.aero_1d_tables ? 1 : 0;
     return d;
 }
 
@@ -582,8 +619,9 @@ int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg 
     *out = nullptr;
     if (cfg->task < 0 || cfg->task > 2) return fail("cfg.task must be NP_TASK_HEADING/CONTROL/TRACKING");
     if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
-    std::vector<float> kb;
-    if (pack_kblob(weights_blob, nbytes, kb)) return 1;
+    std::vector<float> kb, pwl, pwl_unnorm;
+    if (pack_kblob(weights_blob, nbytes, kb, pwl, pwl_unnorm)) return 1;
+    if (cfg->aero_1d_tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
@@ -594,10 +632,14 @@ int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg 
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("device arch ") + prop.gcnArchName + " is not gfx950 (MI355X)");
     NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_kblob), kb.data(), sizeof(float) * KBLOB_FLOATS));
+    if (!pwl.empty()) {
+        NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl), pwl.data(), sizeof(float) * pwl.size()));
+        NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl_unnorm), pwl_unnorm.data(), sizeof(float) * pwl_unnorm.size()));
+    }
     {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
         float *d_rc = nullptr;
         NP_HIP(hipMalloc(&d_rc, sizeof(float) * NUM_CACHED));
-        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc);
+        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, cfg->aero_1d_tables ? 1 : 0);
         hipError_t e1 = hipGetLastError();
         hipError_t e2 = hipDeviceSynchronize();
         hipError_t e3 = hipMemcpyToSymbol(HIP_SYMBOL(c_reset_coef), d_rc, sizeof(float) * NUM_CACHED, 0, hipMemcpyDeviceToDevice);
@@ -644,7 +686,7 @@ int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, i
     NP_HIP(guard.enter(ctx->device));
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipLaunchKernelGGL(f16_derived_kernel, grid, block, 0, (hipStream_t)stream, s, u, (long long)ld, out, (long long)ld_out,
-                       (long long)n, ctx->cfg.airspeed);
+                       (long long)n, ctx->cfg.airspeed, ctx->cfg.aero_1d_tables);
     NP_HIP(hipGetLastError());
     return 0;
 }

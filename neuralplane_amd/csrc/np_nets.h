@@ -93,6 +93,23 @@ constexpr NetClass CLASSES[NUM_CLASSES] = {
 
 constexpr int NUM_LIVE_NETS = 42;  // 43 minus the dead delta_Czq_lef
 
+// Exact piecewise-linear tables of the single-input nets (blob PWL section, tools/export_weights.py):
+// per net t[64] breakpoints (sorted, +inf padded), a[64], x0[64], c[64]:  y_norm = fma(a[i], x - x0[i], c[i])
+// on segment i = #{breakpoints <= x}.  Table order = blob order of the 1-input nets.
+constexpr int PWL_SEG = 64;
+constexpr int PWL_TABLE_FLOATS = 4 * PWL_SEG;
+constexpr int NUM_PWL_TABLES = 22;
+constexpr bool net_is_1d(int net) {
+    return (net >= N_Cxq && net <= N_Cnp) || (net >= N_dCxq_lef && net <= N_dCnp_lef) || (net >= N_dCnbeta && net <= N_eta_el);
+}
+constexpr int pwl_index(int net) {  // position among the 1-input nets in NetId order; -1 for the others
+    if (!net_is_1d(net)) return -1;
+    int k = 0;
+    for (int i = 0; i < net; i++) k += net_is_1d(i) ? 1 : 0;
+    return k;
+}
+static_assert(pwl_index(N_eta_el) == NUM_PWL_TABLES - 1 && pwl_index(N_Cxq) == 0 && pwl_index(N_Cx) == -1, "PWL table order");
+
 // parameters (weights + biases) of one net of a class, as in the asset blob
 constexpr int class_params(const NetClass &c) {
     int tot = c.n_in * c.h1 + c.h1 + c.h1 * c.h2 + c.h2;

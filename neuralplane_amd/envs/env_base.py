@@ -13,7 +13,8 @@ from .utils.utils import parse_config
 
 
 class BaseEnv(Env):
-    def __init__(self, num_envs=10, config='heading', model='F16', random_seed=None, device='cuda:0', row0=0):
+    def __init__(self, num_envs=10, config='heading', model='F16', random_seed=None, device='cuda:0', row0=0,
+                 aero_1d_tables=None):
         super().__init__()
         self.config = parse_config(config)
         self.num_envs = num_envs
@@ -22,6 +23,7 @@ class BaseEnv(Env):
         self.device = torch.device(device)
         self.create_records = False
         self._row0 = row0
+        self._aero_1d_tables = aero_1d_tables  # numerics option; None -> scenario key / env var / off
         self.load(random_seed, config, model)
 
     def load(self, random_seed, config, model):
@@ -31,7 +33,8 @@ class BaseEnv(Env):
         # random_seed=None: the reference leaves torch's global generator unseeded; here the
         # counter-based RNG simply needs a key
         seed = 0 if random_seed is None else int(random_seed)
-        self._batch = F16Batch(self.n, self.config, task, self.device, seed=seed, row0=self._row0)
+        self._batch = F16Batch(self.n, self.config, task, self.device, seed=seed, row0=self._row0,
+                               aero_1d_tables=self._aero_1d_tables)
         self.device = self._batch.device
         return self._batch
 

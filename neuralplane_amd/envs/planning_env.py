@@ -41,8 +41,8 @@ class _ActorArgs:  # planning_env.py:18-29
 
 class PlanningEnv(BaseEnv):
     def __init__(self, num_envs=1, config='tracking', model='F16', random_seed=None, device='cuda:0', controller=None,
-                 controller_checkpoint=None, row0=0):
-        super().__init__(num_envs, config, model, random_seed, device, row0=row0)
+                 controller_checkpoint=None, row0=0, aero_1d_tables=None):
+        super().__init__(num_envs, config, model, random_seed, device, row0=row0, aero_1d_tables=aero_1d_tables)
         self.low_level_action_space = Box(low=-np.inf, high=np.inf, shape=(4,))
         self.controller = controller if controller is not None else self._load_reference_actor(controller_checkpoint)
         self.ego_rnn_states = torch.zeros((self.n, 1, 128), device=self.device)

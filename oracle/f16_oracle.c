@@ -48,6 +48,7 @@ typedef struct {
     float out_mean, out_std;
     const float *w[4];
     const float *b[4];
+    const float *pwl; /* NULL, or t[64], a[64], x0[64], c[64] (blob PWL section) */
 } net_t;
 
 struct f16o_model {
@@ -65,11 +66,11 @@ f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
     uint32_t ver, nn;
     memcpy(&ver, p + 8, 4);
     memcpy(&nn, p + 12, 4);
-    if (ver != 1 || nn != F16O_NUM_NETS) return NULL;
+    if ((ver != 1 && ver != 2) || nn != F16O_NUM_NETS) return NULL;
     size_t hdr = 16 + (size_t)nn * sizeof(blob_rec);
     if (nbytes < hdr) return NULL;
     f16o_model *m = (f16o_model *)calloc(1, sizeof(*m));
-    size_t pbytes = nbytes - hdr;
+    size_t pbytes = nbytes - hdr, n_par_total = 0;
     m->params = (float *)malloc(pbytes);
     memcpy(m->params, p + hdr, pbytes);
     for (uint32_t i = 0; i < nn; i++) {
@@ -101,6 +102,26 @@ f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
             used += (size_t)out;
         }
         if (used != r.n_params || (off + used) * 4 > pbytes) goto bad;
+        if (off + used > n_par_total) n_par_total = off + used;
+    }
+    if (ver >= 2) { /* PWL section: "PWL1", n_tables, seg_cap, then {net_index, n_segments, t, a, x0, c} */
+        const unsigned char *q = p + hdr + n_par_total * 4;
+        const unsigned char *end = p + nbytes;
+        uint32_t nt, cap;
+        if (q + 12 > end || memcmp(q, "PWL1", 4) != 0) goto bad;
+        memcpy(&nt, q + 4, 4);
+        memcpy(&cap, q + 8, 4);
+        if (cap != 64) goto bad;
+        q += 12;
+        for (uint32_t k = 0; k < nt; k++) {
+            uint32_t idx, nseg;
+            if (q + 8 + 4 * 64 * 4 > end) goto bad;
+            memcpy(&idx, q, 4);
+            memcpy(&nseg, q + 4, 4);
+            if (idx >= nn || m->net[idx].n_in != 1 || nseg < 1 || nseg > 64) goto bad;
+            m->net[idx].pwl = m->params + (q + 8 - (p + hdr)) / 4;
+            q += 8 + 4 * 64 * 4;
+        }
     }
     return m;
 bad:
@@ -359,6 +380,16 @@ void f16o_rng_normals(uint64_t seed, uint64_t call_idx, int64_t row, float z22[F
 static float net_eval(const net_t *t, const float in3[3]) {
     float x[20], y[20];
     for (int i = 0; i < t->n_in; i++) x[i] = (in3[t->sel[i]] - t->in_mean[i]) / t->in_std[i]; /* normalize :32-33 */
+    if ((g_mode & F16O_MODE_PWL) && t->pwl) {
+        /* numerics spec, "aero_1d_tables": a ReLU MLP of one input is exactly piecewise linear; binary search
+         * over the sorted breakpoints, then y = fma(a, x - x0, c) on the segment */
+        const float *tb = t->pwl, *ta = t->pwl + 64, *tx0 = t->pwl + 128, *tc = t->pwl + 192;
+        int idx = 0;
+        for (int h = 32; h >= 1; h >>= 1)
+            if (x[0] >= tb[idx + h - 1]) idx += h;
+        float yn = fmaf(ta[idx], x[0] - tx0[idx], tc[idx]);
+        return yn * t->out_std + t->out_mean;
+    }
     if (g_mode & F16O_MODE_MLP_F64) {
         double xd[20], yd[20];
         for (int i = 0; i < t->n_in; i++) xd[i] = (double)x[i];

@@ -55,6 +55,7 @@ void f16o_model_free(f16o_model *m);
 /* mode bits (f16o_set_mode): default 0 = the shipped numerics spec. */
 #define F16O_MODE_MLP_F64 1  /* pin mode: MLPs evaluated in fp64 from fp32 inputs, rounded once */
 #define F16O_MODE_LIBM 2     /* transcendental functions from the host libm (sinf/cosf/tanf/powf) */
+#define F16O_MODE_PWL 4      /* single-input nets through their exact piecewise-linear tables (blob PWL section) */
 void f16o_set_mode(int mode);
 int f16o_get_mode(void);
 

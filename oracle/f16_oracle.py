@@ -21,6 +21,7 @@ TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
 MODE_MLP_F64 = 1
 MODE_LIBM = 2
+MODE_PWL = 4
 
 
 class Cfg(C.Structure):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.np_abi_version() == 3
+    assert lib.np_abi_version() == 4
 
 
 def test_struct_layout_matches_ctypes(tmp_path):

@@ -11,15 +11,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle.f16_oracle import Oracle  # noqa: E402  (the checker; test infrastructure)
+from oracle.f16_oracle import MODE_PWL, Oracle  # noqa: E402  (the checker; test infrastructure)
 
 TASKS = ['heading', 'control', 'tracking']
 
 
-def _batch(task, n, solver=None, seed=0, row0=0):
+def _batch(task, n, solver=None, seed=0, row0=0, tables=False):
     from neuralplane_amd.core import F16Batch
     from neuralplane_amd.envs.utils.utils import parse_config
-    return F16Batch(n, parse_config(task), task, 'cuda:0', seed=seed, solver=solver, row0=row0)
+    return F16Batch(n, parse_config(task), task, 'cuda:0', seed=seed, solver=solver, row0=row0, aero_1d_tables=tables)
 
 
 def _load_state(b, st):
@@ -48,10 +48,11 @@ def _check_equal(b, obs, rew, flags, st, o_obs, o_rew, what):
         assert _same(rew.cpu().numpy(), o_rew), f'{what}: reward differs'
 
 
+@pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
 @pytest.mark.parametrize('task,fixture,solver', [('heading', 'step_kat_heading', None), ('control', 'step_kat_control', None),
                                                  ('tracking', 'step_kat_tracking', None),
                                                  ('heading', 'step_kat_heading_rk4', 'rk4')])
-def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solver, golden_dir):
+def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solver, tables, golden_dir):
     g = np.load(f'{golden_dir}/{fixture}.npz')
     n = g['action'].shape[0]
     for pre, ru, nz in [('', 'rand_u', 'noise'), ('first_', 'first_rand_u', 'first_noise')]:
@@ -59,11 +60,11 @@ def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solv
             st = {k: g['in_' + k].copy() for k in ['s', 'u', 'tgt', 'step_count', 'done', 'bad', 'timeout']}
         else:
             st = Oracle.new_state(n)
-        b = _batch(task, n, solver=solver)
+        b = _batch(task, n, solver=solver, tables=tables)
         _load_state(b, st)
         obs, rew, flags = b.step(torch.from_numpy(g['action']).cuda(), rand_u=g[ru], noise=g[nz])
         torch.cuda.synchronize()
-        o = Oracle(task, solver=solver)
+        o = Oracle(task, solver=solver, mode=MODE_PWL if tables else 0)
         o_obs, o_rew, _, _, _ = o.step(st, g['action'], rand_u=g[ru], noise=g[nz])
         _check_equal(b, obs, rew, flags, st, o_obs, o_rew, f'{fixture}/{pre or "mid"}')
         # reference (plain ATen arithmetic): 1e-4 relative with per-state floors, masks exact
@@ -80,13 +81,14 @@ def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solv
         assert np.nanmax(eo) <= 1e-4
 
 
+@pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
 @pytest.mark.parametrize('task', TASKS)
-def test_free_running_production_rng_bit_exact_vs_oracle(task):
+def test_free_running_production_rng_bit_exact_vs_oracle(task, tables):
     """reset + 60 free-running steps with the in-kernel Philox RNG: HIP == oracle bit for bit,
     including auto-resets (hazard-rich actions) and the ragged tail of the last workgroup."""
     n, steps, seed, row0 = 1000, 60, 1234, 7_000_000_000
-    b = _batch(task, n, seed=seed, row0=row0)
-    o = Oracle(task)
+    b = _batch(task, n, seed=seed, row0=row0, tables=tables)
+    o = Oracle(task, mode=MODE_PWL if tables else 0)
     st = Oracle.new_state(n)
     rng = np.random.RandomState(5)
     obs = b.reset()
