@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 4
+#define NP_ABI_VERSION 5
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -137,7 +137,70 @@ int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, i
 int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, const float *tgt3, int64_t ld,
                         float *obs, void *stream);
 
-/* Average duration in ms of the `count` most recent np_f16_step launches on this context,
+/* ---------------------------------------------------------------------------------------------------
+ * SingleCombat 1v1 (envs/singlecombat_env.py).  n = 2*num_envs aircraft; rows 2k / 2k+1 are the ego /
+ * enemy aircraft of env k (singlecombat_env.py:98-99).  One launch = one SingleCombatEnv.step: pairwise
+ * auto-reset, 5 x {demand filters, attitude PID stack (algorithms/pid/controller.py:43-74), one FDM step,
+ * step_count += 1, terminations}, observation + reward at the final state, blood update.
+ * ------------------------------------------------------------------------------------------------- */
+#define NP_NUM_OBS_COMBAT 15 /* singlecombat_env.py:64-138 */
+#define NP_NUM_PID 11        /* roll_dem, pitch_dem, {roll, pitch, yaw} x {error, integrator, last_out} */
+
+/* algorithms/pid/config/{roll,pitch,yaw}controller.yaml */
+typedef struct np_pid_gains {
+    double Kp, Ki, Kd, Kff, Kimax, tau, rmax_pos, rmax_neg;
+} np_pid_gains;
+
+/* envs/configs/selfplay.yaml (+ the getattr defaults of singlecombat_env.py:29-44 and of the condition
+ * classes), the three PID YAMLs and Controller.__init__'s airspeed bounds (controller.py:15) */
+typedef struct np_f16_combat_cfg {
+    int32_t solver;      /* NP_SOLVER_* */
+    int32_t inner_steps; /* FDM steps per env.step (singlecombat_env.py:243: 5); 1..16 */
+    double dt, airspeed;
+    double altitude_limit, acceleration_limit, max_velocity, min_velocity;
+    double min_alpha, max_alpha, min_beta, max_beta;
+    double distance_limit;  /* crash.py:17 */
+    int64_t max_steps;      /* timeout.py:15 */
+    double init_T, target_dist;
+    double max_altitude, min_altitude, max_vt, min_vt, max_heading, min_heading;
+    double max_npos, min_npos, max_epos, min_epos;
+    np_pid_gains roll, pitch, yaw;
+    double roll_ff, gravity;           /* pitchcontroller.yaml */
+    double airspeed_min, airspeed_max; /* controller.py:15 */
+    int32_t aero_1d_tables;            /* see np_f16_cfg.aero_1d_tables */
+    int32_t reserved_cfg_;
+} np_f16_combat_cfg;
+
+typedef struct np_f16_combat_io {
+    float *s;            /* [12][ld] in/out */
+    float *u;            /* [5][ld]  in/out (T, el, ail, rud, lef) */
+    float *pid;          /* [11][ld] in/out attitude-controller state; never reset by the env (as in the reference) */
+    float *blood;        /* [ld]     in/out SingleCombatEnv.blood (singlecombat_env.py:45) */
+    int64_t ld;
+    int64_t *step_count; /* [n] */
+    const uint8_t *done_in, *bad_in, *timeout_in;
+    uint8_t *done_out, *bad_out, *timeout_out; /* may NOT alias the *_in buffers */
+    const float *action; /* [n][act_stride]: throttle, roll, pitch, yaw demands of each aircraft; NULL for reset */
+    int64_t act_stride;
+    float *obs;          /* [n][15] row-major */
+    float *reward;       /* [n] */
+    const float *rand_u; /* parity hook: [n][5] uniforms (npos, epos, alt, yaw, vt) or NULL -> counter RNG */
+    int32_t pid_first;   /* != 0 on the first step after the controller was created (PID.reset, pid.py:14,23-28) */
+    int32_t reserved_io_;
+    uint64_t seed, call_idx;
+    int64_t row0;        /* global aircraft row of local row 0 (= 2 * first env of this shard) */
+} np_f16_combat_io;
+
+/* Same context type as np_f16_ctx_create; the weights blob is shared. */
+int np_f16_combat_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_combat_cfg *cfg, int device,
+                             np_f16_ctx **out);
+/* SingleCombatEnv.reset_done_envs + obs (singlecombat_env.py:183-238): both aircraft of every env in which a
+ * *_in flag is set are re-initialised (blood = 100, step_count = 0); all *_out flags are written as 0. */
+int np_f16_combat_reset(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream);
+/* SingleCombatEnv.step(action) (singlecombat_env.py:240-274), one kernel launch. */
+int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream);
+
+/* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context,
  * measured with HIP events recorded on the launch stream around each launch (0 disables;
  * enable with np_f16_set_timing(ctx, 1)).  Synchronises on the recorded events. */
 int np_f16_set_timing(np_f16_ctx *ctx, int enable);

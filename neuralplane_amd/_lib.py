@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NpF16Cfg(C.Structure):
@@ -44,8 +44,37 @@ class NpF16Io(C.Structure):
                 ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64)]
 
 
+class NpPidGains(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ('Kp', 'Ki', 'Kd', 'Kff', 'Kimax', 'tau', 'rmax_pos', 'rmax_neg')]
+
+
+class NpF16CombatCfg(C.Structure):
+    _fields_ = [('solver', C.c_int32), ('inner_steps', C.c_int32), ('dt', C.c_double), ('airspeed', C.c_double),
+                ('altitude_limit', C.c_double), ('acceleration_limit', C.c_double), ('max_velocity', C.c_double),
+                ('min_velocity', C.c_double), ('min_alpha', C.c_double), ('max_alpha', C.c_double),
+                ('min_beta', C.c_double), ('max_beta', C.c_double), ('distance_limit', C.c_double),
+                ('max_steps', C.c_int64), ('init_T', C.c_double), ('target_dist', C.c_double),
+                ('max_altitude', C.c_double), ('min_altitude', C.c_double), ('max_vt', C.c_double), ('min_vt', C.c_double),
+                ('max_heading', C.c_double), ('min_heading', C.c_double), ('max_npos', C.c_double), ('min_npos', C.c_double),
+                ('max_epos', C.c_double), ('min_epos', C.c_double),
+                ('roll', NpPidGains), ('pitch', NpPidGains), ('yaw', NpPidGains),
+                ('roll_ff', C.c_double), ('gravity', C.c_double), ('airspeed_min', C.c_double), ('airspeed_max', C.c_double),
+                ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32)]
+
+
+class NpF16CombatIo(C.Structure):
+    _fields_ = [('s', C.c_void_p), ('u', C.c_void_p), ('pid', C.c_void_p), ('blood', C.c_void_p), ('ld', C.c_int64),
+                ('step_count', C.c_void_p),
+                ('done_in', C.c_void_p), ('bad_in', C.c_void_p), ('timeout_in', C.c_void_p),
+                ('done_out', C.c_void_p), ('bad_out', C.c_void_p), ('timeout_out', C.c_void_p),
+                ('action', C.c_void_p), ('act_stride', C.c_int64), ('obs', C.c_void_p), ('reward', C.c_void_p),
+                ('rand_u', C.c_void_p), ('pid_first', C.c_int32), ('reserved_io_', C.c_int32),
+                ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64)]
+
+
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
-           'np_f16_step', 'np_f16_derived', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing')
+           'np_f16_step', 'np_f16_derived', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing',
+           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step')
 
 _lib = None
 
@@ -77,6 +106,9 @@ def load():
                                    C.c_void_p]
     lib.np_f16_lowlevel_obs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.np_f16_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.np_f16_combat_ctx_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(NpF16CombatCfg), C.c_int, C.POINTER(C.c_void_p)]
+    lib.np_f16_combat_reset.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16CombatIo), C.c_void_p]
+    lib.np_f16_combat_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16CombatIo), C.c_void_p]
     lib.np_f16_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if lib.np_abi_version() != ABI_VERSION:
         raise RuntimeError('libneuralplane_hip.so ABI version mismatch')

@@ -218,3 +218,176 @@ class F16Batch:
         ms, cnt = C.c_double(), C.c_int64()
         _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+# =====================================================================================================
+# SingleCombat 1v1
+# =====================================================================================================
+PID_CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'envs', 'configs', 'pid')
+NUM_PID = 11
+NUM_OBS_COMBAT = 15
+
+
+def combat_cfg_from_config(config, solver=None, aero_1d_tables=None, pid_dir=PID_CONFIG_DIR):
+    """selfplay attribute bag + pid/*.yaml -> np_f16_combat_cfg (defaults: singlecombat_env.py:29-44, the condition classes)."""
+    import yaml
+    g = lambda k, d: getattr(config, k, d)  # noqa: E731
+    c = _lib.NpF16CombatCfg()
+    sol = solver or g('solver', 'euler')
+    if sol not in _lib.SOLVERS:
+        raise NotImplementedError(f"solver '{sol}' (supported: euler, rk4)")
+    c.solver = _lib.SOLVERS[sol]
+    c.inner_steps = 5                                          # singlecombat_env.py:243
+    c.dt, c.airspeed = g('dt', 0.02), g('airspeed', 0)
+    c.altitude_limit, c.acceleration_limit = g('altitude_limit', 2500.0), g('acceleration_limit', 300.0)
+    c.max_velocity, c.min_velocity = g('max_velocity', 3), g('min_velocity', 0.01)
+    c.min_alpha, c.max_alpha = g('min_alpha', -20), g('max_alpha', 45)
+    c.min_beta, c.max_beta = g('min_beta', -30), g('max_beta', 30)
+    c.distance_limit = g('distance_limit', 200)                # crash.py:17
+    c.max_steps = g('max_steps', 500)                          # timeout.py:15
+    c.init_T, c.target_dist = g('init_T', 2000), g('target_dist', 3)
+    c.max_altitude, c.min_altitude = g('max_altitude', 20000), g('min_altitude', 19000)
+    c.max_vt, c.min_vt = g('max_vt', 1200), g('min_vt', 1000)
+    c.max_heading, c.min_heading = g('max_heading', 0.5), g('min_heading', -0.5)
+    c.max_npos, c.min_npos = g('max_npos', 5000), g('min_npos', -5000)
+    c.max_epos, c.min_epos = g('max_epos', 5000), g('min_epos', -5000)
+    for name in ('roll', 'pitch', 'yaw'):
+        path = os.path.join(pid_dir, f'{name}controller.yaml')
+        assert os.path.exists(path), f'config path {path} does not exist.'
+        with open(path, 'r', encoding='utf-8') as f:
+            p = yaml.safe_load(f)
+        gains = getattr(c, name)
+        for k in ('Kp', 'Ki', 'Kd', 'Kff', 'Kimax', 'tau'):
+            setattr(gains, k, p[k])
+        gains.rmax_pos, gains.rmax_neg = p.get('rmax_pos', 0), p.get('rmax_neg', 0)
+        if name == 'pitch':
+            c.roll_ff, c.gravity = p['roll_ff'], p['gravity']
+    c.airspeed_min, c.airspeed_max = 100, 2300                 # controller.py:15
+    if aero_1d_tables is None:
+        aero_1d_tables = g('aero_1d_tables', int(os.environ.get('NPF16_AERO_1D_TABLES', '0')))
+    c.aero_1d_tables = 1 if aero_1d_tables else 0
+    return c
+
+
+class F16CombatBatch:
+    """num_envs 1v1 engagements (2*num_envs aircraft, rows 2k / 2k+1 = ego / enemy of env k) on one GPU.
+    `env0` is the global index of local env 0 (sharded batches: partition by env, never by aircraft)."""
+
+    def __init__(self, num_envs, config, device, seed=0, solver=None, env0=0, blob_path=ASSET_BLOB, aero_1d_tables=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError(f"neuralplane_amd runs on MI355X (torch device 'cuda:N'), not on '{device}': "
+                               'there is no CPU fallback')
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.num_envs = int(num_envs)
+        self.n = 2 * self.num_envs
+        self.cfg = combat_cfg_from_config(config, solver, aero_1d_tables)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.env0 = int(env0)
+        self.call_idx = 0
+        with open(blob_path, 'rb') as f:
+            blob = f.read()
+        ctx = C.c_void_p()
+        _lib.check(self.lib.np_f16_combat_ctx_create(blob, len(blob), C.byref(self.cfg), self.device.index, C.byref(ctx)))
+        self._ctx = ctx
+        d, n = self.device, self.n
+        self.s = torch.zeros((12, n), dtype=torch.float32, device=d)
+        self.u = torch.zeros((5, n), dtype=torch.float32, device=d)
+        self.pid = torch.zeros((NUM_PID, n), dtype=torch.float32, device=d)   # Controller state (controller.py:27-40: zeros)
+        self.blood = torch.full((n,), 100.0, dtype=torch.float32, device=d)   # singlecombat_env.py:45
+        self.step_count = torch.zeros(n, dtype=torch.int64, device=d)
+        self.flags = torch.ones((3, n), dtype=torch.uint8, device=d)
+        self.pid_first = True                                                 # PID.reset (pid.py:14)
+        self._version = 0
+        self._derived_ctx = None
+
+    def __del__(self):
+        ctx = getattr(self, '_ctx', None)
+        if ctx:
+            try:
+                self.lib.np_f16_ctx_destroy(ctx)
+            except Exception:
+                pass
+            self._ctx = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _io(self, new_flags, action, obs, reward, rand_u):
+        io = _lib.NpF16CombatIo()
+        io.s, io.u, io.pid, io.blood, io.ld = self.s.data_ptr(), self.u.data_ptr(), self.pid.data_ptr(), self.blood.data_ptr(), self.n
+        io.step_count = self.step_count.data_ptr()
+        f, g = self.flags, new_flags
+        io.done_in, io.bad_in, io.timeout_in = f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr()
+        io.done_out, io.bad_out, io.timeout_out = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
+        if action is not None:
+            io.action, io.act_stride = action.data_ptr(), action.stride(0)
+        io.obs = obs.data_ptr() if obs is not None else None
+        io.reward = reward.data_ptr() if reward is not None else None
+        io.rand_u = rand_u.data_ptr() if rand_u is not None else None
+        io.pid_first = 1 if self.pid_first else 0
+        io.seed, io.call_idx, io.row0 = self.seed, self.call_idx, 2 * self.env0
+        return io
+
+    def _inject(self, t):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, dtype=torch.float32, device=self.device).contiguous()
+        if tuple(t.shape) != (self.n, 5):
+            raise ValueError(f'expected shape ({self.n}, 5), got {tuple(t.shape)}')
+        return t
+
+    def reset(self, rand_u=None):
+        """reset_done_envs + obs: both aircraft of every flagged env are re-initialised; returns obs[n,15]."""
+        obs = torch.empty((self.n, NUM_OBS_COMBAT), dtype=torch.float32, device=self.device)
+        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        io = self._io(new_flags, None, obs, None, self._inject(rand_u))
+        _lib.check(self.lib.np_f16_combat_reset(self._ctx, self.num_envs, C.byref(io), self._stream()))
+        self.flags = new_flags
+        self.call_idx += 1
+        self._version += 1
+        return obs
+
+    def step(self, action, rand_u=None):
+        """SingleCombatEnv.step(action[n,>=4]): ONE kernel launch (5 FDM steps).  Returns obs, reward, flags[3,n]."""
+        if action.device != self.device or action.dtype != torch.float32:
+            action = action.to(device=self.device, dtype=torch.float32)
+        if action.dim() != 2 or action.shape[0] != self.n or action.shape[1] < 4:
+            raise ValueError(f'action must be [n={self.n}, >=4], got {tuple(action.shape)}')
+        if action.stride(1) != 1:
+            action = action.contiguous()
+        obs = torch.empty((self.n, NUM_OBS_COMBAT), dtype=torch.float32, device=self.device)
+        reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        io = self._io(new_flags, action, obs, reward, self._inject(rand_u))
+        _lib.check(self.lib.np_f16_combat_step(self._ctx, self.num_envs, C.byref(io), self._stream()))
+        self.flags = new_flags
+        self.pid_first = False
+        self.call_idx += 1
+        self._version += 1
+        return obs, reward, new_flags
+
+    def state_dict(self):
+        return {'s': self.s.clone(), 'u': self.u.clone(), 'pid': self.pid.clone(), 'blood': self.blood.clone(),
+                'step_count': self.step_count.clone(), 'flags': self.flags.clone(), 'pid_first': bool(self.pid_first),
+                'call_idx': int(self.call_idx), 'seed': int(self.seed), 'env0': int(self.env0), 'num_envs': self.num_envs}
+
+    def load_state_dict(self, sd):
+        if sd['num_envs'] != self.num_envs:
+            raise ValueError(f"checkpoint is for num_envs={sd['num_envs']}; this batch has {self.num_envs}")
+        for k in ('s', 'u', 'pid', 'blood', 'step_count'):
+            getattr(self, k).copy_(sd[k].to(self.device))
+        self.flags = sd['flags'].to(self.device).clone()
+        self.pid_first = bool(sd['pid_first'])
+        self.call_idx, self.seed, self.env0 = int(sd['call_idx']), int(sd['seed']), int(sd['env0'])
+        self._version += 1
+
+    def set_timing(self, enable):
+        _lib.check(self.lib.np_f16_set_timing(self._ctx, int(bool(enable))))
+
+    def get_timing(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

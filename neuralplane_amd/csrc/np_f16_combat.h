@@ -1,0 +1,454 @@
+// np_f16_combat.h — fused SingleCombat (1v1) macro-step kernel for gfx950.
+//
+// Reference: envs/singlecombat_env.py:64-274 (obs, reward, reset_done_envs, step), the attitude PID stack
+// algorithms/pid/{controller,pid,rollController,pitchController,yawController}.py and
+// envs/termination_conditions/{crash,shutdown,timeout}.py.  The reference env file is stale against today's
+// BaseEnv; DESIGN.md §10 lists the composition decisions.
+//
+// Mapping: one lane per aircraft; the two aircraft of an env are ADJACENT lanes (rows 2k, 2k+1), so every
+// pairwise quantity (Crash distance, AO/TA/R, blood) is one DPP/bpermute lane exchange — no LDS, no second
+// kernel.  One launch runs all `inner_steps` FDM steps of an env.step with the state in registers: HBM is
+// touched once per env.step (not once per FDM step), and the 14 force-side alpha/beta-only aero
+// coefficients the Overload check evaluates at the new state stay in this lane's LDS column for the next
+// inner step's integrator (the same reuse the single-aircraft kernel routes through its HBM cache).
+#pragma once
+#include "np_f16_device.h"
+
+namespace npf16 {
+
+struct PidDev {
+    float Kp, Ki, Kd, Kff, Kimax, tau, rmax_pos, rmax_neg;
+    int ki_on;  // `self.Ki != 0 and self.dt > 0` (pid.py:38)
+};
+
+struct CombatDevCfg {
+    float dt;        // integrator step t1 - t0 (F16_model.py:66)
+    float dt_pid;    // Controller(dt=...) (singlecombat_env.py:46)
+    float airspeed;
+    float altitude_limit, acceleration_limit, max_velocity, min_velocity;
+    float min_alpha, max_alpha, min_beta, max_beta;
+    float dist_limit_sq;
+    long long max_steps;
+    float init_T;
+    float alt_span, min_altitude, vt_span, min_vt, yaw_span, min_heading, npos_span, min_npos, epos_span, min_epos;
+    PidDev roll, pitch, yaw;
+    float roll_ff, gravity, scale_min, scale_max;
+    int inner_steps;
+    int aero_1d_tables;
+};
+
+struct CombatArgs {
+    float *s, *u, *pid, *blood;
+    long long ld;
+    long long *step_count;
+    const uint8_t *fin0, *fin1, *fin2;
+    uint8_t *fout0, *fout1, *fout2;
+    const float *action;
+    long long act_stride;
+    float *obs, *reward;
+    const float *rand_u;
+    int pid_first;
+    uint64_t seed, call_idx;
+    long long row0, n;
+    CombatDevCfg cfg;
+};
+
+enum { PID_ROLL_DEM = 0, PID_PITCH_DEM, PID_R_ERR, PID_R_INT, PID_R_LAST, PID_P_ERR, PID_P_INT, PID_P_LAST, PID_Y_ERR,
+       PID_Y_INT, PID_Y_LAST, NUM_PID };
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {  // torch.clamp: NaN stays NaN
+    v = v < lo ? lo : v;
+    return v > hi ? hi : v;
+}
+__device__ __forceinline__ float partner(float v) { return __shfl_xor(v, 1); }
+
+// {Roll,Pitch,Yaw}Controller.get_rate_out + PID.update_all / update_i (pid.py:18-42).  A row whose target or
+// measurement is non-finite holds its previous output (the reference skips the update of the whole batch).
+__device__ __forceinline__ float rate_out(const PidDev &g, float dt, float desired, float scaler, float eas2tas, float rate,
+                                          float &err, float &integ, float &last_out, bool strict, bool first) {
+    const bool limit = strict ? fabsf(last_out) > 45.0f : fabsf(last_out) >= 45.0f;
+    const float target = (desired * scaler) * scaler;
+    const float meas = (rate * scaler) * scaler;
+    const bool ok = ((target - target) == 0.0f) && ((meas - meas) == 0.0f);
+    const float held = clampf(last_out, -45.0f, 45.0f);
+    const float last_error = err;
+    const float e = target - meas;
+    const float deriv = first ? 0.0f : (e - last_error) / dt;
+    float in = first ? 0.0f : integ;
+    if (g.ki_on) {
+        const bool gate = (!limit) | ((e * dt) < 0.0f);
+        in = in + ((e * g.Ki) * dt) * (gate ? 1.0f : 0.0f);
+        in = clampf(in, -g.Kimax, g.Kimax);
+    } else {
+        in = 0.0f;
+    }
+    const float ff = (target * g.Kff) / (scaler * eas2tas + 1e-8f);
+    float out = ((ff + e * g.Kp) + in) + deriv * g.Kd;
+    out = (180.0f * out) / 3.14159265358979323846f;
+    err = ok ? e : err;
+    integ = ok ? in : integ;
+    last_out = ok ? out : last_out;
+    return ok ? clampf(out, -45.0f, 45.0f) : held;
+}
+
+// Controller.stabilize (controller.py:35-74) for one aircraft; rates = Euler-angle rates xdot[3..5]
+__device__ __forceinline__ void stabilize(const CombatDevCfg &cfg, const float (&s)[12], const Trig &tr, float tt,
+                                          float (&pid)[NUM_PID], bool first, float &el, float &ail, float &rud) {
+    const float PI_F = 3.14159265358979323846f;
+    const float P = s[9], Q = s[10], R = s[11];
+    const float roll_rate = P + tt * (Q * tr.sphi + R * tr.cphi);   // F16_dynamics.py:136-138
+    const float pitch_rate = Q * tr.cphi - R * tr.sphi;
+    const float yaw_rate = (Q * tr.sphi + R * tr.cphi) / tr.ct;
+    const float eas2tas = eas2tas_of(s[2]);
+    const float TAS = s[6] + cfg.airspeed * 1.0f;
+    float scaler = (1.0f / (TAS + 1e-8f)) * 1000.0f;                // calc_speed_scaler :35-40
+    scaler = clampf(scaler, cfg.scale_min, cfg.scale_max);
+    const float roll = s[3], pitch = s[4];
+    {   // stabilize_roll :42-46, rollController.py:43-49
+        const float angle_err = np_wrap_pi(pid[PID_ROLL_DEM] - roll);
+        float desired = angle_err / cfg.roll.tau;
+        if (cfg.roll.rmax_pos != 0.0f) desired = clampf(desired, -cfg.roll.rmax_pos, cfg.roll.rmax_pos);
+        ail = rate_out(cfg.roll, cfg.dt_pid, desired, scaler, eas2tas, roll_rate, pid[PID_R_ERR], pid[PID_R_INT], pid[PID_R_LAST],
+                       false, first);
+    }
+    {   // stabilize_pitch :48-52, pitchController.py:47-94
+        const float angle_err = np_wrap_pi(pid[PID_PITCH_DEM] - pitch);
+        float desired = angle_err / cfg.pitch.tau;
+        const float pio2 = (float)(3.141592653589793 / 2.0);
+        const bool m1 = fabsf(roll) < pio2, m2 = roll >= pio2, m3 = roll <= -pio2;
+        const float r1 = clampf(roll, (float)(-4.0 * 3.141592653589793 / 9.0), (float)(4.0 * 3.141592653589793 / 9.0));
+        const float r2 = clampf(roll, (float)(5.0 * 3.141592653589793 / 9.0), PI_F);
+        const float r3 = clampf(roll, -PI_F, (float)(-5.0 * 3.141592653589793 / 9.0));
+        const bool inverted = !m1;
+        const float rollc = ((m1 ? 1.0f : 0.0f) * r1 + (m2 ? 1.0f : 0.0f) * r2) + (m3 ? 1.0f : 0.0f) * r3;
+        const bool mp = fabsf(pitch) <= (float)(7.0 * 3.141592653589793 / 18.0);
+        float sr, cr, trl;
+        np_sincostan(rollc, sr, cr, trl);
+        float off = ((((1.0f / TAS) * cfg.gravity) * trl) * sr) * eas2tas;
+        off = (((mp ? 1.0f : 0.0f) * tr.ct) * fabsf(off)) * cfg.roll_ff;
+        off = off * (inverted ? 0.0f : 1.0f) - off * (inverted ? 1.0f : 0.0f);
+        float d1 = desired + off;
+        if (cfg.pitch.rmax_pos != 0.0f) d1 = d1 > cfg.pitch.rmax_pos ? cfg.pitch.rmax_pos : d1;
+        if (cfg.pitch.rmax_neg != 0.0f) d1 = d1 < -cfg.pitch.rmax_neg ? -cfg.pitch.rmax_neg : d1;
+        desired = (inverted ? 0.0f : 1.0f) * d1 + (inverted ? 1.0f : 0.0f) * (off - desired);
+        float rw = fabsf(roll);
+        const float pw = fabsf(pitch);
+        const bool mk = rw > pio2;
+        rw = (mk ? 1.0f : 0.0f) * (PI_F - rw) + (mk ? 0.0f : 1.0f) * rw;
+        const bool mq = (rw > (float)(5.0 * 3.141592653589793 / 18.0)) & (pw < (float)(7.0 * 3.141592653589793 / 18.0));
+        float prop = (rw - (float)(5.0 * 3.141592653589793 / 18.0)) / (float)(4.0 * 3.141592653589793 / 18.0);
+        prop = prop * (mq ? 1.0f : 0.0f);
+        desired = desired * (1.0f - prop);
+        el = rate_out(cfg.pitch, cfg.dt_pid, desired, scaler, eas2tas, pitch_rate, pid[PID_P_ERR], pid[PID_P_INT], pid[PID_P_LAST],
+                      true, first);
+    }
+    // stabilize_yaw :54-57: YawController.get_rate_out(yaw_rate_dem == 0)
+    rud = rate_out(cfg.yaw, cfg.dt_pid, 0.0f, scaler, eas2tas, yaw_rate, pid[PID_Y_ERR], pid[PID_Y_INT], pid[PID_Y_LAST], false, first);
+}
+
+// ground velocity xdot[0..2] (F16_dynamics.py:129-135) — the `es[:, :3]` of the pairwise geometry
+__device__ __forceinline__ void ground_velocity(const float (&s)[12], const Trig &tr, float spsi, float cpsi, float (&v)[3]) {
+    float vt = s[6];
+    vt = (vt <= 0.01f ? 1.0f : 0.0f) * 0.01f + (vt > 0.01f ? 1.0f : 0.0f) * vt;
+    const float U = (vt * tr.ca) * tr.cb, V = vt * tr.sb, W = (vt * tr.sa) * tr.cb;
+    const float st = tr.st, ct = tr.ct, sphi = tr.sphi, cphi = tr.cphi;
+    v[0] = (U * (ct * cpsi) + V * ((sphi * cpsi) * st - cphi * spsi)) + W * ((cphi * st) * cpsi + sphi * spsi);
+    v[1] = (U * (ct * spsi) + V * ((sphi * spsi) * st + cphi * cpsi)) + W * ((cphi * st) * spsi - sphi * cpsi);
+    v[2] = (U * st - V * (sphi * ct)) - W * (cphi * ct);
+}
+
+// envs/utils/utils.py:156-205 get_AO_TA_R / get2d_AO_TA_R from the EGO aircraft's point of view
+template <int DIMS>
+__device__ __forceinline__ void ao_ta_r(const float (&ep)[3], const float (&mp)[3], const float (&ev)[3], const float (&mv)[3],
+                                        float &AO, float &TA, float &R, float &side) {
+    const float e2 = DIMS == 3 ? ev[2] : 0.0f, m2 = DIMS == 3 ? mv[2] : 0.0f;
+    const float d0 = mp[0] - ep[0], d1 = mp[1] - ep[1], d2 = DIMS == 3 ? mp[2] - ep[2] : 0.0f;
+    const float ego_v = np_norm3(ev[0], ev[1], e2), enm_v = np_norm3(mv[0], mv[1], m2);
+    const float dist = np_norm3(d0, d1, d2);
+    float proj = np_dot3(d0, d1, d2, ev[0], ev[1], e2);
+    AO = np_acos(clampf(proj / (dist * ego_v + 1e-8f), -1.0f, 1.0f));
+    proj = np_dot3(d0, d1, d2, mv[0], mv[1], m2);
+    TA = np_acos(clampf(proj / (dist * enm_v + 1e-8f), -1.0f, 1.0f));
+    R = dist;
+    const float c = ev[0] * d1 - ev[1] * d0;
+    side = (c != c) ? c : (float)((c > 0.0f) - (c < 0.0f));
+}
+
+__device__ __forceinline__ float orientation_reward_v2(float AO, float TA) {  // utils.py:207-218
+    const float PI_F = 3.14159265358979323846f;
+    const float a = (1.0f / ((AO * 50.0f) / PI_F + 2.0f)) * 1.0f + 0.5f;
+    float m = (TA * 1.9f) / PI_F;
+    const float floor_ = 1e-4f * 1.0f;
+    m = (m != m) ? m : (m > floor_ ? m : floor_);
+    float t = np_atanh(1.0f - m) / (float)(2.0 * 3.141592653589793);
+    t = (t != t) ? t : (t < 0.0f ? t : 0.0f);
+    return (a + t) + 0.5f;
+}
+__device__ __forceinline__ float range_reward_v3(float R) {  // utils.py:220-233, R in km
+    const float near_ = R < 5.0f ? 1.0f : 0.0f;
+    const float poly = clampf((-0.032f * (R * R) + 0.284f * R) + 0.38f, 0.0f, 1.0f);
+    const float tail = clampf(np_exp(-0.16f * R), 0.0f, 0.2f);
+    return (near_ + (R >= 5.0f ? 1.0f : 0.0f) * poly) + tail;
+}
+__device__ __forceinline__ float orientation_fn(float AO) {  // utils.py:235-243
+    const float PI_F = 3.14159265358979323846f;
+    const float pi6 = (float)(3.141592653589793 / 6.0);
+    const float m3 = ((AO >= 0.0f) & (AO <= pi6)) ? 1.0f : 0.0f, m4 = ((AO <= 0.0f) & (AO >= -pi6)) ? 1.0f : 0.0f;
+    const float q = (6.0f * AO) / PI_F;
+    return (1.0f - q) * m3 + (1.0f + q) * m4;
+}
+__device__ __forceinline__ float distance_fn(float R) {  // utils.py:245-249
+    const float m1 = R <= 1.0f ? 1.0f : 0.0f, m2 = ((R > 1.0f) & (R <= 3.0f)) ? 1.0f : 0.0f;
+    return m1 + ((3.0f - R) / 2.0f) * m2;
+}
+
+constexpr int COMBAT_OBS = 15;
+constexpr int COMBAT_BLOCK = 128;
+constexpr int COMBAT_LDS_FLOATS = NUM_LIVE_NETS * COMBAT_BLOCK;  // > COMBAT_BLOCK * COMBAT_OBS
+static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as the observation transpose tile");
+
+// STEP=true: SingleCombatEnv.step; STEP=false: reset_done_envs + obs
+template <int SOLVER, bool STEP>
+__global__ __launch_bounds__(COMBAT_BLOCK, 2) void f16_combat_kernel(const CombatArgs a) {
+    constexpr int B = COMBAT_BLOCK;
+    __shared__ float lds[COMBAT_LDS_FLOATS];
+    const int t = threadIdx.x;
+    float *coef = lds + t;
+    const long long i0 = (long long)blockIdx.x * B;
+    const long long i = i0 + t;
+    const bool valid = i < a.n;
+    const long long ic = valid ? i : a.n - 1;  // n is even and B is even: a pair never straddles workgroups
+    const CombatDevCfg &cfg = a.cfg;
+    const bool tables = cfg.aero_1d_tables != 0;
+    const bool is_ego = (t & 1) == 0;
+    const float PI_F = 3.14159265358979323846f;
+
+    float s[12], u[4], pid[NUM_PID];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = a.s[k * a.ld + ic];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = a.u[k * a.ld + ic];
+    float blood = a.blood[ic];
+    long long sc = a.step_count[ic];
+    const int own_flag = (a.fin0[ic] | a.fin1[ic] | a.fin2[ic]) != 0 ? 1 : 0;
+    const bool flagged = (own_flag | __shfl_xor(own_flag, 1)) != 0;
+
+    // ---- reset_done_envs (singlecombat_env.py:207-238): both aircraft of a flagged env ----
+    if (flagged) {
+        float ru[5];
+        if (a.rand_u) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) ru[k] = a.rand_u[ic * 5 + k];
+        } else {
+            uint32_t w0[4], w1[4];
+            rng_block(a.seed, a.call_idx, a.row0 + ic, 0, w0);
+            rng_block(a.seed, a.call_idx, a.row0 + ic, 1, w1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ru[k] = (float)(w0[k] >> 8) * 5.9604644775390625e-08f;
+            ru[4] = (float)(w1[0] >> 8) * 5.9604644775390625e-08f;
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) s[k] = 0.0f;
+        u[1] = u[2] = u[3] = 0.0f;
+        s[0] = ru[0] * cfg.npos_span + cfg.min_npos;
+        s[1] = ru[1] * cfg.epos_span + cfg.min_epos;
+        s[2] = ru[2] * cfg.alt_span + cfg.min_altitude;
+        s[5] = ru[3] * cfg.yaw_span + cfg.min_heading;
+        s[6] = ru[4] * cfg.vt_span + cfg.min_vt;
+        u[0] = cfg.init_T;
+        blood = 100.0f;
+        sc = 0;
+    }
+
+    Trig tr;
+    float tt, spsi, cpsi;
+    trig_of(s, tr, tt);
+    np_sincos(s[5], spsi, cpsi);
+
+    bool f_done = false, f_bad = false, f_to = false;
+    if (STEP) {
+#pragma unroll
+        for (int k = 0; k < NUM_PID; k++) pid[k] = a.pid[k * a.ld + ic];
+        float act[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) act[k] = clampf(a.action[ic * a.act_stride + k], -1.0f, 1.0f);
+        // shutdown.py:31-38 reads the blood of the previous env.step for all inner steps
+        const float blood_o = partner(blood);
+        const bool m1 = (is_ego ? blood : blood_o) <= 0.0f, m2 = (is_ego ? blood_o : blood) <= 0.0f;
+        // the 14 force-side alpha/beta-only coefficients at the current state -> this lane's LDS column; from
+        // here on every integrator evaluation finds them there (left by the previous Overload evaluation)
+        {
+            const float r2d = (float)(180.0 / 3.141592653589793);
+            float xn[NUM_NORM_GROUPS];
+            normalise_inputs(s[7] * r2d, s[8] * r2d, u[1], xn);
+            eval_ab<B, AB_FORCE>(xn, coef, tables);
+        }
+#pragma nounroll
+        for (int it = 0; it < cfg.inner_steps; it++) {
+            // ---- demand filters (:245-246) and Controller.stabilize ----
+            pid[PID_ROLL_DEM] = 0.9f * pid[PID_ROLL_DEM] + (((0.1f * act[1]) * 4.0f) * PI_F) / 9.0f;
+            pid[PID_PITCH_DEM] = 0.9f * pid[PID_PITCH_DEM] + ((0.1f * act[2]) * PI_F) / 12.0f;
+            float el, ail, rud;
+            stabilize(cfg, s, tr, tt, pid, a.pid_first != 0 && it == 0, el, ail, rud);
+            u[0] = 0.9f * u[0] + (((0.1f * act[0]) * 0.225f) * 76300.0f) / 0.3048f;  // :251
+            u[1] = -el;                                                                 // :252-255, written straight to u
+            u[2] = -ail;
+            u[3] = -rud;
+            // ---- one integrator step (F16_model.py:64-67) ----
+            const float dt = cfg.dt;
+            if (SOLVER == 0) {
+                float k1[12];
+                nlplant<true, AB_REST, B>(s, u, tr, tt, spsi, cpsi, coef, tables, k1);
+#pragma unroll
+                for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
+            } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
+                const float third = (float)(1.0 / 3.0);
+                float y[12], k1[12], k2[12], k3[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) y[k] = s[k];
+#pragma nounroll
+                for (int stage = 0; stage < 4; stage++) {
+                    float kk[12];
+                    if (stage == 0) nlplant<true, AB_REST, B>(y, u, tr, tt, spsi, cpsi, coef, tables, kk);
+                    else xdot_full<AB_ALL, B>(y, u, coef, tables, kk);
+                    if (stage == 0) {
+#pragma unroll
+                        for (int k = 0; k < 12; k++) {
+                            k1[k] = kk[k];
+                            y[k] = s[k] + (dt * k1[k]) * third;
+                        }
+                    } else if (stage == 1) {
+#pragma unroll
+                        for (int k = 0; k < 12; k++) {
+                            k2[k] = kk[k];
+                            y[k] = s[k] + dt * (k2[k] - k1[k] * third);
+                        }
+                    } else if (stage == 2) {
+#pragma unroll
+                        for (int k = 0; k < 12; k++) {
+                            k3[k] = kk[k];
+                            y[k] = s[k] + dt * ((k1[k] - k2[k]) + k3[k]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 12; k++) y[k] = s[k] + (((k1[k] + 3.0f * (k2[k] + k3[k])) + kk[k]) * dt) * 0.125f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 12; k++) s[k] = y[k];
+            }
+            sc += 1;
+            // ---- terminations at the new state ----
+            trig_of(s, tr, tt);
+            np_sincos(s[5], spsi, cpsi);
+            float xd[12], acc3[3];
+            nlplant<false, AB_FORCE, B>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd);
+            body_acceleration(s, tr, xd, acc3);
+            const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
+            bool b = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
+            b |= (s[2] - cfg.altitude_limit) < 0.0f;               // low_altitude.py:29-30
+            const float TAS = s[6] + cfg.airspeed * 1.0f;
+            const float vel = (TAS * 0.3048f) / 340.0f;
+            b |= (vel - cfg.max_velocity) >= 0.0f;                 // high_speed.py:29-30
+            b |= (vel - cfg.min_velocity) <= 0.0f;                 // low_speed.py:29-30
+            const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
+            b |= (alpha < cfg.min_alpha) | (alpha > cfg.max_alpha);  // extreme_state.py:32-36
+            b |= (beta < cfg.min_beta) | (beta > cfg.max_beta);
+            // crash.py:33-43 (ego - enemy, squared distance in fp32)
+            const float on = partner(s[0]), oe = partner(s[1]), oa = partner(s[2]);
+            const float dn = is_ego ? s[0] - on : on - s[0], de = is_ego ? s[1] - oe : oe - s[1], da = is_ego ? s[2] - oa : oa - s[2];
+            b |= ((dn * dn + de * de) + da * da) <= cfg.dist_limit_sq;
+            b |= m1;                                               // shutdown.py:36-38
+            f_bad |= b;
+            f_done |= m2 & !m1;
+            f_to |= (sc - cfg.max_steps) >= 0;                     // timeout.py:29
+        }
+    }
+
+    // ---- observation (:64-138), reward (:140-181) and blood (:264-271) at the final state ----
+    float gv[3];
+    ground_velocity(s, tr, spsi, cpsi, gv);
+    const float vel_u = (s[6] * tr.cb) * tr.ca, vel_v = s[6] * tr.sb, vel_w = (s[6] * tr.cb) * tr.sa;  // get_velocity
+    float op[3], ogv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        op[k] = partner(s[k]);
+        ogv[k] = partner(gv[k]);
+    }
+    const float o_vel_u = partner(vel_u);
+    float ep[3], mp[3], ev[3], mv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ep[k] = is_ego ? s[k] : op[k];
+        mp[k] = is_ego ? op[k] : s[k];
+        ev[k] = is_ego ? gv[k] : ogv[k];
+        mv[k] = is_ego ? ogv[k] : gv[k];
+    }
+    float AO2, TA2, R2, side;
+    ao_ta_r<2>(ep, mp, ev, mv, AO2, TA2, R2, side);
+    float o[COMBAT_OBS];
+    o[0] = (s[2] * 0.3048f) / 5000.0f;
+    o[1] = tr.sphi;
+    o[2] = tr.cphi;
+    o[3] = tr.st;
+    o[4] = tr.ct;
+    o[5] = (vel_u * 0.3048f) / 340.0f;
+    o[6] = (vel_v * 0.3048f) / 340.0f;
+    o[7] = (vel_w * 0.3048f) / 340.0f;
+    o[8] = (s[6] * 0.3048f) / 340.0f;
+    o[9] = ((o_vel_u - vel_u) * 0.3048f) / 340.0f;
+    o[10] = ((op[2] - s[2]) * 0.3048f) / 1000.0f;
+    o[11] = is_ego ? AO2 : PI_F - TA2;
+    o[12] = is_ego ? TA2 : PI_F - AO2;
+    o[13] = (R2 * 0.3048f) / 10000.0f;
+    o[14] = is_ego ? side : -side;
+
+    float reward = 0.0f;
+    if (STEP) {
+        float AO, TA, R, side3;
+        ao_ta_r<3>(ep, mp, ev, mv, AO, TA, R, side3);
+        const float Rkm = (R * 0.3048f) / 1000.0f;
+        const float rr = range_reward_v3(Rkm);
+        const float orient = is_ego ? orientation_reward_v2(AO, TA) : orientation_reward_v2(PI_F - TA, PI_F - AO);
+        reward = 0.01f * (orient * rr);
+        const float dfn = distance_fn(Rkm);
+        // blood[enm] -= orientation_fn(AO) * dfn; blood[ego] -= orientation_fn(pi - TA) * dfn
+        blood = blood - (is_ego ? orientation_fn(PI_F - TA) : orientation_fn(AO)) * dfn;
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) a.s[k * a.ld + i] = s[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.u[k * a.ld + i] = u[k];
+        a.u[4 * a.ld + i] = 0.0f;
+        a.blood[i] = blood;
+        a.step_count[i] = sc;
+        a.fout0[i] = f_done ? 1 : 0;
+        a.fout1[i] = f_bad ? 1 : 0;
+        a.fout2[i] = f_to ? 1 : 0;
+        if (STEP) {
+#pragma unroll
+            for (int k = 0; k < NUM_PID; k++) a.pid[k * a.ld + i] = pid[k];
+            a.reward[i] = reward;
+        }
+    }
+
+    // ---- [n][15] observation rows: transpose through LDS, store coalesced ----
+    if (a.obs) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < COMBAT_OBS; k++) lds[t * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
+        __syncthreads();
+        const long long rows = (a.n - i0) < B ? (a.n - i0) : B;
+        const int total = (int)rows * COMBAT_OBS;
+        float *dst = a.obs + i0 * COMBAT_OBS;
+#pragma unroll
+        for (int itr = 0; itr < COMBAT_OBS; itr++) {
+            const int L = itr * B + t;
+            if (L < total) dst[L] = lds[L];
+        }
+    }
+}
+
+}  // namespace npf16

@@ -19,6 +19,7 @@
 
 #include "../../include/neuralplane_amd.h"
 #include "np_f16_device.h"
+#include "np_f16_combat.h"
 
 namespace npf16 {
 
@@ -367,6 +368,8 @@ struct np_f16_ctx {
     int device;
     int task, solver;
     DevCfg cfg;
+    bool combat;  // created by np_f16_combat_ctx_create: only the combat entry points accept it
+    CombatDevCfg ccfg;
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -547,6 +550,7 @@ struct DeviceGuard {
 template <bool STEP>
 int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     if (!ctx || !io) return fail("null ctx/io");
+    if (ctx->combat) return fail("combat context: use np_f16_combat_reset / np_f16_combat_step");
     if (n <= 0) return 0;
     if (!io->s || !io->u || !io->tgt || !io->step_count || !io->done_in || !io->bad_in || !io->timeout_in ||
         !io->done_out || !io->bad_out || !io->timeout_out)
@@ -606,6 +610,106 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     return 0;
 }
 
+
+PidDev make_pid(const np_pid_gains &g, double dt) {
+    PidDev p;
+    p.Kp = (float)g.Kp;
+    p.Ki = (float)g.Ki;
+    p.Kd = (float)g.Kd;
+    p.Kff = (float)g.Kff;
+    p.Kimax = (float)g.Kimax;
+    p.tau = (float)(g.tau < 0.05 ? 0.05 : g.tau);  // rollController.py:44-45
+    p.rmax_pos = (float)g.rmax_pos;
+    p.rmax_neg = (float)g.rmax_neg;
+    p.ki_on = (g.Ki != 0.0 && dt > 0.0) ? 1 : 0;
+    return p;
+}
+
+CombatDevCfg make_combat_devcfg(const np_f16_combat_cfg &c) {
+    CombatDevCfg d;
+    d.dt = (float)c.dt - 0.0f;
+    d.dt_pid = (float)c.dt;
+    d.airspeed = (float)c.airspeed;
+    d.altitude_limit = (float)c.altitude_limit;
+    d.acceleration_limit = (float)c.acceleration_limit;
+    d.max_velocity = (float)c.max_velocity;
+    d.min_velocity = (float)c.min_velocity;
+    d.min_alpha = (float)c.min_alpha;
+    d.max_alpha = (float)c.max_alpha;
+    d.min_beta = (float)c.min_beta;
+    d.max_beta = (float)c.max_beta;
+    d.dist_limit_sq = (float)(c.distance_limit * c.distance_limit);  // `self.distance_limit ** 2` is Python arithmetic
+    d.max_steps = c.max_steps;
+    d.init_T = (float)c.init_T;
+    d.alt_span = (float)(c.max_altitude - c.min_altitude);
+    d.min_altitude = (float)c.min_altitude;
+    d.vt_span = (float)(c.max_vt - c.min_vt);
+    d.min_vt = (float)c.min_vt;
+    d.yaw_span = (float)(c.max_heading - c.min_heading);
+    d.min_heading = (float)c.min_heading;
+    d.npos_span = (float)(c.max_npos - c.min_npos);
+    d.min_npos = (float)c.min_npos;
+    d.epos_span = (float)(c.max_epos - c.min_epos);
+    d.min_epos = (float)c.min_epos;
+    d.roll = make_pid(c.roll, c.dt);
+    d.pitch = make_pid(c.pitch, c.dt);
+    d.yaw = make_pid(c.yaw, c.dt);
+    d.roll_ff = (float)c.roll_ff;
+    d.gravity = (float)c.gravity;
+    d.scale_min = (float)std::min(0.5, 1000.0 / (2.0 * c.airspeed_max));   // controller.py:36-37
+    d.scale_max = (float)std::max(2.0, 1000.0 / (0.7 * c.airspeed_min));
+    d.inner_steps = c.inner_steps;
+    d.aero_1d_tables = c.aero_1d_tables ? 1 : 0;
+    return d;
+}
+
+template <bool STEP>
+int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream) {
+    if (!ctx || !io) return fail("null ctx/io");
+    if (!ctx->combat) return fail("context was not created by np_f16_combat_ctx_create");
+    if (num_envs <= 0) return 0;
+    const int64_t n = 2 * num_envs;
+    if (!io->s || !io->u || !io->blood || !io->step_count || !io->done_in || !io->bad_in || !io->timeout_in || !io->done_out ||
+        !io->bad_out || !io->timeout_out)
+        return fail("null state/flag buffer");
+    if (io->ld < n) return fail("ld < n");
+    if (STEP && (!io->pid || !io->action || !io->obs || !io->reward || io->act_stride < 4))
+        return fail("step needs pid, action (>=4 columns), obs and reward buffers");
+    if (io->done_out == io->done_in || io->bad_out == io->bad_in || io->timeout_out == io->timeout_in)
+        return fail("flag outputs may not alias flag inputs");
+    if (io->row0 & 1) return fail("row0 must be even (2 * first env of the shard)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    CombatArgs a;
+    a.s = io->s; a.u = io->u; a.pid = io->pid; a.blood = io->blood; a.ld = io->ld; a.step_count = (long long *)io->step_count;
+    a.fin0 = io->done_in; a.fin1 = io->bad_in; a.fin2 = io->timeout_in;
+    a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
+    a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward; a.rand_u = io->rand_u;
+    a.pid_first = io->pid_first; a.seed = io->seed; a.call_idx = io->call_idx; a.row0 = io->row0; a.n = n; a.cfg = ctx->ccfg;
+    const dim3 grid((unsigned)((n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)), block(COMBAT_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = STEP && ctx->timing;
+    if (timed) {
+        if (!ctx->pool.empty()) {
+            ev = ctx->pool.back();
+            ctx->pool.pop_back();
+        } else {
+            NP_HIP(hipEventCreate(&ev.first));
+            NP_HIP(hipEventCreate(&ev.second));
+        }
+        NP_HIP(hipEventRecord(ev.first, st));
+    }
+    if (STEP && ctx->solver == 1) hipLaunchKernelGGL((f16_combat_kernel<1, STEP>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((f16_combat_kernel<0, STEP>), grid, block, 0, st, a);
+    NP_HIP(hipGetLastError());
+    if (timed) {
+        NP_HIP(hipEventRecord(ev.second, st));
+        ctx->events.push_back(ev);
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -614,14 +718,10 @@ int np_abi_version(void) { return NP_ABI_VERSION; }
 int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHED; }
 const char *np_last_error(void) { return g_err.c_str(); }
 
-int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg *cfg, int device, np_f16_ctx **out) {
-    if (!out || !cfg) return fail("null argument");
-    *out = nullptr;
-    if (cfg->task < 0 || cfg->task > 2) return fail("cfg.task must be NP_TASK_HEADING/CONTROL/TRACKING");
-    if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
+static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables, int device, np_f16_ctx **out) {
     std::vector<float> kb, pwl, pwl_unnorm;
     if (pack_kblob(weights_blob, nbytes, kb, pwl, pwl_unnorm)) return 1;
-    if (cfg->aero_1d_tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
+    if (tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
@@ -639,7 +739,7 @@ int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg 
     {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
         float *d_rc = nullptr;
         NP_HIP(hipMalloc(&d_rc, sizeof(float) * NUM_CACHED));
-        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, cfg->aero_1d_tables ? 1 : 0);
+        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, tables ? 1 : 0);
         hipError_t e1 = hipGetLastError();
         hipError_t e2 = hipDeviceSynchronize();
         hipError_t e3 = hipMemcpyToSymbol(HIP_SYMBOL(c_reset_coef), d_rc, sizeof(float) * NUM_CACHED, 0, hipMemcpyDeviceToDevice);
@@ -650,14 +750,51 @@ int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg 
     }
     np_f16_ctx *ctx = new np_f16_ctx();
     ctx->device = device;
-    ctx->task = cfg->task;
-    ctx->solver = cfg->solver;
-    ctx->cfg = make_devcfg(*cfg);
+    ctx->task = 0;
+    ctx->solver = 0;
+    ctx->combat = false;
     ctx->timing = false;
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
     *out = ctx;
     return 0;
+}
+
+int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg *cfg, int device, np_f16_ctx **out) {
+    if (!out || !cfg) return fail("null argument");
+    *out = nullptr;
+    if (cfg->task < 0 || cfg->task > 2) return fail("cfg.task must be NP_TASK_HEADING/CONTROL/TRACKING");
+    if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
+    if (ctx_create_common(weights_blob, nbytes, cfg->aero_1d_tables, device, out)) return 1;
+    (*out)->task = cfg->task;
+    (*out)->solver = cfg->solver;
+    (*out)->cfg = make_devcfg(*cfg);
+    return 0;
+}
+
+int np_f16_combat_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_combat_cfg *cfg, int device,
+                             np_f16_ctx **out) {
+    if (!out || !cfg) return fail("null argument");
+    *out = nullptr;
+    if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
+    if (cfg->inner_steps < 1 || cfg->inner_steps > 16) return fail("cfg.inner_steps must be in 1..16");
+    if (!(cfg->dt > 0.0)) return fail("cfg.dt must be positive");
+    if (ctx_create_common(weights_blob, nbytes, cfg->aero_1d_tables, device, out)) return 1;
+    (*out)->solver = cfg->solver;
+    (*out)->combat = true;
+    (*out)->ccfg = make_combat_devcfg(*cfg);
+    (*out)->cfg = DevCfg();
+    (*out)->cfg.airspeed = (float)cfg->airspeed;
+    (*out)->cfg.aero_1d_tables = cfg->aero_1d_tables ? 1 : 0;
+    return 0;
+}
+
+int np_f16_combat_reset(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream) {
+    return launch_combat<false>(ctx, num_envs, io, stream);
+}
+
+int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream) {
+    return launch_combat<true>(ctx, num_envs, io, stream);
 }
 
 void np_f16_ctx_destroy(np_f16_ctx *ctx) {

@@ -87,13 +87,11 @@ __device__ __forceinline__ void np_sincostan(float x, float &s, float &c, float 
 #define NPM_INV_LN2 (1.44269504088896338700e+00)
 #define NPM_LN2 (6.93147180559945286227e-01)
 
-// x^y = exp2(y*log2 x) in fp64, fixed operation sequence (only caller: the atmosphere model's tfac^4.14)
-__device__ __forceinline__ float np_pow(float xf, float yf) {
-    const double x = (double)xf, y = (double)yf;
-    if (x != x || y != y) return __builtin_nanf("");
-    if (x < 0.0) return __builtin_nanf("");
-    if (x == 0.0) return y > 0.0 ? 0.0f : __builtin_inff();
-    if (x == (double)__builtin_inff()) return y > 0.0 ? __builtin_inff() : 0.0f;
+// log2(x) in fp64, fixed operation sequence (fdlibm e_log.c kernel on the mantissa)
+__device__ __forceinline__ double log2_d(double x) {
+    if (x != x || x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_inf();
+    if (x == __builtin_inf()) return __builtin_inf();
     uint64_t bits = (uint64_t)__double_as_longlong(x);
     int e = (int)((bits >> 52) & 0x7FF) - 1023;
     bits = (bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
@@ -111,8 +109,12 @@ __device__ __forceinline__ float np_pow(float xf, float yf) {
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double lnm = f - (hfsq - s * (hfsq + R));
-    const double l2 = fma(lnm, NPM_INV_LN2, (double)e);
-    double P = y * l2;
+    return fma(lnm, NPM_INV_LN2, (double)e);
+}
+
+// 2^P in fp64, fixed operation sequence
+__device__ __forceinline__ double exp2_d(double P) {
+    if (P != P) return __builtin_nan("");
     if (P > 2000.0) P = 2000.0;
     if (P < -2000.0) P = -2000.0;
     const double k = rint(P);
@@ -131,7 +133,73 @@ __device__ __forceinline__ float np_pow(float xf, float yf) {
     q = fma(q, t, 0.5);
     q = fma(q, t, 1.0);
     q = fma(q, t, 1.0);
-    return (float)ldexp(q, (int)k);
+    return ldexp(q, (int)k);
+}
+
+// x^y = exp2(y*log2 x) in fp64 (atmosphere model's tfac^4.14)
+__device__ __forceinline__ float np_pow(float xf, float yf) {
+    const double x = (double)xf, y = (double)yf;
+    if (x != x || y != y) return __builtin_nanf("");
+    if (x < 0.0) return __builtin_nanf("");
+    if (x == 0.0) return y > 0.0 ? 0.0f : __builtin_inff();
+    if (x == (double)__builtin_inff()) return y > 0.0 ? __builtin_inff() : 0.0f;
+    return (float)exp2_d(y * log2_d(x));
+}
+
+// ---- pairwise geometry / reward functions of the combat envs (envs/utils/utils.py:156-249) ----
+#define NPM_PS0 (1.66666666666666657415e-01)
+#define NPM_PS1 (-3.25565818622400915405e-01)
+#define NPM_PS2 (2.01212532134862925881e-01)
+#define NPM_PS3 (-4.00555345006794114027e-02)
+#define NPM_PS4 (7.91534994289814532176e-04)
+#define NPM_PS5 (3.47933107596021167570e-05)
+#define NPM_QS1 (-2.40339491173441421878e+00)
+#define NPM_QS2 (2.02094576023350569471e+00)
+#define NPM_QS3 (-6.88283971605453293030e-01)
+#define NPM_QS4 (7.70381505559019352791e-02)
+#define NPM_PIO2_D (1.57079632679489655800e+00)
+#define NPM_PI_D (3.14159265358979311600e+00)
+
+// acos on [-1, 1] in fp64 (fdlibm e_acos.c rational kernel), rounded once
+__device__ __forceinline__ float np_acos(float xf) {
+    const double x = (double)xf;
+    if (x != x) return __builtin_nanf("");
+    const double ax = fabs(x);
+    const bool small = ax < 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    double p = fma(z, NPM_PS5, NPM_PS4);
+    p = fma(z, p, NPM_PS3);
+    p = fma(z, p, NPM_PS2);
+    p = fma(z, p, NPM_PS1);
+    p = fma(z, p, NPM_PS0);
+    p = z * p;
+    double q = fma(z, NPM_QS4, NPM_QS3);
+    q = fma(z, q, NPM_QS2);
+    q = fma(z, q, NPM_QS1);
+    q = fma(z, q, 1.0);
+    const double r = p / q;
+    if (small) return (float)(NPM_PIO2_D - fma(x, r, x));
+    const double s = sqrt(z);
+    const double t = 2.0 * fma(s, r, s);
+    return (float)(x > 0.0 ? t : NPM_PI_D - t);
+}
+
+// atanh(x) = ln((1+x)/(1-x)) / 2 for x in (-1, 1)
+__device__ __forceinline__ float np_atanh(float xf) {
+    const double x = (double)xf;
+    return (float)(0.5 * (log2_d((1.0 + x) / (1.0 - x)) * NPM_LN2));
+}
+
+__device__ __forceinline__ float np_exp(float xf) { return (float)exp2_d((double)xf * NPM_INV_LN2); }
+
+// torch.linalg.norm / torch.sum over the 3 components of a row: fp64, rounded once (numerics spec)
+__device__ __forceinline__ float np_norm3(float a, float b, float c) {
+    const double ad = a, bd = b, cd = c;
+    return (float)sqrt((ad * ad + bd * bd) + cd * cd);
+}
+__device__ __forceinline__ float np_dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    const float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+    return (float)(((double)p0 + (double)p1) + (double)p2);
 }
 
 // envs/utils/utils.py:144-154 wrap_PI: torch.remainder (exact fmod, then +divisor on sign mismatch),

@@ -210,13 +210,12 @@ static const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-
                     LG7 = 1.479819860511658591e-01;
 static const double INV_LN2 = 1.44269504088896338700e+00, LN2 = 6.93147180559945286227e-01;
 
-/* x^y for the atmosphere model: exp2(y*log2(x)) in fp64, fixed operation sequence. */
-static double pow_d(double x, double y) {
-    if (x != x || y != y) return NAN;
-    if (x < 0.0) return NAN; /* non-integer exponent */
-    if (x == 0.0) return y > 0.0 ? 0.0 : INFINITY;
-    if (x == INFINITY) return y > 0.0 ? INFINITY : 0.0;
-    /* x is a positive finite double (from a float: always a normal double) */
+/* log2(x) in fp64, fixed operation sequence (fdlibm e_log.c kernel on the mantissa). */
+static double log2_d(double x) {
+    if (x != x || x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return INFINITY;
+    /* x is a positive finite double (from float arithmetic: always a normal double) */
     uint64_t bits;
     memcpy(&bits, &x, 8);
     int e = (int)((bits >> 52) & 0x7FF) - 1023;
@@ -236,8 +235,12 @@ static double pow_d(double x, double y) {
     double R = t2 + t1;
     double hfsq = 0.5 * f * f;
     double lnm = f - (hfsq - s * (hfsq + R));
-    double l2 = fma(lnm, INV_LN2, (double)e);
-    double P = y * l2;
+    return fma(lnm, INV_LN2, (double)e);
+}
+
+/* 2^P in fp64, fixed operation sequence. */
+static double exp2_d(double P) {
+    if (P != P) return NAN;
     if (P > 2000.0) P = 2000.0;
     if (P < -2000.0) P = -2000.0;
     double k = rint(P);
@@ -258,6 +261,15 @@ static double pow_d(double x, double y) {
     q = fma(q, t, 1.0);
     q = fma(q, t, 1.0);
     return ldexp(q, (int)k);
+}
+
+/* x^y for the atmosphere model: exp2(y*log2(x)) in fp64. */
+static double pow_d(double x, double y) {
+    if (x != x || y != y) return NAN;
+    if (x < 0.0) return NAN; /* non-integer exponent */
+    if (x == 0.0) return y > 0.0 ? 0.0 : INFINITY;
+    if (x == INFINITY) return y > 0.0 ? INFINITY : 0.0;
+    return exp2_d(y * log2_d(x));
 }
 
 float f16o_pow(float x, float y) {
@@ -700,6 +712,27 @@ int f16o_reset(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, fl
     return 0;
 }
 
+/* one torchdiffeq fixed-grid step of the 17-vector x = [s, u] (F16_model.py:64-67); writes s' */
+static void integrate_x(const f16o_model *m, int solver, double dt_cfg, const float x[17], float *s) {
+    const float dt = (float)dt_cfg - 0.0f; /* t = tensor([0., dt]); dt = t1 - t0 */
+    float k1[12];
+    nlplant_row(m, x, k1);
+    if (solver == F16O_SOLVER_EULER) {
+        for (int k = 0; k < 12; k++) s[k] = x[k] + dt * k1[k];
+    } else { /* torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule); parity UNPINNED (see header) */
+        const float third = (float)(1.0 / 3.0);
+        float y[17], k2[12], k3[12], k4[12];
+        memcpy(y, x, sizeof(y));
+        for (int k = 0; k < 12; k++) y[k] = x[k] + (dt * k1[k]) * third;
+        nlplant_row(m, y, k2);
+        for (int k = 0; k < 12; k++) y[k] = x[k] + dt * (k2[k] - k1[k] * third);
+        nlplant_row(m, y, k3);
+        for (int k = 0; k < 12; k++) y[k] = x[k] + dt * ((k1[k] - k2[k]) + k3[k]);
+        nlplant_row(m, y, k4);
+        for (int k = 0; k < 12; k++) s[k] = x[k] + (((k1[k] + 3.0f * (k2[k] + k3[k])) + k4[k]) * dt) * 0.125f;
+    }
+}
+
 /* F16Model.update — envs/models/F16_model.py:51-67 (+ integrator, Appendix A.4 of SURVEY.md) */
 static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float *u, const float *a_in) {
     float a[4];
@@ -716,23 +749,7 @@ static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float
     x[14] = 0.9f * u[2] + (0.1f * a[2]) * 45.0f;
     x[15] = 0.9f * u[3] + (0.1f * a[3]) * 45.0f;
     x[16] = 0.0f;
-    const float dt = (float)cfg->dt - 0.0f; /* t = tensor([0., dt]); dt = t1 - t0 */
-    float k1[12];
-    nlplant_row(m, x, k1);
-    if (cfg->solver == F16O_SOLVER_EULER) {
-        for (int k = 0; k < 12; k++) s[k] = x[k] + dt * k1[k];
-    } else { /* torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule); parity UNPINNED (see header) */
-        const float third = (float)(1.0 / 3.0);
-        float y[17], k2[12], k3[12], k4[12];
-        memcpy(y, x, sizeof(y));
-        for (int k = 0; k < 12; k++) y[k] = x[k] + (dt * k1[k]) * third;
-        nlplant_row(m, y, k2);
-        for (int k = 0; k < 12; k++) y[k] = x[k] + dt * (k2[k] - k1[k] * third);
-        nlplant_row(m, y, k3);
-        for (int k = 0; k < 12; k++) y[k] = x[k] + dt * ((k1[k] - k2[k]) + k3[k]);
-        nlplant_row(m, y, k4);
-        for (int k = 0; k < 12; k++) s[k] = x[k] + (((k1[k] + 3.0f * (k2[k] + k3[k])) + k4[k]) * dt) * 0.125f;
-    }
+    integrate_x(m, cfg->solver, cfg->dt, x, s);
     for (int k = 0; k < 5; k++) u[k] = x[12 + k];
 }
 
@@ -873,3 +890,5 @@ int f16o_num_threads(void) {
     return 1;
 #endif
 }
+
+#include "f16_combat.inc"

@@ -111,6 +111,54 @@ int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *
 /* PlanningEnv.low_level_obs (envs/planning_env.py:60-142); tgt3[n][3] = (target_pitch, target_heading, target_vt) */
 void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs);
 
+/* ------------------------------------------------------------------------------------------ */
+/* SingleCombat 1v1 restatement (f16_combat.inc) — envs/singlecombat_env.py + algorithms/pid/  */
+/* ------------------------------------------------------------------------------------------ */
+#define F16O_NPID 11        /* roll_dem, pitch_dem, {roll,pitch,yaw} x {error, integrator, last_out} */
+#define F16O_NOBS_COMBAT 15
+
+/* algorithms/pid/config/{roll,pitch,yaw}controller.yaml */
+typedef struct f16o_pid_gains {
+    double Kp, Ki, Kd, Kff, Kimax, tau, rmax_pos, rmax_neg;
+} f16o_pid_gains;
+
+/* envs/configs/selfplay.yaml + the PID YAMLs + Controller.__init__ defaults (controller.py:15-23) */
+typedef struct f16o_combat_cfg {
+    int32_t solver, inner_steps;
+    double dt, airspeed;
+    double altitude_limit, acceleration_limit, max_velocity, min_velocity;
+    double min_alpha, max_alpha, min_beta, max_beta;
+    double distance_limit;
+    int64_t max_steps;
+    double init_T, target_dist;
+    double max_altitude, min_altitude, max_vt, min_vt, max_heading, min_heading;
+    double max_npos, min_npos, max_epos, min_epos;
+    f16o_pid_gains roll, pitch, yaw;
+    double roll_ff, gravity;
+    double airspeed_min, airspeed_max;
+} f16o_combat_cfg;
+
+float f16o_acos(float x);
+float f16o_atanh(float x);
+float f16o_exp(float x);
+/* pure pairwise functions (envs/utils/utils.py:156-249); out11 per pair = AO, TA, R, AO2d, TA2d, R2d, side,
+ * orientation_reward('v2'), range_reward('v3', R km), orientation_fn(AO), distance_fn(R km) */
+void f16o_pairwise(int64_t n, const float *ego_pos, const float *enm_pos, const float *ego_vel, const float *enm_vel,
+                   float target_dist, float *out11);
+/* Controller.stabilize for n aircraft (s[n][12], pid[n][F16O_NPID] in/out); out3 = (el, ail, rud) outputs */
+void f16o_stabilize(const f16o_combat_cfg *cfg, int64_t n, const float *s, float *pid, int first, float *out3);
+/* Pairwise reset: both aircraft of an env in which any flag is set are re-initialised (rand_u[n][5] =
+ * U_npos, U_epos, U_alt, U_yaw, U_vt or NULL -> counter RNG keyed by global aircraft row 2*env0+i), then all
+ * flags are cleared; obs[n][15] may be NULL. */
+int f16o_combat_reset(const f16o_model *m, const f16o_combat_cfg *cfg, int64_t num_envs, float *s, float *u, float *blood,
+                      int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *rand_u, uint64_t seed,
+                      uint64_t call_idx, int64_t env0, float *obs);
+/* One SingleCombatEnv.step (n = 2*num_envs aircraft, rows 2k = ego, 2k+1 = enemy of env k). */
+int f16o_combat_step(const f16o_model *m, const f16o_combat_cfg *cfg, int64_t num_envs, float *s, float *u, float *pid,
+                     float *blood, int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
+                     int64_t act_stride, const float *rand_u, int pid_first, uint64_t seed, uint64_t call_idx, int64_t env0,
+                     float *obs, float *reward);
+
 int f16o_num_threads(void);
 void f16o_set_threads(int n); /* OpenMP threads used by the batched entry points */
 

@@ -41,7 +41,7 @@ class Cfg(C.Structure):
 
 def build(force=False):
     """Compile oracle/_build/libf16oracle.so with gcc (Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_oracle.h', 'Makefile'))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_oracle.h', 'Makefile'))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
         subprocess.run(['make', '-C', _HERE], check=True, stdout=subprocess.DEVNULL)
     return _SO
@@ -258,5 +258,122 @@ class Oracle:
                                 _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(a),
                                 C.c_int64(a.shape[1]), _p(ru), _p(nz), C.c_uint64(seed), C.c_uint64(call_idx),
                                 C.c_int64(row0), _p(obs), _p(rew))
+        assert rc == 0
+        return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()
+
+
+# =====================================================================================================
+# SingleCombat 1v1 (f16_combat.inc)
+# =====================================================================================================
+class PidGains(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ('Kp', 'Ki', 'Kd', 'Kff', 'Kimax', 'tau', 'rmax_pos', 'rmax_neg')]
+
+
+class CombatCfg(C.Structure):
+    _fields_ = [('solver', C.c_int32), ('inner_steps', C.c_int32), ('dt', C.c_double), ('airspeed', C.c_double),
+                ('altitude_limit', C.c_double), ('acceleration_limit', C.c_double), ('max_velocity', C.c_double),
+                ('min_velocity', C.c_double), ('min_alpha', C.c_double), ('max_alpha', C.c_double),
+                ('min_beta', C.c_double), ('max_beta', C.c_double), ('distance_limit', C.c_double),
+                ('max_steps', C.c_int64), ('init_T', C.c_double), ('target_dist', C.c_double),
+                ('max_altitude', C.c_double), ('min_altitude', C.c_double), ('max_vt', C.c_double), ('min_vt', C.c_double),
+                ('max_heading', C.c_double), ('min_heading', C.c_double), ('max_npos', C.c_double), ('min_npos', C.c_double),
+                ('max_epos', C.c_double), ('min_epos', C.c_double),
+                ('roll', PidGains), ('pitch', PidGains), ('yaw', PidGains),
+                ('roll_ff', C.c_double), ('gravity', C.c_double), ('airspeed_min', C.c_double), ('airspeed_max', C.c_double)]
+
+
+def load_combat_cfg(config='selfplay', solver=None, overrides=None):
+    """selfplay.yaml + pid/*.yaml -> CombatCfg with the defaults of singlecombat_env.py:29-44 / the condition classes."""
+    with open(os.path.join(CONFIG_DIR, f'{config}.yaml')) as f:
+        y = yaml.safe_load(f)
+    y.update(overrides or {})
+    g = y.get
+    c = CombatCfg()
+    c.solver = SOLVERS[solver or g('solver', 'euler')]
+    c.inner_steps = 5
+    c.dt, c.airspeed = g('dt', 0.02), g('airspeed', 0)
+    c.altitude_limit, c.acceleration_limit = g('altitude_limit', 2500.0), g('acceleration_limit', 300.0)
+    c.max_velocity, c.min_velocity = g('max_velocity', 3), g('min_velocity', 0.01)
+    c.min_alpha, c.max_alpha, c.min_beta, c.max_beta = g('min_alpha', -20), g('max_alpha', 45), g('min_beta', -30), g('max_beta', 30)
+    c.distance_limit, c.max_steps = g('distance_limit', 200), g('max_steps', 500)
+    c.init_T, c.target_dist = g('init_T', 2000), g('target_dist', 3)
+    c.max_altitude, c.min_altitude = g('max_altitude', 20000), g('min_altitude', 19000)
+    c.max_vt, c.min_vt = g('max_vt', 1200), g('min_vt', 1000)
+    c.max_heading, c.min_heading = g('max_heading', 0.5), g('min_heading', -0.5)
+    c.max_npos, c.min_npos, c.max_epos, c.min_epos = g('max_npos', 5000), g('min_npos', -5000), g('max_epos', 5000), g('min_epos', -5000)
+    for name in ('roll', 'pitch', 'yaw'):
+        with open(os.path.join(CONFIG_DIR, 'pid', f'{name}controller.yaml')) as f:
+            p = yaml.safe_load(f)
+        gains = getattr(c, name)
+        for k in ('Kp', 'Ki', 'Kd', 'Kff', 'Kimax', 'tau'):
+            setattr(gains, k, p[k])
+        gains.rmax_pos, gains.rmax_neg = p.get('rmax_pos', 0), p.get('rmax_neg', 0)
+        if name == 'pitch':
+            c.roll_ff, c.gravity = p['roll_ff'], p['gravity']
+    c.airspeed_min, c.airspeed_max = 100, 2300   # Controller.__init__ defaults (controller.py:15)
+    return c
+
+
+class CombatOracle(Oracle):
+    """1v1 combat macro-step on top of the same model blob.  Rows 2k / 2k+1 = ego / enemy of env k."""
+
+    def __init__(self, config='selfplay', solver=None, overrides=None, blob_path=DEFAULT_BLOB, mode=0, threads=None):
+        super().__init__('heading', None, None, blob_path, mode, threads)
+        self.ccfg = load_combat_cfg(config, solver, overrides)
+        for fn in ('f16o_acos', 'f16o_atanh', 'f16o_exp'):
+            getattr(self.lib, fn).restype = C.c_float
+            getattr(self.lib, fn).argtypes = [C.c_float]
+
+    @staticmethod
+    def new_state(num_envs):
+        n = 2 * num_envs
+        return dict(s=np.zeros((n, 12), np.float32), u=np.zeros((n, 5), np.float32), pid=np.zeros((n, 11), np.float32),
+                    blood=np.full(n, 100, np.float32), step_count=np.zeros(n, np.int64),
+                    done=np.ones(n, np.uint8), bad=np.ones(n, np.uint8), timeout=np.ones(n, np.uint8))
+
+    def unary(self, name, x):
+        self._set_mode()
+        fn = getattr(self.lib, 'f16o_' + name)
+        return np.array([fn(C.c_float(v)) for v in _f32(x).reshape(-1)], dtype=np.float32)
+
+    def pairwise(self, ego_pos, enm_pos, ego_vel, enm_vel):
+        self._set_mode()
+        a, b, c, d = (_f32(v) for v in (ego_pos, enm_pos, ego_vel, enm_vel))
+        out = np.empty((a.shape[0], 11), np.float32)
+        self.lib.f16o_pairwise(C.c_int64(a.shape[0]), _p(a), _p(b), _p(c), _p(d), C.c_float(self.ccfg.target_dist), _p(out))
+        return out
+
+    def stabilize(self, s, pid, first):
+        self._set_mode()
+        s = _f32(s)
+        out = np.empty((s.shape[0], 3), np.float32)
+        self.lib.f16o_stabilize(C.byref(self.ccfg), C.c_int64(s.shape[0]), _p(s), _p(pid), C.c_int(int(first)), _p(out))
+        return out
+
+    def combat_reset(self, st, rand_u=None, seed=0, call_idx=0, env0=0):
+        self._set_mode()
+        n = st['s'].shape[0]
+        obs = np.empty((n, 15), np.float32)
+        ru = None if rand_u is None else _f32(rand_u)
+        rc = self.lib.f16o_combat_reset(C.c_void_p(self.model), C.byref(self.ccfg), C.c_int64(n // 2), _p(st['s']), _p(st['u']),
+                                        _p(st['blood']), _p(st['step_count'], C.c_int64), _p(st['done'], C.c_uint8),
+                                        _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(ru), C.c_uint64(seed),
+                                        C.c_uint64(call_idx), C.c_int64(env0), _p(obs))
+        assert rc == 0
+        return obs
+
+    def combat_step(self, st, action, rand_u=None, pid_first=False, seed=0, call_idx=0, env0=0):
+        self._set_mode()
+        n = st['s'].shape[0]
+        a = _f32(action)
+        assert a.ndim == 2 and a.shape[0] == n and a.shape[1] >= 4
+        obs = np.empty((n, 15), np.float32)
+        rew = np.empty(n, np.float32)
+        ru = None if rand_u is None else _f32(rand_u)
+        rc = self.lib.f16o_combat_step(C.c_void_p(self.model), C.byref(self.ccfg), C.c_int64(n // 2), _p(st['s']), _p(st['u']),
+                                       _p(st['pid']), _p(st['blood']), _p(st['step_count'], C.c_int64),
+                                       _p(st['done'], C.c_uint8), _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(a),
+                                       C.c_int64(a.shape[1]), _p(ru), C.c_int(int(pid_first)), C.c_uint64(seed),
+                                       C.c_uint64(call_idx), C.c_int64(env0), _p(obs), _p(rew))
         assert rc == 0
         return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()

@@ -32,28 +32,40 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.np_abi_version() == 4
+    assert lib.np_abi_version() == 5
+
+
+def _flat_fields(struct, prefix=''):
+    out = []
+    for name, typ in struct._fields_:
+        if isinstance(typ, type) and issubclass(typ, C.Structure):
+            base = getattr(struct, name).offset
+            out += [(prefix + name + '.' + n, base + o) for n, o in _flat_fields(typ)]
+        else:
+            out.append((prefix + name, getattr(struct, name).offset))
+    return out
 
 
 def test_struct_layout_matches_ctypes(tmp_path):
     """Compile a tiny C program against the public header and compare sizeof/offsetof with ctypes."""
     from neuralplane_amd import _lib
-    fields_cfg = [f[0] for f in _lib.NpF16Cfg._fields_]
-    fields_io = [f[0] for f in _lib.NpF16Io._fields_]
-    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){',
-            'printf("%zu %zu\\n", sizeof(np_f16_cfg), sizeof(np_f16_io));']
-    prog += [f'printf("%zu\\n", offsetof(np_f16_cfg, {f}));' for f in fields_cfg]
-    prog += [f'printf("%zu\\n", offsetof(np_f16_io, {f}));' for f in fields_io]
+    pairs = [('np_f16_cfg', _lib.NpF16Cfg), ('np_f16_io', _lib.NpF16Io), ('np_pid_gains', _lib.NpPidGains),
+             ('np_f16_combat_cfg', _lib.NpF16CombatCfg), ('np_f16_combat_io', _lib.NpF16CombatIo)]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
+    exp = []
+    for cname, st in pairs:
+        prog.append(f'printf("%zu\\n", sizeof({cname}));')
+        exp.append(C.sizeof(st))
+        for f, off in _flat_fields(st):
+            prog.append(f'printf("%zu\\n", offsetof({cname}, {f}));')
+            exp.append(off)
     prog += ['return 0;}']
     c = tmp_path / 'layout.c'
     c.write_text('\n'.join(prog))
     exe = tmp_path / 'layout'
     subprocess.run(['gcc', '-std=c11', '-o', str(exe), str(c)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == C.sizeof(_lib.NpF16Cfg) and int(out[1]) == C.sizeof(_lib.NpF16Io)
-    offs = [int(x) for x in out[2:]]
-    exp = [getattr(_lib.NpF16Cfg, f).offset for f in fields_cfg] + [getattr(_lib.NpF16Io, f).offset for f in fields_io]
-    assert offs == exp
+    assert [int(x) for x in out] == exp
 
 
 def test_header_cites_reference_interfaces():
@@ -86,6 +98,12 @@ def test_ctx_create_validates_blob_and_fails_loudly_without_gpu(lib):
             ControlEnv(num_envs=4, config='heading', model='F16', random_seed=0, device='cuda:0')
         with pytest.raises(RuntimeError, match='no CPU fallback'):
             ControlEnv(num_envs=4, config='heading', model='F16', random_seed=0, device='cpu')
+        from neuralplane_amd.core import combat_cfg_from_config
+        ccfg = combat_cfg_from_config(parse_config('selfplay'))
+        assert lib.np_f16_combat_ctx_create(blob, len(blob), C.byref(ccfg), 0, C.byref(ctx)) != 0 and not ctx.value
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+            SingleCombatEnv(num_envs=2, config='selfplay', random_seed=0, device='cpu')
 
 
 def test_product_never_touches_the_oracle():

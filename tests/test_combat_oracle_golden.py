@@ -1,0 +1,137 @@
+"""CPU tests: the SingleCombat part of the oracle (oracle/f16_combat.inc) against golden vectors recorded from
+the REFERENCE's own components (tools/gen_golden.py gen_pairwise / gen_combat):
+
+* pairwise_kat.npz  — envs/utils/utils.py get_AO_TA_R / get2d_AO_TA_R / orientation_reward / range_reward /
+  orientation_fn / distance_fn on 512 geometries (tail chase, head-on, co-located, stationary included);
+* combat_kat{,_pin}.npz — 48 env.steps of 24 engagements: F16Model dynamics + torchdiffeq step, the
+  algorithms/pid Controller.stabilize, the eight termination-condition classes, SingleCombatEnv.obs/.reward
+  (unbound) and the blood update, composed as envs/singlecombat_env.py:207-274 prescribes (the env file itself
+  is stale and cannot be constructed).  Crash, Timeout and both Shutdown outcomes fire.
+
+Pin mode (libraries evaluated in fp64 and rounded once on both sides) must agree BIT-EXACTLY; the plain
+recordings (ATen sgemm / SLEEF / VML) within the tolerances written in each test.
+"""
+import numpy as np
+import pytest
+
+from oracle.f16_oracle import MODE_MLP_F64, CombatOracle
+
+PAIR_NAMES = ['AO', 'TA', 'R', 'AO2', 'TA2', 'R2', 'side', 'orient', 'range', 'ofn', 'dfn']
+STATE_FLOORS = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1, .1, .1, .1], np.float32)
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return bool(np.all((a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))))
+
+
+def test_acos_atanh_exp_are_fp64_evaluations_rounded_once():
+    o = CombatOracle()
+    rng = np.random.RandomState(5)
+    x = np.concatenate([rng.uniform(-1, 1, 4000), [1.0, -1.0, 0.0, 0.5, -0.5, 0.99999994, -0.99999994, 1e-20]]).astype(np.float32)
+    ref = np.arccos(x.astype(np.float64)).astype(np.float32)
+    got = o.unary('acos', x)
+    assert np.max(np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32))) <= 1   # <= 1 ulp (double-rounding ties)
+    assert np.mean(got == ref) > 0.999
+    y = np.concatenate([rng.uniform(-0.9, 0.9999, 4000), [0.0, 1e-7, -1e-7, 0.9999]]).astype(np.float32)
+    ref = np.arctanh(y.astype(np.float64)).astype(np.float32)
+    got = o.unary('atanh', y)
+    assert np.max(np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32))) <= 1
+    assert np.mean(got == ref) > 0.999
+    z = np.concatenate([rng.uniform(-30, 2, 4000), [0.0, -0.16, -100.0]]).astype(np.float32)
+    ref = np.exp(z.astype(np.float64)).astype(np.float32)
+    got = o.unary('exp', z)
+    assert np.max(np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32))) <= 1
+    assert np.mean(got == ref) > 0.999
+    assert np.isnan(o.unary('acos', [np.nan])[0]) and np.isnan(o.unary('atanh', [np.nan])[0]) and np.isnan(o.unary('exp', [np.nan])[0])
+
+
+def test_pairwise_functions_match_reference(golden_dir):
+    pk = np.load(f'{golden_dir}/pairwise_kat.npz')
+    out = CombatOracle().pairwise(pk['ego_pos'], pk['enm_pos'], pk['ego_vel'], pk['enm_vel'])
+    for j, nm in enumerate(PAIR_NAMES):
+        assert same(out[:, j], pk[nm + '_pin']), nm                 # pin mode: bit-exact
+        ref = pk[nm]
+        ok = np.isfinite(ref)
+        # plain (SLEEF acos/atanh/exp, ATen fp32 norm/sum): angles to 1e-4 rad absolute (acos amplifies the fp32
+        # rounding of its argument by 1/sqrt(1-x^2) near 0 and pi), everything else to 1e-5 relative
+        tol = 1e-4 if nm in ('AO', 'TA', 'AO2', 'TA2') else 1e-5 * np.maximum(np.abs(ref[ok]), 1.0)
+        assert np.all(np.abs(out[ok, j] - ref[ok]) <= tol), nm
+
+
+def _load_state(o, d, n):
+    st = o.new_state(n // 2)
+    st['s'][:], st['u'][:], st['blood'][:], st['step_count'][:] = d['s_init'], d['u_init'], d['blood_init'], d['step_count_init']
+    st['done'][:] = 0
+    st['bad'][:] = 0
+    st['timeout'][:] = 0
+    return st
+
+
+@pytest.mark.parametrize('teacher_forced', [True, False])
+def test_combat_macro_step_bit_exact_in_pin_mode(golden_dir, teacher_forced):
+    d = np.load(f'{golden_dir}/combat_kat_pin.npz')
+    K, n = d['actions'].shape[:2]
+    o = CombatOracle(mode=MODE_MLP_F64)
+    st = _load_state(o, d, n)
+    fired = np.zeros(3, np.int64)
+    for k in range(K):
+        obs, rew, done, bad, tmo = o.combat_step(st, d['actions'][k], rand_u=d['rand_u'][k], pid_first=(k == 0))
+        for nm, x in (('s', st['s']), ('u', st['u']), ('pid', st['pid']), ('blood', st['blood']), ('step_count', st['step_count']),
+                      ('obs', obs), ('reward', rew)):
+            assert same(x, d[f'{nm}_{k}']), (nm, k)
+        assert np.array_equal(np.stack([done, bad, tmo]), d[f'flags_{k}']), k
+        fired += d[f'flags_{k}'].astype(np.int64).sum(axis=1)
+        if teacher_forced:
+            st['s'][:], st['u'][:], st['pid'][:], st['blood'][:] = d[f's_{k}'], d[f'u_{k}'], d[f'pid_{k}'], d[f'blood_{k}']
+            st['step_count'][:] = d[f'step_count_{k}']
+            st['done'][:], st['bad'][:], st['timeout'][:] = d[f'flags_{k}']
+    assert fired[0] >= 2 and fired[1] >= 4 and fired[2] >= 2     # Shutdown(done), Crash + Shutdown(bad), Timeout all exercised
+
+
+def test_combat_macro_step_close_to_plain_reference(golden_dir):
+    """Shipped numerics spec vs the reference as it runs (ATen sgemm / SLEEF), teacher-forced per env.step.
+
+    The attitude loop is a high-gain saturating rate PID (Kp = 10 x 180/pi deg per rad/s, outputs clamped to
+    +-45 deg, written straight to the control surfaces): it amplifies a 1e-7 difference by about x10 per FDM step,
+    so two implementations that differ in the last bit of one MLP output are 1e-3 apart after one env.step
+    (5 FDM steps) and decorrelated after three.  Free-running agreement is therefore only meaningful bit-exactly
+    (the pin-mode test above); here each env.step starts from the recorded state."""
+    d = np.load(f'{golden_dir}/combat_kat.npz')
+    K, n = d['actions'].shape[:2]
+    o = CombatOracle()
+    st = _load_state(o, d, n)
+    for k in range(K):
+        obs, rew, done, bad, tmo = o.combat_step(st, d['actions'][k], rand_u=d['rand_u'][k], pid_first=(k == 0))
+        err = float(np.max(np.abs(st['s'] - d[f's_{k}']) / np.maximum(np.abs(d[f's_{k}']), STATE_FLOORS)))
+        assert err < 5e-3, (k, err)
+        assert np.max(np.abs(st['s'][:, :9] - d[f's_{k}'][:, :9]) / np.maximum(np.abs(d[f's_{k}'][:, :9]), STATE_FLOORS[:9])) < 1e-4
+        assert np.array_equal(np.stack([done, bad, tmo]), d[f'flags_{k}']), k
+        assert np.allclose(obs, d[f'obs_{k}'], rtol=0, atol=1e-4), k
+        assert np.allclose(rew, d[f'reward_{k}'], rtol=0, atol=2e-6), k
+        assert np.allclose(st['blood'], d[f'blood_{k}'], rtol=0, atol=1e-4), k
+        st['s'][:], st['u'][:], st['pid'][:], st['blood'][:] = d[f's_{k}'], d[f'u_{k}'], d[f'pid_{k}'], d[f'blood_{k}']
+        st['step_count'][:] = d[f'step_count_{k}']
+        st['done'][:], st['bad'][:], st['timeout'][:] = d[f'flags_{k}']
+
+
+def test_pairwise_reset_and_counter_rng():
+    """reset_done_envs re-initialises BOTH aircraft of a flagged env (and only those); the counter RNG is keyed by
+    the global aircraft row, so a shard sees the draws of the unsharded batch."""
+    o = CombatOracle()
+    st = o.new_state(6)
+    o.combat_reset(st, seed=9, call_idx=0)
+    full = {k: v.copy() for k, v in st.items()}
+    assert np.all(st['s'][:, 2] >= 19000) and np.all(st['s'][:, 2] <= 20000) and np.all(np.abs(st['s'][:, 5]) <= 0.5)
+    assert np.all(np.abs(st['s'][:, :2]) <= 5000) and np.all(st['u'][:, 0] == 2000) and np.all(st['blood'] == 100)
+    # flag one aircraft of env 2 -> rows 4 and 5 are redrawn, the others untouched
+    st['bad'][5] = 1
+    st['blood'][:] = 50
+    o.combat_reset(st, seed=9, call_idx=1)
+    changed = np.any(st['s'] != full['s'], axis=1)
+    assert changed.tolist() == [False] * 4 + [True, True] + [False] * 6
+    assert st['blood'].tolist() == [50] * 4 + [100, 100] + [50] * 6
+    # shard: envs 2..5 of the same batch
+    sh = o.new_state(4)
+    o.combat_reset(sh, seed=9, call_idx=0, env0=2)
+    assert np.array_equal(sh['s'], full['s'][4:])

@@ -1,0 +1,210 @@
+"""GPU parity of the fused SingleCombat macro-step (np_f16_combat_step, one launch per env.step) against the CPU
+oracle and the fixtures recorded from the reference's components.  All calls go through the C ABI
+(neuralplane_amd.core.F16CombatBatch -> libneuralplane_hip.so).
+
+Bar: HIP == oracle BIT-EXACT for states, controls, controller state, blood, counters, the three masks,
+observations and rewards — free-running, because the closed attitude loop amplifies any last-bit difference
+(tests/test_combat_oracle_golden.py explains) — and HIP vs the reference's plain recording per env.step within
+the tolerances of the CPU test.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.f16_oracle import MODE_PWL, CombatOracle  # noqa: E402  (the checker; test infrastructure)
+
+STATE_FLOORS = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1, .1, .1, .1], np.float32)
+
+
+def _batch(num_envs, solver=None, seed=0, env0=0, tables=False):
+    from neuralplane_amd.core import F16CombatBatch
+    from neuralplane_amd.envs.utils.utils import parse_config
+    return F16CombatBatch(num_envs, parse_config('selfplay'), 'cuda:0', seed=seed, solver=solver, env0=env0, aero_1d_tables=tables)
+
+
+def _load(b, st):
+    b.s.copy_(torch.from_numpy(st['s'].T.copy()))
+    b.u.copy_(torch.from_numpy(st['u'].T.copy()))
+    b.pid.copy_(torch.from_numpy(st['pid'].T.copy()))
+    b.blood.copy_(torch.from_numpy(st['blood']))
+    b.step_count.copy_(torch.from_numpy(st['step_count']))
+    b.flags.copy_(torch.from_numpy(np.stack([st['done'], st['bad'], st['timeout']])))
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return bool(np.all((a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))))
+
+
+def _check(b, obs, rew, flags, st, o_obs, o_rew, what, rows=slice(None)):
+    assert _same(b.s.cpu().numpy().T[rows], st['s']), f'{what}: state'
+    assert _same(b.u.cpu().numpy().T[rows], st['u']), f'{what}: controls'
+    assert _same(b.pid.cpu().numpy().T[rows], st['pid']), f'{what}: controller state'
+    assert _same(b.blood.cpu().numpy()[rows], st['blood']), f'{what}: blood'
+    assert np.array_equal(b.step_count.cpu().numpy()[rows], st['step_count']), f'{what}: step_count'
+    f = flags.cpu().numpy()
+    assert np.array_equal(f[0][rows], st['done']) and np.array_equal(f[1][rows], st['bad']) and \
+        np.array_equal(f[2][rows], st['timeout']), f'{what}: masks'
+    assert _same(obs.cpu().numpy()[rows], o_obs), f'{what}: obs'
+    if rew is not None:
+        assert _same(rew.cpu().numpy()[rows], o_rew), f'{what}: reward'
+
+
+def _fixture_state(o, d, n):
+    st = o.new_state(n // 2)
+    st['s'][:], st['u'][:], st['blood'][:], st['step_count'][:] = d['s_init'], d['u_init'], d['blood_init'], d['step_count_init']
+    st['done'][:] = 0
+    st['bad'][:] = 0
+    st['timeout'][:] = 0
+    return st
+
+
+@pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
+def test_combat_fixture_free_running_bit_exact_vs_oracle(golden_dir, tables):
+    """The 48 recorded env.steps (Crash, Timeout, both Shutdown outcomes, pairwise auto-resets with injected draws)."""
+    d = np.load(f'{golden_dir}/combat_kat.npz')
+    K, n = d['actions'].shape[:2]
+    o = CombatOracle(mode=MODE_PWL if tables else 0)
+    st = _fixture_state(o, d, n)
+    b = _batch(n // 2, tables=tables)
+    _load(b, st)
+    fired = np.zeros(3, np.int64)
+    for k in range(K):
+        obs, rew, flags = b.step(torch.from_numpy(d['actions'][k]).cuda(), rand_u=d['rand_u'][k])
+        o_obs, o_rew, dn, bd, tm = o.combat_step(st, d['actions'][k], rand_u=d['rand_u'][k], pid_first=(k == 0))
+        _check(b, obs, rew, flags, st, o_obs, o_rew, f'fixture step {k}')
+        fired += np.array([dn.sum(), bd.sum(), tm.sum()])
+    assert fired[0] >= 2 and fired[1] >= 4 and fired[2] >= 2
+
+
+def test_combat_fixture_vs_reference_teacher_forced(golden_dir):
+    """HIP vs the reference's own (plain ATen) recording, each env.step started from the recorded state."""
+    d = np.load(f'{golden_dir}/combat_kat.npz')
+    K, n = d['actions'].shape[:2]
+    b = _batch(n // 2)
+    st = _fixture_state(CombatOracle, d, n)
+    for k in range(K):
+        _load(b, st)
+        b.pid_first = (k == 0)
+        obs, rew, flags = b.step(torch.from_numpy(d['actions'][k]).cuda(), rand_u=d['rand_u'][k])
+        s = b.s.cpu().numpy().T
+        ref = d[f's_{k}']
+        assert np.max(np.abs(s - ref) / np.maximum(np.abs(ref), STATE_FLOORS)) < 5e-3, k
+        assert np.max(np.abs(s[:, :9] - ref[:, :9]) / np.maximum(np.abs(ref[:, :9]), STATE_FLOORS[:9])) < 1e-4, k
+        assert np.array_equal(flags.cpu().numpy(), d[f'flags_{k}']), k
+        assert np.allclose(obs.cpu().numpy(), d[f'obs_{k}'], rtol=0, atol=1e-4), k
+        assert np.allclose(rew.cpu().numpy(), d[f'reward_{k}'], rtol=0, atol=2e-6), k
+        assert np.allclose(b.blood.cpu().numpy(), d[f'blood_{k}'], rtol=0, atol=1e-4), k
+        st = dict(s=d[f's_{k}'], u=d[f'u_{k}'], pid=d[f'pid_{k}'], blood=d[f'blood_{k}'], step_count=d[f'step_count_{k}'],
+                  done=d[f'flags_{k}'][0], bad=d[f'flags_{k}'][1], timeout=d[f'flags_{k}'][2])
+
+
+@pytest.mark.parametrize('solver', ['euler', 'rk4'])
+def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver):
+    """reset + 40 env.steps (200 FDM steps) with the in-kernel Philox reset draws, hazard-rich demands, a ragged last
+    workgroup and a non-zero first env (shard offset)."""
+    num_envs, steps, seed, env0 = 333, 40, 77, 3_000_000_000
+    n = 2 * num_envs
+    b = _batch(num_envs, solver=solver, seed=seed, env0=env0)
+    o = CombatOracle(solver=solver)
+    st = o.new_state(num_envs)
+    rng = np.random.RandomState(8)
+    obs = b.reset()
+    o_obs = o.combat_reset(st, seed=seed, call_idx=0, env0=env0)   # new_state: every flag set -> every env drawn
+    _check(b, obs, None, b.flags, st, o_obs, None, 'reset')
+    # a short fuse: some pairs close together / low on blood / near the step limit (same edits on both sides)
+    st['s'][11, :3] = st['s'][10, :3] + np.float32([120, 50, -30])
+    st['blood'][20:30] = np.float32(0.4)
+    st['step_count'][40:44] = 1980
+    _load(b, st)
+    total = np.zeros(3, np.int64)
+    for t in range(steps):
+        a = rng.uniform(-1.4, 1.4, (n, 4)).astype(np.float32)
+        a[:, 0] = rng.uniform(0, 1.2, n)
+        obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, dn, bd, tm = o.combat_step(st, a, pid_first=(t == 0), seed=seed, call_idx=t + 1, env0=env0)
+        _check(b, obs, rew, flags, st, o_obs, o_rew, f'{solver}: step {t}')
+        total += np.array([dn.sum(), bd.sum(), tm.sum()])
+    assert total[1] > 0 and total[2] > 0
+
+
+def test_combat_sharding_by_env_is_invariant():
+    """Engagements are independent: a shard [e0, e1) of the batch reproduces the same rows bit for bit."""
+    E, seed = 700, 5
+    rng = np.random.RandomState(2)
+    acts = rng.uniform(-1.2, 1.2, (6, 2 * E, 4)).astype(np.float32)
+    full = _batch(E, seed=seed)
+    full.reset()
+    lo, hi = 257, 600   # odd boundaries: pairs must stay together
+    part = _batch(hi - lo, seed=seed, env0=lo)
+    part.reset()
+    for k in range(6):
+        of, rf, ff = full.step(torch.from_numpy(acts[k]).cuda())
+        op, rp, fp = part.step(torch.from_numpy(acts[k][2 * lo:2 * hi]).cuda())
+        assert torch.equal(of[2 * lo:2 * hi], op) and torch.equal(rf[2 * lo:2 * hi], rp) and torch.equal(ff[:, 2 * lo:2 * hi], fp)
+    assert torch.equal(full.s[:, 2 * lo:2 * hi], part.s) and torch.equal(full.blood[2 * lo:2 * hi], part.blood)
+
+
+def test_singlecombat_env_surface_and_vec_wrapper():
+    """The reference-shaped surface: constructor, attributes, shapes, GPUVecEnv [E, 2, .] reshape, checkpoint."""
+    from neuralplane_amd.envs.env_wrappers import GPUVecEnv
+    from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+    env = SingleCombatEnv(num_envs=6, config='selfplay', random_seed=3, device='cuda:0')
+    assert (env.num_agents, env.n, env.num_observation, env.num_actions) == (2, 12, 15, 4)
+    assert env.observation_space.shape == (15,) and env.action_space.shape == (4,)
+    obs = env.reset()
+    assert obs.shape == (12, 15) and obs.device.type == 'cuda' and torch.isfinite(obs).all()
+    assert env.s.shape == (12, 12) and env.u.shape == (12, 5) and env.blood.shape == (12,) and bool((env.blood == 100).all())
+    # pair symmetry of the observation: relative slots are mirrored between the two aircraft of an env
+    o = obs.view(6, 2, 15)
+    assert torch.equal(o[:, 0, 9], -o[:, 1, 9]) and torch.equal(o[:, 0, 10], -o[:, 1, 10])
+    assert torch.equal(o[:, 0, 13], o[:, 1, 13]) and torch.equal(o[:, 0, 14], -o[:, 1, 14])
+    a = torch.zeros(12, 4, device='cuda')
+    a[:, 0] = 0.5
+    out = env.step(a)
+    assert len(out) == 6 and out[0].shape == (12, 15) and out[1].shape == (12,) and all(x.dtype == torch.bool for x in out[2:5])
+    assert bool((env.step_count == 5).all())                      # 5 FDM steps per env.step
+    sd = env.state_dict()
+    ref = [env.step(a) for _ in range(3)]
+    env2 = SingleCombatEnv(num_envs=6, config='selfplay', random_seed=3, device='cuda:0')
+    env2.load_state_dict(sd)
+    for r in ref:
+        got = env2.step(a)
+        assert all(torch.equal(x, y) for x, y in zip(r[:5], got[:5]))
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(11, 4, device='cuda'))
+    vec = GPUVecEnv([lambda: SingleCombatEnv(num_envs=4, config='selfplay', random_seed=0, device='cuda:0')])
+    o0 = vec.reset()
+    assert o0.shape == (4, 2, 15) and isinstance(o0, np.ndarray)
+    o1, r1, d1, b1, t1, _ = vec.step(np.zeros((4, 2, 4), np.float32))
+    assert o1.shape == (4, 2, 15) and r1.shape == (4, 2, 1) and d1.shape == b1.shape == t1.shape == (4, 2, 1) and d1.dtype == np.bool_
+
+
+def test_combat_full_size_sampled_blocks_vs_oracle():
+    """BASELINE.json config 5 size (1e5 engagements = 2e5 aircraft, one GPU's worth): 3 env.steps at full size, sampled
+    workgroups compared bit for bit with the oracle, plus determinism of the whole batch."""
+    E, seed = 100_000, 11
+    n = 2 * E
+    g = torch.Generator(device='cpu').manual_seed(4)
+    acts = [(torch.rand((n, 4), generator=g) * 2.4 - 1.2) for _ in range(3)]
+    runs = []
+    for rep in range(2):
+        b = _batch(E, seed=seed)
+        b.reset()
+        outs = [b.step(a.cuda()) for a in acts]
+        runs.append((b, outs))
+    (b, outs), (b2, outs2) = runs
+    for (o1, r1, f1), (o2, r2, f2) in zip(outs, outs2):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(f1, f2)
+    assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][1]).all()
+    o = CombatOracle()
+    for e0 in (0, 64 * 700 + 13, E - 96):      # first, a middle (odd offset) and the last block of engagements
+        cnt = 96
+        st = o.new_state(cnt)
+        o.combat_reset(st, seed=seed, call_idx=0, env0=e0)
+        rows = slice(2 * e0, 2 * (e0 + cnt))
+        for k, a in enumerate(acts):
+            o_obs, o_rew, _, _, _ = o.combat_step(st, a.numpy()[rows], pid_first=(k == 0), seed=seed, call_idx=k + 1, env0=e0)
+        _check(b, outs[-1][0], outs[-1][1], outs[-1][2], st, o_obs, o_rew, f'block at env {e0}', rows=rows)

@@ -510,10 +510,207 @@ def gen_planning(n=48, outer=3):
     np.savez_compressed(os.path.join(OUT, 'planning_kat.npz'), hi_actions=hi_actions, **data)
 
 
+# ------------------------------------------------------------------------------------------------
+# SingleCombat (1v1): the reference's env file is stale (it targets an older BaseEnv API and cannot be
+# constructed), but every COMPONENT it calls is importable.  The fixtures below run those components —
+# F16Model dynamics + torchdiffeq step, algorithms/pid Controller.stabilize, the termination-condition
+# classes, SingleCombatEnv.obs/.reward as unbound methods, utils.{get_AO_TA_R,orientation_fn,...} — in the
+# order envs/singlecombat_env.py:207-274 prescribes.  The glue that stands in for the stale lines is listed
+# in DESIGN.md §10 (held policy action, direct control write, per-inner-step terminations).
+# ------------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def pin_mode_combat(mlp_cls):
+    """pin_mode + the extra implementation-defined calls of the pairwise geometry/reward functions."""
+    names = ('arccos', 'arctanh', 'exp', 'sum')
+    orig = {k: getattr(torch, k) for k in names}
+    o_norm = torch.linalg.norm
+    torch.arccos = lambda x: orig['arccos'](x.double()).float()
+    torch.arctanh = lambda x: orig['arctanh'](x.double()).float()
+    torch.exp = lambda x: orig['exp'](x.double()).float()
+
+    def tsum(x, *a, **k):
+        if x.dtype == torch.float32:
+            return orig['sum'](x.double(), *a, **k).float()
+        return orig['sum'](x, *a, **k)
+
+    torch.sum = tsum
+    torch.linalg.norm = lambda x, *a, **k: o_norm(x.double(), *a, **k).float()
+    try:
+        with pin_mode(mlp_cls):
+            yield
+    finally:
+        for k in names:
+            setattr(torch, k, orig[k])
+        torch.linalg.norm = o_norm
+
+
+def gen_pairwise():
+    """Known-answer vectors of the pure pairwise functions (envs/utils/utils.py:156-249)."""
+    from utils.utils import get_AO_TA_R, get2d_AO_TA_R, orientation_reward, range_reward, orientation_fn, distance_fn
+    rng = np.random.RandomState(41)
+    n = 512
+    ego_pos = rng.uniform(-2e4, 2e4, (n, 3)).astype(np.float32)
+    enm_pos = (ego_pos + rng.normal(0, 1, (n, 3)) * rng.choice([50, 500, 5000, 30000], (n, 1))).astype(np.float32)
+    ego_vel = (rng.normal(0, 1, (n, 3)) * 600).astype(np.float32)
+    enm_vel = (rng.normal(0, 1, (n, 3)) * 600).astype(np.float32)
+    # edge rows: tail chase (AO = 0), head-on, co-located, stationary
+    enm_pos[0] = ego_pos[0] + ego_vel[0] * 2
+    enm_vel[0] = ego_vel[0]
+    enm_pos[1] = ego_pos[1] + ego_vel[1] * 3
+    enm_vel[1] = -ego_vel[1]
+    enm_pos[2] = ego_pos[2]
+    ego_vel[3] = 0
+    out = {}
+    for tag, ctx in (('', contextlib.nullcontext()), ('_pin', pin_mode_combat(type(make_env('heading', 1).model.dynamics.hifi_F16.Cx_model)))):
+        with ctx, quiet():
+            T = [torch.from_numpy(x) for x in (ego_pos, enm_pos, ego_vel, enm_vel)]
+            AO, TA, R = get_AO_TA_R(*T)
+            AO2, TA2, R2, side = get2d_AO_TA_R(*T, return_side=True)
+            Rkm = R * 0.3048 / 1000
+            out.update({f'AO{tag}': AO, f'TA{tag}': TA, f'R{tag}': R, f'AO2{tag}': AO2, f'TA2{tag}': TA2, f'R2{tag}': R2,
+                        f'side{tag}': side, f'orient{tag}': orientation_reward(AO, TA), f'range{tag}': range_reward(3, Rkm),
+                        f'ofn{tag}': orientation_fn(AO), f'dfn{tag}': distance_fn(Rkm)})
+    np.savez_compressed(os.path.join(OUT, 'pairwise_kat.npz'), ego_pos=ego_pos, enm_pos=enm_pos, ego_vel=ego_vel, enm_vel=enm_vel,
+                        **{k: v.numpy() for k, v in out.items()})
+
+
+PID_STATE = ('roll_dem', 'pitch_dem', 'roll_err', 'roll_int', 'roll_last', 'pitch_err', 'pitch_int', 'pitch_last',
+             'yaw_err', 'yaw_int', 'yaw_last')
+
+
+def _pid_state(c):
+    cols = [c.roll_dem, c.pitch_dem]
+    for rc in (c.roll_controller, c.pitch_controller, c.yaw_controller):
+        cols += [rc.rate_pid.error, rc.rate_pid.integrator, rc.last_out]
+    return torch.hstack([x.reshape(-1, 1) for x in cols]).numpy().copy()
+
+
+def gen_combat(num_envs=24, outer=48, pin=True):
+    from types import SimpleNamespace
+    from utils.utils import parse_config, get_AO_TA_R, orientation_fn, distance_fn
+    from models.F16_model import F16Model
+    from torchdiffeq import odeint_adjoint as odeint
+    import envs.singlecombat_env as sce
+    from algorithms.pid.controller import Controller
+    cfg = parse_config('selfplay')
+    cfg.init_state = {'init_T': cfg.init_T}   # F16Model reads config.init_state (heading.yaml layout)
+    n = 2 * num_envs
+    dev = torch.device('cpu')
+    with quiet():
+        model = F16Model(cfg, n, 'cpu', 0)
+        ctrl = Controller(dt=cfg.dt, n=n, device='cpu')
+        conds = [sce.Overload(cfg), sce.LowAltitude(cfg), sce.HighSpeed(cfg), sce.LowSpeed(cfg), sce.ExtremeState(cfg),
+                 sce.Crash(cfg, 'cpu'), sce.Timeout(cfg), sce.Shutdown(cfg, 'cpu')]
+    mlp_cls = type(model.dynamics.hifi_F16.Cx_model)
+    E = SimpleNamespace(model=model, n=n, num_envs=num_envs, num_agents=2, device=dev, target_dist=cfg.target_dist,
+                        blood=100 * torch.ones(n), step_count=torch.zeros(n, dtype=torch.int64),
+                        is_done=torch.ones(n, dtype=torch.bool), bad_done=torch.ones(n, dtype=torch.bool),
+                        exceed_time_limit=torch.ones(n, dtype=torch.bool), s=model.s)
+    rng = np.random.RandomState(43)
+    actions = rng.uniform(-1.3, 1.3, (outer, n, 4)).astype(np.float32)
+    actions[:, :, 0] = rng.uniform(0.0, 1.2, (outer, n))
+    rand_u = rng.uniform(0, 1, (outer, n, 5)).astype(np.float32)
+    data = {}
+
+    def reset_done_envs(ru):  # singlecombat_env.py:207-238 (pairwise: both aircraft of a flagged env)
+        flagged = (E.is_done | E.bad_done) | E.exceed_time_limit
+        env_reset = torch.any(flagged.reshape(num_envs, 2), dim=-1)
+        ra = torch.nonzero(env_reset.repeat_interleave(2)).squeeze(-1)
+        U = torch.from_numpy(ru)
+        model.s[ra, :] = 0
+        model.u[ra, :] = 0
+        model.s[ra, 0] = U[ra, 0] * (cfg.max_npos - cfg.min_npos) + cfg.min_npos
+        model.s[ra, 1] = U[ra, 1] * (cfg.max_epos - cfg.min_epos) + cfg.min_epos
+        model.s[ra, 2] = U[ra, 2] * (cfg.max_altitude - cfg.min_altitude) + cfg.min_altitude
+        model.s[ra, 5] = U[ra, 3] * (cfg.max_heading - cfg.min_heading) + cfg.min_heading
+        model.s[ra, 6] = U[ra, 4] * (cfg.max_vt - cfg.min_vt) + cfg.min_vt
+        model.u[ra, 0] = cfg.init_T
+        E.blood[ra] = 100
+        E.step_count[ra] = 0
+        E.is_done[:] = 0
+        E.bad_done[:] = 0
+        E.exceed_time_limit[:] = 0
+
+    def outer_step(a_np, ru):
+        reset_done_envs(ru)
+        if outer_step.first:   # fixture-only state injection so that Crash / Timeout / Shutdown fire within the fixture
+            outer_step.first = False
+            model.s[1, :3] = model.s[0, :3] + torch.tensor([60.0, -80.0, 40.0])   # pair 0: 108 ft apart -> Crash
+            E.step_count[2:4] = 1993                                              # pair 1: Timeout at 2000
+            E.blood[4] = -0.5                                                     # pair 2: ego already shot down -> Shutdown bad_done
+            E.blood[7] = 0.25                                                     # pair 3: enemy nearly shot down
+            model.s[5, :3] = model.s[4, :3] + torch.tensor([900.0, 300.0, 0.0])   # pairs 2,3: close, nose-on geometry
+            model.s[5, 5] = 3.0
+            model.s[4, 5] = 0.32
+            model.s[7, :3] = model.s[6, :3] + torch.tensor([1500.0, 0.0, 50.0])
+            model.s[6, 5] = 0.0
+            model.s[7, 5] = 0.0
+            data['s_init'] = model.s.numpy().copy()
+            data['u_init'] = model.u.numpy().copy()
+            data['blood_init'] = E.blood.numpy().copy()
+            data['step_count_init'] = E.step_count.numpy().copy()
+        action = torch.from_numpy(a_np)
+        for _ in range(5):                                                        # :243-262
+            act = torch.clamp(action, -1, 1)
+            ctrl.roll_dem = 0.9 * ctrl.roll_dem + 0.1 * act[:, 1].reshape(-1, 1) * 4 * torch.pi / 9
+            ctrl.pitch_dem = 0.9 * ctrl.pitch_dem + 0.1 * act[:, 2].reshape(-1, 1) * torch.pi / 12
+            E.s = model.s
+            ctrl.stabilize(E)
+            T = 0.9 * model.u[:, 0].reshape(-1, 1) + 0.1 * act[:, 0].reshape(-1, 1) * 0.225 * 76300 / 0.3048
+            lef = torch.zeros((n, 1))
+            model.u = torch.hstack((T, -ctrl.el, -ctrl.ail, -ctrl.rud, lef))
+            model.s = odeint(model.dynamics, torch.hstack((model.s, model.u)), torch.tensor([0., model.dt]),
+                             method=model.solver)[1, :, :model.num_states]        # F16_model.py:64-67
+            E.s = model.s
+            E.step_count += 1
+            for c in conds:                                                       # task_base.py:75-96, env_base.py:70-75
+                bad, done, tmo, _ = c.get_termination(None, E)
+                E.is_done = E.is_done + done
+                E.bad_done = E.bad_done + bad
+                E.exceed_time_limit = E.exceed_time_limit + tmo
+        E.es = model.get_extended_state()
+        E.velocity = torch.stack(model.get_velocity(), dim=1)
+        obs = sce.SingleCombatEnv.obs(E)
+        reward = sce.SingleCombatEnv.reward(E)
+        ego = torch.arange(num_envs) * 2                                         # :264-271
+        enm = ego + 1
+        AO, TA, R = get_AO_TA_R(model.s[ego, :3], model.s[enm, :3], E.es[ego, :3], E.es[enm, :3])
+        E.blood[enm] -= orientation_fn(AO) * distance_fn(R * 0.3048 / 1000)
+        E.blood[ego] -= orientation_fn(torch.pi - TA) * distance_fn(R * 0.3048 / 1000)
+        return obs, reward
+
+    outer_step.first = True
+    ctx = pin_mode_combat(mlp_cls) if pin else contextlib.nullcontext()
+    with ctx, quiet():
+        for k in range(outer):
+            obs, rew = outer_step(actions[k], rand_u[k])
+            data[f's_{k}'] = model.s.numpy().copy()
+            data[f'u_{k}'] = model.u.numpy().copy()
+            data[f'pid_{k}'] = _pid_state(ctrl)
+            data[f'blood_{k}'] = E.blood.numpy().copy()
+            data[f'step_count_{k}'] = E.step_count.numpy().copy()
+            data[f'obs_{k}'] = obs.numpy().copy()
+            data[f'reward_{k}'] = rew.numpy().copy()
+            data[f'flags_{k}'] = np.stack([E.is_done.numpy(), E.bad_done.numpy(), E.exceed_time_limit.numpy()]).astype(np.uint8)
+    tot = np.sum([data[f'flags_{k}'] for k in range(outer)], axis=(0, 2))
+    print('combat', 'pin' if pin else 'plain', 'flag totals done/bad/timeout', tot, 'min blood', min(data[f'blood_{k}'].min() for k in range(outer)))
+    np.savez_compressed(os.path.join(OUT, 'combat_kat_pin.npz' if pin else 'combat_kat.npz'), actions=actions, rand_u=rand_u,
+                        pid_state_names=np.array(PID_STATE), **data)
+
+
+def gen_combat_all():
+    gen_pairwise()
+    gen_combat(pin=True)
+    gen_combat(pin=False)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'planning':
         gen_planning()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'combat':
+        gen_combat_all()
         return
     env = make_env('heading', 4)
     gen_aero(env)
@@ -527,6 +724,7 @@ def main():
     gen_traj('tracking', 64, 300)
     gen_recorded_episode()
     gen_planning()
+    gen_combat_all()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
