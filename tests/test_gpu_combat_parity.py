@@ -75,7 +75,7 @@ def test_combat_fixture_free_running_bit_exact_vs_oracle(golden_dir, tables):
         obs, rew, flags = b.step(torch.from_numpy(d['actions'][k]).cuda(), rand_u=d['rand_u'][k])
         o_obs, o_rew, dn, bd, tm = o.combat_step(st, d['actions'][k], rand_u=d['rand_u'][k], pid_first=(k == 0))
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'fixture step {k}')
-        fired += np.array([dn.sum(), bd.sum(), tm.sum()])
+        fired += np.array([int(dn.sum()), int(bd.sum()), int(tm.sum())])
     assert fired[0] >= 2 and fired[1] >= 4 and fired[2] >= 2
 
 
@@ -126,7 +126,7 @@ def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver):
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
         o_obs, o_rew, dn, bd, tm = o.combat_step(st, a, pid_first=(t == 0), seed=seed, call_idx=t + 1, env0=env0)
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'{solver}: step {t}')
-        total += np.array([dn.sum(), bd.sum(), tm.sum()])
+        total += np.array([int(dn.sum()), int(bd.sum()), int(tm.sum())])
     assert total[1] > 0 and total[2] > 0
 
 

@@ -1,0 +1,16 @@
+import time, torch, sys
+sys.path.insert(0, '.')
+from neuralplane_amd.core import F16CombatBatch
+from neuralplane_amd.envs.utils.utils import parse_config
+for E in (100_000, 500_000):
+    b = F16CombatBatch(E, parse_config('selfplay'), 'cuda:0', seed=1)
+    b.reset()
+    a = torch.rand(2*E, 4, device='cuda')*2-1
+    for _ in range(5): b.step(a)
+    b.set_timing(True)
+    torch.cuda.synchronize(); t0=time.time()
+    K=50
+    for _ in range(K): b.step(a)
+    torch.cuda.synchronize(); dt=(time.time()-t0)/K
+    ms,cnt=b.get_timing()
+    print(f'E={E}: {dt*1e3:.3f} ms/env.step wall, kernel {ms:.3f} ms; aircraft-FDM-steps/s = {2*E*5/dt:.3e}; env-steps/s (pairs) = {E/dt:.3e}')
