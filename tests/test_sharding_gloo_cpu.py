@@ -10,6 +10,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -79,3 +80,70 @@ def test_two_rank_sharded_run_equals_unsharded_run():
     for t in range(steps):
         o_obs, o_rew, _, o_bad, _ = o.step(st, acts[t], seed=11, call_idx=t + 1, row0=0)
     assert np.array_equal(s, st['s']) and np.array_equal(obs, o_obs) and np.array_equal(rew, o_rew) and np.array_equal(bad, o_bad)
+
+
+# ---------------------------------------------------------------------------------------------------
+# SingleCombat: shard by env + the opponent-observation exchange of the self-play setup
+# ---------------------------------------------------------------------------------------------------
+def _combat_worker(rank, world, port, e_total, steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    from neuralplane_amd import sharding
+    from oracle.f16_oracle import CombatOracle
+    d = sharding.init_distributed('gloo')
+    env0, e_loc = sharding.shard_rows(e_total, world, rank)
+    o = CombatOracle()
+    st = o.new_state(e_loc)
+    obs = torch.from_numpy(o.combat_reset(st, seed=21, call_idx=0, env0=env0))
+    W = torch.linspace(-1, 1, 15 * 4).reshape(15, 4)      # a fixed linear "policy" for both sides
+    for t in range(steps):
+        ego_obs, opp_obs = sharding.split_ego_opponent(obs, e_loc)
+        # opponent policy lives on rank (world - 1): every rank contributes its opponent observations, the
+        # host of the opponent policy acts on ALL of them, and the actions travel back the same way
+        opp_all = sharding.all_gather_opponent(opp_obs, d)
+        assert opp_all.shape == (e_total, 15)
+        act_all = torch.tanh(opp_all @ W) if rank == world - 1 else torch.zeros(e_total, 4)
+        d.broadcast(act_all, src=world - 1)
+        opp_act = act_all[env0:env0 + e_loc]
+        ego_act = torch.tanh(ego_obs @ W)
+        a = sharding.merge_actions(ego_act, opp_act)
+        o_np, rew, dn, bd, tm = o.combat_step(st, a.numpy(), pid_first=(t == 0), seed=21, call_idx=t + 1, env0=env0)
+        obs = torch.from_numpy(o_np)
+    parts = [None] * world
+    d.all_gather_object(parts, (env0, st['s'], o_np, rew, st['blood']))
+    if rank == 0:
+        q.put(parts)
+    d.barrier()
+    d.destroy_process_group()
+
+
+@pytest.mark.parametrize('e_total', [21, 20], ids=['ragged_padded_all_gather', 'equal_all_gather_into_tensor'])
+def test_two_rank_combat_shards_with_opponent_exchange_equal_single_process_run(e_total):
+    steps, world = 6, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_combat_worker, args=(r, world, port, e_total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    parts.sort(key=lambda x: x[0])
+    s, obs, rew, blood = (np.concatenate([p[k] for p in parts]) for k in (1, 2, 3, 4))
+
+    sys.path.insert(0, ROOT)
+    from neuralplane_amd import sharding
+    from oracle.f16_oracle import CombatOracle
+    o = CombatOracle()
+    st = o.new_state(e_total)
+    ob = torch.from_numpy(o.combat_reset(st, seed=21, call_idx=0, env0=0))
+    W = torch.linspace(-1, 1, 15 * 4).reshape(15, 4)
+    for t in range(steps):
+        ego_obs, opp_obs = sharding.split_ego_opponent(ob, e_total)
+        a = sharding.merge_actions(torch.tanh(ego_obs @ W), torch.tanh(opp_obs @ W))
+        o_np, o_rew, _, _, _ = o.combat_step(st, a.numpy(), pid_first=(t == 0), seed=21, call_idx=t + 1, env0=0)
+        ob = torch.from_numpy(o_np)
+    assert np.array_equal(s, st['s']) and np.array_equal(obs, o_np) and np.array_equal(rew, o_rew) and np.array_equal(blood, st['blood'])
