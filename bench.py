@@ -193,6 +193,32 @@ def main():
             out['optional_modes'] = {'aero_1d_tables': {'value': n * k2 / el2, 'unit': 'aircraft-steps/s', 'kernel_avg_ms': ms2,
                                                        'steps': k2, 'note': 'not the headline: changes the rounding of 22 of the 42 aero '
                                                        'coefficients by ~1e-5 rel (tests: masks identical to the reference, HIP == oracle bit-exact)'}}
+        if world == 1 and not args.no_cpu_baseline:
+            # BASELINE.json configs[4] (a parity-test case, reported beside the headline, never as `value`): SingleCombat 1v1,
+            # 1e5 engagements = 2e5 aircraft, one launch per env.step = 5 FDM steps behind the attitude PID stack
+            from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+            torch.cuda.empty_cache()
+            E = 100_000
+            cenv = SingleCombatEnv(num_envs=E, config='selfplay', random_seed=0, device=str(dev))
+            cenv.reset()
+            g2 = torch.Generator(device='cpu').manual_seed(5)
+            cpool = [(torch.rand((2 * E, 4), generator=g2) * 2 - 1).to(dev) for _ in range(4)]
+            for i in range(10):
+                cenv.step(cpool[i % 4])
+            cenv._batch.set_timing(True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            k3 = min(args.steps, 100)
+            for i in range(k3):
+                cenv.step(cpool[i % 4])
+            torch.cuda.synchronize(dev)
+            el3 = time.perf_counter() - t1
+            ms3, _ = cenv._batch.get_timing()
+            out.setdefault('optional_modes', {})['singlecombat_1v1'] = {
+                'value': E * k3 / el3, 'unit': 'engagement-steps/s', 'aircraft_fdm_steps_per_s': 2 * E * 5 * k3 / el3,
+                'kernel_avg_ms': ms3, 'steps': k3, 'engagements': E,
+                'note': 'one f16_combat_kernel launch per SingleCombatEnv.step (pairwise reset, 5 x {PID stack, FDM step, '
+                        'terminations}, pairwise obs/reward/blood); HIP == oracle bit-exact (tests/test_gpu_combat_parity.py)'}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -202,6 +202,9 @@ __device__ __forceinline__ float distance_fn(float R) {  // utils.py:245-249
     return m1 + ((3.0f - R) / 2.0f) * m2;
 }
 
+#ifndef NPF16_COMBAT_MINWAVES
+#define NPF16_COMBAT_MINWAVES 2  // waves per SIMD the register allocator must leave room for (256 VGPRs at 2)
+#endif
 constexpr int COMBAT_OBS = 15;
 constexpr int COMBAT_BLOCK = 128;
 constexpr int COMBAT_LDS_FLOATS = NUM_LIVE_NETS * COMBAT_BLOCK;  // > COMBAT_BLOCK * COMBAT_OBS
@@ -209,7 +212,7 @@ static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as th
 
 // STEP=true: SingleCombatEnv.step; STEP=false: reset_done_envs + obs
 template <int SOLVER, bool STEP>
-__global__ __launch_bounds__(COMBAT_BLOCK, 2) void f16_combat_kernel(const CombatArgs a) {
+__global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_combat_kernel(const CombatArgs a) {
     constexpr int B = COMBAT_BLOCK;
     __shared__ float lds[COMBAT_LDS_FLOATS];
     const int t = threadIdx.x;
