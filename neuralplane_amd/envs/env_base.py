@@ -99,6 +99,22 @@ class BaseEnv(Env):
         """
         obs, reward, flags = self._batch.step(action, rand_u=rand_u, noise=noise)
         if render:
-            raise NotImplementedError('TacView rendering is outside the accelerated path (SURVEY.md §8f N4)')
+            self.render(count=count)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
+
+    def render(self, count, filename='./tracks/F16SimRecording-', max_aircraft=64):
+        """Append one TacView frame (env_base.py:111-151).  A new file `<filename><count>.txt.acmi` is started at
+        count == 0 and after any aircraft terminated, as in the reference; ids 100+i, Name=F16, Color=Red.  The reference
+        loop is only meaningful for n == 1; here the first `max_aircraft` rows are drawn."""
+        from .utils.acmi import AcmiRecorder
+        if count == 0:
+            self.create_records = False
+        if not self.create_records:
+            self._acmi = AcmiRecorder(filename + str(count) + '.txt.acmi')
+            self.create_records = True
+        k = min(self.n, max_aircraft)
+        rows = self._batch.s[:6, :k].t().cpu().numpy()            # one small D2H copy per rendered frame
+        self._acmi.frame(float(self._batch.step_count[0].item()) * self.model.dt, rows)
+        if bool(self._batch.flags.any().item()):
+            self.create_records = False

@@ -89,6 +89,6 @@ class PlanningEnv(BaseEnv):
                 ego_actions, _, self.ego_rnn_states = self.controller(ego_obs, self.ego_rnn_states, masks, deterministic=True)
             obs, reward, flags = b.step(ego_actions, inner=True)
             if render:
-                raise NotImplementedError('TacView rendering is outside the accelerated path')
+                self.render(count=count)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()

@@ -104,3 +104,12 @@ class SingleCombatEnv(Env):
         obs, reward, flags = self._batch.step(action, rand_u=rand_u)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
+
+    def render(self, count, filepath='./F16SimRecording.txt.acmi', env_index=0):
+        """Append one TacView frame of engagement `env_index` (singlecombat_env.py:276-321): id 100 Red = ego, 101 Blue = enemy."""
+        from .utils.acmi import AcmiRecorder
+        if not self.create_records:
+            self._acmi = AcmiRecorder(filepath)
+            self.create_records = True
+        rows = self._batch.s[:6, 2 * env_index:2 * env_index + 2].t().cpu().numpy()
+        self._acmi.frame(count * self.dt, rows, colors=('Red', 'Blue'))

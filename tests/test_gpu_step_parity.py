@@ -254,3 +254,25 @@ def test_planning_env_bit_exact_vs_oracle_and_close_to_reference(golden_dir):
         PlanningEnv(num_envs=4, config='tracking', model='F16', random_seed=0, device='cuda:0')   # no controller, no checkpoint
     with pytest.raises(NotImplementedError):
         PlanningEnv(num_envs=4, config='heading', model='F16', random_seed=0, device='cuda:0', controller=ctrl)
+
+
+def test_render_writes_tacview_frames(tmp_path):
+    """env.step(render=True) appends TacView frames (env_base.py:111-151) without disturbing the trajectory."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.utils.acmi import parse_acmi
+    a = torch.zeros(3, 4, device='cuda')
+    env = ControlEnv(num_envs=3, config='heading', model='F16', random_seed=1, device='cuda:0')
+    ref = ControlEnv(num_envs=3, config='heading', model='F16', random_seed=1, device='cuda:0')
+    env.reset()
+    ref.reset()
+    base = str(tmp_path / 'tracks' / 'rec-')
+    for k in range(3):
+        env._batch.step(a)
+        env.render(count=k, filename=base)
+        ref.step(a)
+    assert torch.equal(env.model.s, ref.model.s)
+    header, frames = parse_acmi(open(base + '0.txt.acmi').read())
+    assert header[0] == 'FileType=text/acmi/tacview' and len(frames) == 3 and [len(f[1]) for f in frames] == [3, 3, 3]
+    assert frames[2][0] == pytest.approx(0.06) and frames[2][1][1][0] == 101
+    alt_m = env.model.s[0, 2].item() * 0.3048
+    assert abs(frames[2][1][0][1][2] - alt_m) < 1.0

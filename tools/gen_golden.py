@@ -698,6 +698,34 @@ def gen_combat(num_envs=24, outer=48, pin=True):
                         pid_state_names=np.array(PID_STATE), **data)
 
 
+def gen_acmi():
+    """TacView recording (envs/env_base.py:111-151) of a 1-aircraft ControlEnv for a few steps + enu_to_geodetic
+    known answers (envs/utils/utils.py:74-142).  The fixture holds the text the reference wrote and the states it drew."""
+    import tempfile
+    from utils.utils import enu_to_geodetic
+    rng = np.random.RandomState(51)
+    pts = np.concatenate([rng.uniform(-3e5, 3e5, (200, 2)), rng.uniform(0, 2e4, (200, 1))], axis=1)
+    pts[0] = [0.0, 1e-3, 0.0]
+    geo = np.array([enu_to_geodetic(float(e), float(n), float(u), 0, 0, 0) for e, n, u in pts])
+    env = make_env('heading', 1, seed=3)
+    cwd = os.getcwd()
+    states = []
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        os.makedirs('tracks')
+        try:
+            with quiet():
+                env.reset()
+                for k in range(4):
+                    env.step(torch.tensor([[0.6, 0.2, -0.1, 0.05]]), render=True, count=k)
+                    states.append(np.concatenate([env.model.s.numpy()[0], [float(env.step_count[0])]]))
+            text = open(os.path.join('tracks', 'F16SimRecording-0.txt.acmi')).read()
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, 'acmi_kat.npz'), enu=pts, geodetic=geo, states=np.array(states), text=np.array(text))
+    print('acmi: frames', text.count('#'), 'bytes', len(text))
+
+
 def gen_combat_all():
     gen_pairwise()
     gen_combat(pin=True)
@@ -712,6 +740,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'combat':
         gen_combat_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'acmi':
+        gen_acmi()
+        return
     env = make_env('heading', 4)
     gen_aero(env)
     gen_nlplant(env)
@@ -725,6 +756,7 @@ def main():
     gen_recorded_episode()
     gen_planning()
     gen_combat_all()
+    gen_acmi()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
