@@ -16,9 +16,6 @@
 namespace npf16 {
 
 __constant__ float c_kblob[KBLOB_FLOATS];
-// the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once per
-// context by the same device code (f16_reset_coef_kernel) so that they are bit-identical to an in-line evaluation
-__constant__ float c_reset_coef[NUM_CACHED];
 // numerics-spec option "aero_1d_tables": exact piecewise-linear tables of the 22 single-input nets + (out_std, out_mean)
 __constant__ float c_pwl[NUM_PWL_TABLES * PWL_TABLE_FLOATS];
 __constant__ float c_pwl_unnorm[NUM_PWL_TABLES * 2];

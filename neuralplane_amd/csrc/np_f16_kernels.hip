@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,6 +57,10 @@ struct KArgs {
     uint64_t seed, call_idx;
     long long row0, n;
     DevCfg cfg;
+    // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once
+    // per context by the same device code (f16_reset_coef_kernel), so they are bit-identical to an in-line evaluation;
+    // per context (kernel argument, not __constant__): contexts with different numerics options can coexist on a device
+    float reset_coef[NUM_CACHED];
 };
 
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
@@ -124,12 +130,12 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) {
             const float c = cache_blk[k * BLOCK];
-            coef[cached_slot(k) * BLOCK] = (flagged && !a.inner) ? c_reset_coef[k] : c;
+            coef[cached_slot(k) * BLOCK] = (flagged && !a.inner) ? a.reset_coef[k] : c;
         }
     }
     if (!STEP && a.cache && flagged && valid && !a.inner) {  // reset(): keep the cache consistent for re-initialised rows
 #pragma unroll
-        for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = c_reset_coef[k];
+        for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = a.reset_coef[k];
     }
 
     if (STEP) {
@@ -368,6 +374,7 @@ struct np_f16_ctx {
     int device;
     int task, solver;
     DevCfg cfg;
+    float reset_coef[NUM_CACHED];
     bool combat;  // created by np_f16_combat_ctx_create: only the combat entry points accept it
     CombatDevCfg ccfg;
     bool timing;
@@ -570,6 +577,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.inner = io->inner_step ? 1 : 0;
     a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
+    std::memcpy(a.reset_coef, ctx->reset_coef, sizeof(a.reset_coef));
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t st = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -718,9 +726,28 @@ int np_abi_version(void) { return NP_ABI_VERSION; }
 int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHED; }
 const char *np_last_error(void) { return g_err.c_str(); }
 
+// The packed weights live in __constant__ memory, i.e. once per device per process: every live context on a device must
+// have been created from the same blob (checked here; contexts may differ in everything else).
+static std::mutex g_blob_mu;
+static std::map<int, std::pair<uint64_t, int>> g_blob_live;  // device -> (blob hash, live contexts)
+
+static uint64_t fnv1a(const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
 static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables, int device, np_f16_ctx **out) {
     std::vector<float> kb, pwl, pwl_unnorm;
     if (pack_kblob(weights_blob, nbytes, kb, pwl, pwl_unnorm)) return 1;
+    const uint64_t blob_hash = fnv1a(weights_blob, nbytes);
+    std::lock_guard<std::mutex> lock(g_blob_mu);
+    {
+        auto it = g_blob_live.find(device);
+        if (it != g_blob_live.end() && it->second.second > 0 && it->second.first != blob_hash)
+            return fail("a context created from a different weights blob is alive on this device (weights are per device)");
+    }
     if (tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
@@ -736,23 +763,28 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
         NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl), pwl.data(), sizeof(float) * pwl.size()));
         NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl_unnorm), pwl_unnorm.data(), sizeof(float) * pwl_unnorm.size()));
     }
+    float rc[NUM_CACHED];
     {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
         float *d_rc = nullptr;
         NP_HIP(hipMalloc(&d_rc, sizeof(float) * NUM_CACHED));
         hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, tables ? 1 : 0);
         hipError_t e1 = hipGetLastError();
-        hipError_t e2 = hipDeviceSynchronize();
-        hipError_t e3 = hipMemcpyToSymbol(HIP_SYMBOL(c_reset_coef), d_rc, sizeof(float) * NUM_CACHED, 0, hipMemcpyDeviceToDevice);
+        hipError_t e2 = hipMemcpy(rc, d_rc, sizeof(rc), hipMemcpyDeviceToHost);  // synchronises with the launch
         (void)hipFree(d_rc);
         NP_HIP(e1);
         NP_HIP(e2);
-        NP_HIP(e3);
     }
     np_f16_ctx *ctx = new np_f16_ctx();
     ctx->device = device;
     ctx->task = 0;
     ctx->solver = 0;
     ctx->combat = false;
+    {
+        auto &slot = g_blob_live[device];
+        if (slot.second == 0) slot.first = blob_hash;
+        slot.second += 1;
+    }
+    std::memcpy(ctx->reset_coef, rc, sizeof(rc));
     ctx->timing = false;
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
@@ -799,6 +831,11 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
 
 void np_f16_ctx_destroy(np_f16_ctx *ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(g_blob_mu);
+        auto it = g_blob_live.find(ctx->device);
+        if (it != g_blob_live.end() && it->second.second > 0) it->second.second -= 1;
+    }
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);

@@ -276,3 +276,27 @@ def test_render_writes_tacview_frames(tmp_path):
     assert frames[2][0] == pytest.approx(0.06) and frames[2][1][1][0] == 101
     alt_m = env.model.s[0, 2].item() * 0.3048
     assert abs(frames[2][1][0][1][2] - alt_m) < 1.0
+
+
+def test_contexts_with_different_numerics_options_coexist():
+    """Two live contexts on one device (MLP numerics and aero_1d_tables), stepped alternately with resets in flight:
+    each stays bit-identical to its own oracle (the reset coefficients are per context)."""
+    n, seed = 400, 3
+    bs = [_batch('heading', n, seed=seed, tables=False), _batch('heading', n, seed=seed, tables=True)]
+    os_ = [Oracle('heading'), Oracle('heading', mode=MODE_PWL)]
+    sts = [Oracle.new_state(n), Oracle.new_state(n)]
+    for b, o, st in zip(bs, os_, sts):
+        obs = b.reset()
+        o_obs = o.reset(st, seed=seed, call_idx=0)
+        _check_equal(b, obs, None, b.flags, st, o_obs, None, 'reset')
+    rng = np.random.RandomState(1)
+    resets = 0
+    for t in range(90):
+        a = rng.uniform(-2.0, 2.0, (n, 4)).astype(np.float32)
+        a[:, 1] = 1.0 if t < 45 else -1.0      # full elevator: drives alpha out of the envelope -> resets in flight
+        for b, o, st in zip(bs, os_, sts):
+            obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+            o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t + 1)
+            _check_equal(b, obs, rew, flags, st, o_obs, o_rew, f'step {t}')
+            resets += int(st['bad'].sum())
+    assert resets > 0
