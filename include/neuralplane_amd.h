@@ -96,6 +96,10 @@ typedef struct np_f16_io {
     uint64_t seed;         /* RNG key */
     uint64_t call_idx;     /* RNG counter word: the caller increments it once per reset()/step() call */
     int64_t row0;
+    /* Optional DEVICE word added to call_idx inside the kernel (NULL = 0).  Lets a fixed sequence of launches be
+     * captured in a HIP graph once and replayed: the captured call_idx values are offsets, the base advances on the
+     * device between replays (PlanningEnv's 1 + 50 launches per step). */
+    const uint64_t *call_idx_base;
 } np_f16_io;
 
 typedef struct np_f16_ctx np_f16_ctx;

@@ -94,6 +94,8 @@ class F16Batch:
         self._derived = None
         self._derived_key = None
         self._version = 0
+        # device-side RNG counter base for launches replayed from a HIP graph (np_f16_io.call_idx_base)
+        self.call_base = torch.zeros(1, dtype=torch.int64, device=d)
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -107,6 +109,31 @@ class F16Batch:
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- graph-safe raw launches: caller-owned static buffers, no Python-side state is touched -------------
+    def launch_static(self, flags_in, flags_out, call_offset, action=None, obs=None, reward=None, inner=False, cache_valid=False):
+        """One np_f16_reset (action is None) or np_f16_step launch on fixed buffers, RNG counter = *call_base + call_offset.
+        Safe to capture in a HIP graph (torch.cuda.graph): every argument is baked, the counter base lives on the device."""
+        io = _lib.NpF16Io()
+        io.s, io.u, io.tgt, io.ld = self.s.data_ptr(), self.u.data_ptr(), self.tgt.data_ptr(), self.n
+        io.step_count = self.step_count.data_ptr()
+        io.done_in, io.bad_in, io.timeout_in = flags_in[0].data_ptr(), flags_in[1].data_ptr(), flags_in[2].data_ptr()
+        io.done_out, io.bad_out, io.timeout_out = flags_out[0].data_ptr(), flags_out[1].data_ptr(), flags_out[2].data_ptr()
+        if action is not None:
+            io.action, io.act_stride = action.data_ptr(), action.stride(0)
+        io.obs = obs.data_ptr() if obs is not None else None
+        io.reward = reward.data_ptr() if reward is not None else None
+        io.coef_cache = self.coef_cache.data_ptr()
+        io.cache_valid = 1 if (cache_valid and not os.environ.get('NPF16_NO_CACHE')) else 0
+        io.inner_step = 1 if inner else 0
+        io.seed, io.call_idx, io.row0 = self.seed, int(call_offset), self.row0
+        io.call_idx_base = self.call_base.data_ptr()
+        fn = self.lib.np_f16_reset if action is None else self.lib.np_f16_step
+        _lib.check(fn(self._ctx, self.n, C.byref(io), self._stream()))
+
+    def lowlevel_obs_into(self, tgt3, obs):
+        _lib.check(self.lib.np_f16_lowlevel_obs(self._ctx, self.n, self.s.data_ptr(), self.u.data_ptr(), tgt3.data_ptr(), self.n,
+                                                obs.data_ptr(), self._stream()))
 
     def _io(self, new_flags, action, obs, reward, rand_u, noise, inner=False):
         io = _lib.NpF16Io()

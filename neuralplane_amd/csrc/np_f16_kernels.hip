@@ -55,12 +55,14 @@ struct KArgs {
     int inner;     // one low-level iteration of PlanningEnv.step: no auto-reset, flagged rows frozen, flags accumulate
     float *cache;  // [workgroup][14][BLOCK] force-side alpha/beta-only coefficients at the current state (may be null)
     uint64_t seed, call_idx;
+    const uint64_t *call_idx_base;  // optional device word added to call_idx (launches replayed from a HIP graph)
     long long row0, n;
     DevCfg cfg;
     // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once
     // per context by the same device code (f16_reset_coef_kernel), so they are bit-identical to an in-line evaluation;
-    // per context (kernel argument, not __constant__): contexts with different numerics options can coexist on a device
-    float reset_coef[NUM_CACHED];
+    // per context (a small device buffer, not __constant__): contexts with different numerics options can coexist on a
+    // device; read only inside the `flagged` branches
+    const float *reset_coef;
 };
 
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     const long long ic = valid ? i : a.n - 1;  // tail lanes shadow the last row; their stores are masked
     const DevCfg &cfg = a.cfg;
     const bool tables = cfg.aero_1d_tables != 0;
+    const uint64_t call_idx = a.call_idx + (a.call_idx_base ? *a.call_idx_base : 0ull);
 
     // ---- de-phasing -----------------------------------------------------------------------------------
     // Every workgroup does identical work: load state (HBM) -> ~45 K VALU cycles -> store.  Launched
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
             for (int k = 0; k < 5; k++) ru[k] = a.rand_u[ic * 5 + k];
         } else {
             uint32_t w0[4], w1[4];
-            rng_block(a.seed, a.call_idx, a.row0 + ic, 0, w0);
-            rng_block(a.seed, a.call_idx, a.row0 + ic, 1, w1);
+            rng_block(a.seed, call_idx, a.row0 + ic, 0, w0);
+            rng_block(a.seed, call_idx, a.row0 + ic, 1, w1);
 #pragma unroll
             for (int k = 0; k < 4; k++) ru[k] = (float)(w0[k] >> 8) * 5.9604644775390625e-08f;
             ru[4] = (float)(w1[0] >> 8) * 5.9604644775390625e-08f;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma unroll
         for (int k = 0; k < 22; k++) o[k] = o[k] + a.noise[ic * 22 + k] * cfg.noise_scale;
     } else if (cfg.noise_scale != 0.0f) {
-        add_rng_noise(a.seed, a.call_idx, a.row0 + ic, cfg.noise_scale, o);
+        add_rng_noise(a.seed, call_idx, a.row0 + ic, cfg.noise_scale, o);
     }
 
     bool done = false, bad = false;
@@ -374,7 +377,7 @@ struct np_f16_ctx {
     int device;
     int task, solver;
     DevCfg cfg;
-    float reset_coef[NUM_CACHED];
+    float *d_reset_coef;  // [NUM_CACHED] device buffer owned by the context
     bool combat;  // created by np_f16_combat_ctx_create: only the combat entry points accept it
     CombatDevCfg ccfg;
     bool timing;
@@ -576,8 +579,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward;
     a.inner = io->inner_step ? 1 : 0;
     a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
+    a.call_idx_base = io->call_idx_base;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
-    std::memcpy(a.reset_coef, ctx->reset_coef, sizeof(a.reset_coef));
+    a.reset_coef = ctx->d_reset_coef;
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t st = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -763,14 +767,13 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
         NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl), pwl.data(), sizeof(float) * pwl.size()));
         NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl_unnorm), pwl_unnorm.data(), sizeof(float) * pwl_unnorm.size()));
     }
-    float rc[NUM_CACHED];
+    float *d_rc = nullptr;
     {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
-        float *d_rc = nullptr;
         NP_HIP(hipMalloc(&d_rc, sizeof(float) * NUM_CACHED));
         hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, tables ? 1 : 0);
         hipError_t e1 = hipGetLastError();
-        hipError_t e2 = hipMemcpy(rc, d_rc, sizeof(rc), hipMemcpyDeviceToHost);  // synchronises with the launch
-        (void)hipFree(d_rc);
+        hipError_t e2 = hipDeviceSynchronize();
+        if (e1 != hipSuccess || e2 != hipSuccess) (void)hipFree(d_rc);
         NP_HIP(e1);
         NP_HIP(e2);
     }
@@ -784,7 +787,7 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
         if (slot.second == 0) slot.first = blob_hash;
         slot.second += 1;
     }
-    std::memcpy(ctx->reset_coef, rc, sizeof(rc));
+    ctx->d_reset_coef = d_rc;
     ctx->timing = false;
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
@@ -835,6 +838,10 @@ void np_f16_ctx_destroy(np_f16_ctx *ctx) {
         std::lock_guard<std::mutex> lock(g_blob_mu);
         auto it = g_blob_live.find(ctx->device);
         if (it != g_blob_live.end() && it->second.second > 0) it->second.second -= 1;
+    }
+    if (ctx->d_reset_coef) {
+        DeviceGuard guard;
+        if (guard.enter(ctx->device) == hipSuccess) (void)hipFree(ctx->d_reset_coef);
     }
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.first);

@@ -46,6 +46,8 @@ class PlanningEnv(BaseEnv):
         self.low_level_action_space = Box(low=-np.inf, high=np.inf, shape=(4,))
         self.controller = controller if controller is not None else self._load_reference_actor(controller_checkpoint)
         self.ego_rnn_states = torch.zeros((self.n, 1, 128), device=self.device)
+        self._graph_enabled = False
+        self._graph = None
 
     def load(self, random_seed, config, model):
         if model != 'F16':
@@ -76,6 +78,8 @@ class PlanningEnv(BaseEnv):
         return self._batch.lowlevel_obs(torch.stack((target_pitch, target_heading, target_vt)))
 
     def step(self, action, render=False, count=0):
+        if self._graph_enabled and not render:
+            return self._step_graph(action)
         b = self._batch
         b.reset(want_obs=False)                                    # self.reset()           :145
         action = torch.clamp(torch.as_tensor(action, dtype=torch.float32, device=self.device), -1, 1)
@@ -92,3 +96,82 @@ class PlanningEnv(BaseEnv):
                 self.render(count=count)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
+
+    # -- the whole macro-step as ONE HIP graph -------------------------------------------------
+    def enable_graph(self, enable=True):
+        """Replay PlanningEnv.step (1 reset + 50 x {low-level obs, controller forward, fused inner step} = ~100 kernel
+        launches of this library plus the controller's own) from a single captured HIP graph: the step is launch-bound
+        for small and medium batches.  Requirements: the controller is a pure torch module on this device (capturable),
+        and nobody replaces `env.ego_rnn_states` / the state tensors between steps (in-place edits are fine).
+        Results are bit-identical to the eager path (same kernels, RNG counter kept on the device)."""
+        self._graph_enabled = bool(enable)
+        if not enable:
+            self._graph = None
+
+    def _macro_body(self, g):
+        b = self._batch
+        b.launch_static(g['fa'], g['fb'], 0)                                                     # self.reset()
+        action = torch.clamp(g['action'], -1, 1)
+        tgt3 = torch.stack((b.s[4] + action[:, 0] * 0.3, b.s[5] + action[:, 1] * 0.3, b.s[6] + action[:, 2] * 30))
+        fin, fout = g['fb'], g['fa']
+        for k in range(INNER_STEPS):
+            b.lowlevel_obs_into(tgt3, g['ll_obs'])
+            ego_actions, _, rnn = self.controller(g['ll_obs'], g['rnn'], g['masks'], deterministic=True)
+            g['rnn'].copy_(rnn)
+            ego_actions = ego_actions.to(torch.float32).contiguous()
+            # the first inner step re-evaluates the cached coefficients: the caller may have edited `s` between steps
+            b.launch_static(fin, fout, 1 + k, action=ego_actions, obs=g['obs'], reward=g['reward'], inner=True, cache_valid=(k > 0))
+            fin, fout = fout, fin
+        g['fa'].copy_(fin)                       # 1 + 50 flips end in the other buffer; the next replay starts from `fa`
+        b.call_base.add_(1 + INNER_STEPS)
+
+    def _capture(self):
+        b, d, n = self._batch, self.device, self.n
+        g = {'action': torch.zeros((n, 3), dtype=torch.float32, device=d),
+             'fa': torch.empty((3, n), dtype=torch.uint8, device=d), 'fb': torch.empty((3, n), dtype=torch.uint8, device=d),
+             'll_obs': torch.empty((n, 22), dtype=torch.float32, device=d), 'obs': torch.empty((n, 22), dtype=torch.float32, device=d),
+             'reward': torch.empty(n, dtype=torch.float32, device=d), 'masks': torch.ones((n, 1), device=d),
+             'rnn': self.ego_rnn_states.detach().clone()}
+        # warm-up on a side stream (library handles, autotuning) with the env state saved and restored around it
+        saved = (b.state_dict(), b.coef_cache.clone(), g['rnn'].clone())
+        g['fa'].copy_(b.flags)
+        b.call_base.fill_(b.call_idx)
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side), torch.no_grad():
+            self._macro_body(g)
+        torch.cuda.current_stream(d).wait_stream(side)
+        b.load_state_dict(saved[0])
+        b.coef_cache.copy_(saved[1])
+        g['rnn'].copy_(saved[2])
+        graph = torch.cuda.CUDAGraph()
+        g['fa'].copy_(b.flags)
+        b.call_base.fill_(b.call_idx)
+        with torch.cuda.graph(graph), torch.no_grad():
+            self._macro_body(g)
+        # capture does not execute: the device counter and the flags are still those of the current state
+        self._graph, self._gbuf = graph, g
+        self._graph_call_idx = b.call_idx
+
+    def _step_graph(self, action):
+        b = self._batch
+        if getattr(self, '_graph', None) is None:
+            self._capture()
+        g = self._gbuf
+        if b.call_idx != self._graph_call_idx or b.flags.data_ptr() != g['fa'].data_ptr():
+            # somebody stepped / reset / restored the batch outside the graph: re-synchronise the device-side inputs
+            g['fa'].copy_(b.flags)
+            b.call_base.fill_(b.call_idx)
+        if self.ego_rnn_states.data_ptr() != g['rnn'].data_ptr():
+            g['rnn'].copy_(self.ego_rnn_states)
+        g['action'].copy_(torch.as_tensor(action, dtype=torch.float32, device=self.device))
+        self._graph.replay()
+        b.call_idx += 1 + INNER_STEPS
+        self._graph_call_idx = b.call_idx
+        b.flags = g['fa']
+        b._cache_valid = True
+        b._s_version = b.s._version
+        b._version += 1
+        self.ego_rnn_states = g['rnn']
+        f = g['fa'].clone().view(torch.bool)
+        return g['obs'].clone(), g['reward'].clone(), f[0], f[1], f[2], self.info()

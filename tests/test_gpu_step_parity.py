@@ -300,3 +300,53 @@ def test_contexts_with_different_numerics_options_coexist():
             _check_equal(b, obs, rew, flags, st, o_obs, o_rew, f'step {t}')
             resets += int(st['bad'].sum())
     assert resets > 0
+
+
+class _TinyActor(torch.nn.Module):
+    """Capturable stand-in with the interface of the reference's PPOActor (obs, rnn_states, masks) -> (actions, _, rnn_states)."""
+
+    def __init__(self):
+        super().__init__()
+        self.base = torch.nn.Sequential(torch.nn.LayerNorm(22), torch.nn.Linear(22, 64), torch.nn.ReLU())
+        self.gru = torch.nn.GRUCell(64, 128)
+        self.head = torch.nn.Linear(128, 4)
+
+    def forward(self, obs, rnn, masks, deterministic=True):
+        h = self.gru(self.base(obs), rnn[:, 0] * masks)
+        return torch.tanh(self.head(h)) * 1.5, None, h.unsqueeze(1)
+
+
+def test_planning_env_hip_graph_replay_equals_eager():
+    """enable_graph(): the 1 + 50 x 2 launches of a PlanningEnv.step (plus the controller) replayed from one HIP graph give
+    the eager path's results bit for bit — obs noise included (device-side RNG counter), across eager/graph interleaving
+    and a checkpoint restore."""
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    n = 300
+    torch.manual_seed(0)
+    ctrl = _TinyActor().cuda().eval()
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=4, device='cuda:0', controller=ctrl) for _ in range(2)]
+    envs[1].enable_graph()
+    g = torch.Generator(device='cpu').manual_seed(1)
+    acts = [(torch.rand((n, 3), generator=g) * 2.4 - 1.2).cuda() for _ in range(6)]
+    terminated = 0
+    for k, a in enumerate(acts):
+        if k == 3:       # one eager step in the middle of the graph-mode env, then back
+            envs[1].enable_graph(False)
+        if k == 4:
+            envs[1].enable_graph(True)
+        outs = [e.step(a) for e in envs]
+        for x, y in zip(outs[0][:5], outs[1][:5]):
+            assert torch.equal(x, y), f'macro-step {k}'
+        assert torch.equal(envs[0].model.s, envs[1].model.s) and torch.equal(envs[0].model.u, envs[1].model.u)
+        assert torch.equal(envs[0].step_count, envs[1].step_count) and torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
+        terminated += int(outs[0][3].sum())
+    assert envs[0]._batch.call_idx == envs[1]._batch.call_idx == 6 * 51
+    # restore a checkpoint into the graph-mode env and continue: still identical
+    sd = envs[0].state_dict()
+    rnn = envs[0].ego_rnn_states.clone()
+    ref = envs[0].step(acts[0])
+    envs[1].load_state_dict(sd)
+    envs[1].ego_rnn_states.copy_(rnn)
+    got = envs[1].step(acts[0])
+    for x, y in zip(ref[:5], got[:5]):
+        assert torch.equal(x, y)

@@ -1,0 +1,40 @@
+import sys, time, torch
+sys.path.insert(0, '.')
+from neuralplane_amd.envs.planning_env import PlanningEnv
+
+
+class Ctrl(torch.nn.Module):
+    """Stand-in with the shape of the reference's PPOActor (MLP 22-128-128, GRU 128, head 128-128-4)."""
+    def __init__(s):
+        super().__init__()
+        s.ln = torch.nn.LayerNorm(22)
+        s.base = torch.nn.Sequential(torch.nn.Linear(22, 128), torch.nn.ReLU(), torch.nn.LayerNorm(128), torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.LayerNorm(128))
+        s.gru = torch.nn.GRU(128, 128, 1)
+        s.norm = torch.nn.LayerNorm(128)
+        s.head = torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 4))
+
+    def forward(s, obs, rnn, masks, deterministic=True):
+        x = s.base(s.ln(obs))
+        h = (rnn * masks.unsqueeze(-1)).transpose(0, 1).contiguous()
+        y, h = s.gru(x.unsqueeze(0), h)
+        return torch.tanh(s.head(s.norm(y.squeeze(0)))), None, h.transpose(0, 1)
+
+
+for n in (1024, 16384, 262144):
+    torch.manual_seed(0)
+    ctrl = Ctrl().cuda().eval()
+    env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cuda:0', controller=ctrl)
+    a = torch.rand(n, 3, device='cuda') * 2 - 1
+    for mode in ('eager', 'graph'):
+        if mode == 'graph':
+            if not hasattr(env, 'enable_graph'):
+                break
+            env.enable_graph()
+        for _ in range(2):
+            env.step(a)
+        torch.cuda.synchronize(); t0 = time.time()
+        K = 5
+        for _ in range(K):
+            env.step(a)
+        torch.cuda.synchronize(); dt = (time.time() - t0) / K
+        print(f'n={n} {mode}: {dt*1e3:.2f} ms per PlanningEnv.step (50 inner) -> {n*50/dt:.3e} aircraft-FDM-steps/s')
