@@ -170,7 +170,12 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
             return;
         }
     }
-#if NPF16_ASM_MLP
+#if defined(NPF16_EXP) && (NPF16_EXP & 4)  // timing experiment only: no MLP evaluation
+    if constexpr (n > 0) {
+#pragma unroll
+        for (int i = 0; i < n; i++) out[(class_slot(CL) + FIRST + i) * LD] = xn[c.grp[0]] * 1e-3f;
+    }
+#elif NPF16_ASM_MLP
     if constexpr (n > 0) {
         // one asm statement for the whole class; `out` points into LDS: the low 32 bits of the flat
         // address are the LDS byte offset ds_write_b32 wants
@@ -221,6 +226,29 @@ template <int N_C, int N_ETA, int LD>
 __device__ __forceinline__ void eval_el(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
     eval_class<CL_C, N_C, LD>(xn, out, tables);
     eval_class<CL_ETA, N_ETA, LD>(xn, out, tables);
+}
+
+// All nets of one nlplant evaluation.  With the asm bodies and the default numerics the whole sequence of classes is ONE
+// asm statement (tools/gen_mlp_asm.py, "phase functions"): the weight stream keeps running across class boundaries.
+#ifndef NPF16_PHASE_ASM
+#define NPF16_PHASE_ASM 1
+#endif
+template <int LD, int PART, bool FULL>
+__device__ __forceinline__ void eval_nets(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+#if NPF16_ASM_MLP && NPF16_PHASE_ASM && !defined(NPF16_EXP)
+    constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
+    if constexpr (has_phase) {
+        if (!tables) {  // wave-uniform
+            const unsigned lds_base = (unsigned)(unsigned long long)out;
+            if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_ALL_START, lds_base, xn);
+            else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_REST_START, lds_base, xn);
+            else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_FORCE2_START, lds_base, xn);
+            return;
+        }
+    }
+#endif
+    eval_ab<LD, PART>(xn, out, tables);
+    eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, out, tables);
 }
 
 // The 9 distinct input normalisations (X - mean) / std of mean_std.csv.
@@ -291,8 +319,7 @@ __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4
     const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
     const bool ok = (chk == chk);
     const float qnan = __builtin_nanf("");
-    eval_ab<LD, PART>(xn, coef, tables);
-    eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, coef, tables);
+    eval_nets<LD, PART, FULL>(xn, coef, tables);
 #define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
 
     const float inv2vt = 1.0f / (2.0f * vt);

@@ -210,7 +210,9 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma unroll
         for (int k = 0; k < 22; k++) o[k] = o[k] + a.noise[ic * 22 + k] * cfg.noise_scale;
     } else if (cfg.noise_scale != 0.0f) {
+#if !(defined(NPF16_EXP) && (NPF16_EXP & 1))  // timing experiment only: no observation noise
         add_rng_noise(a.seed, call_idx, a.row0 + ic, cfg.noise_scale, o);
+#endif
     }
 
     bool done = false, bad = false;
@@ -219,7 +221,11 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         // Overload needs xdot[6..8] at the NEW (s,u) (overload.py:37-42): the 14 force-side alpha/beta-only
         // nets (kept for the next step's integrator -> cache) plus the force-side Cx, Cz
         float xd[12];
+#if defined(NPF16_EXP) && (NPF16_EXP & 2)  // timing experiment only: no Overload evaluation
+        for (int k = 0; k < 12; k++) xd[k] = s[k];
+#else
         nlplant<false, AB_FORCE, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd);
+#endif
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
         // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum

@@ -36,6 +36,7 @@ GROUP = 16 * CPG # floats per group
 S_W0 = 4         # s[4:99] six 16-dword weight buffers
 S_BASE = 100     # s[100:101] record pointer
 S_CNT = 'vcc_lo' # remaining nets
+S_NEXT = 2       # s[2:3] (phase functions only): pointer of the record that follows the current one in the SEQUENCE
 V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
 V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
 V_Y = 126        # net output
@@ -61,7 +62,8 @@ def record_len(IN, H1, H2, H3):
 class Body:
     """Instruction list of one net evaluation, given the buffer parity of its first group."""
 
-    def __init__(self, shape, parity):
+    def __init__(self, shape, parity, use_next=False):
+        self.use_next = use_next  # overrun prefetches (first group of the FOLLOWING record) go through S_NEXT
         self.IN, self.H1, self.H2, self.H3 = shape
         self.len = record_len(*shape)
         self.nch = self.len // 16
@@ -86,9 +88,13 @@ class Body:
             self.cur_group += 1
             c = CPG * self.cur_group
             self.ins.append('s_waitcnt lgkmcnt(0)')
-            for cc in range(c + CPG, c + 2 * CPG):  # next group (runs into the next record when cc >= nch: contiguous)
+            for cc in range(c + CPG, c + 2 * CPG):  # next group (runs into the next record when cc >= nch)
+                if self.use_next and cc >= self.nch:
+                    base, off = S_NEXT, (cc - self.nch) * 64
+                else:
+                    base, off = S_BASE, cc * 64
                 self.ins.append(f's_load_dwordx16 s[{self.buf_of_chunk(cc)}:{self.buf_of_chunk(cc) + 15}], '
-                                f's[{S_BASE}:{S_BASE + 1}], 0x{cc * 64:x}')
+                                f's[{base}:{base + 1}], 0x{off:x}')
 
     def spair(self, pos):
         assert pos % 2 == 0
@@ -214,6 +220,138 @@ def gen_function(shape):
     return lines, name
 
 
+
+# ------------------------------------------------------------------------------------------------
+# Phase functions: ONE asm statement for a whole sequence of classes (np_nets.h::CLASSES order).
+# Inside a class the records are contiguous; between classes the stream jumps.  Every net body
+# prefetches "the first group of the record that follows in the sequence" through S_NEXT, which is
+# the next record of the class or, for the last net of a class, the first record of the next class
+# (a compile-time byte delta).  So the weight stream never drains between classes: one prologue and
+# one epilogue per PHASE instead of per class (19 -> 3 exposed scalar-load latencies per env.step).
+# ------------------------------------------------------------------------------------------------
+G = {'G_A_C': 0, 'G_A_DAMP': 1, 'G_A_LEF': 2, 'G_A_DLEF': 3, 'G_A_RUD': 4, 'G_B_C': 5, 'G_B_O': 6, 'G_E_C': 7, 'G_E_ETA': 8}
+KBLOB_HEADER = 2 * len(G)
+# (name, shape, input groups, count, n_force) — mirror of np_nets.h::CLASSES, cross-checked by static_asserts in the output
+CLASSES = [
+    ('CL_DAMP', (1, 20, 10, 0), ('G_A_DAMP',), 12, 4),
+    ('CL_DLEF', (1, 20, 10, 0), ('G_A_DLEF',), 7, 2),
+    ('CL_D_RUD', (2, 20, 10, 0), ('G_A_RUD', 'G_B_O'), 2, 1),
+    ('CL_D_LEF', (2, 20, 10, 0), ('G_A_LEF', 'G_B_O'), 2, 1),
+    ('CL_E_LEF', (2, 20, 10, 5), ('G_A_LEF', 'G_B_O'), 4, 2),
+    ('CL_E_RUD', (2, 20, 10, 5), ('G_A_RUD', 'G_B_O'), 4, 1),
+    ('CL_F', (2, 20, 20, 10), ('G_A_LEF', 'G_B_O'), 3, 1),
+    ('CL_YPLEF', (1, 20, 10, 5), ('G_A_DLEF',), 1, 1),
+    ('CL_YA20', (2, 20, 10, 10), ('G_A_RUD', 'G_B_O'), 1, 1),
+    ('CL_C', (3, 20, 10, 0), ('G_A_C', 'G_B_C', 'G_E_C'), 5, 2),
+    ('CL_ETA', (1, 20, 10, 0), ('G_E_ETA',), 1, 0),
+]
+NUM_AB = 9
+
+
+def class_base(ci):
+    return KBLOB_HEADER + sum(c[3] * record_len(*c[1]) for c in CLASSES[:ci])
+
+
+def class_slot(ci):
+    return sum(c[3] for c in CLASSES[:ci])
+
+
+def phase_items(kind):
+    ab = range(NUM_AB)
+    if kind == 'ALL':
+        items = [(ci, 0, CLASSES[ci][3]) for ci in ab] + [(9, 0, 5), (10, 0, 1)]
+    elif kind == 'REST':
+        items = [(ci, CLASSES[ci][4], CLASSES[ci][3] - CLASSES[ci][4]) for ci in ab] + [(9, 0, 5), (10, 0, 1)]
+    elif kind == 'FORCE2':
+        items = [(ci, 0, CLASSES[ci][4]) for ci in ab] + [(9, 0, 2)]
+    else:
+        raise ValueError(kind)
+    return [it for it in items if it[2] > 0]
+
+
+def gen_phase(kind):
+    items = phase_items(kind)
+    name = f'mlp_phase_asm_{kind}'
+    lines = []
+    A = lines.append
+    A(f'// phase {kind}: ' + ', '.join(f'{CLASSES[ci][0]}[{first}:{first + n}]' for ci, first, n in items))
+    A('template <int LDS_STEP>')
+    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base, const float (&xn)[{len(G)}]) {{')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    used_x = sorted({G[g] for ci, _, _ in items for g in CLASSES[ci][2]})
+    emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
+    shape0 = CLASSES[items[0][0]][1]
+    for c in range(CPG):   # prologue: first group of the first net of the first class
+        emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
+    parity = 0
+    for idx, (ci, first, n) in enumerate(items):
+        cname, shape, grps, _, _ = CLASSES[ci]
+        ln = record_len(*shape)
+        ngroups = ln // GROUP
+        start = class_base(ci) + first * ln
+        has_next = idx + 1 < len(items)
+        if has_next:
+            nci, nfirst, _ = items[idx + 1]
+            nstart = class_base(nci) + nfirst * record_len(*CLASSES[nci][1])
+            delta = nstart - (start + (n - 1) * ln)
+            assert delta > 0, (kind, cname, delta)
+        emit(f's_mov_b32 {S_CNT}, {n}')
+        for k, g in enumerate(grps):
+            emit(f'v_mov_b32 v{V_X + 2 * k}, %[x{G[g]}]')
+        emit(f'v_add_u32 v{V_ADDR}, %[step]*{class_slot(ci) + first}, %[addr]')
+        emit(f'.LNP_L{idx}_%=:')
+        pars = [parity, 1 - parity] if (ngroups % 2 == 1 and n > 1) else [parity]
+        for pi, par in enumerate(pars):
+            emit(f's_mov_b32 s{S_NEXT}, 0x{ln * 4:x}')
+            if has_next:
+                emit(f's_cmp_eq_u32 {S_CNT}, 1')
+                emit(f's_cmov_b32 s{S_NEXT}, 0x{delta * 4:x}')
+            emit(f's_add_u32 s{S_NEXT}, s{S_BASE}, s{S_NEXT}')
+            emit(f's_addc_u32 s{S_NEXT + 1}, s{S_BASE + 1}, 0')
+            for ins in Body(shape, par, use_next=True).build():
+                emit(ins)
+            emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
+            emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
+            emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], s[{S_NEXT}:{S_NEXT + 1}]')
+            emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
+            emit(f's_cmp_lg_u32 {S_CNT}, 0')
+            if len(pars) == 2 and pi == 0:
+                emit(f's_cbranch_scc0 .LNP_D{idx}_%=')
+            else:
+                emit(f's_cbranch_scc1 .LNP_L{idx}_%=')
+        emit(f'.LNP_D{idx}_%=:')
+        parity = (parity + n * ngroups) % 2
+    emit('s_waitcnt lgkmcnt(0)')  # retire the dangling prefetch after the last record of the phase
+    A('        :')
+    ops = '[w] "s"(w), [addr] "v"(lds_base), [step] "n"(LDS_STEP), ' + ', '.join(f'[x{k}] "v"(xn[{k}])' for k in used_x)
+    A(f'        : {ops}')
+    clob = ', '.join([f'"v{r}"' for r in V_CLOBBER] + [f'"s{r}"' for r in S_CLOBBER + [S_NEXT, S_NEXT + 1]] + ['"vcc"', '"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+    A('')
+    first_off = class_base(items[0][0]) + items[0][1] * record_len(*CLASSES[items[0][0]][1])
+    A(f'constexpr int MLP_PHASE_{kind}_START = {first_off};  // KBLOB offset of the first record of the phase')
+    A('')
+    return lines
+
+
+def phase_checks():
+    out = ['// the class table the phase functions were generated from (checked against np_nets.h::CLASSES)']
+    for ci, (cname, shape, grps, count, nforce) in enumerate(CLASSES):
+        IN, H1, H2, H3 = shape
+        conds = [f'CLASSES[{cname}].n_in == {IN}', f'CLASSES[{cname}].h1 == {H1}', f'CLASSES[{cname}].h2 == {H2}', f'CLASSES[{cname}].h3 == {H3}',
+                 f'CLASSES[{cname}].count == {count}', f'CLASSES[{cname}].n_force == {nforce}', f'class_base({cname}) == {class_base(ci)}',
+                 f'class_slot({cname}) == {class_slot(ci)}', f'(int){cname} == {ci}']
+        conds += [f'CLASSES[{cname}].grp[{k}] == {g}' for k, g in enumerate(grps)]
+        out.append(f'static_assert({" && ".join(conds)}, "phase asm: class table mismatch ({cname})");')
+    out.append(f'static_assert(KBLOB_HEADER == {KBLOB_HEADER} && NUM_AB_CLASSES == {NUM_AB}, "phase asm: KBLOB header / class split");')
+    return out + ['']
+
+
 def main():
     out = ['// GENERATED by tools/gen_mlp_asm.py — do not edit.  See that file for the design notes.',
            '// One asm statement per net class: double-buffered scalar weight stream + v_pk_fma_f32 chains.',
@@ -237,6 +375,10 @@ def main():
         first = False
     out.append('    else static_assert(IN < 0, "no asm body for this MLP shape");')
     out.append('}')
+    out.append('')
+    out += phase_checks()
+    for kind in ('ALL', 'REST', 'FORCE2'):
+        out += gen_phase(kind)
     with open(OUT, 'w') as f:
         f.write('\n'.join(out) + '\n')
     print('wrote', OUT, sum(len(l) for l in out), 'bytes')
