@@ -207,7 +207,7 @@ __device__ __forceinline__ float distance_fn(float R) {  // utils.py:245-249
 #endif
 constexpr int COMBAT_OBS = 15;
 constexpr int COMBAT_BLOCK = 128;
-constexpr int COMBAT_LDS_FLOATS = NUM_LIVE_NETS * COMBAT_BLOCK;  // > COMBAT_BLOCK * COMBAT_OBS
+constexpr int COMBAT_LDS_FLOATS = NUM_LDS_SLOTS * COMBAT_BLOCK;  // > COMBAT_BLOCK * COMBAT_OBS
 static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as the observation transpose tile");
 
 // STEP=true: SingleCombatEnv.step; STEP=false: reset_done_envs + obs
@@ -420,20 +420,22 @@ __global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_comba
     }
 
     if (valid) {
+        long long iw = i;
+        asm volatile("" : "+v"(iw));  // re-derive the store addresses here instead of keeping the load addresses alive
 #pragma unroll
-        for (int k = 0; k < 12; k++) a.s[k * a.ld + i] = s[k];
+        for (int k = 0; k < 12; k++) a.s[k * a.ld + iw] = s[k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) a.u[k * a.ld + i] = u[k];
-        a.u[4 * a.ld + i] = 0.0f;
-        a.blood[i] = blood;
-        a.step_count[i] = sc;
-        a.fout0[i] = f_done ? 1 : 0;
-        a.fout1[i] = f_bad ? 1 : 0;
-        a.fout2[i] = f_to ? 1 : 0;
+        for (int k = 0; k < 4; k++) a.u[k * a.ld + iw] = u[k];
+        a.u[4 * a.ld + iw] = 0.0f;
+        a.blood[iw] = blood;
+        a.step_count[iw] = sc;
+        a.fout0[iw] = f_done ? 1 : 0;
+        a.fout1[iw] = f_bad ? 1 : 0;
+        a.fout2[iw] = f_to ? 1 : 0;
         if (STEP) {
 #pragma unroll
-            for (int k = 0; k < NUM_PID; k++) a.pid[k * a.ld + i] = pid[k];
-            a.reward[i] = reward;
+            for (int k = 0; k < NUM_PID; k++) a.pid[k * a.ld + iw] = pid[k];
+            a.reward[iw] = reward;
         }
     }
 

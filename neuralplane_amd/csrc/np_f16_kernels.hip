@@ -40,7 +40,7 @@ constexpr int FIRST_GENERATION = 256 * 4 * NPF16_MINWAVES / (BLOCK / 64);
 constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
 // LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
 // (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
-constexpr int LDS_FLOATS = (NUM_LIVE_NETS * BLOCK > BLOCK * OBS_LD) ? NUM_LIVE_NETS * BLOCK : BLOCK * OBS_LD;
+constexpr int LDS_FLOATS = (NUM_LDS_SLOTS * BLOCK > BLOCK * OBS_LD) ? NUM_LDS_SLOTS * BLOCK : BLOCK * OBS_LD;
 
 struct KArgs {
     float *s, *u, *tgt;
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     const bool flagged = (a.fin0[ic] | a.fin1[ic] | a.fin2[ic]) != 0;
 
     const bool frozen = a.inner && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
+    const bool tmo_prev = a.inner && a.fin2[ic] != 0;
     // ---- self.reset(): re-initialise rows flagged by the previous step (env_base.py:83-95) ----
     if (flagged && !a.inner) {
         float ru[5];
@@ -234,20 +235,25 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     }
 
     if (valid) {
+        // re-derive the store addresses from the row index here: without the empty asm the compiler keeps the ~25 64-bit
+        // load addresses of the top of the kernel alive across both MLP phases (and spills some of them to scratch)
+        long long iw = i;
+        asm volatile("" : "+v"(iw));
 #pragma unroll
-        for (int k = 0; k < 12; k++) a.s[k * a.ld + i] = s[k];
+        for (int k = 0; k < 12; k++) a.s[k * a.ld + iw] = s[k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) a.u[k * a.ld + i] = u[k];
+        for (int k = 0; k < 4; k++) a.u[k * a.ld + iw] = u[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) a.tgt[k * a.ld + i] = tgt[k];
-        a.step_count[i] = sc;
-        a.fout0[i] = done ? 1 : 0;
-        a.fout1[i] = bad ? 1 : 0;
-        a.fout2[i] = (a.inner && a.fin2[ic] != 0) ? 1 : 0;
-        if (STEP) a.reward[i] = reward;
+        for (int k = 0; k < 3; k++) a.tgt[k * a.ld + iw] = tgt[k];
+        a.step_count[iw] = sc;
+        a.fout0[iw] = done ? 1 : 0;
+        a.fout1[iw] = bad ? 1 : 0;
+        a.fout2[iw] = tmo_prev ? 1 : 0;
+        if (STEP) a.reward[iw] = reward;
         if (STEP && a.cache) {
+            float *cache_w = a.cache + ((long long)blockIdx.x * NUM_CACHED) * BLOCK + (iw - i0);
 #pragma unroll
-            for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = coef[cached_slot(k) * BLOCK];
+            for (int k = 0; k < NUM_CACHED; k++) cache_w[k * BLOCK] = coef[cached_slot(k) * BLOCK];
         }
     }
 
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                             long long ld, float *__restrict__ out, long long ld_out,
                                                             long long n, float airspeed, int tables) {
-    __shared__ float lds[NUM_LIVE_NETS * BLOCK];
+    __shared__ float lds[NUM_LDS_SLOTS * BLOCK];
     float *coef = lds + threadIdx.x;
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = i < n;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__
 
 // cached coefficients of a reset aircraft (alpha = beta = 0) -> out[14]; run once per context
 __global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out, int tables) {
-    __shared__ float lds[NUM_LIVE_NETS * BLOCK];
+    __shared__ float lds[NUM_LDS_SLOTS * BLOCK];
     float *coef = lds + threadIdx.x;
     float xn[NUM_NORM_GROUPS];
     const float r2d = (float)(180.0 / 3.141592653589793);

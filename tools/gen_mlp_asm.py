@@ -231,6 +231,7 @@ def gen_function(shape):
 # ------------------------------------------------------------------------------------------------
 G = {'G_A_C': 0, 'G_A_DAMP': 1, 'G_A_LEF': 2, 'G_A_DLEF': 3, 'G_A_RUD': 4, 'G_B_C': 5, 'G_B_O': 6, 'G_E_C': 7, 'G_E_ETA': 8}
 KBLOB_HEADER = 2 * len(G)
+NUM_LIVE = 42    # output slots; the normalised inputs live in LDS slots NUM_LIVE .. NUM_LIVE + 8 (np_nets.h::NUM_LDS_SLOTS)
 # (name, shape, input groups, count, n_force) — mirror of np_nets.h::CLASSES, cross-checked by static_asserts in the output
 CLASSES = [
     ('CL_DAMP', (1, 20, 10, 0), ('G_A_DAMP',), 12, 4),
@@ -276,7 +277,7 @@ def gen_phase(kind):
     A = lines.append
     A(f'// phase {kind}: ' + ', '.join(f'{CLASSES[ci][0]}[{first}:{first + n}]' for ci, first, n in items))
     A('template <int LDS_STEP>')
-    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base, const float (&xn)[{len(G)}]) {{')
+    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base) {{')
     A('    asm volatile(')
 
     def emit(s):
@@ -300,8 +301,8 @@ def gen_phase(kind):
             delta = nstart - (start + (n - 1) * ln)
             assert delta > 0, (kind, cname, delta)
         emit(f's_mov_b32 {S_CNT}, {n}')
-        for k, g in enumerate(grps):
-            emit(f'v_mov_b32 v{V_X + 2 * k}, %[x{G[g]}]')
+        for k, g in enumerate(grps):   # inputs of the class from this lane's LDS slots NUM_LIVE + g (retired by the first group wait)
+            emit(f'ds_read_b32 v{V_X + 2 * k}, %[addr] offset:%[step]*{NUM_LIVE + G[g]}')
         emit(f'v_add_u32 v{V_ADDR}, %[step]*{class_slot(ci) + first}, %[addr]')
         emit(f'.LNP_L{idx}_%=:')
         pars = [parity, 1 - parity] if (ngroups % 2 == 1 and n > 1) else [parity]
@@ -327,8 +328,7 @@ def gen_phase(kind):
         parity = (parity + n * ngroups) % 2
     emit('s_waitcnt lgkmcnt(0)')  # retire the dangling prefetch after the last record of the phase
     A('        :')
-    ops = '[w] "s"(w), [addr] "v"(lds_base), [step] "n"(LDS_STEP), ' + ', '.join(f'[x{k}] "v"(xn[{k}])' for k in used_x)
-    A(f'        : {ops}')
+    A('        : [w] "s"(w), [addr] "v"(lds_base), [step] "n"(LDS_STEP)')
     clob = ', '.join([f'"v{r}"' for r in V_CLOBBER] + [f'"s{r}"' for r in S_CLOBBER + [S_NEXT, S_NEXT + 1]] + ['"vcc"', '"scc"', '"memory"'])
     A(f'        : {clob});')
     A('}')
@@ -348,7 +348,8 @@ def phase_checks():
                  f'class_slot({cname}) == {class_slot(ci)}', f'(int){cname} == {ci}']
         conds += [f'CLASSES[{cname}].grp[{k}] == {g}' for k, g in enumerate(grps)]
         out.append(f'static_assert({" && ".join(conds)}, "phase asm: class table mismatch ({cname})");')
-    out.append(f'static_assert(KBLOB_HEADER == {KBLOB_HEADER} && NUM_AB_CLASSES == {NUM_AB}, "phase asm: KBLOB header / class split");')
+    out.append(f'static_assert(KBLOB_HEADER == {KBLOB_HEADER} && NUM_AB_CLASSES == {NUM_AB} && NUM_LIVE_NETS == {NUM_LIVE} && '
+               f'NUM_LDS_SLOTS == {NUM_LIVE + len(G)}, "phase asm: KBLOB header / class split / LDS slots");')
     return out + ['']
 
 

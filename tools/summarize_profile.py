@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Post-process gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the tracked evidence
+under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_summary.csv, <tag>_pmc_traffic.json, <tag>_bench.json.
+
+    python tools/summarize_profile.py r01e
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    return hits[0] if hits else None
+
+
+def main(tag):
+    src = os.path.join(ROOT, 'gpurun_out', tag)
+    dst = os.path.join(ROOT, 'profiles')
+    # bench JSON line
+    bj = os.path.join(src, 'bench.json')
+    if os.path.exists(bj):
+        line = [ln for ln in open(bj).read().splitlines() if ln.startswith('{')][-1]
+        json.dump(json.loads(line), open(os.path.join(dst, f'{tag}_bench.json'), 'w'), indent=1)
+    # kernel stats (names truncated so that the csv stays readable)
+    for sub, out in (('stats', f'{tag}_kernel_stats.csv'), ('stats_combat', f'{tag}_combat_kernel_stats.csv')):
+        ks = find(os.path.join(src, sub, '**', '*kernel_stats.csv'))
+        if ks:
+            rows = list(csv.reader(open(ks)))
+            with open(os.path.join(dst, out), 'w', newline='') as f:
+                w = csv.writer(f)
+                for r in rows:
+                    w.writerow([c[:100] for c in r])
+    # PMC passes: mean per launch / per wave for the dominant kernel
+    summary, traffic = [], {}
+    for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
+        if not os.path.isdir(d):
+            continue
+        cc = find(os.path.join(d, '**', '*counter_collection.csv'))
+        if not cc:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(cc)):
+            if 'f16_env_kernel' not in r.get('Kernel_Name', '') or 'true, true' not in r['Kernel_Name']:
+                continue
+            key = r['Counter_Name']
+            a = acc.setdefault(key, {})
+            a.setdefault(r['Dispatch_Id'], 0.0)
+            a[r['Dispatch_Id']] += float(r['Counter_Value'])
+            grid = int(r.get('Grid_Size', 0) or 0)
+            acc[key]['_waves'] = grid / 64 if grid else None
+        for key, a in acc.items():
+            waves = a.pop('_waves', None)
+            vals = list(a.values())
+            mean = sum(vals) / len(vals)
+            summary.append((key, len(vals), mean, mean / waves if waves else float('nan')))
+            if key in ('FETCH_SIZE', 'WRITE_SIZE'):
+                traffic[key] = mean
+    if summary:
+        with open(os.path.join(dst, f'{tag}_pmc_summary.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['counter', 'launches', 'mean_per_launch', 'mean_per_wave'])
+            for row in sorted(summary):
+                w.writerow([row[0], row[1], f'{row[2]:.6g}', f'{row[3]:.4g}'])
+    if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
+        n = json.load(open(os.path.join(dst, f'{tag}_bench.json')))['config']['aircraft_per_gpu'] if os.path.exists(os.path.join(dst, f'{tag}_bench.json')) else 1000000
+        json.dump({'round': 1, 'kernel': 'f16_env_kernel<0, 0, true, true>', 'n': n, 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
+                   'WRITE_SIZE_KB': traffic['WRITE_SIZE'],
+                   'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), mean over the '
+                           'cached-kernel launches. MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at '
+                           '64 B -> doubled; WRITE_SIZE taken as is (uncalibrated).',
+                   'traffic_bytes_per_launch': (2 * traffic['FETCH_SIZE'] + traffic['WRITE_SIZE']) * 1024.0},
+                  open(os.path.join(dst, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
+    print('profiles/ updated for', tag, ':', sorted(f for f in os.listdir(dst) if f.startswith(tag)))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
