@@ -194,6 +194,28 @@ def main():
                                                        'steps': k2, 'note': 'not the headline: changes the rounding of 22 of the 42 aero '
                                                        'coefficients by ~1e-5 rel (tests: masks identical to the reference, HIP == oracle bit-exact)'}}
         if world == 1 and not args.no_cpu_baseline:
+            # the other integrator of the reference (`solver: rk4`, torchdiffeq's 3/8 rule: 4 aero evaluations per step)
+            torch.cuda.empty_cache()
+            env4 = ControlEnv(num_envs=n, config=args.task, model='F16', random_seed=0, device=str(dev), row0=row0, solver='rk4')
+            env4.reset()
+            for i in range(5):
+                env4.step(pool[i % len(pool)])
+            env4._batch.set_timing(True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            k4 = min(args.steps, 50)
+            for i in range(k4):
+                env4.step(pool[i % len(pool)])
+            torch.cuda.synchronize(dev)
+            el4 = time.perf_counter() - t1
+            ms4, _ = env4._batch.get_timing()
+            out.setdefault('optional_modes', {})['solver_rk4'] = {
+                'value': n * k4 / el4, 'unit': 'aircraft-steps/s', 'kernel_avg_ms': ms4, 'steps': k4,
+                'algorithmic_tflops': n * 105e3 / (ms4 * 1e-3) / 1e12 if ms4 > 0 else 0.0,
+                'note': '4 x 23.8 KFLOP aero evaluations + the Overload re-evaluation = 105 KFLOP per aircraft-step (SURVEY 8d); '
+                        'reference parity of rk4 is unpinned (no artefact exercises it), HIP == oracle bit-exact'}
+            del env4
+        if world == 1 and not args.no_cpu_baseline:
             # BASELINE.json configs[4] (a parity-test case, reported beside the headline, never as `value`): SingleCombat 1v1,
             # 1e5 engagements = 2e5 aircraft, one launch per env.step = 5 FDM steps behind the attitude PID stack
             from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv

@@ -239,13 +239,18 @@ __device__ __forceinline__ void eval_nets(const float (&xn)[NUM_NORM_GROUPS], fl
     constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
     if constexpr (has_phase) {
         if (!tables) {  // wave-uniform
-            // the 9 normalised inputs go to this lane's LDS slots 42..50; each class of the statement reads its own
+            const unsigned lds_base = (unsigned)(unsigned long long)out;
+#if NPF16_PHASE_X_IN_LDS  // the 9 normalised inputs go to this lane's LDS slots 42..50; each class of the statement reads its own
 #pragma unroll
             for (int g = 0; g < NUM_NORM_GROUPS; g++) out[(NUM_LIVE_NETS + g) * LD] = xn[g];
-            const unsigned lds_base = (unsigned)(unsigned long long)out;
-            if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_ALL_START, lds_base);
-            else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_REST_START, lds_base);
-            else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_FORCE2_START, lds_base);
+#define NPF16_PHASE_ARGS lds_base
+#else
+#define NPF16_PHASE_ARGS lds_base, xn
+#endif
+            if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_ALL_START, NPF16_PHASE_ARGS);
+            else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_REST_START, NPF16_PHASE_ARGS);
+            else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_FORCE2_START, NPF16_PHASE_ARGS);
+#undef NPF16_PHASE_ARGS
             return;
         }
     }

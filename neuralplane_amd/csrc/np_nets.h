@@ -92,9 +92,10 @@ constexpr NetClass CLASSES[NUM_CLASSES] = {
 };
 
 constexpr int NUM_LIVE_NETS = 42;  // 43 minus the dead delta_Czq_lef
-// per-lane LDS column of a kernel that evaluates the nets: 42 coefficient slots + the 9 normalised inputs (the phase asm
-// statements read their inputs from there instead of holding 9 VGPRs across a whole phase)
-constexpr int NUM_LDS_SLOTS = NUM_LIVE_NETS + 9;
+// per-lane LDS column of a kernel that evaluates the nets: the 42 coefficient slots.  (Nine more slots for the normalised
+// inputs — tools/gen_mlp_asm.py X_IN_LDS — push a 128-lane workgroup to 26 KB: only 5 instead of 6 workgroups per CU, which
+// costs the aero_1d_tables mode 10 %; the inputs therefore stay in VGPRs.)
+constexpr int NUM_LDS_SLOTS = NUM_LIVE_NETS;
 
 // Exact piecewise-linear tables of the single-input nets (blob PWL section, tools/export_weights.py):
 // per net t[64] breakpoints (sorted, +inf padded), a[64], x0[64], c[64]:  y_norm = fma(a[i], x - x0[i], c[i])

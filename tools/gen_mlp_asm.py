@@ -231,6 +231,7 @@ def gen_function(shape):
 # ------------------------------------------------------------------------------------------------
 G = {'G_A_C': 0, 'G_A_DAMP': 1, 'G_A_LEF': 2, 'G_A_DLEF': 3, 'G_A_RUD': 4, 'G_B_C': 5, 'G_B_O': 6, 'G_E_C': 7, 'G_E_ETA': 8}
 KBLOB_HEADER = 2 * len(G)
+X_IN_LDS = False  # True: the phase statements read their inputs from LDS slots NUM_LIVE.. (51 slots/lane: only 5 workgroups per CU)
 NUM_LIVE = 42    # output slots; the normalised inputs live in LDS slots NUM_LIVE .. NUM_LIVE + 8 (np_nets.h::NUM_LDS_SLOTS)
 # (name, shape, input groups, count, n_force) — mirror of np_nets.h::CLASSES, cross-checked by static_asserts in the output
 CLASSES = [
@@ -277,7 +278,10 @@ def gen_phase(kind):
     A = lines.append
     A(f'// phase {kind}: ' + ', '.join(f'{CLASSES[ci][0]}[{first}:{first + n}]' for ci, first, n in items))
     A('template <int LDS_STEP>')
-    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base) {{')
+    if X_IN_LDS:
+        A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base) {{')
+    else:
+        A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base, const float (&xn)[{len(G)}]) {{')
     A('    asm volatile(')
 
     def emit(s):
@@ -301,8 +305,11 @@ def gen_phase(kind):
             delta = nstart - (start + (n - 1) * ln)
             assert delta > 0, (kind, cname, delta)
         emit(f's_mov_b32 {S_CNT}, {n}')
-        for k, g in enumerate(grps):   # inputs of the class from this lane's LDS slots NUM_LIVE + g (retired by the first group wait)
-            emit(f'ds_read_b32 v{V_X + 2 * k}, %[addr] offset:%[step]*{NUM_LIVE + G[g]}')
+        for k, g in enumerate(grps):
+            if X_IN_LDS:   # from this lane's LDS slots NUM_LIVE + g (retired by the first group wait)
+                emit(f'ds_read_b32 v{V_X + 2 * k}, %[addr] offset:%[step]*{NUM_LIVE + G[g]}')
+            else:
+                emit(f'v_mov_b32 v{V_X + 2 * k}, %[x{G[g]}]')
         emit(f'v_add_u32 v{V_ADDR}, %[step]*{class_slot(ci) + first}, %[addr]')
         emit(f'.LNP_L{idx}_%=:')
         pars = [parity, 1 - parity] if (ngroups % 2 == 1 and n > 1) else [parity]
@@ -328,7 +335,10 @@ def gen_phase(kind):
         parity = (parity + n * ngroups) % 2
     emit('s_waitcnt lgkmcnt(0)')  # retire the dangling prefetch after the last record of the phase
     A('        :')
-    A('        : [w] "s"(w), [addr] "v"(lds_base), [step] "n"(LDS_STEP)')
+    ops = '[w] "s"(w), [addr] "v"(lds_base), [step] "n"(LDS_STEP)'
+    if not X_IN_LDS:
+        ops += ', ' + ', '.join(f'[x{k}] "v"(xn[{k}])' for k in used_x)
+    A(f'        : {ops}')
     clob = ', '.join([f'"v{r}"' for r in V_CLOBBER] + [f'"s{r}"' for r in S_CLOBBER + [S_NEXT, S_NEXT + 1]] + ['"vcc"', '"scc"', '"memory"'])
     A(f'        : {clob});')
     A('}')
@@ -349,7 +359,8 @@ def phase_checks():
         conds += [f'CLASSES[{cname}].grp[{k}] == {g}' for k, g in enumerate(grps)]
         out.append(f'static_assert({" && ".join(conds)}, "phase asm: class table mismatch ({cname})");')
     out.append(f'static_assert(KBLOB_HEADER == {KBLOB_HEADER} && NUM_AB_CLASSES == {NUM_AB} && NUM_LIVE_NETS == {NUM_LIVE} && '
-               f'NUM_LDS_SLOTS == {NUM_LIVE + len(G)}, "phase asm: KBLOB header / class split / LDS slots");')
+               f'NUM_LDS_SLOTS == {NUM_LIVE + (len(G) if X_IN_LDS else 0)}, "phase asm: KBLOB header / class split / LDS slots");')
+    out.append(f'#define NPF16_PHASE_X_IN_LDS {1 if X_IN_LDS else 0}')
     return out + ['']
 
 
