@@ -62,6 +62,11 @@ __device__ __forceinline__ void sincos_d(double x, double &sn, double &cs) {
 }
 
 __device__ __forceinline__ void np_sincos(float x, float &s, float &c) {
+#if defined(NPF16_EXP) && (NPF16_EXP & 8)  // timing experiment only: hardware approximations instead of the fp64 sequences
+    s = __sinf(x);
+    c = __cosf(x);
+    return;
+#endif
     double sd, cd;
     sincos_d((double)x, sd, cd);
     s = (float)sd;
@@ -70,6 +75,12 @@ __device__ __forceinline__ void np_sincos(float x, float &s, float &c) {
 
 // sin, cos and tan of the same angle (tan = sin/cos in fp64, rounded once)
 __device__ __forceinline__ void np_sincostan(float x, float &s, float &c, float &t) {
+#if defined(NPF16_EXP) && (NPF16_EXP & 8)
+    s = __sinf(x);
+    c = __cosf(x);
+    t = s / c;
+    return;
+#endif
     double sd, cd;
     sincos_d((double)x, sd, cd);
     s = (float)sd;
@@ -138,6 +149,9 @@ __device__ __forceinline__ double exp2_d(double P) {
 
 // x^y = exp2(y*log2 x) in fp64 (atmosphere model's tfac^4.14)
 __device__ __forceinline__ float np_pow(float xf, float yf) {
+#if defined(NPF16_EXP) && (NPF16_EXP & 8)
+    return __powf(xf, yf);
+#endif
     const double x = (double)xf, y = (double)yf;
     if (x != x || y != y) return __builtin_nanf("");
     if (x < 0.0) return __builtin_nanf("");
