@@ -759,10 +759,14 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     if (pack_kblob(weights_blob, nbytes, kb, pwl, pwl_unnorm)) return 1;
     const uint64_t blob_hash = fnv1a(weights_blob, nbytes);
     std::lock_guard<std::mutex> lock(g_blob_mu);
+    bool resident = false;  // the same blob is already in this device's constant memory (kernels of live contexts read it)
     {
         auto it = g_blob_live.find(device);
-        if (it != g_blob_live.end() && it->second.second > 0 && it->second.first != blob_hash)
-            return fail("a context created from a different weights blob is alive on this device (weights are per device)");
+        if (it != g_blob_live.end() && it->second.second > 0) {
+            if (it->second.first != blob_hash)
+                return fail("a context created from a different weights blob is alive on this device (weights are per device)");
+            resident = true;
+        }
     }
     if (tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
     int ndev = 0;
@@ -774,8 +778,8 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     NP_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("device arch ") + prop.gcnArchName + " is not gfx950 (MI355X)");
-    NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_kblob), kb.data(), sizeof(float) * KBLOB_FLOATS));
-    if (!pwl.empty()) {
+    if (!resident) NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_kblob), kb.data(), sizeof(float) * KBLOB_FLOATS));
+    if (!resident && !pwl.empty()) {
         NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl), pwl.data(), sizeof(float) * pwl.size()));
         NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl_unnorm), pwl_unnorm.data(), sizeof(float) * pwl_unnorm.size()));
     }
