@@ -390,3 +390,23 @@ def test_hip_free_running_trajectory_vs_reference_recording(task, n, T, golden_d
         if t < 100:
             assert np.max(e) < 1e-4, (t, np.max(e))
         assert np.median(e) < 1e-4 and np.percentile(e, 90) < 5e-4, (t, np.median(e), np.percentile(e, 90))
+
+
+def test_pinned_vec_env_equals_gpu_vec_env():
+    """PinnedVecEnv (page-locked staging, one sync per step, ring of host buffers) returns what GPUVecEnv returns."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import GPUVecEnv, PinnedVecEnv
+    mk = lambda: ControlEnv(num_envs=500, config='heading', model='F16', random_seed=2, device='cuda:0')  # noqa: E731
+    a, b = GPUVecEnv([mk]), PinnedVecEnv([mk], ring=2)
+    oa, ob = a.reset(), b.reset()
+    assert isinstance(ob, np.ndarray) and ob.shape == (500, 1, 22) and np.array_equal(oa, ob)
+    rng = np.random.RandomState(3)
+    prev = None
+    for k in range(6):
+        act = rng.uniform(-1.5, 1.5, (500, 1, 4)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra[:5], rb[:5]):
+            assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y)
+        if prev is not None:      # ring = 2: the arrays of the previous step are still intact
+            assert np.array_equal(prev[0], prev[1])
+        prev = (ra[0].copy(), rb[0])
