@@ -240,6 +240,27 @@ def main():
                 'note': 'N = 1e7 aircraft on one GPU (3 GB of state + observations of the 288 GB): same kernel, same numerics'}
             del env5, ab
         if world == 1 and not args.no_cpu_baseline:
+            # BASELINE.json configs[0] size (N = 256 = 4 waves): the latency regime — microseconds per env.step, not a roofline
+            envs = ControlEnv(num_envs=256, config=args.task, model='F16', random_seed=0, device=str(dev))
+            envs.reset()
+            a_s = torch.rand((256, 4), generator=g, device=dev) * 2 - 1
+            for i in range(50):
+                envs.step(a_s)
+            envs._batch.set_timing(True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            k6 = 1000
+            for i in range(k6):
+                envs.step(a_s)
+            torch.cuda.synchronize(dev)
+            el6 = time.perf_counter() - t1
+            ms6, _ = envs._batch.get_timing()
+            out.setdefault('optional_modes', {})['latency_n256'] = {
+                'value': 1e6 * el6 / k6, 'unit': 'us per env.step (wall, back-to-back launches)', 'kernel_avg_us': 1e3 * ms6, 'steps': k6,
+                'aircraft_steps_per_s': 256 * k6 / el6,
+                'note': 'one wave executes the whole step serially (~12.6 K VALU instructions): latency-bound, the GPU is idle otherwise'}
+            del envs
+        if world == 1 and not args.no_cpu_baseline:
             # BASELINE.json configs[4] (a parity-test case, reported beside the headline, never as `value`): SingleCombat 1v1,
             # 1e5 engagements = 2e5 aircraft, one launch per env.step = 5 FDM steps behind the attitude PID stack
             from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
