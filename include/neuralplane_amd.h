@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 5
+#define NP_ABI_VERSION 6
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -205,6 +205,13 @@ int np_f16_combat_ctx_create(const void *weights_blob, size_t nbytes, const np_f
 int np_f16_combat_reset(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream);
 /* SingleCombatEnv.step(action) (singlecombat_env.py:240-274), one kernel launch. */
 int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream);
+
+/* np_f16_step has two bit-identical kernel variants: "throughput" (one lane per aircraft, two independent waves per
+ * workgroup — large batches) and "latency" (four waves share a tile of 64 aircraft and split the 44 net evaluations of a
+ * step — a step takes about half of a lone wave's 44 us; chosen automatically for n <= 65536 (the measured
+ * crossover), Euler solver).  This call pins the choice for a context (tests, tuning). */
+enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2 };
+int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
 /* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context,
  * measured with HIP events recorded on the launch stream around each launch (0 disables;

@@ -228,35 +228,113 @@ __device__ __forceinline__ void eval_el(const float (&xn)[NUM_NORM_GROUPS], floa
     eval_class<CL_ETA, N_ETA, LD>(xn, out, tables);
 }
 
+// ---- latency variant: the nets of one evaluation split over the 4 waves of a workgroup that share ONE tile of 64
+// aircraft (small batches: a lone wave needs ~44 us per env.step, most of it the serial chain of 44 net evaluations).
+// Every wave evaluates whole classes (or net ranges of a class) into the shared coefficient columns; plans are balanced
+// by FLOPs (1-in 20-10: 460, 2-in 20-10: 500, 2-in 20-10-5: 610, 2-in 20-20-10: 1300, 3-in 20-10: 540 per net).
+struct SplitItem {
+    int cl, first, cnt;
+};
+constexpr int SPLIT_WAVES = 4, SPLIT_MAX = 4;
+struct SplitPlan {
+    SplitItem it[SPLIT_WAVES][SPLIT_MAX];
+};
+constexpr SplitItem NO_ITEM = {-1, 0, 0};
+// AB_REST + C[0:5] + ETA (cached integrator evaluation, 28 nets)
+constexpr SplitPlan PLAN_REST = {{{{CL_DAMP, 4, 8}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                  {{CL_DLEF, 2, 5}, {CL_D_RUD, 1, 1}, {CL_D_LEF, 1, 1}, {CL_ETA, 0, 1}},
+                                  {{CL_E_LEF, 2, 2}, {CL_F, 1, 2}, NO_ITEM, NO_ITEM},
+                                  {{CL_E_RUD, 1, 3}, {CL_C, 0, 5}, NO_ITEM, NO_ITEM}}};
+// AB_ALL + C[0:5] + ETA (un-cached evaluation, 42 nets)
+constexpr SplitPlan PLAN_ALL = {{{{CL_DAMP, 0, 12}, {CL_ETA, 0, 1}, NO_ITEM, NO_ITEM},
+                                 {{CL_DLEF, 0, 7}, {CL_C, 0, 5}, NO_ITEM, NO_ITEM},
+                                 {{CL_F, 0, 3}, {CL_D_RUD, 0, 2}, {CL_D_LEF, 0, 2}, NO_ITEM},
+                                 {{CL_E_LEF, 0, 4}, {CL_E_RUD, 0, 4}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}}}};
+// AB_FORCE + C[0:2] (Overload re-evaluation, 16 nets)
+constexpr SplitPlan PLAN_FORCE2 = {{{{CL_DAMP, 0, 4}, {CL_D_RUD, 0, 1}, NO_ITEM, NO_ITEM},
+                                    {{CL_DLEF, 0, 2}, {CL_E_LEF, 0, 2}, NO_ITEM, NO_ITEM},
+                                    {{CL_F, 0, 1}, {CL_C, 0, 2}, NO_ITEM, NO_ITEM},
+                                    {{CL_D_LEF, 0, 1}, {CL_E_RUD, 0, 1}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}}}};
+// a plan must cover exactly the nets eval_ab<PART> + eval_el<N_C, N_ETA> evaluate, each once
+constexpr bool plan_covers(const SplitPlan &p, int part, int n_c, int n_eta) {
+    for (int cl = 0; cl < NUM_CLASSES; cl++) {
+        int lo = 0, hi = 0;
+        if (cl < NUM_AB_CLASSES) {
+            lo = part == AB_REST ? CLASSES[cl].n_force : 0;
+            hi = part == AB_FORCE ? CLASSES[cl].n_force : CLASSES[cl].count;
+        } else {
+            hi = cl == CL_C ? n_c : n_eta;
+        }
+        for (int net = 0; net < CLASSES[cl].count; net++) {
+            int hits = 0;
+            for (int w = 0; w < SPLIT_WAVES; w++)
+                for (int k = 0; k < SPLIT_MAX; k++)
+                    if (p.it[w][k].cl == cl && net >= p.it[w][k].first && net < p.it[w][k].first + p.it[w][k].cnt) hits++;
+            if (hits != ((net >= lo && net < hi) ? 1 : 0)) return false;
+        }
+    }
+    return true;
+}
+static_assert(plan_covers(PLAN_REST, AB_REST, 5, 1) && plan_covers(PLAN_ALL, AB_ALL, 5, 1) && plan_covers(PLAN_FORCE2, AB_FORCE, 2, 0),
+              "split plans must cover each net of their phase exactly once");
+
+template <const SplitPlan &P, int W, int LD>
+__device__ __forceinline__ void eval_plan_wave(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+#define NPF16_ITEM(K)                                                                                         \
+    if constexpr (P.it[W][K].cnt > 0) eval_class<P.it[W][K].cl, P.it[W][K].cnt, LD, P.it[W][K].first>(xn, out, tables)
+    NPF16_ITEM(0);
+    NPF16_ITEM(1);
+    NPF16_ITEM(2);
+    NPF16_ITEM(3);
+#undef NPF16_ITEM
+}
+
 // All nets of one nlplant evaluation.  With the asm bodies and the default numerics the whole sequence of classes is ONE
 // asm statement (tools/gen_mlp_asm.py, "phase functions"): the weight stream keeps running across class boundaries.
+// WPT = 4: the latency variant above; `part` is the wave's index within its workgroup (wave-uniform).
 #ifndef NPF16_PHASE_ASM
 #define NPF16_PHASE_ASM 1
 #endif
-template <int LD, int PART, bool FULL>
-__device__ __forceinline__ void eval_nets(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
-#if NPF16_ASM_MLP && NPF16_PHASE_ASM && !defined(NPF16_EXP)
+template <int LD, int PART, bool FULL, int WPT = 1>
+__device__ __forceinline__ void eval_nets(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables, int part = 0) {
     constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
-    if constexpr (has_phase) {
-        if (!tables) {  // wave-uniform
-            const unsigned lds_base = (unsigned)(unsigned long long)out;
+    if constexpr (WPT == 4) {
+        static_assert(has_phase, "no split plan for this evaluation");
+        __syncthreads();  // every wave has finished reading the coefficients of the previous evaluation
+#define NPF16_WAVE(W)                                                                                          \
+    if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN_ALL, W, LD>(xn, out, tables);                  \
+    else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN_REST, W, LD>(xn, out, tables);           \
+    else eval_plan_wave<PLAN_FORCE2, W, LD>(xn, out, tables)
+        if (part == 0) { NPF16_WAVE(0); }
+        else if (part == 1) { NPF16_WAVE(1); }
+        else if (part == 2) { NPF16_WAVE(2); }
+        else { NPF16_WAVE(3); }
+#undef NPF16_WAVE
+        __syncthreads();  // all 42 / 16 coefficient columns are complete
+        return;
+    } else {
+#if NPF16_ASM_MLP && NPF16_PHASE_ASM && !defined(NPF16_EXP)
+        if constexpr (has_phase) {
+            if (!tables) {  // wave-uniform
+                const unsigned lds_base = (unsigned)(unsigned long long)out;
 #if NPF16_PHASE_X_IN_LDS  // the 9 normalised inputs go to this lane's LDS slots 42..50; each class of the statement reads its own
 #pragma unroll
-            for (int g = 0; g < NUM_NORM_GROUPS; g++) out[(NUM_LIVE_NETS + g) * LD] = xn[g];
+                for (int g = 0; g < NUM_NORM_GROUPS; g++) out[(NUM_LIVE_NETS + g) * LD] = xn[g];
 #define NPF16_PHASE_ARGS lds_base
 #else
 #define NPF16_PHASE_ARGS lds_base, xn
 #endif
-            if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_ALL_START, NPF16_PHASE_ARGS);
-            else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_REST_START, NPF16_PHASE_ARGS);
-            else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_FORCE2_START, NPF16_PHASE_ARGS);
+                if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_ALL_START, NPF16_PHASE_ARGS);
+                else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_REST_START, NPF16_PHASE_ARGS);
+                else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_FORCE2_START, NPF16_PHASE_ARGS);
 #undef NPF16_PHASE_ARGS
-            return;
+                return;
+            }
         }
-    }
 #endif
-    eval_ab<LD, PART>(xn, out, tables);
-    eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, out, tables);
+        eval_ab<LD, PART>(xn, out, tables);
+        eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, out, tables);
+    }
 }
 
 // The 9 distinct input normalisations (X - mean) / std of mean_std.csv.
@@ -281,9 +359,9 @@ struct Trig {  // sines/cosines of the attitude and flow angles of one state
 // PART: which alpha/beta-only nets are evaluated here — AB_ALL, AB_FORCE (FULL=false), or AB_REST
 // when the 14 force-side slots of `coef` already hold the values of THIS state (carried over from
 // the Overload evaluation of the previous step).
-template <bool FULL, int PART, int LD>
+template <bool FULL, int PART, int LD, int WPT = 1>
 __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
-                                        float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12]) {
+                                        float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
     const float xc = (float)(0.35 - 0.30);
@@ -327,7 +405,7 @@ __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4
     const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
     const bool ok = (chk == chk);
     const float qnan = __builtin_nanf("");
-    eval_nets<LD, PART, FULL>(xn, coef, tables);
+    eval_nets<LD, PART, FULL, WPT>(xn, coef, tables, part);
 #define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
 
     const float inv2vt = 1.0f / (2.0f * vt);
@@ -392,14 +470,14 @@ __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &t
 }
 
 // full derivative at (s,u) including the heading terms
-template <int PART, int LD>
+template <int PART, int LD, int WPT = 1>
 __device__ __forceinline__ void xdot_full(const float (&s)[12], const float (&u)[4], float *__restrict__ coef, bool tables,
-                                          float (&xd)[12]) {
+                                          float (&xd)[12], int part = 0) {
     Trig tr;
     float tt, spsi, cpsi;
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
-    nlplant<true, PART, LD>(s, u, tr, tt, spsi, cpsi, coef, tables, xd);
+    nlplant<true, PART, LD, WPT>(s, u, tr, tt, spsi, cpsi, coef, tables, xd, part);
 }
 
 // F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)

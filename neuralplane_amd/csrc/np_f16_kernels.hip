@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -37,6 +38,7 @@ namespace npf16 {
 constexpr int BLOCK = NPF16_BLOCK;
 // workgroups resident at once: 256 CUs x 4 SIMDs x NPF16_MINWAVES wave slots / waves per workgroup
 constexpr int FIRST_GENERATION = 256 * 4 * NPF16_MINWAVES / (BLOCK / 64);
+constexpr int CACHE_TILE = 64;  // rows per tile of the cross-step coefficient cache
 constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
 // LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
 // (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
@@ -53,7 +55,7 @@ struct KArgs {
     float *obs, *reward;
     const float *rand_u, *noise;
     int inner;     // one low-level iteration of PlanningEnv.step: no auto-reset, flagged rows frozen, flags accumulate
-    float *cache;  // [workgroup][14][BLOCK] force-side alpha/beta-only coefficients at the current state (may be null)
+    float *cache;  // [row / 64][14][row % 64] force-side alpha/beta-only coefficients at the current state (may be null)
     uint64_t seed, call_idx;
     const uint64_t *call_idx_base;  // optional device word added to call_idx (launches replayed from a HIP graph)
     long long row0, n;
@@ -69,13 +71,19 @@ struct KArgs {
 // STEP=false: BaseEnv.reset (env_base.py:83-97)
 // CACHED    : a.cache holds, for every row, the 14 force-side alpha/beta-only coefficients of its CURRENT
 //             state (written by the previous step's Overload evaluation) -> the integrator skips them.
-template <int TASK, int SOLVER, bool STEP, bool CACHED>
-__global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KArgs a) {
-    __shared__ float lds[LDS_FLOATS];
+// TILE, WPT : aircraft per workgroup and waves that share them.  Throughput variant: TILE = 128, WPT = 1 (2 independent
+//             waves).  Latency variant (small batches): TILE = 64, WPT = 4 — four waves hold the SAME 64 aircraft, split the
+//             net evaluations (eval_nets<.., 4>, np_f16_device.h) and redo the cheap non-MLP arithmetic redundantly, so a
+//             step takes ~1/2 of a lone wave's time; wave 0 stores.  Results are bit-identical between the variants.
+template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1>
+__global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(const KArgs a) {
+    constexpr int TILE_LDS = (NUM_LDS_SLOTS * TILE > TILE * OBS_LD) ? NUM_LDS_SLOTS * TILE : TILE * OBS_LD;
+    __shared__ float lds[TILE_LDS];
     float *obs_tile = lds;
-    const int t = threadIdx.x;
-    float *coef = lds + t;  // this lane's coefficient column, stride BLOCK
-    const long long i0 = (long long)blockIdx.x * BLOCK;
+    const int t = WPT == 1 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
+    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform
+    float *coef = lds + t;  // this lane's coefficient column, stride TILE
+    const long long i0 = (long long)blockIdx.x * TILE;
     const long long i = i0 + t;
     const bool valid = i < a.n;
     const long long ic = valid ? i : a.n - 1;  // tail lanes shadow the last row; their stores are masked
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     // worse: 0.45 ms); later workgroups inherit the phase of the workgroup whose slot they take.  Only done
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
-    if (STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
+    if (WPT == 1 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
         const long long wait = (long long)(blockIdx.x % 3) * NPF16_STAGGER_CYCLES;
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
@@ -129,17 +137,18 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
     }
 
     // cache tile of this workgroup: 14 rows of BLOCK floats, contiguous
-    float *cache_blk = a.cache ? a.cache + ((long long)blockIdx.x * NUM_CACHED) * BLOCK + t : nullptr;
+    // cache layout (private to the library, the same for every kernel variant): [row / 64][14][row % 64]
+    float *cache_blk = a.cache ? a.cache + ((i >> 6) * NUM_CACHED) * CACHE_TILE + (i & (CACHE_TILE - 1)) : nullptr;
     if (STEP && CACHED) {  // coefficient columns <- cache (a reset aircraft sits at alpha = beta = 0)
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) {
-            const float c = cache_blk[k * BLOCK];
-            coef[cached_slot(k) * BLOCK] = (flagged && !a.inner) ? a.reset_coef[k] : c;
+            const float c = cache_blk[k * CACHE_TILE];
+            coef[cached_slot(k) * TILE] = (flagged && !a.inner) ? a.reset_coef[k] : c;
         }
     }
-    if (!STEP && a.cache && flagged && valid && !a.inner) {  // reset(): keep the cache consistent for re-initialised rows
+    if (!STEP && a.cache && flagged && valid && !a.inner && part == 0) {  // reset(): keep the cache consistent for re-initialised rows
 #pragma unroll
-        for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * BLOCK] = a.reset_coef[k];
+        for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * CACHE_TILE] = a.reset_coef[k];
     }
 
     if (STEP) {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         const float dt = cfg.dt;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
-            xdot_full<(CACHED ? AB_REST : AB_ALL), BLOCK>(s, u, coef, tables, k1);
+            xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(s, u, coef, tables, k1, part);
 #pragma unroll
             for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
         } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
@@ -170,8 +179,8 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #pragma nounroll
             for (int stage = 0; stage < 4; stage++) {
                 float kk[12];
-                if (CACHED && stage == 0) xdot_full<AB_REST, BLOCK>(y, u, coef, tables, kk);  // y == s: cached coefficients apply
-                else xdot_full<AB_ALL, BLOCK>(y, u, coef, tables, kk);
+                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(y, u, coef, tables, kk, part);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, TILE, WPT>(y, u, coef, tables, kk, part);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
 #if defined(NPF16_EXP) && (NPF16_EXP & 2)  // timing experiment only: no Overload evaluation
         for (int k = 0; k < 12; k++) xd[k] = s[k];
 #else
-        nlplant<false, AB_FORCE, BLOCK>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd);
+        nlplant<false, AB_FORCE, TILE, WPT>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
 #endif
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward);
     }
 
-    if (valid) {
+    if (valid && part == 0) {
         // re-derive the store addresses from the row index here: without the empty asm the compiler keeps the ~25 64-bit
         // load addresses of the top of the kernel alive across both MLP phases (and spills some of them to scratch)
         long long iw = i;
@@ -251,24 +260,27 @@ __global__ __launch_bounds__(BLOCK, NPF16_MINWAVES) void f16_env_kernel(const KA
         a.fout2[iw] = tmo_prev ? 1 : 0;
         if (STEP) a.reward[iw] = reward;
         if (STEP && a.cache) {
-            float *cache_w = a.cache + ((long long)blockIdx.x * NUM_CACHED) * BLOCK + (iw - i0);
+            float *cache_w = a.cache + ((iw >> 6) * NUM_CACHED) * CACHE_TILE + (iw & (CACHE_TILE - 1));
 #pragma unroll
-            for (int k = 0; k < NUM_CACHED; k++) cache_w[k * BLOCK] = coef[cached_slot(k) * BLOCK];
+            for (int k = 0; k < NUM_CACHED; k++) cache_w[k * CACHE_TILE] = coef[cached_slot(k) * TILE];
         }
     }
 
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
     if (a.obs) {
         __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
+        if (part == 0) {
 #pragma unroll
-        for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
+            for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
+        }
         __syncthreads();
-        const long long rows = (a.n - i0) < BLOCK ? (a.n - i0) : BLOCK;
+        const long long rows = (a.n - i0) < TILE ? (a.n - i0) : TILE;
         const int total = (int)rows * 22;
         float *dst = a.obs + i0 * 22;
+        constexpr int THREADS = TILE * WPT;
 #pragma unroll
-        for (int it = 0; it < 22; it++) {
-            const int L = it * BLOCK + t;
+        for (int it = 0; it < (22 * TILE + THREADS - 1) / THREADS; it++) {
+            const int L = it * THREADS + (int)threadIdx.x;
             if (L < total) {
                 const int r = L / 22, c = L - r * 22;
                 dst[L] = obs_tile[r * OBS_LD + c];
@@ -390,6 +402,7 @@ struct np_f16_ctx {
     int task, solver;
     DevCfg cfg;
     float *d_reset_coef;  // [NUM_CACHED] device buffer owned by the context
+    int variant;          // NP_KERNEL_AUTO / _LATENCY / _THROUGHPUT
     bool combat;  // created by np_f16_combat_ctx_create: only the combat entry points accept it
     CombatDevCfg ccfg;
     bool timing;
@@ -569,6 +582,19 @@ struct DeviceGuard {
     }
 };
 
+constexpr int LAT_TILE = 64;
+constexpr int64_t LAT_MAX_N = 65536;  // measured crossover (tools/microbench/small_n.py): 65536: 53.6 vs 58.9 us, 98304: 73.5 vs 59.2 us
+bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
+    static const int forced = [] {  // process-wide override for experiments: NPF16_KERNEL=latency|throughput
+        const char *e = std::getenv("NPF16_KERNEL");
+        if (!e) return (int)NP_KERNEL_AUTO;
+        return std::strcmp(e, "latency") == 0 ? (int)NP_KERNEL_LATENCY : std::strcmp(e, "throughput") == 0 ? (int)NP_KERNEL_THROUGHPUT : (int)NP_KERNEL_AUTO;
+    }();
+    const int v = ctx->variant != NP_KERNEL_AUTO ? ctx->variant : forced;
+    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY;
+    return n <= LAT_MAX_N;
+}
+
 template <bool STEP>
 int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     if (!ctx || !io) return fail("null ctx/io");
@@ -594,7 +620,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.call_idx_base = io->call_idx_base;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
-    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
+    const bool latency = STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
+    const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)), block(latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = STEP && ctx->timing;
@@ -610,10 +638,13 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     }
     const bool cached = STEP && io->coef_cache && io->cache_valid;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
-#define NP_LAUNCH(T, S)                                                                                   \
-    do {                                                                                                  \
-        if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP>), grid, block, 0, st, a);        \
-        else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false>), grid, block, 0, st, a);              \
+#define NP_LAUNCH(T, S)                                                                                           \
+    do {                                                                                                          \
+        if (latency && S == 0) {                                                                                  \
+            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4>), grid, block, 0, st, a);   \
+            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4>), grid, block, 0, st, a);         \
+        } else if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP>), grid, block, 0, st, a);         \
+        else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false>), grid, block, 0, st, a);                      \
     } while (0)
     const int key = ctx->task * 2 + (STEP ? ctx->solver : 0);
     switch (key) {
@@ -798,6 +829,7 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     ctx->task = 0;
     ctx->solver = 0;
     ctx->combat = false;
+    ctx->variant = NP_KERNEL_AUTO;
     {
         auto &slot = g_blob_live[device];
         if (slot.second == 0) slot.first = blob_hash;
@@ -899,6 +931,13 @@ int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float 
     hipLaunchKernelGGL(f16_lowlevel_obs_kernel, grid, block, 0, (hipStream_t)stream, s, u, tgt3, (long long)ld, obs, (long long)n,
                        ctx->cfg);
     NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
+    if (!ctx) return fail("null ctx");
+    if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT) return fail("unknown kernel variant");
+    ctx->variant = variant;
     return 0;
 }
 

@@ -101,8 +101,8 @@ class BaseEnv(Env):
         obs, reward, flags = self._batch.step(action, rand_u=rand_u, noise=noise)
         if render:
             self.render(count=count)
-        f = flags.view(torch.bool)
-        return obs, reward, f[0], f[1], f[2], self.info()
+        done, bad_done, exceed_time_limit = flags.view(torch.bool).unbind(0)
+        return obs, reward, done, bad_done, exceed_time_limit, self.info()
 
     def render(self, count, filename='./tracks/F16SimRecording-', max_aircraft=64):
         """Append one TacView frame (env_base.py:111-151).  A new file `<filename><count>.txt.acmi` is started at

@@ -16,10 +16,15 @@ from oracle.f16_oracle import MODE_PWL, Oracle  # noqa: E402  (the checker; test
 TASKS = ['heading', 'control', 'tracking']
 
 
-def _batch(task, n, solver=None, seed=0, row0=0, tables=False):
+def _batch(task, n, solver=None, seed=0, row0=0, tables=False, variant='auto'):
     from neuralplane_amd.core import F16Batch
     from neuralplane_amd.envs.utils.utils import parse_config
-    return F16Batch(n, parse_config(task), task, 'cuda:0', seed=seed, solver=solver, row0=row0, aero_1d_tables=tables)
+    b = F16Batch(n, parse_config(task), task, 'cuda:0', seed=seed, solver=solver, row0=row0, aero_1d_tables=tables)
+    b.set_kernel_variant(variant)   # 'auto' picks the 4-waves-per-tile latency kernel at these sizes
+    return b
+
+
+VARIANTS = ['latency', 'throughput']
 
 
 def _load_state(b, st):
@@ -48,11 +53,12 @@ def _check_equal(b, obs, rew, flags, st, o_obs, o_rew, what):
         assert _same(rew.cpu().numpy(), o_rew), f'{what}: reward differs'
 
 
+@pytest.mark.parametrize('variant', VARIANTS)
 @pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
 @pytest.mark.parametrize('task,fixture,solver', [('heading', 'step_kat_heading', None), ('control', 'step_kat_control', None),
                                                  ('tracking', 'step_kat_tracking', None),
                                                  ('heading', 'step_kat_heading_rk4', 'rk4')])
-def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solver, tables, golden_dir):
+def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solver, tables, variant, golden_dir):
     g = np.load(f'{golden_dir}/{fixture}.npz')
     n = g['action'].shape[0]
     for pre, ru, nz in [('', 'rand_u', 'noise'), ('first_', 'first_rand_u', 'first_noise')]:
@@ -60,7 +66,7 @@ def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solv
             st = {k: g['in_' + k].copy() for k in ['s', 'u', 'tgt', 'step_count', 'done', 'bad', 'timeout']}
         else:
             st = Oracle.new_state(n)
-        b = _batch(task, n, solver=solver, tables=tables)
+        b = _batch(task, n, solver=solver, tables=tables, variant=variant)
         _load_state(b, st)
         obs, rew, flags = b.step(torch.from_numpy(g['action']).cuda(), rand_u=g[ru], noise=g[nz])
         torch.cuda.synchronize()
@@ -81,13 +87,14 @@ def test_step_kat_bit_exact_vs_oracle_and_close_to_reference(task, fixture, solv
         assert np.nanmax(eo) <= 1e-4
 
 
+@pytest.mark.parametrize('variant', VARIANTS)
 @pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
 @pytest.mark.parametrize('task', TASKS)
-def test_free_running_production_rng_bit_exact_vs_oracle(task, tables):
+def test_free_running_production_rng_bit_exact_vs_oracle(task, tables, variant):
     """reset + 60 free-running steps with the in-kernel Philox RNG: HIP == oracle bit for bit,
     including auto-resets (hazard-rich actions) and the ragged tail of the last workgroup."""
     n, steps, seed, row0 = 1000, 60, 1234, 7_000_000_000
-    b = _batch(task, n, seed=seed, row0=row0, tables=tables)
+    b = _batch(task, n, seed=seed, row0=row0, tables=tables, variant=variant)
     o = Oracle(task, mode=MODE_PWL if tables else 0)
     st = Oracle.new_state(n)
     rng = np.random.RandomState(5)
