@@ -432,3 +432,7 @@ class F16CombatBatch:
         ms, cnt = C.c_double(), C.c_int64()
         _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def set_kernel_variant(self, variant):
+        """'auto' (default: latency kernel while n <= 49152 aircraft), 'latency', 'throughput' — bit-identical results."""
+        _lib.check(self.lib.np_f16_set_kernel_variant(self._ctx, _lib.KERNEL_VARIANTS[variant]))

@@ -207,15 +207,17 @@ __device__ __forceinline__ float distance_fn(float R) {  // utils.py:245-249
 #endif
 constexpr int COMBAT_OBS = 15;
 constexpr int COMBAT_BLOCK = 128;
-constexpr int COMBAT_LDS_FLOATS = NUM_LDS_SLOTS * COMBAT_BLOCK;  // > COMBAT_BLOCK * COMBAT_OBS
 static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as the observation transpose tile");
 
 // STEP=true: SingleCombatEnv.step; STEP=false: reset_done_envs + obs
-template <int SOLVER, bool STEP>
-__global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_combat_kernel(const CombatArgs a) {
-    constexpr int B = COMBAT_BLOCK;
-    __shared__ float lds[COMBAT_LDS_FLOATS];
-    const int t = threadIdx.x;
+// TILE, WPT: as f16_env_kernel — (128, 1) throughput variant, (64, 4) latency variant: four waves hold the same 64 aircraft
+// (32 engagements), split the net evaluations and repeat the rest; the pair exchange stays inside each wave.
+template <int SOLVER, bool STEP, int TILE = COMBAT_BLOCK, int WPT = 1>
+__global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_kernel(const CombatArgs a) {
+    constexpr int B = TILE;
+    __shared__ float lds[NUM_LDS_SLOTS * TILE];  // > TILE * COMBAT_OBS
+    const int t = WPT == 1 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
+    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform
     float *coef = lds + t;
     const long long i0 = (long long)blockIdx.x * B;
     const long long i = i0 + t;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_comba
             const float dt = cfg.dt;
             if (SOLVER == 0) {
                 float k1[12];
-                nlplant<true, AB_REST, B>(s, u, tr, tt, spsi, cpsi, coef, tables, k1);
+                nlplant<true, AB_REST, B, WPT>(s, u, tr, tt, spsi, cpsi, coef, tables, k1, part);
 #pragma unroll
                 for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
             } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
@@ -312,8 +314,8 @@ __global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_comba
 #pragma nounroll
                 for (int stage = 0; stage < 4; stage++) {
                     float kk[12];
-                    if (stage == 0) nlplant<true, AB_REST, B>(y, u, tr, tt, spsi, cpsi, coef, tables, kk);
-                    else xdot_full<AB_ALL, B>(y, u, coef, tables, kk);
+                    if (stage == 0) nlplant<true, AB_REST, B, WPT>(y, u, tr, tt, spsi, cpsi, coef, tables, kk, part);
+                    else xdot_full<AB_ALL, B, WPT>(y, u, coef, tables, kk, part);
                     if (stage == 0) {
 #pragma unroll
                         for (int k = 0; k < 12; k++) {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_comba
             trig_of(s, tr, tt);
             np_sincos(s[5], spsi, cpsi);
             float xd[12], acc3[3];
-            nlplant<false, AB_FORCE, B>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd);
+            nlplant<false, AB_FORCE, B, WPT>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
             body_acceleration(s, tr, xd, acc3);
             const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
             bool b = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_comba
         blood = blood - (is_ego ? orientation_fn(PI_F - TA) : orientation_fn(AO)) * dfn;
     }
 
-    if (valid) {
+    if (valid && part == 0) {
         long long iw = i;
         asm volatile("" : "+v"(iw));  // re-derive the store addresses here instead of keeping the load addresses alive
 #pragma unroll
@@ -442,15 +444,18 @@ __global__ __launch_bounds__(COMBAT_BLOCK, NPF16_COMBAT_MINWAVES) void f16_comba
     // ---- [n][15] observation rows: transpose through LDS, store coalesced ----
     if (a.obs) {
         __syncthreads();
+        if (part == 0) {
 #pragma unroll
-        for (int k = 0; k < COMBAT_OBS; k++) lds[t * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
+            for (int k = 0; k < COMBAT_OBS; k++) lds[t * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
+        }
         __syncthreads();
         const long long rows = (a.n - i0) < B ? (a.n - i0) : B;
         const int total = (int)rows * COMBAT_OBS;
         float *dst = a.obs + i0 * COMBAT_OBS;
+        constexpr int THREADS = TILE * WPT;
 #pragma unroll
-        for (int itr = 0; itr < COMBAT_OBS; itr++) {
-            const int L = itr * B + t;
+        for (int itr = 0; itr < (COMBAT_OBS * TILE + THREADS - 1) / THREADS; itr++) {
+            const int L = itr * THREADS + (int)threadIdx.x;
             if (L < total) dst[L] = lds[L];
         }
     }

@@ -583,6 +583,7 @@ struct DeviceGuard {
 };
 
 constexpr int LAT_TILE = 64;
+constexpr int64_t COMBAT_LAT_MAX_N = 49152;  // aircraft (24576 engagements: 0.211 vs 0.258 ms; 32768 engagements: a tie)
 constexpr int64_t LAT_MAX_N = 65536;  // measured crossover (tools/microbench/small_n.py): 65536: 53.6 vs 58.9 us, 98304: 73.5 vs 59.2 us
 bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
     static const int forced = [] {  // process-wide override for experiments: NPF16_KERNEL=latency|throughput
@@ -741,7 +742,11 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward; a.rand_u = io->rand_u;
     a.pid_first = io->pid_first; a.seed = io->seed; a.call_idx = io->call_idx; a.row0 = io->row0; a.n = n; a.cfg = ctx->ccfg;
-    const dim3 grid((unsigned)((n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)), block(COMBAT_BLOCK);
+    // small batches: the latency variant (one generation of 4-wave workgroups at 2 waves per SIMD = 512 x 64 aircraft)
+    const bool latency = STEP && ctx->solver == 0 &&
+                         (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= COMBAT_LAT_MAX_N));
+    const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)),
+        block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = STEP && ctx->timing;
@@ -755,7 +760,8 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
         }
         NP_HIP(hipEventRecord(ev.first, st));
     }
-    if (STEP && ctx->solver == 1) hipLaunchKernelGGL((f16_combat_kernel<1, STEP>), grid, block, 0, st, a);
+    if (latency) hipLaunchKernelGGL((f16_combat_kernel<0, STEP, LAT_TILE, 4>), grid, block, 0, st, a);
+    else if (STEP && ctx->solver == 1) hipLaunchKernelGGL((f16_combat_kernel<1, STEP>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((f16_combat_kernel<0, STEP>), grid, block, 0, st, a);
     NP_HIP(hipGetLastError());
     if (timed) {

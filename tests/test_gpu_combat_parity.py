@@ -18,10 +18,12 @@ from oracle.f16_oracle import MODE_PWL, CombatOracle  # noqa: E402  (the checker
 STATE_FLOORS = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1, .1, .1, .1], np.float32)
 
 
-def _batch(num_envs, solver=None, seed=0, env0=0, tables=False):
+def _batch(num_envs, solver=None, seed=0, env0=0, tables=False, variant='auto'):
     from neuralplane_amd.core import F16CombatBatch
     from neuralplane_amd.envs.utils.utils import parse_config
-    return F16CombatBatch(num_envs, parse_config('selfplay'), 'cuda:0', seed=seed, solver=solver, env0=env0, aero_1d_tables=tables)
+    b = F16CombatBatch(num_envs, parse_config('selfplay'), 'cuda:0', seed=seed, solver=solver, env0=env0, aero_1d_tables=tables)
+    b.set_kernel_variant(variant)   # 'auto' picks the 4-waves-per-tile latency kernel at these sizes (Euler)
+    return b
 
 
 def _load(b, st):
@@ -61,14 +63,15 @@ def _fixture_state(o, d, n):
     return st
 
 
+@pytest.mark.parametrize('variant', ['latency', 'throughput'])
 @pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
-def test_combat_fixture_free_running_bit_exact_vs_oracle(golden_dir, tables):
+def test_combat_fixture_free_running_bit_exact_vs_oracle(golden_dir, tables, variant):
     """The 48 recorded env.steps (Crash, Timeout, both Shutdown outcomes, pairwise auto-resets with injected draws)."""
     d = np.load(f'{golden_dir}/combat_kat.npz')
     K, n = d['actions'].shape[:2]
     o = CombatOracle(mode=MODE_PWL if tables else 0)
     st = _fixture_state(o, d, n)
-    b = _batch(n // 2, tables=tables)
+    b = _batch(n // 2, tables=tables, variant=variant)
     _load(b, st)
     fired = np.zeros(3, np.int64)
     for k in range(K):
@@ -101,13 +104,13 @@ def test_combat_fixture_vs_reference_teacher_forced(golden_dir):
                   done=d[f'flags_{k}'][0], bad=d[f'flags_{k}'][1], timeout=d[f'flags_{k}'][2])
 
 
-@pytest.mark.parametrize('solver', ['euler', 'rk4'])
-def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver):
+@pytest.mark.parametrize('solver,variant', [('euler', 'latency'), ('euler', 'throughput'), ('rk4', 'auto')])
+def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver, variant):
     """reset + 40 env.steps (200 FDM steps) with the in-kernel Philox reset draws, hazard-rich demands, a ragged last
     workgroup and a non-zero first env (shard offset)."""
     num_envs, steps, seed, env0 = 333, 40, 77, 3_000_000_000
     n = 2 * num_envs
-    b = _batch(num_envs, solver=solver, seed=seed, env0=env0)
+    b = _batch(num_envs, solver=solver, seed=seed, env0=env0, variant=variant)
     o = CombatOracle(solver=solver)
     st = o.new_state(num_envs)
     rng = np.random.RandomState(8)
