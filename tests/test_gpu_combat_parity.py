@@ -211,3 +211,40 @@ def test_combat_full_size_sampled_blocks_vs_oracle():
         for k, a in enumerate(acts):
             o_obs, o_rew, _, _, _ = o.combat_step(st, a.numpy()[rows], pid_first=(k == 0), seed=seed, call_idx=k + 1, env0=e0)
         _check(b, outs[-1][0], outs[-1][1], outs[-1][2], st, o_obs, o_rew, f'block at env {e0}', rows=rows)
+
+
+@pytest.mark.parametrize('variant', ['latency', 'throughput'])
+def test_combat_hostile_inputs(variant):
+    """NaN / inf demands and poisoned states: the per-row "non-finite target or measurement holds the previous PID output" rule,
+    NaN-compares-false in Crash / Shutdown / Timeout and the pair exchange must agree with the oracle lane by lane."""
+    E, seed = 96, 13
+    n = 2 * E
+    b = _batch(E, seed=seed, variant=variant)
+    o = CombatOracle()
+    st = o.new_state(E)
+    rng = np.random.RandomState(4)
+    b.reset()
+    o.combat_reset(st, seed=seed, call_idx=0)
+    s = st['s']
+    s[0, 6] = 0.0
+    s[3, 2] = np.nan                  # NaN altitude of an enemy aircraft: poisons its pair's geometry too
+    s[4, 9] = np.inf
+    s[7, 3] = 2.0e9
+    s[8, 4] = np.float32(np.pi / 2)
+    s[11, :3] = s[10, :3]             # co-located pair: R = 0
+    s[12, 6] = 1.0e6
+    st['blood'][14] = np.nan
+    st['blood'][17] = -np.inf
+    st['pid'][20:30] = rng.normal(0, 100, (10, 11)).astype(np.float32)
+    st['pid'][30, 4] = np.nan         # last_out NaN: the hold path returns NaN
+    _load(b, st)
+    b.pid_first = False
+    for t in range(5):
+        a = rng.uniform(-1.5, 1.5, (n, 4)).astype(np.float32)
+        a[40, 1] = np.nan
+        a[41, 2] = np.inf
+        a[42, 0] = -np.inf
+        a[43] = [1e30, -1e30, 1e-40, -0.0]
+        obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _, _, _ = o.combat_step(st, a, pid_first=False, seed=seed, call_idx=t + 1)
+        _check(b, obs, rew, flags, st, o_obs, o_rew, f'hostile step {t}')
