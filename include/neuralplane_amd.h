@@ -35,6 +35,7 @@ extern "C" {
 #define NP_NUM_TARGETS 3   /* task targets (heading: alt,heading,vt | control: pitch,heading,vt | tracking: n,e,alt) */
 #define NP_NUM_OBS 22      /* envs/tasks/heading_task.py:71-152                                                   */
 #define NP_NUM_DERIVED 20  /* rows written by np_f16_derived()                                                    */
+#define NP_NUM_TERM_COUNTERS 7 /* per-condition termination counters (np_f16_io.term_counters)                      */
 #define NP_NUM_CACHED 14   /* values per aircraft in the cross-step coefficient cache (np_f16_io.coef_cache)      */
 
 enum { NP_TASK_HEADING = 0, NP_TASK_CONTROL = 1, NP_TASK_TRACKING = 2 }; /* envs/control_env.py:28-35 */
@@ -100,6 +101,11 @@ typedef struct np_f16_io {
      * captured in a HIP graph once and replayed: the captured call_idx values are offsets, the base advances on the
      * device between replays (PlanningEnv's 1 + 50 launches per step). */
     const uint64_t *call_idx_base;
+    /* Optional DEVICE counters [NP_NUM_TERM_COUNTERS] (uint32, caller-zeroed, accumulated by np_f16_step): how many aircraft
+     * tripped each termination condition at the state reached by the step — what the reference prints per condition
+     * (`print(torch.sum(bad_done), ...)`, envs/termination_conditions/*.py) at the price of a host sync each.  Order:
+     * overload, low_altitude, high_speed, low_speed, extreme_state, unreach_* (bad), target reached (done). */
+    uint32_t *term_counters;
 } np_f16_io;
 
 typedef struct np_f16_ctx np_f16_ctx;

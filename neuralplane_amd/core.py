@@ -98,6 +98,8 @@ class F16Batch:
         self._version = 0
         # device-side RNG counter base for launches replayed from a HIP graph (np_f16_io.call_idx_base)
         self.call_base = torch.zeros(1, dtype=torch.int64, device=d)
+        # per-condition termination counters (np_f16_io.term_counters), accumulated on the device, read lazily
+        self.term_counters = torch.zeros(7, dtype=torch.int32, device=d)
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -130,6 +132,7 @@ class F16Batch:
         io.inner_step = 1 if inner else 0
         io.seed, io.call_idx, io.row0 = self.seed, int(call_offset), self.row0
         io.call_idx_base = self.call_base.data_ptr()
+        io.term_counters = self.term_counters.data_ptr()
         fn = self.lib.np_f16_reset if action is None else self.lib.np_f16_step
         _lib.check(fn(self._ctx, self.n, C.byref(io), self._stream()))
 
@@ -145,6 +148,7 @@ class F16Batch:
             io.step_count = self.step_count.data_ptr()
             io.coef_cache = self.coef_cache.data_ptr()
             io.call_idx_base = None
+            io.term_counters = self.term_counters.data_ptr()
         n = self.n
         if not self.flags.is_contiguous():
             self.flags = self.flags.contiguous()
@@ -255,6 +259,16 @@ class F16Batch:
         ms, cnt = C.c_double(), C.c_int64()
         _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    TERM_NAMES = ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'unreach', 'reached')
+
+    def termination_counts(self, reset=False):
+        """{condition: aircraft that tripped it since the last reset of the counters} — one small D2H copy, on demand (the
+        reference prints these sums from inside every condition on every step, a host sync each)."""
+        c = self.term_counters.cpu().tolist()
+        if reset:
+            self.term_counters.zero_()
+        return dict(zip(self.TERM_NAMES, c))
 
     def set_kernel_variant(self, variant):
         """'auto' (default: latency kernel while n <= 65536), 'latency', 'throughput' — bit-identical results."""

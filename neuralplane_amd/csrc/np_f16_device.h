@@ -611,18 +611,19 @@ __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, 
 template <int TASK>
 __device__ __forceinline__ void done_and_reward(const DevCfg &cfg, const float (&s)[12], const float (&tgt)[3],
                                                 const float (&acc3)[3], long long step_count, bool done_prev, bool bad_prev,
-                                                bool &done, bool &bad, float &reward) {
+                                                bool &done, bool &bad, float &reward, unsigned &reasons) {
+    // `reasons`: which condition fired at THIS state (NP_TERM_* bits) — what the reference prints per condition
     const float PI_F = 3.14159265358979323846f;
     const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
-    bool b = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
-    b |= (s[2] - cfg.altitude_limit) < 0.0f;               // low_altitude.py:29-30
+    const bool r_over = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
+    const bool r_low = (s[2] - cfg.altitude_limit) < 0.0f;             // low_altitude.py:29-30
     const float TAS = s[6] + cfg.airspeed * 1.0f;
     const float vel = (TAS * 0.3048f) / 340.0f;
-    b |= (vel - cfg.max_velocity) >= 0.0f;                 // high_speed.py:29-30
-    b |= (vel - cfg.min_velocity) <= 0.0f;                 // low_speed.py:29-30
+    const bool r_fast = (vel - cfg.max_velocity) >= 0.0f;              // high_speed.py:29-30
+    const bool r_slow = (vel - cfg.min_velocity) <= 0.0f;              // low_speed.py:29-30
     const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
-    b |= (alpha < cfg.min_alpha) | (alpha > cfg.max_alpha);  // extreme_state.py:32-36
-    b |= (beta < cfg.min_beta) | (beta > cfg.max_beta);
+    const bool r_ext = ((alpha < cfg.min_alpha) | (alpha > cfg.max_alpha)) | ((beta < cfg.min_beta) | (beta > cfg.max_beta));  // extreme_state.py:32-36
+    bool b = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
     const float pi36 = (float)(3.141592653589793 / 36.0);
     const bool m1 = step_count >= cfg.max_check_interval;
     bool m2 = true, m3, m4, m5;
@@ -656,9 +657,12 @@ __device__ __forceinline__ void done_and_reward(const DevCfg &cfg, const float (
         rew = 0.1f * ((-(dn * dn) + -(de * de)) + -(da * da));
     }
     const bool off = (m3 | m4) | m5;
-    b |= m1 & off;
+    const bool r_unreach = m1 & off, r_reach = ((!off) & (!m1)) & m2;
+    reasons = (r_over ? 1u : 0u) | (r_low ? 2u : 0u) | (r_fast ? 4u : 0u) | (r_slow ? 8u : 0u) | (r_ext ? 16u : 0u) |
+              (r_unreach ? 32u : 0u) | (r_reach ? 64u : 0u);
+    b |= r_unreach;
     b |= bad_prev;                                               // env_base.py:72-74: flags accumulate until the next reset()
-    const bool d = (((!off) & (!m1)) & m2) | done_prev;
+    const bool d = r_reach | done_prev;
     rew = 0.0f + rew;                                            // task_base.py:70-72
     rew = rew + (float)(-200 * (int)b + 200 * (int)d);           // event_driven_reward.py:28
     done = d;

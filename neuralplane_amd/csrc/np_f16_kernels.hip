@@ -58,6 +58,7 @@ struct KArgs {
     float *cache;  // [row / 64][14][row % 64] force-side alpha/beta-only coefficients at the current state (may be null)
     uint64_t seed, call_idx;
     const uint64_t *call_idx_base;  // optional device word added to call_idx (launches replayed from a HIP graph)
+    unsigned *term_counters;        // optional [NP_NUM_TERM_COUNTERS] per-condition counters (one atomic per wave and condition)
     long long row0, n;
     DevCfg cfg;
     // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once
@@ -240,7 +241,18 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         body_acceleration(s, tr, xd, acc3);
         // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
         const bool done_prev = a.inner && a.fin0[ic] != 0, bad_prev = a.inner && a.fin1[ic] != 0;
-        done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward);
+        unsigned reasons = 0;
+        done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
+        if (a.term_counters) {
+            // the reference prints torch.sum(mask) per termination condition and step (a host sync each); here: one wave
+            // ballot per condition, population count, ONE atomic per wave for a condition that fired at all
+            const bool counted = valid && part == 0;
+#pragma unroll
+            for (int k = 0; k < NP_NUM_TERM_COUNTERS; k++) {
+                const unsigned long long m = __ballot(counted && ((reasons >> k) & 1u));
+                if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(a.term_counters + k, (unsigned)__popcll(m));
+            }
+        }
     }
 
     if (valid && part == 0) {
@@ -619,6 +631,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.inner = io->inner_step ? 1 : 0;
     a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
     a.call_idx_base = io->call_idx_base;
+    a.term_counters = io->term_counters;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides

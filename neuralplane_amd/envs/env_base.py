@@ -81,6 +81,10 @@ class BaseEnv(Env):
     def seed(self, random_seed):
         self._batch.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
 
+    def termination_counts(self, reset=False):
+        """Per-condition termination statistics accumulated on the device (the reference prints them every step)."""
+        return self._batch.termination_counts(reset=reset)
+
     def state_dict(self):
         """Env-state checkpoint (tensors on the env device); see F16Batch.state_dict."""
         return self._batch.state_dict()

@@ -756,23 +756,24 @@ static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float
 /* terminations (envs/termination_conditions/)) + rewards (envs/reward_functions/)) for one row */
 static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const float *s, const float *u,
                             const float *tgt, int64_t step_count, int done_prev, int bad_prev, int timeout_prev,
-                            uint8_t *done_o, uint8_t *bad_o, uint8_t *timeout_o, float *reward_o) {
+                            uint8_t *done_o, uint8_t *bad_o, uint8_t *timeout_o, float *reward_o, uint8_t *reasons_o) {
     /* Overload — overload.py:37-42 */
     float a[3];
     acceleration_row(m, s, u, a);
     float acc = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
-    int bad = (acc - (float)cfg->acceleration_limit) > 0.0f;
+    int r_over = (acc - (float)cfg->acceleration_limit) > 0.0f;
     /* LowAltitude — low_altitude.py:29-30 */
-    bad |= (s[2] - (float)cfg->altitude_limit) < 0.0f;
+    int r_low = (s[2] - (float)cfg->altitude_limit) < 0.0f;
     /* HighSpeed / LowSpeed — high_speed.py:29-30, low_speed.py:29-30 */
     float TAS = s[6] + (float)cfg->airspeed * 1.0f;
     float vel = (TAS * 0.3048f) / 340.0f;
-    bad |= (vel - (float)cfg->max_velocity) >= 0.0f;
-    bad |= (vel - (float)cfg->min_velocity) <= 0.0f;
+    int r_fast = (vel - (float)cfg->max_velocity) >= 0.0f;
+    int r_slow = (vel - (float)cfg->min_velocity) <= 0.0f;
     /* ExtremeState — extreme_state.py:32-36 */
     float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
-    bad |= (alpha < (float)cfg->min_alpha) | (alpha > (float)cfg->max_alpha);
-    bad |= (beta < (float)cfg->min_beta) | (beta > (float)cfg->max_beta);
+    int r_ext = ((alpha < (float)cfg->min_alpha) | (alpha > (float)cfg->max_alpha)) |
+                ((beta < (float)cfg->min_beta) | (beta > (float)cfg->max_beta));
+    int bad = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
     /* Unreach{Heading,Posture,Target} — unreach_heading.py:38-53, unreach_posture.py:40-55, unreach_target.py:38-47 */
     const float pi36 = (float)(3.141592653589793 / 36.0);
     int m1 = step_count >= cfg->max_check_interval, m2 = 1, m3, m4, m5;
@@ -807,8 +808,11 @@ static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const floa
         rew = 0.1f * ((-(dn * dn) + -(de * de)) + -(da * da));
     }
     int off = (m3 | m4) | m5;
-    bad |= m1 & off;
-    int done = ((!off) & (!m1)) & m2;
+    int r_unreach = m1 & off, r_reach = ((!off) & (!m1)) & m2;
+    if (reasons_o) /* which condition fired at this state: what each condition class prints (torch.sum(mask)) */
+        *reasons_o = (uint8_t)(r_over | (r_low << 1) | (r_fast << 2) | (r_slow << 3) | (r_ext << 4) | (r_unreach << 5) | (r_reach << 6));
+    bad |= r_unreach;
+    int done = r_reach;
     /* BaseEnv.done (env_base.py:70-75): self.is_done = self.is_done + done, ... — the env flags accumulate
      * until the next reset(); inside BaseEnv.step they were just cleared, inside PlanningEnv.step's 50
      * iterations (planning_env.py:153-176) they are not */
@@ -846,7 +850,7 @@ static int step_impl(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float 
         step_count[i] += 1;                                  /* :102 */
         obs_row(cfg, si, ui, ti, obs + F16O_NOBS * i);       /* :103 */
         add_noise(cfg, obs + F16O_NOBS * i, noise ? noise + F16O_NOBS * i : NULL, seed, call_idx, row0 + i);
-        done_reward_row(m, cfg, si, ui, ti, step_count[i], dp, bp, tp, done + i, bad + i, timeout + i, reward + i); /* :105-106 */
+        done_reward_row(m, cfg, si, ui, ti, step_count[i], dp, bp, tp, done + i, bad + i, timeout + i, reward + i, NULL); /* :105-106 */
     }
     return 0;
 }
@@ -866,6 +870,17 @@ int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *
                     float *obs, float *reward) {
     return step_impl(m, cfg, n, s, u, tgt, step_count, done, bad, timeout, action, act_stride, NULL, noise, seed, call_idx,
                      row0, obs, reward, 1);
+}
+
+/* per-condition termination bits at the given (post-step) state: bit 0 overload, 1 low_altitude, 2 high_speed, 3 low_speed,
+ * 4 extreme_state, 5 unreach_* (bad), 6 target reached (done) — what the condition classes count and print */
+void f16o_termination_reasons(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u,
+                              const float *tgt, const int64_t *step_count, uint8_t *reasons) {
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t d, b, t;
+        float r;
+        done_reward_row(m, cfg, s + 12 * i, u + 5 * i, tgt + 3 * i, step_count[i], 0, 0, 0, &d, &b, &t, &r, reasons + i);
+    }
 }
 
 /* PlanningEnv.low_level_obs — envs/planning_env.py:60-142: ControlTask-style observation, caller's targets, no noise */

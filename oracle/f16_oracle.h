@@ -108,6 +108,9 @@ int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *
                     int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
                     int64_t act_stride, const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0,
                     float *obs, float *reward);
+/* per-condition termination bits of the state (s, u, tgt, step_count) — see f16_oracle.c */
+void f16o_termination_reasons(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u,
+                              const float *tgt, const int64_t *step_count, uint8_t *reasons);
 /* PlanningEnv.low_level_obs (envs/planning_env.py:60-142); tgt3[n][3] = (target_pitch, target_heading, target_vt) */
 void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs);
 

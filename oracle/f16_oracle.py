@@ -220,6 +220,16 @@ class Oracle:
         assert rc == 0
         return obs
 
+    def termination_reasons(self, st):
+        """uint8[n] bit mask of the conditions that fire at the state in `st` (bits: overload, low_altitude, high_speed,
+        low_speed, extreme_state, unreach (bad), target reached (done))."""
+        self._set_mode()
+        n = st['s'].shape[0]
+        out = np.zeros(n, np.uint8)
+        self.lib.f16o_termination_reasons(C.c_void_p(self.model), C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']),
+                                          _p(st['tgt']), _p(st['step_count'], C.c_int64), _p(out, C.c_uint8))
+        return out
+
     def lowlevel_obs(self, st, tgt3):
         """PlanningEnv.low_level_obs for tgt3[n,3] = (target_pitch, target_heading, target_vt)."""
         self._set_mode()

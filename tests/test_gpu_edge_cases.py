@@ -136,9 +136,7 @@ OVERRIDES = [
 @pytest.mark.parametrize('task', ['heading', 'control', 'tracking'])
 @pytest.mark.parametrize('ov', range(len(OVERRIDES)))
 def test_scenario_constants_far_from_the_shipped_yaml(task, ov, variant):
-    overrides = dict(OVERRIDES[ov])
-    if 'max_altitude' in overrides or True:
-        overrides.setdefault('init_state', {'init_T': 3333.0})
+    overrides = dict(OVERRIDES[ov], init_state={'init_T': 3333.0})
     n = 150
     b, o = _mk(task, n, variant, overrides=overrides, seed=21)
     st = Oracle.new_state(n)
@@ -148,3 +146,27 @@ def test_scenario_constants_far_from_the_shipped_yaml(task, ov, variant):
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
         o_obs, o_rew, _, _, _ = o.step(st, a, seed=21, call_idx=t)
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'{task} overrides {ov} step {t}')
+
+
+@pytest.mark.parametrize('variant', VARIANTS)
+@pytest.mark.parametrize('task', ['heading', 'control', 'tracking'])
+def test_termination_counters_match_per_condition_sums(task, variant):
+    """np_f16_io.term_counters (wave ballot + popcount + one atomic per wave) == the per-condition sums the reference
+    prints, computed by the oracle on the same states — over a run with plenty of terminations of every kind."""
+    n, seed = 700, 6
+    b, o = _mk(task, n, variant, seed=seed, overrides={'max_check_interval': 30, 'min_check_interval': 5})
+    st = Oracle.new_state(n)
+    rng = np.random.RandomState(1)
+    expect = np.zeros(7, np.int64)
+    for t in range(70):
+        a = rng.uniform(-1.0, 1.0, (n, 4)).astype(np.float32)
+        a[:, 1] = 1.0 if (t // 20) % 2 == 0 else -1.0
+        obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t)
+        r = o.termination_reasons(st)
+        expect += np.array([int(((r >> k) & 1).sum()) for k in range(7)])
+    _check(b, obs, rew, flags, st, o_obs, o_rew, 'final step')
+    got = b.termination_counts()
+    assert list(got.values()) == expect.tolist(), (got, expect)
+    assert sum(1 for v in got.values() if v > 0) >= 3
+    assert b.termination_counts(reset=True) == got and sum(b.termination_counts().values()) == 0
