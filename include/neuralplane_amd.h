@@ -156,6 +156,7 @@ int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float 
  * step_count += 1, terminations}, observation + reward at the final state, blood update.
  * ------------------------------------------------------------------------------------------------- */
 #define NP_NUM_OBS_COMBAT 15 /* singlecombat_env.py:64-138 */
+#define NP_NUM_COMBAT_TERM_COUNTERS 9
 #define NP_NUM_PID 11        /* roll_dem, pitch_dem, {roll, pitch, yaw} x {error, integrator, last_out} */
 
 /* algorithms/pid/config/{roll,pitch,yaw}controller.yaml */
@@ -201,6 +202,9 @@ typedef struct np_f16_combat_io {
     int32_t reserved_io_;
     uint64_t seed, call_idx;
     int64_t row0;        /* global aircraft row of local row 0 (= 2 * first env of this shard) */
+    /* optional DEVICE counters [NP_NUM_COMBAT_TERM_COUNTERS] (see np_f16_io.term_counters), one evaluation per inner FDM step:
+     * overload, low_altitude, high_speed, low_speed, extreme_state, crash, timeout, shutdown (bad), shutdown (done) */
+    uint32_t *term_counters;
 } np_f16_combat_io;
 
 /* Same context type as np_f16_ctx_create; the weights blob is shared. */

@@ -355,6 +355,7 @@ class F16CombatBatch:
         self.step_count = torch.zeros(n, dtype=torch.int64, device=d)
         self.flags = torch.ones((3, n), dtype=torch.uint8, device=d)
         self.pid_first = True                                                 # PID.reset (pid.py:14)
+        self.term_counters = torch.zeros(9, dtype=torch.int32, device=d)     # np_f16_combat_io.term_counters
         self._version = 0
         self._derived_ctx = None
 
@@ -383,6 +384,7 @@ class F16CombatBatch:
         io.reward = reward.data_ptr() if reward is not None else None
         io.rand_u = rand_u.data_ptr() if rand_u is not None else None
         io.pid_first = 1 if self.pid_first else 0
+        io.term_counters = self.term_counters.data_ptr()
         io.seed, io.call_idx, io.row0 = self.seed, self.call_idx, 2 * self.env0
         return io
 
@@ -450,3 +452,13 @@ class F16CombatBatch:
     def set_kernel_variant(self, variant):
         """'auto' (default: latency kernel while n <= 49152 aircraft), 'latency', 'throughput' — bit-identical results."""
         _lib.check(self.lib.np_f16_set_kernel_variant(self._ctx, _lib.KERNEL_VARIANTS[variant]))
+
+    TERM_NAMES = ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'crash', 'timeout', 'shutdown_bad',
+                  'shutdown_done')
+
+    def termination_counts(self, reset=False):
+        """{condition: evaluations that fired since the counters were reset} (one evaluation per aircraft and inner FDM step)."""
+        c = self.term_counters.cpu().tolist()
+        if reset:
+            self.term_counters.zero_()
+        return dict(zip(self.TERM_NAMES, c))

@@ -50,6 +50,7 @@ struct CombatArgs {
     int pid_first;
     uint64_t seed, call_idx;
     long long row0, n;
+    unsigned *term_counters;  // optional [NP_NUM_COMBAT_TERM_COUNTERS]
     CombatDevCfg cfg;
 };
 
@@ -350,23 +351,35 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             nlplant<false, AB_FORCE, B, WPT>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
             body_acceleration(s, tr, xd, acc3);
             const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
-            bool b = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
-            b |= (s[2] - cfg.altitude_limit) < 0.0f;               // low_altitude.py:29-30
+            const bool r_over = (acc - cfg.acceleration_limit) > 0.0f;   // overload.py:37-42
+            const bool r_low = (s[2] - cfg.altitude_limit) < 0.0f;        // low_altitude.py:29-30
             const float TAS = s[6] + cfg.airspeed * 1.0f;
             const float vel = (TAS * 0.3048f) / 340.0f;
-            b |= (vel - cfg.max_velocity) >= 0.0f;                 // high_speed.py:29-30
-            b |= (vel - cfg.min_velocity) <= 0.0f;                 // low_speed.py:29-30
+            const bool r_fast = (vel - cfg.max_velocity) >= 0.0f;         // high_speed.py:29-30
+            const bool r_slow = (vel - cfg.min_velocity) <= 0.0f;         // low_speed.py:29-30
             const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
-            b |= (alpha < cfg.min_alpha) | (alpha > cfg.max_alpha);  // extreme_state.py:32-36
-            b |= (beta < cfg.min_beta) | (beta > cfg.max_beta);
+            const bool r_ext = ((alpha < cfg.min_alpha) | (alpha > cfg.max_alpha)) | ((beta < cfg.min_beta) | (beta > cfg.max_beta));  // extreme_state.py:32-36
+            bool b = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
             // crash.py:33-43 (ego - enemy, squared distance in fp32)
             const float on = partner(s[0]), oe = partner(s[1]), oa = partner(s[2]);
             const float dn = is_ego ? s[0] - on : on - s[0], de = is_ego ? s[1] - oe : oe - s[1], da = is_ego ? s[2] - oa : oa - s[2];
-            b |= ((dn * dn + de * de) + da * da) <= cfg.dist_limit_sq;
+            const bool r_crash = ((dn * dn + de * de) + da * da) <= cfg.dist_limit_sq;
+            const bool r_tmo = (sc - cfg.max_steps) >= 0;           // timeout.py:29
+            b |= r_crash;
             b |= m1;                                               // shutdown.py:36-38
             f_bad |= b;
             f_done |= m2 & !m1;
-            f_to |= (sc - cfg.max_steps) >= 0;                     // timeout.py:29
+            f_to |= r_tmo;
+            if (a.term_counters) {  // per-condition sums (the reference prints them per evaluation): ballot + popcount + 1 atomic
+                const unsigned bits = (r_over ? 1u : 0u) | (r_low ? 2u : 0u) | (r_fast ? 4u : 0u) | (r_slow ? 8u : 0u) | (r_ext ? 16u : 0u) |
+                                      (r_crash ? 32u : 0u) | (r_tmo ? 64u : 0u) | (m1 ? 128u : 0u) | ((m2 & !m1) ? 256u : 0u);
+                const bool counted = valid && part == 0;
+#pragma unroll
+                for (int k = 0; k < NP_NUM_COMBAT_TERM_COUNTERS; k++) {
+                    const unsigned long long mk = __ballot(counted && ((bits >> k) & 1u));
+                    if (mk != 0 && (threadIdx.x & 63) == 0) atomicAdd(a.term_counters + k, (unsigned)__popcll(mk));
+                }
+            }
         }
     }
 

@@ -755,6 +755,7 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward; a.rand_u = io->rand_u;
     a.pid_first = io->pid_first; a.seed = io->seed; a.call_idx = io->call_idx; a.row0 = io->row0; a.n = n; a.cfg = ctx->ccfg;
+    a.term_counters = io->term_counters;
     // small batches: the latency variant (one generation of 4-wave workgroups at 2 waves per SIMD = 512 x 64 aircraft)
     const bool latency = STEP && ctx->solver == 0 &&
                          (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= COMBAT_LAT_MAX_N));

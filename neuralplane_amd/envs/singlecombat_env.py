@@ -83,6 +83,9 @@ class SingleCombatEnv(Env):
     def seed(self, random_seed):
         self._batch.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
 
+    def termination_counts(self, reset=False):
+        return self._batch.termination_counts(reset=reset)
+
     def state_dict(self):
         return self._batch.state_dict()
 

@@ -119,6 +119,7 @@ void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const flo
 /* ------------------------------------------------------------------------------------------ */
 #define F16O_NPID 11        /* roll_dem, pitch_dem, {roll,pitch,yaw} x {error, integrator, last_out} */
 #define F16O_NOBS_COMBAT 15
+#define F16O_NUM_COMBAT_TERM 9 /* overload, low_altitude, high_speed, low_speed, extreme_state, crash, timeout, shutdown(bad), shutdown(done) */
 
 /* algorithms/pid/config/{roll,pitch,yaw}controller.yaml */
 typedef struct f16o_pid_gains {
@@ -160,7 +161,7 @@ int f16o_combat_reset(const f16o_model *m, const f16o_combat_cfg *cfg, int64_t n
 int f16o_combat_step(const f16o_model *m, const f16o_combat_cfg *cfg, int64_t num_envs, float *s, float *u, float *pid,
                      float *blood, int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
                      int64_t act_stride, const float *rand_u, int pid_first, uint64_t seed, uint64_t call_idx, int64_t env0,
-                     float *obs, float *reward);
+                     float *obs, float *reward, uint32_t *term_counts /* nullable [F16O_NUM_COMBAT_TERM], accumulated */);
 
 int f16o_num_threads(void);
 void f16o_set_threads(int n); /* OpenMP threads used by the batched entry points */

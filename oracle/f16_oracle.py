@@ -374,7 +374,7 @@ class CombatOracle(Oracle):
         assert rc == 0
         return obs
 
-    def combat_step(self, st, action, rand_u=None, pid_first=False, seed=0, call_idx=0, env0=0):
+    def combat_step(self, st, action, rand_u=None, pid_first=False, seed=0, call_idx=0, env0=0, term_counts=None):
         self._set_mode()
         n = st['s'].shape[0]
         a = _f32(action)
@@ -386,6 +386,6 @@ class CombatOracle(Oracle):
                                        _p(st['pid']), _p(st['blood']), _p(st['step_count'], C.c_int64),
                                        _p(st['done'], C.c_uint8), _p(st['bad'], C.c_uint8), _p(st['timeout'], C.c_uint8), _p(a),
                                        C.c_int64(a.shape[1]), _p(ru), C.c_int(int(pid_first)), C.c_uint64(seed),
-                                       C.c_uint64(call_idx), C.c_int64(env0), _p(obs), _p(rew))
+                                       C.c_uint64(call_idx), C.c_int64(env0), _p(obs), _p(rew), _p(term_counts, C.c_uint32))
         assert rc == 0
         return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()

@@ -123,14 +123,18 @@ def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver, variant)
     st['step_count'][40:44] = 1980
     _load(b, st)
     total = np.zeros(3, np.int64)
+    counts = np.zeros(9, np.uint32)
+    b.termination_counts(reset=True)
     for t in range(steps):
         a = rng.uniform(-1.4, 1.4, (n, 4)).astype(np.float32)
         a[:, 0] = rng.uniform(0, 1.2, n)
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
-        o_obs, o_rew, dn, bd, tm = o.combat_step(st, a, pid_first=(t == 0), seed=seed, call_idx=t + 1, env0=env0)
+        o_obs, o_rew, dn, bd, tm = o.combat_step(st, a, pid_first=(t == 0), seed=seed, call_idx=t + 1, env0=env0, term_counts=counts)
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'{solver}: step {t}')
         total += np.array([int(dn.sum()), int(bd.sum()), int(tm.sum())])
     assert total[1] > 0 and total[2] > 0
+    got = b.termination_counts()
+    assert list(got.values()) == counts.tolist() and got['crash'] > 0 and got['timeout'] > 0 and got['shutdown_bad'] + got['shutdown_done'] >= 0
 
 
 def test_combat_sharding_by_env_is_invariant():
