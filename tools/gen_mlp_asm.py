@@ -41,7 +41,7 @@ V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
 V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
 V_Y = 126        # net output
 V_ADDR = 127     # LDS byte address of the output slot
-V_CLOBBER = list(range(70, 128))
+V_CLOBBER = list(range(68 if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1' else 70, 128))
 S_CLOBBER = list(range(S_W0, S_W0 + 16 * NBUF)) + [S_BASE, S_BASE + 1]
 
 
@@ -116,11 +116,15 @@ class Body:
         """hidden layer with ReLU: bias row then n_in weight rows, pairs via v_pk_fma_f32."""
         row = pad2(n_out)
         p0 = self.pos
-        for j in range(0, n_out - 1, 2):
-            sp = self.spair(p0 + j)
-            self.ins.append(f'v_pk_mov_b32 {self.vpair(out_base + j)}, {sp}, {sp} op_sel:[0,1]')
-        if n_out & 1:
-            self.ins.append(f'v_mov_b32 v{out_base + n_out - 1}, {self.s1(p0 + n_out - 1)}')
+        no_bias = os.environ.get('NPF16_GEN_NO_BIAS') == '1'   # TIMING EXPERIMENT ONLY (wrong results): upper bound of what
+        if not no_bias:                                        # getting the bias moves off the VALU could gain
+            for j in range(0, n_out - 1, 2):
+                sp = self.spair(p0 + j)
+                self.ins.append(f'v_pk_mov_b32 {self.vpair(out_base + j)}, {sp}, {sp} op_sel:[0,1]')
+                if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1':   # TIMING EXPERIMENT ONLY: what one bias move costs
+                    self.ins.append(f'v_pk_mov_b32 v[68:69], {sp}, {sp} op_sel:[0,1]')
+            if n_out & 1:
+                self.ins.append(f'v_mov_b32 v{out_base + n_out - 1}, {self.s1(p0 + n_out - 1)}')
         for k in range(n_in):
             pk = p0 + row * (k + 1)
             xr = in_regs[k]
@@ -129,6 +133,9 @@ class Body:
             for j in range(0, n_out - 1, 2):
                 sp = self.spair(pk + j)
                 acc = self.vpair(out_base + j)
+                if no_bias and k == 0:
+                    self.ins.append(f'v_pk_mul_f32 {acc}, {sp}, {xp} op_sel:[0,{e}] op_sel_hi:[1,{e}]')
+                    continue
                 self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {xp}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]')
             if n_out & 1:
                 j = n_out - 1
