@@ -417,3 +417,16 @@ def test_pinned_vec_env_equals_gpu_vec_env():
         if prev is not None:      # ring = 2: the arrays of the previous step are still intact
             assert np.array_equal(prev[0], prev[1])
         prev = (ra[0].copy(), rb[0])
+
+
+def test_drop_in_example_runs_against_the_reference_import_paths():
+    """examples/drop_in_rollout.py: host code written against `from envs.control_env import ControlEnv` /
+    `from envs.env_wrappers import GPUVecEnv` runs unchanged once `envs` is aliased."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'examples', 'drop_in_rollout.py'), '512', '40'], cwd=root,
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'numpy VecEnv loop' in r.stdout and 'device-resident loop' in r.stdout and 'termination statistics' in r.stdout
