@@ -88,10 +88,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--n', type=int, default=1_000_000, help='aircraft per GPU')
+    ap.add_argument('--n', '--aircraft', dest='n', type=int, default=1_000_000,
+                    help='aircraft per GPU (use --aircraft under torch.distributed.run, whose parser treats --n as an abbreviation)')
     ap.add_argument('--task', default='heading', choices=['heading', 'control', 'tracking'])
     ap.add_argument('--actions', default='random', choices=['random', 'constant'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend of the timing barrier: 'nccl' = RCCL (default); 'gloo' lets the multi-rank path "
+                         'be exercised on a box with fewer GPUs than ranks (ranks then share GPUs: a functional check, not a benchmark)')
     ap.add_argument('--aero-1d-tables', type=int, default=None, choices=[0, 1],
                     help='numerics option (DESIGN.md §4); default: scenario / NPF16_AERO_1D_TABLES / off')
     args = ap.parse_args()
@@ -105,9 +109,12 @@ def main():
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = sharding.init_distributed('nccl', dev)  # RCCL; used for the timing barrier / max only
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and local_rank >= ndev:
+        raise SystemExit(f'LOCAL_RANK={local_rank} but only {ndev} GPU(s) visible')
+    dev = torch.device('cuda', local_rank % ndev)
+    torch.cuda.set_device(dev)
+    dist = sharding.init_distributed(args.backend, dev)  # RCCL; used for the timing barrier / max only
 
     from neuralplane_amd.envs.control_env import ControlEnv
     n = args.n  # weak scaling: every GPU simulates args.n aircraft, global rows [rank*n, (rank+1)*n)
@@ -141,7 +148,7 @@ def main():
     kern_ms, kern_cnt = env._batch.get_timing()
     env._batch.set_timing(False)
 
-    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
+    elapsed = sharding.max_over_ranks(elapsed, dist, dev if args.backend == 'nccl' else 'cpu')
     # sanity of the timed region: states finite for live rows, counters advanced
     fin = bool(torch.isfinite(env.model.s).all().item())
 

@@ -97,3 +97,30 @@ def test_same_seed_same_trajectory_and_flagged_rows_are_reinitialised():
     assert bool((sc == 1).all())
     alt0 = e.model.s[bad, 2]
     assert bool(((alt0 > 18000) & (alt0 < 21000)).all())
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank) — with
+    the gloo backend so that two ranks can share this box's single GPU: sharding, barrier, max-over-ranks and the rank-0
+    JSON line of the weak-scaling path are exercised on real hardware (RCCL itself is not)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '3',
+           '--aircraft', '200000', '--backend', 'gloo']
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 20 and d['scaling'] == 'weak' and d['state_finite'] is True
+    assert d['value'] == pytest.approx(2 * 200000 * 20 / (d['ms_per_step'] * 1e-3 * 20), rel=1e-6)
+    assert 'cpu_baseline' not in d and d['roofline']['frac'] > 0
