@@ -1,10 +1,11 @@
 // np_f16_kernels.hip — fused F-16 env.step / env.reset kernels for gfx950 and the C ABI around them
 // (include/neuralplane_amd.h).  One kernel launch per BaseEnv.step (reference: envs/env_base.py:99-109).
 //
-// Mapping: one lane per aircraft, 256-thread workgroups (one wave per SIMD), SoA state in HBM so
-// every state load/store is a coalesced dword access; actions are read as one 16-byte load per
-// lane; the [n][22] observation rows are transposed through LDS and stored as coalesced dwords.
-// The MLP weights are wave-uniform __constant__ data (scalar loads -> SGPR operands of v_fmac).
+// Mapping: one lane per aircraft, SoA state in HBM so every state load/store is a coalesced dword access; the [n][22]
+// observation rows are transposed through LDS and stored as coalesced dwords.  The MLP weights are wave-uniform
+// __constant__ data streamed through the scalar unit (s_load -> SGPR-pair operands of v_pk_fma_f32, np_mlp_asm.inc).
+// Two variants of the same kernel: 128-thread workgroups of two independent waves (throughput), or four waves sharing
+// one tile of 64 aircraft and splitting the net evaluations (latency, small batches) — bit-identical results.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see neuralplane_amd/build.py).
 #include <hip/hip_runtime.h>
