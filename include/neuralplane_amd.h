@@ -118,8 +118,9 @@ const char *np_last_error(void);
 /* Upload the 43-MLP asset blob (NPF16MLP v1, neuralplane_amd/assets/f16_aero_mlp.bin) and the
  * scenario constants to `device`.  Replaces F16Dynamics/hifi_F16 construction
  * (envs/models/F16/hifi_F16_AeroData.py:40-129) + parse_config (envs/utils/utils.py:12-27).
- * The packed weights are held once per device per process: all contexts alive on a device must come from the same blob
- * (creation fails otherwise); scenario constants, task, solver and numerics options are per context. */
+ * A context owns its packed weights (one device allocation): contexts created from different blobs — a second aircraft
+ * type with the same 43-net topology, BASELINE's "second aero-table set, same kernel template" — coexist on a device;
+ * scenario constants, task, solver and numerics options are per context as well. */
 int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg *cfg, int device, np_f16_ctx **out);
 void np_f16_ctx_destroy(np_f16_ctx *ctx);
 

@@ -51,6 +51,7 @@ struct CombatArgs {
     uint64_t seed, call_idx;
     long long row0, n;
     unsigned *term_counters;  // optional [NP_NUM_COMBAT_TERM_COUNTERS]
+    AeroWeights wt;
     CombatDevCfg cfg;
 };
 
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
         {
             const float r2d = (float)(180.0 / 3.141592653589793);
             float xn[NUM_NORM_GROUPS];
-            normalise_inputs(s[7] * r2d, s[8] * r2d, u[1], xn);
-            eval_ab<B, AB_FORCE>(xn, coef, tables);
+            normalise_inputs(a.wt, s[7] * r2d, s[8] * r2d, u[1], xn);
+            eval_ab<B, AB_FORCE>(a.wt, xn, coef, tables);
         }
 #pragma nounroll
         for (int it = 0; it < cfg.inner_steps; it++) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             const float dt = cfg.dt;
             if (SOLVER == 0) {
                 float k1[12];
-                nlplant<true, AB_REST, B, WPT>(s, u, tr, tt, spsi, cpsi, coef, tables, k1, part);
+                nlplant<true, AB_REST, B, WPT>(a.wt, s, u, tr, tt, spsi, cpsi, coef, tables, k1, part);
 #pragma unroll
                 for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
             } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
 #pragma nounroll
                 for (int stage = 0; stage < 4; stage++) {
                     float kk[12];
-                    if (stage == 0) nlplant<true, AB_REST, B, WPT>(y, u, tr, tt, spsi, cpsi, coef, tables, kk, part);
-                    else xdot_full<AB_ALL, B, WPT>(y, u, coef, tables, kk, part);
+                    if (stage == 0) nlplant<true, AB_REST, B, WPT>(a.wt, y, u, tr, tt, spsi, cpsi, coef, tables, kk, part);
+                    else xdot_full<AB_ALL, B, WPT>(a.wt, y, u, coef, tables, kk, part);
                     if (stage == 0) {
 #pragma unroll
                         for (int k = 0; k < 12; k++) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             trig_of(s, tr, tt);
             np_sincos(s[5], spsi, cpsi);
             float xd[12], acc3[3];
-            nlplant<false, AB_FORCE, B, WPT>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
+            nlplant<false, AB_FORCE, B, WPT>(a.wt, s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
             body_acceleration(s, tr, xd, acc3);
             const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
             const bool r_over = (acc - cfg.acceleration_limit) > 0.0f;   // overload.py:37-42

@@ -15,10 +15,17 @@
 
 namespace npf16 {
 
-__constant__ float c_kblob[KBLOB_FLOATS];
-// numerics-spec option "aero_1d_tables": exact piecewise-linear tables of the 22 single-input nets + (out_std, out_mean)
-__constant__ float c_pwl[NUM_PWL_TABLES * PWL_TABLE_FLOATS];
-__constant__ float c_pwl_unnorm[NUM_PWL_TABLES * 2];
+// The packed weights of one aircraft type (np_nets.h KBLOB layout + the optional PWL tables) live in device buffers owned
+// by a context, so contexts with different weight sets (a second aircraft with the same net topology) coexist on a device.
+// device code reads them through the CONSTANT address space (read-only for the lifetime of a launch): invariant loads the
+// compiler may reorder, scalarise and merge exactly as it did when the data were __constant__ symbols
+typedef const float __attribute__((address_space(4))) *cf32_ptr;
+#define NPF16_CONST(p) ((cf32_ptr)(unsigned long long)(p))
+struct AeroWeights {
+    const float *kblob;       // [KBLOB_FLOATS]
+    const float *pwl;         // [NUM_PWL_TABLES * PWL_TABLE_FLOATS] or null
+    const float *pwl_unnorm;  // [NUM_PWL_TABLES * 2] or null
+};
 
 // Scenario constants, pre-rounded on the host exactly where the reference rounds them.
 struct DevCfg {
@@ -48,16 +55,18 @@ typedef f32x16 f32x16_u __attribute__((aligned(4)));
 
 template <int NBUF, int LEN>  // LEN = floats in the record
 struct WStream {
+    const float *kb;  // KBLOB base (wave-uniform)
     int off;  // KBLOB offset of the record, wave-uniform
     f32x16 buf[NBUF];
     int p;  // position in the record; a compile-time constant after full unrolling
 
-    __device__ __forceinline__ void start(int base) {
+    __device__ __forceinline__ void start(const float *kblob, int base) {
+        kb = kblob;
         off = base;
         p = 0;
 #pragma unroll
         for (int b = 0; b < NBUF; b++)
-            if (16 * b < LEN) buf[b] = *(const f32x16_u *)(c_kblob + off + 16 * b);
+            if (16 * b < LEN) buf[b] = *(const f32x16_u *)(kb + off + 16 * b);
     }
     __device__ __forceinline__ float next() {
         const int c = p / 16, l = p % 16;
@@ -69,7 +78,7 @@ struct WStream {
             asm volatile("" : "+s"(buf[c % NBUF]));
             asm volatile("" : "+s"(off));
             if (c > 0 && 16 * (c - 1 + NBUF) < LEN)
-                buf[(c - 1) % NBUF] = *(const f32x16_u *)(c_kblob + off + 16 * (c - 1 + NBUF));
+                buf[(c - 1) % NBUF] = *(const f32x16_u *)(kb + off + 16 * (c - 1 + NBUF));
         }
         p++;
         return buf[c % NBUF][l];
@@ -97,10 +106,10 @@ __device__ __forceinline__ void dense(WS &ws, const float (&x)[IN], float (&y)[O
 constexpr int WS_NBUF = 3;
 
 template <int IN, int H1, int H2, int H3>
-__device__ __forceinline__ float mlp_body(int w, const float (&x)[IN]) {
+__device__ __forceinline__ float mlp_body(const float *kblob, int w, const float (&x)[IN]) {
     constexpr int LEN = asm_record_len(IN, H1, H2, H3);
     WStream<WS_NBUF, LEN> ws;
-    ws.start(w);
+    ws.start(kblob, w);
     float h1[H1], h2[H2];
     dense<IN, H1, true>(ws, x, h1);
     dense<H1, H2, true>(ws, h1, h2);
@@ -137,8 +146,9 @@ __device__ __forceinline__ float mlp_body(int w, const float (&x)[IN]) {
 // breakpoints, then one fma on the segment's line.  The searches of all nets of the class are interleaved so
 // that their dependent gathers (per-lane addresses into __constant__ tables, served by the vector L1) overlap.
 template <int CL, int COUNT, int LD, int FIRST>
-__device__ __forceinline__ void eval_class_pwl(float x, float *__restrict__ out) {
+__device__ __forceinline__ void eval_class_pwl(const AeroWeights &wt, float x, float *__restrict__ out) {
     constexpr NetClass c = CLASSES[CL];
+    const cf32_ptr pwl = NPF16_CONST(wt.pwl), pwl_unnorm = NPF16_CONST(wt.pwl_unnorm);
     int idx[COUNT > 0 ? COUNT : 1];
 #pragma unroll
     for (int m = 0; m < COUNT; m++) idx[m] = 0;
@@ -147,26 +157,26 @@ __device__ __forceinline__ void eval_class_pwl(float x, float *__restrict__ out)
 #pragma unroll
         for (int m = 0; m < COUNT; m++) {
             const int tb = pwl_index(c.nets[FIRST + m]) * PWL_TABLE_FLOATS;
-            idx[m] += (x >= c_pwl[tb + idx[m] + h - 1]) ? h : 0;
+            idx[m] += (x >= pwl[tb + idx[m] + h - 1]) ? h : 0;
         }
     }
 #pragma unroll
     for (int m = 0; m < COUNT; m++) {
         const int ti = pwl_index(c.nets[FIRST + m]);
         const int tb = ti * PWL_TABLE_FLOATS;
-        const float yn = fmaf(c_pwl[tb + PWL_SEG + idx[m]], x - c_pwl[tb + 2 * PWL_SEG + idx[m]], c_pwl[tb + 3 * PWL_SEG + idx[m]]);
-        out[(class_slot(CL) + FIRST + m) * LD] = yn * c_pwl_unnorm[2 * ti] + c_pwl_unnorm[2 * ti + 1];
+        const float yn = fmaf(pwl[tb + PWL_SEG + idx[m]], x - pwl[tb + 2 * PWL_SEG + idx[m]], pwl[tb + 3 * PWL_SEG + idx[m]]);
+        out[(class_slot(CL) + FIRST + m) * LD] = yn * pwl_unnorm[2 * ti] + pwl_unnorm[2 * ti + 1];
     }
 }
 
 template <int CL, int COUNT, int LD, int FIRST = 0>  // nets [FIRST, FIRST+COUNT) of class CL
-__device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+__device__ __forceinline__ void eval_class(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
     constexpr NetClass c = CLASSES[CL];
     constexpr int n = COUNT;
     static_assert(COUNT >= 0 && FIRST >= 0 && FIRST + COUNT <= c.count, "class range");
     if constexpr (c.n_in == 1 && n > 0) {
         if (tables) {  // wave-uniform
-            eval_class_pwl<CL, COUNT, LD, FIRST>(xn[c.grp[0]], out);
+            eval_class_pwl<CL, COUNT, LD, FIRST>(wt, xn[c.grp[0]], out);
             return;
         }
     }
@@ -183,7 +193,7 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
         const float x0 = xn[c.grp[0]];
         const float x1 = c.n_in > 1 ? xn[c.grp[c.n_in > 1 ? 1 : 0]] : 0.0f;
         const float x2 = c.n_in > 2 ? xn[c.grp[c.n_in > 2 ? 2 : 0]] : 0.0f;
-        mlp_class_asm<c.n_in, c.h1, c.h2, c.h3, n, (int)(LD * sizeof(float))>(c_kblob + class_base(CL) + FIRST * class_stride(CL), lds_addr, x0, x1, x2);
+        mlp_class_asm<c.n_in, c.h1, c.h2, c.h3, n, (int)(LD * sizeof(float))>(wt.kblob + class_base(CL) + FIRST * class_stride(CL), lds_addr, x0, x1, x2);
     }
 #else
     if constexpr (n > 0) {
@@ -194,7 +204,7 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
         float *__restrict__ o = out + (class_slot(CL) + FIRST) * LD;
 #pragma nounroll
         for (int i = 0; i < n; i++) {
-            *o = mlp_body<c.n_in, c.h1, c.h2, c.h3>(w, x);
+            *o = mlp_body<c.n_in, c.h1, c.h2, c.h3>(wt.kblob, w, x);
             w += class_stride(CL);
             o += LD;
         }
@@ -206,10 +216,10 @@ __device__ __forceinline__ void eval_class(const float (&xn)[NUM_NORM_GROUPS], f
 // xdot[6..8] (force side, 14 in total) come first.
 enum AbPart : int { AB_ALL = 0, AB_FORCE = 1, AB_REST = 2 };
 template <int LD, int PART>
-__device__ __forceinline__ void eval_ab(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+__device__ __forceinline__ void eval_ab(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
 #define NPF16_CLS(cl)                                                                                      \
     eval_class<cl, (PART == AB_ALL ? CLASSES[cl].count : PART == AB_FORCE ? CLASSES[cl].n_force : CLASSES[cl].count - CLASSES[cl].n_force), \
-               LD, (PART == AB_REST ? CLASSES[cl].n_force : 0)>(xn, out, tables)
+               LD, (PART == AB_REST ? CLASSES[cl].n_force : 0)>(wt, xn, out, tables)
     NPF16_CLS(CL_DAMP);
     NPF16_CLS(CL_DLEF);
     NPF16_CLS(CL_D_RUD);
@@ -223,9 +233,9 @@ __device__ __forceinline__ void eval_ab(const float (&xn)[NUM_NORM_GROUPS], floa
 }
 // the el-dependent nets: the first N_C of (Cx Cz Cm Cn Cl) and eta_el -> slots 36..41
 template <int N_C, int N_ETA, int LD>
-__device__ __forceinline__ void eval_el(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
-    eval_class<CL_C, N_C, LD>(xn, out, tables);
-    eval_class<CL_ETA, N_ETA, LD>(xn, out, tables);
+__device__ __forceinline__ void eval_el(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+    eval_class<CL_C, N_C, LD>(wt, xn, out, tables);
+    eval_class<CL_ETA, N_ETA, LD>(wt, xn, out, tables);
 }
 
 // ---- latency variant: the nets of one evaluation split over the 4 waves of a workgroup that share ONE tile of 64
@@ -279,9 +289,9 @@ static_assert(plan_covers(PLAN_REST, AB_REST, 5, 1) && plan_covers(PLAN_ALL, AB_
               "split plans must cover each net of their phase exactly once");
 
 template <const SplitPlan &P, int W, int LD>
-__device__ __forceinline__ void eval_plan_wave(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+__device__ __forceinline__ void eval_plan_wave(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
 #define NPF16_ITEM(K)                                                                                         \
-    if constexpr (P.it[W][K].cnt > 0) eval_class<P.it[W][K].cl, P.it[W][K].cnt, LD, P.it[W][K].first>(xn, out, tables)
+    if constexpr (P.it[W][K].cnt > 0) eval_class<P.it[W][K].cl, P.it[W][K].cnt, LD, P.it[W][K].first>(wt, xn, out, tables)
     NPF16_ITEM(0);
     NPF16_ITEM(1);
     NPF16_ITEM(2);
@@ -296,15 +306,15 @@ __device__ __forceinline__ void eval_plan_wave(const float (&xn)[NUM_NORM_GROUPS
 #define NPF16_PHASE_ASM 1
 #endif
 template <int LD, int PART, bool FULL, int WPT = 1>
-__device__ __forceinline__ void eval_nets(const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables, int part = 0) {
+__device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables, int part = 0) {
     constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
     if constexpr (WPT == 4) {
         static_assert(has_phase, "no split plan for this evaluation");
         __syncthreads();  // every wave has finished reading the coefficients of the previous evaluation
 #define NPF16_WAVE(W)                                                                                          \
-    if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN_ALL, W, LD>(xn, out, tables);                  \
-    else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN_REST, W, LD>(xn, out, tables);           \
-    else eval_plan_wave<PLAN_FORCE2, W, LD>(xn, out, tables)
+    if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN_ALL, W, LD>(wt, xn, out, tables);                  \
+    else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN_REST, W, LD>(wt, xn, out, tables);           \
+    else eval_plan_wave<PLAN_FORCE2, W, LD>(wt, xn, out, tables)
         if (part == 0) { NPF16_WAVE(0); }
         else if (part == 1) { NPF16_WAVE(1); }
         else if (part == 2) { NPF16_WAVE(2); }
@@ -324,25 +334,25 @@ __device__ __forceinline__ void eval_nets(const float (&xn)[NUM_NORM_GROUPS], fl
 #else
 #define NPF16_PHASE_ARGS lds_base, xn
 #endif
-                if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_ALL_START, NPF16_PHASE_ARGS);
-                else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_REST_START, NPF16_PHASE_ARGS);
-                else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(c_kblob + MLP_PHASE_FORCE2_START, NPF16_PHASE_ARGS);
+                if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_ALL<(int)(LD * sizeof(float))>(wt.kblob + MLP_PHASE_ALL_START, NPF16_PHASE_ARGS);
+                else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_REST<(int)(LD * sizeof(float))>(wt.kblob + MLP_PHASE_REST_START, NPF16_PHASE_ARGS);
+                else mlp_phase_asm_FORCE2<(int)(LD * sizeof(float))>(wt.kblob + MLP_PHASE_FORCE2_START, NPF16_PHASE_ARGS);
 #undef NPF16_PHASE_ARGS
                 return;
             }
         }
 #endif
-        eval_ab<LD, PART>(xn, out, tables);
-        eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(xn, out, tables);
+        eval_ab<LD, PART>(wt, xn, out, tables);
+        eval_el<(FULL ? 5 : 2), (FULL ? 1 : 0), LD>(wt, xn, out, tables);
     }
 }
 
 // The 9 distinct input normalisations (X - mean) / std of mean_std.csv.
-__device__ __forceinline__ void normalise_inputs(float alpha_deg, float beta_deg, float el, float (&xn)[NUM_NORM_GROUPS]) {
+__device__ __forceinline__ void normalise_inputs(const AeroWeights &wt, float alpha_deg, float beta_deg, float el, float (&xn)[NUM_NORM_GROUPS]) {
 #pragma unroll
     for (int g = 0; g < NUM_NORM_GROUPS; g++) {
         const float v = (g <= G_A_RUD) ? alpha_deg : (g <= G_B_O ? beta_deg : el);
-        xn[g] = (v - c_kblob[2 * g]) / c_kblob[2 * g + 1];
+        xn[g] = (v - NPF16_CONST(wt.kblob)[2 * g]) / NPF16_CONST(wt.kblob)[2 * g + 1];
     }
 }
 
@@ -360,7 +370,7 @@ struct Trig {  // sines/cosines of the attitude and flow angles of one state
 // when the 14 force-side slots of `coef` already hold the values of THIS state (carried over from
 // the Overload evaluation of the previous step).
 template <bool FULL, int PART, int LD, int WPT = 1>
-__device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
+__device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
                                         float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
@@ -400,12 +410,12 @@ __device__ __forceinline__ void nlplant(const float (&s)[12], const float (&u)[4
     }
 
     float xn[NUM_NORM_GROUPS];
-    normalise_inputs(alpha, beta, el, xn);
+    normalise_inputs(wt, alpha, beta, el, xn);
     // non-finite inputs poison every coefficient (numerics spec, "non-finite inputs")
     const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
     const bool ok = (chk == chk);
     const float qnan = __builtin_nanf("");
-    eval_nets<LD, PART, FULL, WPT>(xn, coef, tables, part);
+    eval_nets<LD, PART, FULL, WPT>(wt, xn, coef, tables, part);
 #define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
 
     const float inv2vt = 1.0f / (2.0f * vt);
@@ -471,13 +481,13 @@ __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &t
 
 // full derivative at (s,u) including the heading terms
 template <int PART, int LD, int WPT = 1>
-__device__ __forceinline__ void xdot_full(const float (&s)[12], const float (&u)[4], float *__restrict__ coef, bool tables,
+__device__ __forceinline__ void xdot_full(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], float *__restrict__ coef, bool tables,
                                           float (&xd)[12], int part = 0) {
     Trig tr;
     float tt, spsi, cpsi;
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
-    nlplant<true, PART, LD, WPT>(s, u, tr, tt, spsi, cpsi, coef, tables, xd, part);
+    nlplant<true, PART, LD, WPT>(wt, s, u, tr, tt, spsi, cpsi, coef, tables, xd, part);
 }
 
 // F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)

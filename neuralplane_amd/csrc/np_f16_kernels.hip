@@ -16,8 +16,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,6 +65,7 @@ struct KArgs {
     // per context (a small device buffer, not __constant__): contexts with different numerics options can coexist on a
     // device; read only inside the `flagged` branches
     const float *reset_coef;
+    AeroWeights wt;
 };
 
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         const float dt = cfg.dt;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
-            xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(s, u, coef, tables, k1, part);
+            xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, part);
 #pragma unroll
             for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
         } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
@@ -181,8 +180,8 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
 #pragma nounroll
             for (int stage = 0; stage < 4; stage++) {
                 float kk[12];
-                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(y, u, coef, tables, kk, part);  // y == s: cached coefficients apply
-                else xdot_full<AB_ALL, TILE, WPT>(y, u, coef, tables, kk, part);
+                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(a.wt, y, u, coef, tables, kk, part);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, TILE, WPT>(a.wt, y, u, coef, tables, kk, part);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
 #if defined(NPF16_EXP) && (NPF16_EXP & 2)  // timing experiment only: no Overload evaluation
         for (int k = 0; k < 12; k++) xd[k] = s[k];
 #else
-        nlplant<false, AB_FORCE, TILE, WPT>(s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
+        nlplant<false, AB_FORCE, TILE, WPT>(a.wt, s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
 #endif
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
 // F16Model getters that need the dynamics (F16_model.py:47-49, 132-181): out[20][ld_out]
 __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                             long long ld, float *__restrict__ out, long long ld_out,
-                                                            long long n, float airspeed, int tables) {
+                                                            long long n, float airspeed, int tables, AeroWeights wt) {
     __shared__ float lds[NUM_LDS_SLOTS * BLOCK];
     float *coef = lds + threadIdx.x;
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
     float xd[12];
-    nlplant<true, AB_ALL, BLOCK>(s, u, tr, tt, spsi, cpsi, coef, tables != 0, xd);
+    nlplant<true, AB_ALL, BLOCK>(wt, s, u, tr, tt, spsi, cpsi, coef, tables != 0, xd);
     float a3[3];
     body_acceleration(s, tr, xd, a3);
     const float inv_grav = (float)(1.0 / 32.174), minv_grav = (float)(-1.0 / 32.174);  // F16_model.py:166,176-178
@@ -379,13 +378,13 @@ __global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__
 }
 
 // cached coefficients of a reset aircraft (alpha = beta = 0) -> out[14]; run once per context
-__global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out, int tables) {
+__global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out, int tables, AeroWeights wt) {
     __shared__ float lds[NUM_LDS_SLOTS * BLOCK];
     float *coef = lds + threadIdx.x;
     float xn[NUM_NORM_GROUPS];
     const float r2d = (float)(180.0 / 3.141592653589793);
-    normalise_inputs(0.0f * r2d, 0.0f * r2d, 0.0f, xn);
-    eval_ab<BLOCK, AB_FORCE>(xn, coef, tables != 0);
+    normalise_inputs(wt, 0.0f * r2d, 0.0f * r2d, 0.0f, xn);
+    eval_ab<BLOCK, AB_FORCE>(wt, xn, coef, tables != 0);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) out[k] = coef[cached_slot(k) * BLOCK];
@@ -415,6 +414,8 @@ struct np_f16_ctx {
     int task, solver;
     DevCfg cfg;
     float *d_reset_coef;  // [NUM_CACHED] device buffer owned by the context
+    float *d_weights;     // KBLOB | PWL tables | PWL un-normalisation, one device allocation owned by the context
+    AeroWeights wt;
     int variant;          // NP_KERNEL_AUTO / _LATENCY / _THROUGHPUT
     bool combat;  // created by np_f16_combat_ctx_create: only the combat entry points accept it
     CombatDevCfg ccfg;
@@ -635,6 +636,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.term_counters = io->term_counters;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
+    a.wt = ctx->wt;
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
     const bool latency = STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)), block(latency ? LAT_TILE * 4 : BLOCK);
@@ -757,6 +759,7 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward; a.rand_u = io->rand_u;
     a.pid_first = io->pid_first; a.seed = io->seed; a.call_idx = io->call_idx; a.row0 = io->row0; a.n = n; a.cfg = ctx->ccfg;
     a.term_counters = io->term_counters;
+    a.wt = ctx->wt;
     // small batches: the latency variant (one generation of 4-wave workgroups at 2 waves per SIMD = 512 x 64 aircraft)
     const bool latency = STEP && ctx->solver == 0 &&
                          (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= COMBAT_LAT_MAX_N));
@@ -794,32 +797,9 @@ int np_abi_version(void) { return NP_ABI_VERSION; }
 int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHED; }
 const char *np_last_error(void) { return g_err.c_str(); }
 
-// The packed weights live in __constant__ memory, i.e. once per device per process: every live context on a device must
-// have been created from the same blob (checked here; contexts may differ in everything else).
-static std::mutex g_blob_mu;
-static std::map<int, std::pair<uint64_t, int>> g_blob_live;  // device -> (blob hash, live contexts)
-
-static uint64_t fnv1a(const void *p, size_t n) {
-    const unsigned char *b = (const unsigned char *)p;
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
-    return h;
-}
-
 static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables, int device, np_f16_ctx **out) {
     std::vector<float> kb, pwl, pwl_unnorm;
     if (pack_kblob(weights_blob, nbytes, kb, pwl, pwl_unnorm)) return 1;
-    const uint64_t blob_hash = fnv1a(weights_blob, nbytes);
-    std::lock_guard<std::mutex> lock(g_blob_mu);
-    bool resident = false;  // the same blob is already in this device's constant memory (kernels of live contexts read it)
-    {
-        auto it = g_blob_live.find(device);
-        if (it != g_blob_live.end() && it->second.second > 0) {
-            if (it->second.first != blob_hash)
-                return fail("a context created from a different weights blob is alive on this device (weights are per device)");
-            resident = true;
-        }
-    }
     if (tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
@@ -830,20 +810,32 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     NP_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("device arch ") + prop.gcnArchName + " is not gfx950 (MI355X)");
-    if (!resident) NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_kblob), kb.data(), sizeof(float) * KBLOB_FLOATS));
-    if (!resident && !pwl.empty()) {
-        NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl), pwl.data(), sizeof(float) * pwl.size()));
-        NP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pwl_unnorm), pwl_unnorm.data(), sizeof(float) * pwl_unnorm.size()));
+    // one device allocation per context: KBLOB | PWL tables | PWL (std, mean) — a context is one aircraft type
+    const size_t n_kb = KBLOB_FLOATS, n_pwl = (size_t)NUM_PWL_TABLES * PWL_TABLE_FLOATS, n_un = (size_t)NUM_PWL_TABLES * 2;
+    float *d_w = nullptr, *d_rc = nullptr;
+    NP_HIP(hipMalloc(&d_w, sizeof(float) * (n_kb + n_pwl + n_un)));
+    hipError_t e0 = hipMemcpy(d_w, kb.data(), sizeof(float) * n_kb, hipMemcpyHostToDevice);
+    if (e0 == hipSuccess && !pwl.empty()) {
+        e0 = hipMemcpy(d_w + n_kb, pwl.data(), sizeof(float) * n_pwl, hipMemcpyHostToDevice);
+        if (e0 == hipSuccess) e0 = hipMemcpy(d_w + n_kb + n_pwl, pwl_unnorm.data(), sizeof(float) * n_un, hipMemcpyHostToDevice);
     }
-    float *d_rc = nullptr;
-    {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
-        NP_HIP(hipMalloc(&d_rc, sizeof(float) * NUM_CACHED));
-        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, tables ? 1 : 0);
-        hipError_t e1 = hipGetLastError();
-        hipError_t e2 = hipDeviceSynchronize();
-        if (e1 != hipSuccess || e2 != hipSuccess) (void)hipFree(d_rc);
+    AeroWeights wt;
+    wt.kblob = d_w;
+    wt.pwl = pwl.empty() ? nullptr : d_w + n_kb;
+    wt.pwl_unnorm = pwl.empty() ? nullptr : d_w + n_kb + n_pwl;
+    hipError_t e1 = e0 == hipSuccess ? hipMalloc(&d_rc, sizeof(float) * NUM_CACHED) : e0;
+    hipError_t e2 = hipSuccess, e3 = hipSuccess;
+    if (e1 == hipSuccess) {  // coefficients of a reset aircraft, evaluated by the device code itself (bit-identical to in-line evaluation)
+        hipLaunchKernelGGL(f16_reset_coef_kernel, dim3(1), dim3(BLOCK), 0, 0, d_rc, tables ? 1 : 0, wt);
+        e2 = hipGetLastError();
+        e3 = hipDeviceSynchronize();
+    }
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        (void)hipFree(d_w);
+        if (d_rc) (void)hipFree(d_rc);
         NP_HIP(e1);
         NP_HIP(e2);
+        NP_HIP(e3);
     }
     np_f16_ctx *ctx = new np_f16_ctx();
     ctx->device = device;
@@ -851,12 +843,9 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     ctx->solver = 0;
     ctx->combat = false;
     ctx->variant = NP_KERNEL_AUTO;
-    {
-        auto &slot = g_blob_live[device];
-        if (slot.second == 0) slot.first = blob_hash;
-        slot.second += 1;
-    }
     ctx->d_reset_coef = d_rc;
+    ctx->d_weights = d_w;
+    ctx->wt = wt;
     ctx->timing = false;
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
@@ -904,13 +893,11 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
 void np_f16_ctx_destroy(np_f16_ctx *ctx) {
     if (!ctx) return;
     {
-        std::lock_guard<std::mutex> lock(g_blob_mu);
-        auto it = g_blob_live.find(ctx->device);
-        if (it != g_blob_live.end() && it->second.second > 0) it->second.second -= 1;
-    }
-    if (ctx->d_reset_coef) {
         DeviceGuard guard;
-        if (guard.enter(ctx->device) == hipSuccess) (void)hipFree(ctx->d_reset_coef);
+        if (guard.enter(ctx->device) == hipSuccess) {
+            if (ctx->d_reset_coef) (void)hipFree(ctx->d_reset_coef);  // hipFree waits for kernels still reading the buffers
+            if (ctx->d_weights) (void)hipFree(ctx->d_weights);
+        }
     }
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.first);
@@ -936,7 +923,7 @@ int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, i
     NP_HIP(guard.enter(ctx->device));
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipLaunchKernelGGL(f16_derived_kernel, grid, block, 0, (hipStream_t)stream, s, u, (long long)ld, out, (long long)ld_out,
-                       (long long)n, ctx->cfg.airspeed, ctx->cfg.aero_1d_tables);
+                       (long long)n, ctx->cfg.airspeed, ctx->cfg.aero_1d_tables, ctx->wt);
     NP_HIP(hipGetLastError());
     return 0;
 }

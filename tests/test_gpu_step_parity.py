@@ -430,3 +430,40 @@ def test_drop_in_example_runs_against_the_reference_import_paths():
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0, r.stderr[-2000:]
     assert 'numpy VecEnv loop' in r.stdout and 'device-resident loop' in r.stdout and 'termination statistics' in r.stdout
+
+
+def _second_aircraft_blob(path):
+    """A second aero set with the F-16 topology (what the kernel template is parameterised by): every coefficient's
+    un-normalisation (out_mean, out_std of the 128-byte blob records) is changed, weights and PWL tables stay valid."""
+    import struct
+    from neuralplane_amd.core import ASSET_BLOB
+    blob = bytearray(open(ASSET_BLOB, 'rb').read())
+    for k in range(43):
+        off = 16 + 128 * k + 104
+        mean, std = struct.unpack_from('<dd', blob, off)
+        struct.pack_into('<dd', blob, off, mean + 0.013 * std * ((k % 5) - 2), std * (0.85 + 0.01 * (k % 7)))
+    open(path, 'wb').write(bytes(blob))
+    return path
+
+
+@pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
+def test_two_aircraft_types_coexist_on_one_device(tmp_path, tables):
+    """Per-context weights: an F-16 context and a context built from another blob with the same net topology run side by
+    side (alternating launches); each is bit-identical to the oracle loaded with ITS blob, and they differ from each other."""
+    from neuralplane_amd.core import F16Batch
+    from neuralplane_amd.envs.utils.utils import parse_config
+    other = _second_aircraft_blob(str(tmp_path / 'second_aero_set.bin'))
+    n, seed = 500, 8
+    cfg = parse_config('control')
+    bs = [F16Batch(n, cfg, 'control', 'cuda:0', seed=seed, aero_1d_tables=tables),
+          F16Batch(n, cfg, 'control', 'cuda:0', seed=seed, aero_1d_tables=tables, blob_path=other)]
+    os_ = [Oracle('control', mode=MODE_PWL if tables else 0), Oracle('control', mode=MODE_PWL if tables else 0, blob_path=other)]
+    sts = [Oracle.new_state(n), Oracle.new_state(n)]
+    rng = np.random.RandomState(2)
+    for t in range(30):
+        a = rng.uniform(-1.2, 1.2, (n, 4)).astype(np.float32)
+        for b, o, st in zip(bs, os_, sts):
+            obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+            o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t)
+            _check_equal(b, obs, rew, flags, st, o_obs, o_rew, f'step {t}')
+    assert not np.array_equal(sts[0]['s'], sts[1]['s'])
