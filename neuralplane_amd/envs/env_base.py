@@ -14,7 +14,7 @@ from .utils.utils import parse_config
 
 class BaseEnv(Env):
     def __init__(self, num_envs=10, config='heading', model='F16', random_seed=None, device='cuda:0', row0=0,
-                 aero_1d_tables=None, solver=None):
+                 aero_1d_tables=None, solver=None, weights=None):
         super().__init__()
         self.config = parse_config(config)
         self.num_envs = num_envs
@@ -24,6 +24,7 @@ class BaseEnv(Env):
         self.create_records = False
         self._row0 = row0
         self._aero_1d_tables = aero_1d_tables  # numerics option; None -> scenario key / env var / off
+        self._weights = weights                # None -> the shipped F-16 blob; else the path of another NPF16MLP blob (same topology)
         self._solver = solver                  # None -> the scenario's `solver` key ('euler' | 'rk4', F16_model.py:16)
         self.load(random_seed, config, model)
 
@@ -35,7 +36,8 @@ class BaseEnv(Env):
         # counter-based RNG simply needs a key
         seed = 0 if random_seed is None else int(random_seed)
         self._batch = F16Batch(self.n, self.config, task, self.device, seed=seed, row0=self._row0,
-                               aero_1d_tables=self._aero_1d_tables, solver=self._solver)
+                               aero_1d_tables=self._aero_1d_tables, solver=self._solver,
+                               **({'blob_path': self._weights} if self._weights else {}))
         self.device = self._batch.device
         return self._batch
 
