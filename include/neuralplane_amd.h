@@ -103,7 +103,7 @@ typedef struct np_f16_io {
     const uint64_t *call_idx_base;
     /* Optional DEVICE counters [NP_NUM_TERM_COUNTERS] (uint32, caller-zeroed, accumulated by np_f16_step): how many aircraft
      * tripped each termination condition at the state reached by the step — what the reference prints per condition
-     * (`print(torch.sum(bad_done), ...)`, envs/termination_conditions/*.py) at the price of a host sync each.  Order:
+     * (`print(torch.sum(bad_done), ...)`, envs/termination_conditions/<condition>.py) at the price of a host sync each.  Order:
      * overload, low_altitude, high_speed, low_speed, extreme_state, unreach_* (bad), target reached (done). */
     uint32_t *term_counters;
 } np_f16_io;

@@ -467,3 +467,33 @@ def test_two_aircraft_types_coexist_on_one_device(tmp_path, tables):
             o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t)
             _check_equal(b, obs, rew, flags, st, o_obs, o_rew, f'step {t}')
     assert not np.array_equal(sts[0]['s'], sts[1]['s'])
+
+
+def test_c_abi_from_a_plain_cpp_host_matches_the_python_surface(tmp_path):
+    """examples/c_abi_demo.cpp: a C++ program with no Python and no PyTorch links libneuralplane_hip.so, allocates with
+    hipMalloc, and drives np_f16_ctx_create / np_f16_reset / np_f16_step through the public header.  Its final state must be
+    bit-identical to the same run through the Python env surface."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'c_abi_demo')
+    csrc = os.path.join(root, 'neuralplane_amd', 'csrc')
+    cmd = ['g++', '-O2', '-std=c++17', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I', os.path.join(root, 'include'),
+           os.path.join(root, 'examples', 'c_abi_demo.cpp'), '-o', exe, '-L' + csrc, '-lneuralplane_hip', '-L/opt/rocm/lib', '-lamdhip64',
+           '-Wl,-rpath,' + csrc, '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n, steps = 1000, 30
+    out = str(tmp_path / 'state.bin')
+    r = subprocess.run([exe, os.path.join(root, 'neuralplane_amd', 'assets', 'f16_aero_mlp.bin'), str(n), str(steps), out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'C_ABI_DEMO' in r.stdout, (r.stdout, r.stderr[-2000:])
+    s_c = np.fromfile(out, dtype=np.float32).reshape(12, n)
+    b = _batch('heading', n, seed=42)
+    b.reset()
+    i = np.arange(n)
+    for t in range(steps):
+        a = np.stack([0.5 + 0.25 * ((i + t) % 3), 0.125 * ((i + 2 * t) % 5) - 0.25, 0.0625 * ((i * 3 + t) % 7) - 0.1875,
+                      0.03125 * ((i + 5 * t) % 9) - 0.125], axis=1).astype(np.float32)
+        b.step(torch.from_numpy(a).cuda())
+    assert np.array_equal(b.s.cpu().numpy(), s_c)
