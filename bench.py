@@ -80,7 +80,10 @@ def cpu_baseline(task, budget_s=15.0):
             break
     return {'value': n * steps / el, 'unit': 'aircraft-steps/s', 'cores': int(o.threads), 'kind': 'port',
             'sample': f'F-16 {task}, N={n} aircraft x {steps} steps, oracle/f16_oracle.c (OpenMP, fp32 scalar, '
-                      f'same numerics spec), {el:.1f} s'}
+                      f'same numerics spec), {el:.1f} s',
+            # context only: the reference's own eager-PyTorch path cannot travel to this box (its source never leaves the build
+            # container); measured there and published by its authors
+            'reference_context': {'pytorch_cpu_8_vcpu_N1e5': 4.7e5, 'published_pytorch_cuda_N1e6': 4.75e6, 'unit': 'aircraft-steps/s'}}
 
 
 def main():
