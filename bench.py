@@ -151,6 +151,7 @@ def main():
     kern_ms, kern_cnt = env._batch.get_timing()
     env._batch.set_timing(False)
 
+    mem_mb = torch.cuda.max_memory_allocated(dev) / 2 ** 20   # env state + cache + outputs of one step + the 8-entry action pool
     elapsed = sharding.max_over_ranks(elapsed, dist, dev if args.backend == 'nccl' else 'cpu')
     # sanity of the timed region: states finite for live rows, counters advanced
     fin = bool(torch.isfinite(env.model.s).all().item())
@@ -179,6 +180,8 @@ def main():
             'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                              'frac': ach_gbs / PEAK_HBM_GBS, 'note': '278 algorithmic B per aircraft-step; not the binding roof'},
             'state_finite': fin,
+            # the reference publishes 245.5 MB allocated after its N = 1e6 run (envs/measure_env/gpu_memory_neuralplane.npy)
+            'device_memory_mb': mem_mb,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.task)
