@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 6
+#define NP_ABI_VERSION 7
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -216,6 +216,15 @@ int np_f16_combat_ctx_create(const void *weights_blob, size_t nbytes, const np_f
 int np_f16_combat_reset(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream);
 /* SingleCombatEnv.step(action) (singlecombat_env.py:240-274), one kernel launch. */
 int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io, void *stream);
+
+/* PlanningEnv's frozen low-level controller: PPOActor.forward(obs, rnn_states, masks, deterministic=True)
+ * (algorithms/ppo/ppo_actor.py:38-64 in the configuration of envs/planning_env.py:18-29: feature LayerNorm, MLP 22-128-128,
+ * GRU 128, act MLP 128-128, tanh mean head) as ONE kernel launch.  `weights`: NP_ACTOR_NUM_FLOATS floats on the device, the
+ * actor's state_dict in kernel order (neuralplane_amd/actor.py::pack_ppo_actor documents the layout).  obs [n][22],
+ * h_in / h_out [n][128] (rnn_states with the layer dimension squeezed; may not alias), masks [n], actions [n][4]. */
+#define NP_ACTOR_NUM_FLOATS 153392
+int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
+                     float *actions, float *h_out, int device, void *stream);
 
 /* np_f16_step has two bit-identical kernel variants: "throughput" (one lane per aircraft, two independent waves per
  * workgroup — large batches) and "latency" (four waves share a tile of 64 aircraft and split the 44 net evaluations of a

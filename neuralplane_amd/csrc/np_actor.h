@@ -1,0 +1,219 @@
+// np_actor.h — PlanningEnv's frozen low-level controller as one fused gfx950 kernel.
+//
+// Reference: PPOActor.forward(obs, rnn_states, masks, deterministic=True) (algorithms/ppo/ppo_actor.py:38-64) in the configuration
+// envs/planning_env.py:18-29 builds: LayerNorm(22) -> [Linear, ReLU, LayerNorm] x 2 (128) -> GRU(128) -> LayerNorm -> [Linear, ReLU,
+// LayerNorm] x 2 (128) -> Linear(128, 4) -> tanh  (algorithms/utils/{mlp,gru,act,distributions}.py).  The reference runs it 50
+// times per PlanningEnv.step as ~15 small torch kernels; here one launch per call, activations never leave the CU.
+//
+// Mapping: a workgroup of 8 waves owns a tile of 64 rows (one row per lane, the same 64 rows in every wave).  Wave w computes
+// output features [16w, 16w+16) of every 128-wide layer for all 64 rows: weights are wave-uniform and travel through the scalar
+// unit (k-major packed buffer, one s_load_dwordx16 per input feature), the input activations are read from LDS ([feature][lane],
+// conflict-free), LayerNorm statistics are reduced across the 8 waves through LDS.  151 K fused multiply-adds per row and call.
+//
+// Numerics spec: ordered fmaf chains (bias first, k ascending), LayerNorm sums in blocks of 16 features added
+// in order, explicit fp32 exp — the tests hold this kernel bit-exact to a scalar CPU restatement of the same spec, and within
+// ~1e-5 of the reference's ATen kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace npact {
+
+enum : int {
+    OBS = 22, HID = 128,
+    LN0_G = 0, LN0_B = 22,
+    L1_B = 44, L1_W = L1_B + 128, LN1_G = L1_W + 22 * 128, LN1_B = LN1_G + 128,
+    L2_B = LN1_B + 128, L2_W = L2_B + 128, LN2_G = L2_W + 128 * 128, LN2_B = LN2_G + 128,
+    GI_B = LN2_B + 128, GI_W = GI_B + 384, GH_B = GI_W + 128 * 384, GH_W = GH_B + 384,
+    LN3_G = GH_W + 128 * 384, LN3_B = LN3_G + 128,
+    A1_B = LN3_B + 128, A1_W = A1_B + 128, LN4_G = A1_W + 128 * 128, LN4_B = LN4_G + 128,
+    A2_B = LN4_B + 128, A2_W = A2_B + 128, LN5_G = A2_W + 128 * 128, LN5_B = LN5_G + 128,
+    HD_B = LN5_B + 128, HD_W = HD_B + 4, TOTAL = HD_W + 128 * 4
+};
+static_assert(TOTAL == 153392, "packed actor layout (neuralplane_amd/actor.py)");
+
+constexpr int TILE = 64, WAVES = 8, THREADS = TILE * WAVES, SLICE = HID / WAVES;
+typedef const float __attribute__((address_space(4))) *cw_ptr;  // weights: read-only, wave-uniform -> scalar loads
+
+__device__ __forceinline__ float act_exp(float x) {
+    x = x < -87.0f ? -87.0f : x;
+    x = x > 88.0f ? 88.0f : x;
+    const float k = rintf(x * 1.44269504f);
+    float r = fmaf(k, -0.693145752f, x);
+    r = fmaf(k, -1.42860677e-6f, r);
+    float p = fmaf(r, 1.38888889e-3f, 8.33333333e-3f);
+    p = fmaf(r, p, 4.16666667e-2f);
+    p = fmaf(r, p, 1.66666667e-1f);
+    p = fmaf(r, p, 0.5f);
+    p = fmaf(r, p, 1.0f);
+    p = fmaf(r, p, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + ((uint32_t)(int32_t)k << 23));
+}
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + act_exp(-x)); }
+__device__ __forceinline__ float act_tanh(float x) { return 1.0f - 2.0f / (act_exp(2.0f * x) + 1.0f); }
+
+// 16 outputs [j0, j0+16) of a Linear layer for this lane's row; x[k] comes from LDS column `xin[k * TILE]`
+template <int K, int LD_W>
+__device__ __forceinline__ void dense16(cw_ptr bias, cw_ptr wt, int j0, const float *__restrict__ xin, float (&acc)[SLICE]) {
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) acc[j] = bias[j0 + j];
+#pragma unroll 2
+    for (int k = 0; k < K; k++) {
+        const float xk = xin[k * TILE];
+#pragma unroll
+        for (int j = 0; j < SLICE; j++) acc[j] = fmaf(wt[k * LD_W + j0 + j], xk, acc[j]);
+    }
+}
+
+// LayerNorm over the 128 features of a row held as 8 slices of 16 in the 8 waves; writes y into the LDS matrix `out`.
+__device__ __forceinline__ void layernorm_slices(const float (&v)[SLICE], cw_ptr g, cw_ptr b, int j0, int wave, int lane,
+                                                 float *__restrict__ part_s, float *__restrict__ part_q, float *__restrict__ out) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) s = s + v[j];
+    part_s[wave * TILE + lane] = s;
+    __syncthreads();
+    float total = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) total = total + part_s[w * TILE + lane];
+    const float mean = total / (float)HID;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) {
+        const float d = v[j] - mean;
+        q = fmaf(d, d, q);
+    }
+    part_q[wave * TILE + lane] = q;
+    __syncthreads();
+    float qt = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) qt = qt + part_q[w * TILE + lane];
+    const float rstd = 1.0f / sqrtf(qt / (float)HID + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) out[(j0 + j) * TILE + lane] = fmaf((v[j] - mean) * rstd, g[j0 + j], b[j0 + j]);
+    __syncthreads();  // `out` is complete (and part_s / part_q are free again) before anyone goes on
+}
+
+__device__ __forceinline__ void relu16(float (&v)[SLICE]) {
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+}
+
+__global__ __launch_bounds__(THREADS, 1) void actor_forward_kernel(const float *__restrict__ weights, long long n,
+                                                                   const float *__restrict__ obs, const float *__restrict__ h_in,
+                                                                   const float *__restrict__ mask, float *__restrict__ act,
+                                                                   float *__restrict__ h_out) {
+    extern __shared__ float lds[];
+    float *bufA = lds, *bufB = lds + HID * TILE, *bufC = lds + 2 * HID * TILE;
+    float *part_s = lds + 3 * HID * TILE, *part_q = part_s + WAVES * TILE;
+    const cw_ptr W = (cw_ptr)(unsigned long long)weights;
+    const int lane = (int)(threadIdx.x % TILE);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));
+    const int j0 = wave * SLICE;
+    const long long i = (long long)blockIdx.x * TILE + lane;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;
+
+    // masked recurrent state -> bufC (this wave's 16 features of its lane's row), gru.py:26
+    const float mk = mask[ic];
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) bufC[(j0 + j) * TILE + lane] = h_in[ic * HID + j0 + j] * mk;
+
+    // base.feature_norm: every wave normalises the 22 observations of its lane's row itself (two blocks: 16 + 6)
+    float x0[OBS];
+    {
+        float xr[OBS];
+#pragma unroll
+        for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s0 = s0 + xr[j];
+#pragma unroll
+        for (int j = 16; j < OBS; j++) s1 = s1 + xr[j];
+        const float mean = ((0.0f + s0) + s1) / (float)OBS;
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float d = xr[j] - mean;
+            q0 = fmaf(d, d, q0);
+        }
+#pragma unroll
+        for (int j = 16; j < OBS; j++) {
+            const float d = xr[j] - mean;
+            q1 = fmaf(d, d, q1);
+        }
+        const float rstd = 1.0f / sqrtf(((0.0f + q0) + q1) / (float)OBS + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < OBS; j++) x0[j] = fmaf((xr[j] - mean) * rstd, W[LN0_G + j], W[LN0_B + j]);
+    }
+
+    float v[SLICE];
+    // base.mlp: Linear(22, 128) + ReLU + LayerNorm -> bufA
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) v[j] = W[L1_B + j0 + j];
+#pragma unroll
+    for (int k = 0; k < OBS; k++) {
+#pragma unroll
+        for (int j = 0; j < SLICE; j++) v[j] = fmaf(W[L1_W + k * HID + j0 + j], x0[k], v[j]);
+    }
+    relu16(v);
+    layernorm_slices(v, W + LN1_G, W + LN1_B, j0, wave, lane, part_s, part_q, bufA);
+    // Linear(128, 128) + ReLU + LayerNorm -> bufB
+    dense16<HID, HID>(W + L2_B, W + L2_W, j0, bufA + lane, v);
+    relu16(v);
+    layernorm_slices(v, W + LN2_G, W + LN2_B, j0, wave, lane, part_s, part_q, bufB);
+
+    // rnn: GRU cell (gate order r, z, n as in torch) on x = bufB, h = bufC
+    {
+        float gi[SLICE], gh[SLICE], r[SLICE], z[SLICE];
+        dense16<HID, 3 * HID>(W + GI_B, W + GI_W, j0, bufB + lane, gi);
+        dense16<HID, 3 * HID>(W + GH_B, W + GH_W, j0, bufC + lane, gh);
+#pragma unroll
+        for (int j = 0; j < SLICE; j++) r[j] = act_sigmoid(gi[j] + gh[j]);
+        dense16<HID, 3 * HID>(W + GI_B + HID, W + GI_W + HID, j0, bufB + lane, gi);
+        dense16<HID, 3 * HID>(W + GH_B + HID, W + GH_W + HID, j0, bufC + lane, gh);
+#pragma unroll
+        for (int j = 0; j < SLICE; j++) z[j] = act_sigmoid(gi[j] + gh[j]);
+        dense16<HID, 3 * HID>(W + GI_B + 2 * HID, W + GI_W + 2 * HID, j0, bufB + lane, gi);
+        dense16<HID, 3 * HID>(W + GH_B + 2 * HID, W + GH_W + 2 * HID, j0, bufC + lane, gh);
+#pragma unroll
+        for (int j = 0; j < SLICE; j++) {
+            const float nn = act_tanh(gi[j] + r[j] * gh[j]);
+            const float hm = bufC[(j0 + j) * TILE + lane];
+            v[j] = (hm - nn) * z[j] + nn;
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < SLICE; j++) h_out[i * HID + j0 + j] = v[j];
+        }
+    }
+    layernorm_slices(v, W + LN3_G, W + LN3_B, j0, wave, lane, part_s, part_q, bufA);   // rnn.norm -> bufA
+    // act.mlp
+    dense16<HID, HID>(W + A1_B, W + A1_W, j0, bufA + lane, v);
+    relu16(v);
+    layernorm_slices(v, W + LN4_G, W + LN4_B, j0, wave, lane, part_s, part_q, bufB);
+    dense16<HID, HID>(W + A2_B, W + A2_W, j0, bufB + lane, v);
+    relu16(v);
+    layernorm_slices(v, W + LN5_G, W + LN5_B, j0, wave, lane, part_s, part_q, bufA);
+    // mu_net: Linear(128, 4) + tanh — wave 0
+    if (wave == 0) {
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[j] = W[HD_B + j];
+#pragma unroll 4
+        for (int k = 0; k < HID; k++) {
+            const float xk = bufA[k * TILE + lane];
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[j] = fmaf(W[HD_W + k * 4 + j], xk, m[j]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) act[i * 4 + j] = act_tanh(m[j]);
+        }
+    }
+}
+
+constexpr size_t ACTOR_LDS_BYTES = sizeof(float) * (3 * HID * TILE + 2 * WAVES * TILE);
+
+}  // namespace npact

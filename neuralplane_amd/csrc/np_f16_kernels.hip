@@ -22,6 +22,7 @@
 #include "../../include/neuralplane_amd.h"
 #include "np_f16_device.h"
 #include "np_f16_combat.h"
+#include "np_actor.h"
 
 namespace npf16 {
 
@@ -938,6 +939,29 @@ int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float 
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipLaunchKernelGGL(f16_lowlevel_obs_kernel, grid, block, 0, (hipStream_t)stream, s, u, tgt3, (long long)ld, obs, (long long)n,
                        ctx->cfg);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
+                     float *actions, float *h_out, int device, void *stream) {
+    if (!weights || !obs || !h_in || !masks || !actions || !h_out) return fail("null argument");
+    if (num_floats != npact::TOTAL) return fail("packed actor weights: wrong size (expected NP_ACTOR_NUM_FLOATS)");
+    if (n <= 0) return 0;
+    int ndev = 0;
+    NP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(device));
+    static bool lds_set[64] = {};
+    if (device < 64 && !lds_set[device]) {  // 100 KB of LDS per workgroup: above the 64 KB a kernel may use without asking
+        NP_HIP(hipFuncSetAttribute((const void *)npact::actor_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)npact::ACTOR_LDS_BYTES));
+        lds_set[device] = true;
+    }
+    const dim3 grid((unsigned)((n + npact::TILE - 1) / npact::TILE)), block(npact::THREADS);
+    hipLaunchKernelGGL(npact::actor_forward_kernel, grid, block, npact::ACTOR_LDS_BYTES, (hipStream_t)stream, weights, (long long)n,
+                       obs, h_in, masks, actions, h_out);
     NP_HIP(hipGetLastError());
     return 0;
 }

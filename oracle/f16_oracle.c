@@ -907,3 +907,4 @@ int f16o_num_threads(void) {
 }
 
 #include "f16_combat.inc"
+#include "f16_actor.inc"

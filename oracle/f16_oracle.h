@@ -163,6 +163,12 @@ int f16o_combat_step(const f16o_model *m, const f16o_combat_cfg *cfg, int64_t nu
                      int64_t act_stride, const float *rand_u, int pid_first, uint64_t seed, uint64_t call_idx, int64_t env0,
                      float *obs, float *reward, uint32_t *term_counts /* nullable [F16O_NUM_COMBAT_TERM], accumulated */);
 
+/* PlanningEnv's frozen low-level controller (f16_actor.inc): PPOActor.forward(obs[n][22], rnn_states[n][128], masks[n],
+ * deterministic=True) -> act[n][4], h_out[n][128]; w = f16o_actor_num_floats() packed weights (neuralplane_amd/actor.py) */
+int f16o_actor_num_floats(void);
+void f16o_actor_forward(const float *w, int64_t n, const float *obs, const float *h_in, const float *mask, float *act,
+                        float *h_out);
+
 int f16o_num_threads(void);
 void f16o_set_threads(int n); /* OpenMP threads used by the batched entry points */
 

@@ -41,7 +41,7 @@ class Cfg(C.Structure):
 
 def build(force=False):
     """Compile oracle/_build/libf16oracle.so with gcc (Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_oracle.h', 'Makefile'))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_actor.inc', 'f16_oracle.h', 'Makefile'))
     if os.environ.get('F16O_SO'):      # e.g. the sanitizer build (`make -C oracle asan-test`)
         return os.environ['F16O_SO']
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
@@ -389,3 +389,24 @@ class CombatOracle(Oracle):
                                        C.c_uint64(call_idx), C.c_int64(env0), _p(obs), _p(rew), _p(term_counts, C.c_uint32))
         assert rc == 0
         return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()
+
+
+# =====================================================================================================
+# PlanningEnv's frozen low-level controller (f16_actor.inc)
+# =====================================================================================================
+class ActorOracle:
+    """PPOActor.forward(deterministic=True) for the packed weights of neuralplane_amd.actor.pack_ppo_actor."""
+
+    def __init__(self, weights):
+        self.lib = C.CDLL(build())
+        self.w = _f32(weights).reshape(-1)
+        assert self.w.size == self.lib.f16o_actor_num_floats(), (self.w.size, self.lib.f16o_actor_num_floats())
+
+    def forward(self, obs, h, masks):
+        obs, h = _f32(obs), _f32(h).reshape(-1, 128)
+        m = _f32(masks).reshape(-1)
+        n = obs.shape[0]
+        act = np.empty((n, 4), np.float32)
+        h_out = np.empty((n, 128), np.float32)
+        self.lib.f16o_actor_forward(_p(self.w), C.c_int64(n), _p(obs), _p(h), _p(m), _p(act), _p(h_out))
+        return act, h_out

@@ -1,0 +1,83 @@
+"""GPU tests of the fused low-level controller (np_actor_forward, neuralplane_amd/actor.py::FusedActor) through the C ABI:
+bit-exact against the oracle's restatement, close to the reference's PPOActor recording, and inside PlanningEnv."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.f16_oracle import ActorOracle  # noqa: E402  (the checker; test infrastructure)
+
+
+def _sd(d):
+    return {k[4:]: d[k] for k in d.files if k.startswith('sd::')}
+
+
+def _same(a, b):
+    return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 1000])
+def test_fused_actor_bit_exact_vs_oracle(golden_dir, n):
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    w = pack_ppo_actor(_sd(d))
+    fa, o = FusedActor(w, 'cuda:0'), ActorOracle(w)
+    rng = np.random.RandomState(n)
+    h = (rng.normal(0, 0.5, (n, 1, 128))).astype(np.float32)
+    h_o = h[:, 0].copy()
+    h_t = torch.from_numpy(h).cuda()
+    for t in range(5):
+        obs = (rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 30, (1, 22))).astype(np.float32)
+        masks = (rng.uniform(0, 1, (n, 1)) > 0.2).astype(np.float32)
+        if t == 3:
+            obs[0, 5] = np.float32(1e20)      # saturating inputs: LayerNorm keeps them finite
+        a_t, _, h_t = fa(torch.from_numpy(obs).cuda(), h_t, torch.from_numpy(masks).cuda())
+        a_o, h_o = o.forward(obs, h_o, masks)
+        assert a_t.shape == (n, 4) and h_t.shape == (n, 1, 128)
+        assert _same(a_t.cpu().numpy(), a_o), f'actions differ at call {t}'
+        assert _same(h_t.cpu().numpy()[:, 0], h_o), f'rnn state differs at call {t}'
+
+
+def test_fused_actor_close_to_reference_recording(golden_dir):
+    from neuralplane_amd.actor import FusedActor
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    fa = FusedActor(_sd(d), 'cuda:0')
+    steps, n = d['obs'].shape[:2]
+    h = torch.zeros((n, 1, 128), device='cuda')
+    for t in range(steps):
+        a, _, h = fa(torch.from_numpy(d['obs'][t]).cuda(), h, torch.from_numpy(d['masks'][t]).cuda())
+    assert np.max(np.abs(a.cpu().numpy() - d['actions'][-1])) < 5e-5
+    assert np.max(np.abs(h.cpu().numpy() - d['rnn'][-1])) < 5e-5
+    with pytest.raises(ValueError):
+        FusedActor(np.zeros(10, np.float32), 'cuda:0')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        FusedActor(_sd(d), 'cpu')
+
+
+def test_planning_env_with_fused_actor_eager_and_graph(golden_dir):
+    """PlanningEnv(controller=FusedActor): the whole macro-step is native (1 + 50 x 3 launches); the HIP-graph replay
+    gives the eager results bit for bit, and the low-level actions equal what the oracle's actor computes from the same
+    low-level observations."""
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    w = pack_ppo_actor(_sd(d))
+    n = 200
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=5, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+            for _ in range(2)]
+    envs[1].enable_graph()
+    g = torch.Generator(device='cpu').manual_seed(2)
+    for k in range(3):
+        a = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
+        outs = [e.step(a) for e in envs]
+        for x, y in zip(outs[0][:5], outs[1][:5]):
+            assert torch.equal(x, y), f'macro-step {k}'
+        assert torch.equal(envs[0].model.s, envs[1].model.s) and torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
+    # one more inner iteration by hand: oracle actor on the env's low-level observation
+    env = envs[0]
+    tgt3 = torch.stack((env.model.s[:, 4], env.model.s[:, 5], env.model.s[:, 6]))
+    ll = env._batch.lowlevel_obs(tgt3)
+    act, _, _ = env.controller(ll, env.ego_rnn_states, torch.ones((n, 1), device='cuda'))
+    a_o, _ = ActorOracle(w).forward(ll.cpu().numpy(), env.ego_rnn_states.cpu().numpy()[:, 0], np.ones(n, np.float32))
+    assert _same(act.cpu().numpy(), a_o)

@@ -726,6 +726,53 @@ def gen_acmi():
     print('acmi: frames', text.count('#'), 'bytes', len(text))
 
 
+def gen_actor(n=96, steps=4):
+    """PlanningEnv's low-level controller: the reference's PPOActor (algorithms/ppo/ppo_actor.py) with the argument bag of
+    envs/planning_env.py:18-29 and a seeded random initialisation whose output layers are re-scaled (the shipped gain 0.01
+    would make every action ~0): state_dict, inputs, and the actions / rnn states of `steps` consecutive deterministic calls."""
+    if not hasattr(np, 'product'):
+        np.product = np.prod
+    import gym
+    from algorithms.ppo.ppo_actor import PPOActor
+    import envs.planning_env as pe
+    args = pe.Args() if hasattr(pe, 'Args') else None
+    if args is None:
+        class A:
+            pass
+        args = A()
+        args.gain, args.hidden_size, args.act_hidden_size, args.activation_id = 0.01, '128 128', '128 128', 1
+        args.use_feature_normalization, args.use_recurrent_policy = True, True
+        args.recurrent_hidden_size, args.recurrent_hidden_layers, args.use_prior = 128, 1, False
+    args.use_prior = False
+    torch.manual_seed(123)
+    actor = PPOActor(args, gym.spaces.Box(low=-10, high=10, shape=(22,)), gym.spaces.Box(low=-10, high=10, shape=(4,)),
+                     device=torch.device('cpu'))
+    actor.eval()
+    with torch.no_grad():
+        for k, v in actor.state_dict().items():       # make LayerNorm affine terms and the head non-trivial
+            if k.endswith('norm.weight') or '.fc.2.weight' in k or '.fc.5.weight' in k:
+                v.mul_(1.0 + 0.3 * torch.randn_like(v))
+            if k.endswith('norm.bias') or '.fc.2.bias' in k or '.fc.5.bias' in k or k.endswith('bias_ih_l0') or k.endswith('bias_hh_l0'):
+                v.add_(0.2 * torch.randn_like(v))
+        actor.act.action_out.mu_net.fc[0].weight.mul_(60.0)
+        actor.act.action_out.mu_net.fc[0].bias.add_(0.1 * torch.randn(4))
+    rng = np.random.RandomState(61)
+    obs = (rng.normal(0, 1, (steps, n, 22)) * rng.uniform(0.1, 3, (1, 1, 22))).astype(np.float32)
+    masks = np.ones((steps, n, 1), np.float32)
+    masks[2, ::7] = 0.0                                # a few rows reset their recurrent state
+    h = torch.zeros((n, 1, 128))
+    acts, hs = [], []
+    with torch.no_grad():
+        for t in range(steps):
+            a, _, h = actor(torch.from_numpy(obs[t]), h, torch.from_numpy(masks[t]), deterministic=True)
+            acts.append(a.numpy().copy())
+            hs.append(h.numpy().copy())
+    sd = {k: v.numpy() for k, v in actor.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, 'actor_kat.npz'), obs=obs, masks=masks, actions=np.stack(acts), rnn=np.stack(hs),
+                        **{'sd::' + k: v for k, v in sd.items()})
+    print('actor: |action| max', float(np.abs(np.stack(acts)).max()), 'rnn std', float(np.stack(hs).std()))
+
+
 def gen_combat_all():
     gen_pairwise()
     gen_combat(pin=True)
@@ -743,6 +790,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'acmi':
         gen_acmi()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'actor':
+        gen_actor()
+        return
     env = make_env('heading', 4)
     gen_aero(env)
     gen_nlplant(env)
@@ -757,6 +807,7 @@ def main():
     gen_planning()
     gen_combat_all()
     gen_acmi()
+    gen_actor()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
