@@ -58,7 +58,7 @@ template <int K, int LD_W>
 __device__ __forceinline__ void dense16(cw_ptr bias, cw_ptr wt, int j0, const float *__restrict__ xin, float (&acc)[SLICE]) {
 #pragma unroll
     for (int j = 0; j < SLICE; j++) acc[j] = bias[j0 + j];
-#pragma unroll 2
+#pragma unroll 4
     for (int k = 0; k < K; k++) {
         const float xk = xin[k * TILE];
 #pragma unroll

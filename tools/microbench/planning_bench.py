@@ -20,9 +20,13 @@ class Ctrl(torch.nn.Module):
         return torch.tanh(s.head(s.norm(y.squeeze(0)))), None, h.transpose(0, 1)
 
 
-for n in (1024, 16384, 262144):
+import numpy as np
+from neuralplane_amd.actor import FusedActor, NUM_FLOATS
+
+fused_w = (np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS)).astype(np.float32)
+for n, kind in [(n, k) for n in (1024, 10000, 16384, 262144) for k in ('torch', 'fused')]:
     torch.manual_seed(0)
-    ctrl = Ctrl().cuda().eval()
+    ctrl = Ctrl().cuda().eval() if kind == 'torch' else FusedActor(fused_w, 'cuda:0')
     env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cuda:0', controller=ctrl)
     a = torch.rand(n, 3, device='cuda') * 2 - 1
     for mode in ('eager', 'graph'):
@@ -37,4 +41,4 @@ for n in (1024, 16384, 262144):
         for _ in range(K):
             env.step(a)
         torch.cuda.synchronize(); dt = (time.time() - t0) / K
-        print(f'n={n} {mode}: {dt*1e3:.2f} ms per PlanningEnv.step (50 inner) -> {n*50/dt:.3e} aircraft-FDM-steps/s')
+        print(f'n={n} {kind} controller, {mode}: {dt*1e3:.2f} ms per PlanningEnv.step (50 inner) -> {n*50/dt:.3e} aircraft-FDM-steps/s')
