@@ -17,6 +17,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include "np_actor_asm.inc"
+#ifndef NPACT_EXP
+#define NPACT_EXP 0  // timing-only experiment switches (tools/microbench/README.md); 0 in every shipped build
+#endif
 
 namespace npact {
 
@@ -53,17 +57,22 @@ __device__ __forceinline__ float act_exp(float x) {
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + act_exp(-x)); }
 __device__ __forceinline__ float act_tanh(float x) { return 1.0f - 2.0f / (act_exp(2.0f * x) + 1.0f); }
 
-// 16 outputs [j0, j0+16) of a Linear layer for this lane's row; x[k] comes from LDS column `xin[k * TILE]`
+// 16 outputs [j0, j0+16) of a Linear(128, .) layer for this lane's row; x[k] comes from LDS column `xin[k * TILE]`.
+// acc = bias; acc = fma(W[j][k], x[k], acc), k ascending — as a generated weight-stream asm loop (np_actor_asm.inc): the 16
+// weights of feature k are one s_load_dwordx16 feeding 8 v_pk_fma_f32 as SGPR-pair operands, 3 features per group, double-buffered.
 template <int K, int LD_W>
 __device__ __forceinline__ void dense16(cw_ptr bias, cw_ptr wt, int j0, const float *__restrict__ xin, float (&acc)[SLICE]) {
-#pragma unroll
-    for (int j = 0; j < SLICE; j++) acc[j] = bias[j0 + j];
-#pragma unroll 4
-    for (int k = 0; k < K; k++) {
-        const float xk = xin[k * TILE];
-#pragma unroll
-        for (int j = 0; j < SLICE; j++) acc[j] = fmaf(wt[k * LD_W + j0 + j], xk, acc[j]);
-    }
+    static_assert(K == HID && SLICE == 16 && TILE == 64, "actor_dense16_asm is generated for Linear(128, .) slices of 16");
+#if NPACT_EXP & 1  // timing only (wrong results): every wave streams the same weight slice
+    j0 = 0;
+#endif
+    const float *w = (const float *)(wt + j0), *b = (const float *)(bias + j0);
+    const unsigned xaddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)xin;
+#if NPACT_EXP & 2  // timing only (wrong results): every feature reads the same 64 B of weights (scalar cache always hits)
+    actor_dense16_asm<0>(w, b, xaddr, acc);
+#else
+    actor_dense16_asm<LD_W * 4>(w, b, xaddr, acc);
+#endif
 }
 
 // LayerNorm over the 128 features of a row held as 8 slices of 16 in the 8 waves; writes y into the LDS matrix `out`.
@@ -100,13 +109,15 @@ __device__ __forceinline__ void relu16(float (&v)[SLICE]) {
     for (int j = 0; j < SLICE; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
 }
 
-__global__ __launch_bounds__(THREADS, 1) void actor_forward_kernel(const float *__restrict__ weights, long long n,
+__global__ __launch_bounds__(THREADS, 4) void actor_forward_kernel(const float *__restrict__ weights, long long n,
                                                                    const float *__restrict__ obs, const float *__restrict__ h_in,
                                                                    const float *__restrict__ mask, float *__restrict__ act,
                                                                    float *__restrict__ h_out) {
     extern __shared__ float lds[];
-    float *bufA = lds, *bufB = lds + HID * TILE, *bufC = lds + 2 * HID * TILE;
-    float *part_s = lds + 3 * HID * TILE, *part_q = part_s + WAVES * TILE;
+    // two activation matrices [feature][lane] + the LayerNorm partials: 68 KB, so that TWO tiles are resident per CU and one
+    // tile's barrier / LayerNorm / activation phases overlap the other's weight streams
+    float *bufA = lds, *bufB = lds + HID * TILE;
+    float *part_s = lds + 2 * HID * TILE, *part_q = part_s + WAVES * TILE;
     const cw_ptr W = (cw_ptr)(unsigned long long)weights;
     const int lane = (int)(threadIdx.x % TILE);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));
@@ -115,10 +126,11 @@ __global__ __launch_bounds__(THREADS, 1) void actor_forward_kernel(const float *
     const bool valid = i < n;
     const long long ic = valid ? i : n - 1;
 
-    // masked recurrent state -> bufC (this wave's 16 features of its lane's row), gru.py:26
+    // masked recurrent state (this wave's 16 features of its lane's row), gru.py:26 — held in registers until bufA is free
     const float mk = mask[ic];
+    float hm[SLICE];
 #pragma unroll
-    for (int j = 0; j < SLICE; j++) bufC[(j0 + j) * TILE + lane] = h_in[ic * HID + j0 + j] * mk;
+    for (int j = 0; j < SLICE; j++) hm[j] = h_in[ic * HID + j0 + j] * mk;
 
     // base.feature_norm: every wave normalises the 22 observations of its lane's row itself (two blocks: 16 + 6)
     float x0[OBS];
@@ -164,38 +176,41 @@ __global__ __launch_bounds__(THREADS, 1) void actor_forward_kernel(const float *
     relu16(v);
     layernorm_slices(v, W + LN2_G, W + LN2_B, j0, wave, lane, part_s, part_q, bufB);
 
-    // rnn: GRU cell (gate order r, z, n as in torch) on x = bufB, h = bufC
+    // rnn: GRU cell (gate order r, z, n as in torch) on x = bufB, h = bufA (dead since every wave passed LayerNorm 2's barriers)
+#pragma unroll
+    for (int j = 0; j < SLICE; j++) bufA[(j0 + j) * TILE + lane] = hm[j];
+    __syncthreads();
     {
         float gi[SLICE], gh[SLICE], r[SLICE], z[SLICE];
         dense16<HID, 3 * HID>(W + GI_B, W + GI_W, j0, bufB + lane, gi);
-        dense16<HID, 3 * HID>(W + GH_B, W + GH_W, j0, bufC + lane, gh);
+        dense16<HID, 3 * HID>(W + GH_B, W + GH_W, j0, bufA + lane, gh);
 #pragma unroll
         for (int j = 0; j < SLICE; j++) r[j] = act_sigmoid(gi[j] + gh[j]);
         dense16<HID, 3 * HID>(W + GI_B + HID, W + GI_W + HID, j0, bufB + lane, gi);
-        dense16<HID, 3 * HID>(W + GH_B + HID, W + GH_W + HID, j0, bufC + lane, gh);
+        dense16<HID, 3 * HID>(W + GH_B + HID, W + GH_W + HID, j0, bufA + lane, gh);
 #pragma unroll
         for (int j = 0; j < SLICE; j++) z[j] = act_sigmoid(gi[j] + gh[j]);
         dense16<HID, 3 * HID>(W + GI_B + 2 * HID, W + GI_W + 2 * HID, j0, bufB + lane, gi);
-        dense16<HID, 3 * HID>(W + GH_B + 2 * HID, W + GH_W + 2 * HID, j0, bufC + lane, gh);
+        dense16<HID, 3 * HID>(W + GH_B + 2 * HID, W + GH_W + 2 * HID, j0, bufA + lane, gh);
 #pragma unroll
         for (int j = 0; j < SLICE; j++) {
             const float nn = act_tanh(gi[j] + r[j] * gh[j]);
-            const float hm = bufC[(j0 + j) * TILE + lane];
-            v[j] = (hm - nn) * z[j] + nn;
+            v[j] = (bufA[(j0 + j) * TILE + lane] - nn) * z[j] + nn;  // h again from LDS: 16 fewer live registers across the gate GEMVs
         }
         if (valid) {
 #pragma unroll
             for (int j = 0; j < SLICE; j++) h_out[i * HID + j0 + j] = v[j];
         }
     }
-    layernorm_slices(v, W + LN3_G, W + LN3_B, j0, wave, lane, part_s, part_q, bufA);   // rnn.norm -> bufA
+    // rnn.norm -> bufB: `out` is written after the LayerNorm's two barriers, i.e. after every wave finished reading x and h
+    layernorm_slices(v, W + LN3_G, W + LN3_B, j0, wave, lane, part_s, part_q, bufB);
     // act.mlp
-    dense16<HID, HID>(W + A1_B, W + A1_W, j0, bufA + lane, v);
+    dense16<HID, HID>(W + A1_B, W + A1_W, j0, bufB + lane, v);
     relu16(v);
-    layernorm_slices(v, W + LN4_G, W + LN4_B, j0, wave, lane, part_s, part_q, bufB);
-    dense16<HID, HID>(W + A2_B, W + A2_W, j0, bufB + lane, v);
+    layernorm_slices(v, W + LN4_G, W + LN4_B, j0, wave, lane, part_s, part_q, bufA);
+    dense16<HID, HID>(W + A2_B, W + A2_W, j0, bufA + lane, v);
     relu16(v);
-    layernorm_slices(v, W + LN5_G, W + LN5_B, j0, wave, lane, part_s, part_q, bufA);
+    layernorm_slices(v, W + LN5_G, W + LN5_B, j0, wave, lane, part_s, part_q, bufB);
     // mu_net: Linear(128, 4) + tanh — wave 0
     if (wave == 0) {
         float m[4];
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(THREADS, 1) void actor_forward_kernel(const float *
         for (int j = 0; j < 4; j++) m[j] = W[HD_B + j];
 #pragma unroll 4
         for (int k = 0; k < HID; k++) {
-            const float xk = bufA[k * TILE + lane];
+            const float xk = bufB[k * TILE + lane];
 #pragma unroll
             for (int j = 0; j < 4; j++) m[j] = fmaf(W[HD_W + k * 4 + j], xk, m[j]);
         }
@@ -214,6 +229,6 @@ __global__ __launch_bounds__(THREADS, 1) void actor_forward_kernel(const float *
     }
 }
 
-constexpr size_t ACTOR_LDS_BYTES = sizeof(float) * (3 * HID * TILE + 2 * WAVES * TILE);
+constexpr size_t ACTOR_LDS_BYTES = sizeof(float) * (2 * HID * TILE + 2 * WAVES * TILE);
 
 }  // namespace npact

@@ -371,6 +371,95 @@ def phase_checks():
     return out + ['']
 
 
+# ------------------------------------------------------------------------------------------------
+# The fused low-level controller (np_actor.h): 16 outputs of a Linear(128, .) layer for one wave.  Same weight-stream scheme:
+# the packed weights are k-major, so the 16 weights of input feature k are ONE s_load_dwordx16; groups of 3 input features are
+# double-buffered in s[4:51] / s[52:99]; the per-lane inputs x[k] come from the LDS matrix [feature][lane] by ds_read_b32 issued
+# together with the loads of their group (one s_waitcnt lgkmcnt(0) retires both).  acc = bias; acc = fma(W[j][k], x[k], acc),
+# k ascending — bit-identical to the C++ loop it replaces.
+# ------------------------------------------------------------------------------------------------
+ACTOR_OUT = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_actor_asm.inc')
+A_ACC = 70        # v[70:85] accumulators
+A_X = [86, 87, 88, 89, 90, 91]   # inputs of the two groups in flight
+A_ADDR = 92       # LDS byte address of x[k = first feature of the iteration] for this lane
+A_ROW = 256       # bytes between two features in the LDS matrix (64 lanes x 4)
+
+
+def gen_actor_dense(K=128):
+    lines = []
+    A = lines.append
+    A('// GENERATED by tools/gen_mlp_asm.py (gen_actor_dense) — do not edit.')
+    A('#pragma once')
+    A(f'// 16 outputs of a Linear({K}, .) layer: w = &Wt[0][j0] (rows LD_BYTES apart), b = &bias[j0], xaddr = LDS byte address of x[0] for this lane')
+    A('template <int LD_BYTES>')
+    A('__device__ __forceinline__ void actor_dense16_asm(const float *w, const float *b, unsigned xaddr, float (&acc)[16]) {')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    def sload(buf_set, slot, chunk):   # chunk = feature index relative to the moving base
+        r = S_W0 + 48 * buf_set + 16 * slot
+        emit(f's_load_dwordx16 s[{r}:{r + 15}], s[{S_BASE}:{S_BASE + 1}], %[ld]*{chunk}')
+
+    def xread(reg, feat):
+        emit(f'ds_read_b32 v{reg}, v{A_ADDR} offset:{A_ROW * feat}')
+
+    def compute(buf_set, slot, xreg):
+        r = S_W0 + 48 * buf_set + 16 * slot
+        e = xreg & 1
+        xp = f'v[{xreg - e}:{xreg - e + 1}]'
+        for p in range(8):
+            acc = f'v[{A_ACC + 2 * p}:{A_ACC + 2 * p + 1}]'
+            emit(f'v_pk_fma_f32 {acc}, s[{r + 2 * p}:{r + 2 * p + 1}], {xp}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]')
+
+    iters, tail = divmod(K, 6)
+    assert tail in (0, 2)
+    emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
+    emit(f'v_mov_b32 v{A_ADDR}, %[xaddr]')
+    emit(f's_load_dwordx16 s[{S_W0 + 48}:{S_W0 + 63}], %[b], 0x0')        # bias -> first chunk of set 1
+    for s in range(3):
+        sload(0, s, s)
+        xread(A_X[s], s)
+    emit('s_waitcnt lgkmcnt(0)')
+    for p in range(8):
+        sp = f's[{S_W0 + 48 + 2 * p}:{S_W0 + 48 + 2 * p + 1}]'
+        emit(f'v_pk_mov_b32 v[{A_ACC + 2 * p}:{A_ACC + 2 * p + 1}], {sp}, {sp} op_sel:[0,1]')
+    emit(f's_mov_b32 {S_CNT}, {iters}')
+    emit('.LNA_LOOP_%=:')
+    for s in range(3):                 # group B of this iteration: features 3..5 -> set 1
+        sload(1, s, 3 + s)
+        xread(A_X[3 + s], 3 + s)
+    for s in range(3):
+        compute(0, s, A_X[s])
+    emit('s_waitcnt lgkmcnt(0)')
+    for s in range(3):                 # group A of the next iteration: features 6..8 -> set 0 (the last one runs past K: harmless)
+        sload(0, s, 6 + s)
+        xread(A_X[s], 6 + s)
+    for s in range(3):
+        compute(1, s, A_X[3 + s])
+    emit(f's_add_u32 s{S_BASE}, s{S_BASE}, %[ld]*6')
+    emit(f's_addc_u32 s{S_BASE + 1}, s{S_BASE + 1}, 0')
+    emit(f'v_add_u32 v{A_ADDR}, {A_ROW * 6}, v{A_ADDR}')
+    emit('s_waitcnt lgkmcnt(0)')
+    emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
+    emit(f's_cmp_lg_u32 {S_CNT}, 0')
+    emit('s_cbranch_scc1 .LNA_LOOP_%=')
+    for s in range(tail):              # the last K % 6 features sit in set 0 already
+        compute(0, s, A_X[s])
+    for j in range(16):
+        emit(f'v_mov_b32 %[o{j}], v{A_ACC + j}')
+    outs = ', '.join(f'[o{j}] "=v"(acc[{j}])' for j in range(16))
+    A(f'        : {outs}')
+    A('        : [w] "s"(w), [b] "s"(b), [xaddr] "v"(xaddr), [ld] "n"(LD_BYTES)')
+    clob = ', '.join([f'"v{r}"' for r in range(A_ACC, A_ADDR + 1)] + [f'"s{r}"' for r in S_CLOBBER] + ['"vcc"', '"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+    with open(ACTOR_OUT, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('wrote', ACTOR_OUT)
+
+
 def main():
     out = ['// GENERATED by tools/gen_mlp_asm.py — do not edit.  See that file for the design notes.',
            '// One asm statement per net class: double-buffered scalar weight stream + v_pk_fma_f32 chains.',
@@ -407,3 +496,4 @@ def main():
 
 if __name__ == '__main__':
     main()
+    gen_actor_dense()
