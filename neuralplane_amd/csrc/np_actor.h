@@ -5,10 +5,12 @@
 // LayerNorm] x 2 (128) -> Linear(128, 4) -> tanh  (algorithms/utils/{mlp,gru,act,distributions}.py).  The reference runs it 50
 // times per PlanningEnv.step as ~15 small torch kernels; here one launch per call, activations never leave the CU.
 //
-// Mapping: a workgroup of 8 waves owns a tile of 64 rows (one row per lane, the same 64 rows in every wave).  Wave w computes
-// output features [16w, 16w+16) of every 128-wide layer for all 64 rows: weights are wave-uniform and travel through the scalar
-// unit (k-major packed buffer, one s_load_dwordx16 per input feature), the input activations are read from LDS ([feature][lane],
-// conflict-free), LayerNorm statistics are reduced across the 8 waves through LDS.  151 K fused multiply-adds per row and call.
+// Two kernels, the same arithmetic.  The shipped one (actor_forward_mfma_kernel, second half of this file) runs the 128-wide
+// layers on the matrix cores: 4 waves per 64-row tile, each a chain of K = 1 fp32 MFMAs per layer.  The first half is the
+// vector-FMA formulation it replaced (NPACT_MFMA=0: 8 waves per tile, wave w computes features [16w, 16w+16) with the weights
+// travelling through the scalar unit into v_pk_fma_f32 SGPR operands) — kept as the A/B reference.  In both, activations live in
+// LDS as [feature][row] matrices, LayerNorm statistics are reduced across the waves through LDS, 151 K fused multiply-adds per
+// row and call.
 //
 // Numerics spec: ordered fmaf chains (bias first, k ascending), LayerNorm sums in blocks of 16 features added
 // in order, explicit fp32 exp — the tests hold this kernel bit-exact to a scalar CPU restatement of the same spec, and within
@@ -18,6 +20,10 @@
 
 #include <cstdint>
 #include "np_actor_asm.inc"
+#include "np_actor_mfma_asm.inc"
+#ifndef NPACT_MFMA
+#define NPACT_MFMA 1  // 1: matrix-core kernel (4 waves per tile); 0: the vector-FMA kernel with the scalar weight stream (8 waves per tile)
+#endif
 #ifndef NPACT_EXP
 #define NPACT_EXP 0  // timing-only experiment switches (tools/microbench/README.md); 0 in every shipped build
 #endif
@@ -54,8 +60,13 @@ __device__ __forceinline__ float act_exp(float x) {
     p = fmaf(r, p, 1.0f);
     return __uint_as_float(__float_as_uint(p) + ((uint32_t)(int32_t)k << 23));
 }
+#if NPACT_EXP & 8  // timing only (wrong results): free gate nonlinearities
+__device__ __forceinline__ float act_sigmoid(float x) { return x; }
+__device__ __forceinline__ float act_tanh(float x) { return x; }
+#else
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + act_exp(-x)); }
 __device__ __forceinline__ float act_tanh(float x) { return 1.0f - 2.0f / (act_exp(2.0f * x) + 1.0f); }
+#endif
 
 // 16 outputs [j0, j0+16) of a Linear(128, .) layer for this lane's row; x[k] comes from LDS column `xin[k * TILE]`.
 // acc = bias; acc = fma(W[j][k], x[k], acc), k ascending — as a generated weight-stream asm loop (np_actor_asm.inc): the 16
@@ -211,6 +222,253 @@ __global__ __launch_bounds__(THREADS, 4) void actor_forward_kernel(const float *
     dense16<HID, HID>(W + A2_B, W + A2_W, j0, bufA + lane, v);
     relu16(v);
     layernorm_slices(v, W + LN5_G, W + LN5_B, j0, wave, lane, part_s, part_q, bufB);
+    // mu_net: Linear(128, 4) + tanh — wave 0
+    if (wave == 0) {
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[j] = W[HD_B + j];
+#pragma unroll 4
+        for (int k = 0; k < HID; k++) {
+            const float xk = bufB[k * TILE + lane];
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[j] = fmaf(W[HD_W + k * 4 + j], xk, m[j]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) act[i * 4 + j] = act_tanh(m[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// MFMA variant (the shipped one): the 128-wide layers are GEMMs [64 rows x 128] x [128 x 128], so they run on the matrix cores.
+// v_mfma_f32_32x32x1_2b_f32 performs, per output element, ONE IEEE fused multiply-add per instruction (K = 1), so a chain of
+// them over k IS acc = fmaf(W[f][k], x[k], acc), k ascending — bit-identical to the vector formulation above and to the CPU
+// restatement (tools/microbench/mfma_exact.hip proves this on the hardware, denormals and overflow included).
+//
+// A workgroup of 4 waves owns a tile of 64 rows; wave w computes features [32w, 32w+32) for all 64 rows:
+//   A operand = weights  (lane l -> feature 32w + l%32, the same in both 32-lane halves; coalesced 128 B vector loads from L2),
+//   B operand = inputs   (lane l -> row l: block 0 = rows 0..31, block 1 = rows 32..63; one ds_read_b32 from the LDS matrix),
+//   D (32 VGPRs): register e, lane l -> row 32*(e/16) + l%32, feature 32w + 8*((e%16)/4) + 4*(l/32) + e%4.
+// Results are transposed through the LDS matrix [feature][row] (which the next layer's B operand reads anyway); LayerNorm then
+// runs row-per-lane on 32 features per thread with the same block-of-16 summation order as the spec.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int MW = 4, MTHREADS = TILE * MW, MSLICE = HID / MW;
+
+__device__ __forceinline__ int mf_feat(int e, int half) { return 8 * ((e & 15) >> 2) + 4 * half + (e & 3); }
+__device__ __forceinline__ int mf_row(int e, int l32) { return 32 * (e >> 4) + l32; }
+
+// A operands (weights) of input features 0..7 for this lane, for the FIRST 128-wide layer: requested at kernel entry.  Every later
+// layer gets them from the layer before it (dense_mfma fetches the next layer's first group behind its own last MFMAs), so no
+// chain ever starts by waiting for L2.
+template <int LD_W>
+__device__ __forceinline__ void prefetch_w(const float *__restrict__ wt, int l32, float (&pa)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) pa[u] = wt[u * LD_W + l32];
+}
+
+__device__ __forceinline__ void init_bias(const float *__restrict__ bias, int half, f32x32 &acc) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const float bv = bias[mf_feat(e, half)];
+        acc[e] = bv;
+        acc[e + 16] = bv;
+    }
+}
+
+// acc = bias, then acc = fma(W[f][k], x[k], acc) for k = 0..127 on the matrix cores (generated loop, np_actor_mfma_asm.inc; operands
+// fetched 8 features ahead of their use).  wt = &Wt[0][32w] (rows LD_W apart), bias = &bias[32w], xin = &X[0][lane] (LDS);
+// pa: in = this layer's first 8 A operands, out = those of the layer at wnext (rows LD_NEXT apart).
+template <int LD_W, int LD_NEXT>
+__device__ __forceinline__ void dense_mfma(const float *__restrict__ bias, const float *__restrict__ wt, const float *__restrict__ wnext,
+                                           const float *__restrict__ xin, int l32, int half, float (&pa)[8], f32x32 &acc) {
+    init_bias(bias, half, acc);
+    const unsigned xaddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)xin;
+#if NPACT_EXP & 4  // timing only (wrong results): no GEMV at all — what the rest of the kernel costs
+    (void)xaddr;
+#else
+    actor_dense_mfma_asm<LD_W, LD_NEXT>(wt, wnext, 4u * (unsigned)l32, xaddr, pa, acc);
+#endif
+}
+
+// D registers -> LDS matrix [feature][row]
+template <bool RELU>
+__device__ __forceinline__ void store_transposed(const f32x32 &acc, float *__restrict__ out, int f0, int l32, int half) {
+#pragma unroll
+    for (int e = 0; e < 32; e++) {
+        float x = acc[e];
+        if (RELU) x = x > 0.0f ? x : 0.0f;
+        out[(f0 + mf_feat(e, half)) * TILE + mf_row(e, l32)] = x;
+    }
+}
+
+// in-place LayerNorm of the LDS matrix `buf`: thread (wave, lane) owns row `lane`, features [32 wave, 32 wave + 32) = two of the
+// eight blocks of 16 the spec sums in.  Ends with a barrier: `buf` is complete for every reader.
+template <bool STORE_H>
+__device__ __forceinline__ void layernorm_rows(float *__restrict__ buf, cw_ptr g, cw_ptr b, int wave, int lane, float *__restrict__ part_s,
+                                               float *__restrict__ part_q, float *__restrict__ h_out_row) {
+    const int f0 = wave * MSLICE;
+    float v[MSLICE];
+#pragma unroll
+    for (int j = 0; j < MSLICE; j++) v[j] = buf[(f0 + j) * TILE + lane];
+    if (STORE_H && h_out_row) {
+        float4 *hq = reinterpret_cast<float4 *>(h_out_row + f0);
+#pragma unroll
+        for (int j = 0; j < MSLICE / 4; j++) hq[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) s0 = s0 + v[j];
+#pragma unroll
+    for (int j = 16; j < 32; j++) s1 = s1 + v[j];
+    part_s[(2 * wave) * TILE + lane] = s0;
+    part_s[(2 * wave + 1) * TILE + lane] = s1;
+    __syncthreads();
+    float total = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) total = total + part_s[w * TILE + lane];
+    const float mean = total / (float)HID;
+    float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float d = v[j] - mean;
+        q0 = fmaf(d, d, q0);
+    }
+#pragma unroll
+    for (int j = 16; j < 32; j++) {
+        const float d = v[j] - mean;
+        q1 = fmaf(d, d, q1);
+    }
+    part_q[(2 * wave) * TILE + lane] = q0;
+    part_q[(2 * wave + 1) * TILE + lane] = q1;
+    __syncthreads();
+    float qt = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) qt = qt + part_q[w * TILE + lane];
+    const float rstd = 1.0f / sqrtf(qt / (float)HID + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < MSLICE; j++) buf[(f0 + j) * TILE + lane] = fmaf((v[j] - mean) * rstd, g[f0 + j], b[f0 + j]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma_kernel(const float *__restrict__ weights, long long n,
+                                                                         const float *__restrict__ obs, const float *__restrict__ h_in,
+                                                                         const float *__restrict__ mask, float *__restrict__ act,
+                                                                         float *__restrict__ h_out) {
+    extern __shared__ float lds[];
+    float *bufA = lds, *bufB = lds + HID * TILE;
+    float *part_s = lds + 2 * HID * TILE, *part_q = part_s + 8 * TILE;
+    const cw_ptr W = (cw_ptr)(unsigned long long)weights;  // wave-uniform reads (LayerNorm gains, the head): scalar loads
+    const float *Wv = weights;                             // per-lane reads (MFMA A operands, biases): vector loads
+    const int lane = (int)(threadIdx.x % TILE), l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));
+    const int f0 = wave * MSLICE;
+    const long long i = (long long)blockIdx.x * TILE + lane;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;
+
+    // the first layer's A operands (22 weights per lane) and the masked recurrent state (gru.py:26: this thread's 32 features of
+    // its row, 128 B as 8 x 16 B) are requested first; both are consumed only after the observation LayerNorm
+    float a1[OBS];
+#pragma unroll
+    for (int k = 0; k < OBS; k++) a1[k] = Wv[L1_W + k * HID + f0 + l32];
+    const float mk = mask[ic];
+    float hm[MSLICE];
+    {
+        const float4 *hp = reinterpret_cast<const float4 *>(h_in + ic * HID + f0);
+#pragma unroll
+        for (int j = 0; j < MSLICE / 4; j++) {
+            const float4 q = hp[j];
+            hm[4 * j] = q.x * mk;
+            hm[4 * j + 1] = q.y * mk;
+            hm[4 * j + 2] = q.z * mk;
+            hm[4 * j + 3] = q.w * mk;
+        }
+    }
+
+    // base.feature_norm (two blocks: 16 + 6) -> bufB rows 0..21; every wave computes it, wave 0 stores it
+    {
+        float xr[OBS];
+#pragma unroll
+        for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s0 = s0 + xr[j];
+#pragma unroll
+        for (int j = 16; j < OBS; j++) s1 = s1 + xr[j];
+        const float mean = ((0.0f + s0) + s1) / (float)OBS;
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float d = xr[j] - mean;
+            q0 = fmaf(d, d, q0);
+        }
+#pragma unroll
+        for (int j = 16; j < OBS; j++) {
+            const float d = xr[j] - mean;
+            q1 = fmaf(d, d, q1);
+        }
+        const float rstd = 1.0f / sqrtf(((0.0f + q0) + q1) / (float)OBS + 1e-5f);
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < OBS; j++) bufB[j * TILE + lane] = fmaf((xr[j] - mean) * rstd, W[LN0_G + j], W[LN0_B + j]);
+        }
+    }
+    float pa[8];
+    prefetch_w<HID>(Wv + L2_W + f0, l32, pa);
+    __syncthreads();
+
+    f32x32 acc;
+    // base.mlp: Linear(22, 128) + ReLU + LayerNorm -> bufA
+    init_bias(Wv + L1_B + f0, half, acc);
+#pragma unroll
+    for (int k = 0; k < OBS; k++) acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a1[k], bufB[k * TILE + lane], acc, 0, 0, 0);
+    store_transposed<true>(acc, bufA, f0, l32, half);
+    __syncthreads();
+    layernorm_rows<false>(bufA, W + LN1_G, W + LN1_B, wave, lane, part_s, part_q, nullptr);
+    // Linear(128, 128) + ReLU + LayerNorm -> bufB
+    dense_mfma<HID, 3 * HID>(Wv + L2_B + f0, Wv + L2_W + f0, Wv + GI_W + f0, bufA + lane, l32, half, pa, acc);
+    store_transposed<true>(acc, bufB, f0, l32, half);
+    __syncthreads();  // also: every wave is done reading bufA
+    layernorm_rows<false>(bufB, W + LN2_G, W + LN2_B, wave, lane, part_s, part_q, nullptr);
+
+    // rnn: GRU cell (gate order r, z, n as in torch) on x = bufB, h = bufA
+#pragma unroll
+    for (int j = 0; j < MSLICE; j++) bufA[(f0 + j) * TILE + lane] = hm[j];
+    __syncthreads();
+    {
+        f32x32 gi, gh, r, z;
+        dense_mfma<3 * HID, 3 * HID>(Wv + GI_B + f0, Wv + GI_W + f0, Wv + GH_W + f0, bufB + lane, l32, half, pa, gi);
+        dense_mfma<3 * HID, 3 * HID>(Wv + GH_B + f0, Wv + GH_W + f0, Wv + GI_W + HID + f0, bufA + lane, l32, half, pa, gh);
+#pragma unroll
+        for (int e = 0; e < 32; e++) r[e] = act_sigmoid(gi[e] + gh[e]);
+        dense_mfma<3 * HID, 3 * HID>(Wv + GI_B + HID + f0, Wv + GI_W + HID + f0, Wv + GH_W + HID + f0, bufB + lane, l32, half, pa, gi);
+        dense_mfma<3 * HID, 3 * HID>(Wv + GH_B + HID + f0, Wv + GH_W + HID + f0, Wv + GI_W + 2 * HID + f0, bufA + lane, l32, half, pa, gh);
+#pragma unroll
+        for (int e = 0; e < 32; e++) z[e] = act_sigmoid(gi[e] + gh[e]);
+        dense_mfma<3 * HID, 3 * HID>(Wv + GI_B + 2 * HID + f0, Wv + GI_W + 2 * HID + f0, Wv + GH_W + 2 * HID + f0, bufB + lane, l32, half, pa, gi);
+        dense_mfma<3 * HID, HID>(Wv + GH_B + 2 * HID + f0, Wv + GH_W + 2 * HID + f0, Wv + A1_W + f0, bufA + lane, l32, half, pa, gh);
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+            const float nn = act_tanh(gi[e] + r[e] * gh[e]);
+            const float hp = bufA[(f0 + mf_feat(e, half)) * TILE + mf_row(e, l32)];
+            acc[e] = (hp - nn) * z[e] + nn;
+        }
+    }
+    __syncthreads();  // every wave is done reading x (bufB) and h (bufA)
+    store_transposed<false>(acc, bufB, f0, l32, half);
+    __syncthreads();
+    // new recurrent state out (128 B per thread), then rnn.norm in place
+    layernorm_rows<true>(bufB, W + LN3_G, W + LN3_B, wave, lane, part_s, part_q, valid ? h_out + i * HID : nullptr);
+    // act.mlp
+    dense_mfma<HID, HID>(Wv + A1_B + f0, Wv + A1_W + f0, Wv + A2_W + f0, bufB + lane, l32, half, pa, acc);
+    store_transposed<true>(acc, bufA, f0, l32, half);
+    __syncthreads();
+    layernorm_rows<false>(bufA, W + LN4_G, W + LN4_B, wave, lane, part_s, part_q, nullptr);
+    dense_mfma<HID, HID>(Wv + A2_B + f0, Wv + A2_W + f0, Wv + A2_W + f0, bufA + lane, l32, half, pa, acc);  // nothing follows
+    store_transposed<true>(acc, bufB, f0, l32, half);
+    __syncthreads();
+    layernorm_rows<false>(bufB, W + LN5_G, W + LN5_B, wave, lane, part_s, part_q, nullptr);
     // mu_net: Linear(128, 4) + tanh — wave 0
     if (wave == 0) {
         float m[4];

@@ -947,21 +947,27 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
                      float *actions, float *h_out, int device, void *stream) {
     if (!weights || !obs || !h_in || !masks || !actions || !h_out) return fail("null argument");
     if (num_floats != npact::TOTAL) return fail("packed actor weights: wrong size (expected NP_ACTOR_NUM_FLOATS)");
+    if (((uintptr_t)h_in | (uintptr_t)h_out) & 15) return fail("h_in / h_out must be 16-byte aligned");
     if (n <= 0) return 0;
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
     DeviceGuard guard;
     NP_HIP(guard.enter(device));
+#if NPACT_MFMA
+    const auto kernel = npact::actor_forward_mfma_kernel;
+    const dim3 grid((unsigned)((n + npact::TILE - 1) / npact::TILE)), block(npact::MTHREADS);
+#else
+    const auto kernel = npact::actor_forward_kernel;
+    const dim3 grid((unsigned)((n + npact::TILE - 1) / npact::TILE)), block(npact::THREADS);
+#endif
     static bool lds_set[64] = {};
-    if (device < 64 && !lds_set[device]) {  // 100 KB of LDS per workgroup: above the 64 KB a kernel may use without asking
-        NP_HIP(hipFuncSetAttribute((const void *)npact::actor_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)npact::ACTOR_LDS_BYTES));
+    if (device < 64 && !lds_set[device]) {  // 68 KB of LDS per workgroup: above the 64 KB a kernel may use without asking
+        NP_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)npact::ACTOR_LDS_BYTES));
         lds_set[device] = true;
     }
-    const dim3 grid((unsigned)((n + npact::TILE - 1) / npact::TILE)), block(npact::THREADS);
-    hipLaunchKernelGGL(npact::actor_forward_kernel, grid, block, npact::ACTOR_LDS_BYTES, (hipStream_t)stream, weights, (long long)n,
-                       obs, h_in, masks, actions, h_out);
+    hipLaunchKernelGGL(kernel, grid, block, npact::ACTOR_LDS_BYTES, (hipStream_t)stream, weights, (long long)n, obs, h_in, masks,
+                       actions, h_out);
     NP_HIP(hipGetLastError());
     return 0;
 }

@@ -460,6 +460,139 @@ def gen_actor_dense(K=128):
     print('wrote', ACTOR_OUT)
 
 
+# ------------------------------------------------------------------------------------------------
+# The fused controller on the matrix cores (np_actor.h, actor_forward_mfma_kernel): one wave, 32 output features x 64 rows of a
+# Linear(128, .) layer as a chain of 128 v_mfma_f32_32x32x1_2b_f32 (K = 1 each: one exact fused multiply-add per element, so the
+# chain is acc = fma(W[f][k], x[k], acc), k ascending).  Operands are fetched a group of M_G features ahead: A = weights by
+# global_load_dword (SGPR base + per-lane offset + immediate), B = inputs by ds_read2st64_b32 from the LDS matrix [feature][row].
+# ------------------------------------------------------------------------------------------------
+M_G = 8
+M_A = [222, 238]          # v[222:229] / v[238:245]: A operands of the two groups in flight
+M_B = [230, 246]          # v[230:237] / v[246:253]: B operands
+M_VOFF = 254              # per-lane byte offset of the weight column
+M_XADDR = 255             # LDS byte address of x[first feature of the group][lane]
+M_SBASE = 4               # s[4:5], s[6:7], s[8:9]: row bases (a 12-bit immediate reaches 4095 B)
+M_SCNT = 10
+M_SNEXT = 12              # s[12:17]: row bases of the next layer's first group
+
+
+def gen_actor_mfma(lines, LD, LDN, K=128):
+    A = lines.append
+    stride = LD * 4
+    per_base = min(M_G, 4095 // stride + 1)
+    nbase = (M_G + per_base - 1) // per_base
+    assert nbase <= 3 and K % (2 * M_G) == 0
+    A(f'// 32 features x 64 rows of a Linear({K}, .) layer whose packed rows are {LD} floats apart: w = &Wt[0][f0] (wave-uniform),')
+    A('// voff = 4 * (lane % 32), xaddr = LDS byte address of x[0][lane]; pa = W[f][0..7] of this lane (prefetched); acc holds the bias on entry')
+    A(f'// wnext = &Wt[0][f0] of the layer that runs next (rows {LDN} floats apart): its first 8 A operands are fetched behind the last')
+    A('// MFMAs of this layer and returned in pa, so the next chain starts without waiting for L2')
+    A('template <>')
+    A(f'__device__ __forceinline__ void actor_dense_mfma_asm<{LD}, {LDN}>(const float *w, const float *wnext, unsigned voff, unsigned xaddr,')
+    A('                                                                  float (&pa)[8], f32x32 &acc) {')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    def loads(g):      # the next M_G features into register group g, then advance the bases and the LDS address
+        for u in range(M_G):
+            b, r = divmod(u, per_base)
+            sb = M_SBASE + 2 * b
+            emit(f'global_load_dword v{M_A[g] + u}, v{M_VOFF}, s[{sb}:{sb + 1}] offset:{r * stride}')
+        for u in range(0, M_G, 2):
+            emit(f'ds_read2st64_b32 v[{M_B[g] + u}:{M_B[g] + u + 1}], v{M_XADDR} offset0:{u} offset1:{u + 1}')
+        for b in range(nbase):
+            sb = M_SBASE + 2 * b
+            emit(f's_add_u32 s{sb}, s{sb}, {M_G * stride}')
+            emit(f's_addc_u32 s{sb + 1}, s{sb + 1}, 0')
+        emit(f'v_add_u32 v{M_XADDR}, {M_G * 256}, v{M_XADDR}')
+
+    def mfmas(g, lo, hi):
+        for u in range(lo, hi):
+            emit(f'v_mfma_f32_32x32x1_2b_f32 %[acc], v{M_A[g] + u}, v{M_B[g] + u}, %[acc]')
+
+    def bump_bases():
+        for b in range(nbase):
+            sb = M_SBASE + 2 * b
+            emit(f's_add_u32 s{sb}, s{sb}, {M_G * stride}')
+            emit(f's_addc_u32 s{sb + 1}, s{sb + 1}, 0')
+
+    # prologue: the A operands of features 0..7 were fetched by the caller (before the previous layer's epilogue) and arrive as
+    # inputs; only the B operands (LDS, short latency) are read here
+    emit(f's_mov_b64 s[{M_SBASE}:{M_SBASE + 1}], %[w]')
+    for b in range(1, nbase):
+        sb = M_SBASE + 2 * b
+        emit(f's_add_u32 s{sb}, s{M_SBASE}, {b * per_base * stride}')
+        emit(f's_addc_u32 s{sb + 1}, s{M_SBASE + 1}, 0')
+    emit(f'v_mov_b32 v{M_VOFF}, %[voff]')
+    emit(f'v_mov_b32 v{M_XADDR}, %[xaddr]')
+    for u in range(M_G):
+        emit(f'v_mov_b32 v{M_A[0] + u}, %[p{u}]')
+    for u in range(0, M_G, 2):
+        emit(f'ds_read2st64_b32 v[{M_B[0] + u}:{M_B[0] + u + 1}], v{M_XADDR} offset0:{u} offset1:{u + 1}')
+    bump_bases()
+    emit(f'v_add_u32 v{M_XADDR}, {M_G * 256}, v{M_XADDR}')
+    emit(f's_mov_b32 s{M_SCNT}, {K // (2 * M_G) - 1}')
+    emit('s_waitcnt lgkmcnt(0)')
+    # steady state: the next group's loads are issued behind the first MFMA of the current group (the matrix pipe never drains:
+    # the previous user of the registers they overwrite completed before that MFMA could start, the chain is dependent)
+    emit('.LMF_LOOP_%=:')
+    mfmas(0, 0, 1)
+    loads(1)
+    mfmas(0, 1, M_G)
+    emit('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    mfmas(1, 0, 1)
+    loads(0)
+    mfmas(1, 1, M_G)
+    emit(f's_sub_u32 s{M_SCNT}, s{M_SCNT}, 1')
+    emit('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    emit(f's_cmp_lg_u32 s{M_SCNT}, 0')
+    emit('s_cbranch_scc1 .LMF_LOOP_%=')
+    mfmas(0, 0, 1)
+    loads(1)
+    mfmas(0, 1, M_G)
+    emit('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    mfmas(1, 0, 1)
+    nstride = LDN * 4
+    nper = min(M_G, 4095 // nstride + 1)
+    for b in range((M_G + nper - 1) // nper):
+        sb = M_SNEXT + 2 * b
+        if b == 0:
+            emit(f's_mov_b64 s[{sb}:{sb + 1}], %[wn]')
+        else:
+            emit(f's_add_u32 s{sb}, s{M_SNEXT}, {b * nper * nstride}')
+            emit(f's_addc_u32 s{sb + 1}, s{M_SNEXT + 1}, 0')
+    for u in range(M_G):
+        b, r = divmod(u, nper)
+        sb = M_SNEXT + 2 * b
+        emit(f'global_load_dword %[p{u}], v{M_VOFF}, s[{sb}:{sb + 1}] offset:{r * nstride}')
+    mfmas(1, 1, M_G)
+    emit('s_waitcnt vmcnt(0)')
+    emit('s_nop 15')          # 16-pass XDL result -> the VALU / LDS instructions the compiler places after this statement
+    emit('s_nop 7')
+    outs = ', '.join(f'[p{u}] "+v"(pa[{u}])' for u in range(M_G))   # in: consumed by the v_movs of the prologue; out: the next layer's
+    A(f'        : [acc] "+v"(acc), {outs}')
+    A('        : [w] "s"(w), [wn] "s"(wnext), [voff] "v"(voff), [xaddr] "v"(xaddr)')
+    regs = list(range(M_A[0], M_XADDR + 1))
+    clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in range(M_SBASE, M_SNEXT + 6)] + ['"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+
+
+def gen_actor_mfma_file():
+    out = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_actor_mfma_asm.inc')
+    lines = ['// GENERATED by tools/gen_mlp_asm.py (gen_actor_mfma) — do not edit.', '#pragma once',
+             'typedef float f32x32 __attribute__((ext_vector_type(32)));',
+             'template <int LD, int LD_NEXT>',
+             '__device__ __forceinline__ void actor_dense_mfma_asm(const float *w, const float *wnext, unsigned voff, unsigned xaddr, float (&pa)[8], f32x32 &acc);']
+    for LD in (128, 384):
+        for LDN in (128, 384):
+            gen_actor_mfma(lines, LD, LDN)
+    with open(out, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('wrote', out)
+
+
 def main():
     out = ['// GENERATED by tools/gen_mlp_asm.py — do not edit.  See that file for the design notes.',
            '// One asm statement per net class: double-buffered scalar weight stream + v_pk_fma_f32 chains.',
@@ -497,3 +630,4 @@ def main():
 if __name__ == '__main__':
     main()
     gen_actor_dense()
+    gen_actor_mfma_file()

@@ -7,7 +7,7 @@ cp neuralplane_amd/csrc/libneuralplane_hip.so /tmp/keep.so
 for rep in 1 2; do
   for v in "$@"; do
     cp tools/microbench/libs/$v.so neuralplane_amd/csrc/libneuralplane_hip.so; touch neuralplane_amd/csrc/libneuralplane_hip.so
-    echo "== $v"; timeout 120 python tools/microbench/actor_bench.py 2>&1 | grep -E "n=(16384|262144):"
+    echo "== $v"; timeout 120 python tools/microbench/actor_bench.py 2>&1 | grep -E "n=(64|16384|262144):"
   done
 done
 cp /tmp/keep.so neuralplane_amd/csrc/libneuralplane_hip.so
