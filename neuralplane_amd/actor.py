@@ -82,6 +82,8 @@ class FusedActor:
         n = obs.shape[0]
         obs = obs.to(device=self.device, dtype=torch.float32).contiguous()
         h = rnn_states.to(device=self.device, dtype=torch.float32).reshape(n, HID).contiguous()
+        if h.data_ptr() % 16:  # a view at an odd storage offset: the kernel reads the state 16 bytes at a time
+            h = h.clone()
         m = masks.to(device=self.device, dtype=torch.float32).reshape(n).contiguous()
         act = torch.empty((n, ACT), dtype=torch.float32, device=self.device)
         h_out = torch.empty((n, 1, HID), dtype=torch.float32, device=self.device)

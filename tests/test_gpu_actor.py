@@ -81,3 +81,28 @@ def test_planning_env_with_fused_actor_eager_and_graph(golden_dir):
     act, _, _ = env.controller(ll, env.ego_rnn_states, torch.ones((n, 1), device='cuda'))
     a_o, _ = ActorOracle(w).forward(ll.cpu().numpy(), env.ego_rnn_states.cpu().numpy()[:, 0], np.ones(n, np.float32))
     assert _same(act.cpu().numpy(), a_o)
+
+
+def test_misaligned_recurrent_state(golden_dir):
+    """h_in / h_out are read and written 16 bytes at a time: the raw entry point rejects a misaligned pointer loudly, the
+    FusedActor wrapper realigns a view at an odd storage offset and returns the same result."""
+    import ctypes as C
+    from neuralplane_amd import _lib
+    from neuralplane_amd.actor import FusedActor, NUM_FLOATS
+    g = np.load(f'{golden_dir}/actor_kat.npz')
+    fa = FusedActor(_sd(g), 'cuda:0')
+    n = 70
+    rng = np.random.RandomState(3)
+    obs = torch.from_numpy(rng.normal(0, 1, (n, 22)).astype(np.float32)).cuda()
+    big = torch.from_numpy(rng.normal(0, 0.5, (n * 128 + 1,)).astype(np.float32)).cuda()
+    m = torch.ones(n, 1, device='cuda')
+    h_view = big[1:].view(n, 1, 128)                    # storage offset 1 float: 4-byte aligned only
+    assert h_view.data_ptr() % 16 != 0
+    a0, _, h0 = fa(obs, h_view.clone(), m)
+    a1, _, h1 = fa(obs, h_view, m)
+    assert torch.equal(a0, a1) and torch.equal(h0, h1)
+    act = torch.empty((n, 4), device='cuda')
+    h_out = torch.empty((n, 128), device='cuda')
+    rc = fa.lib.np_actor_forward(fa.weights.data_ptr(), NUM_FLOATS, n, obs.data_ptr(), h_view.data_ptr(), m.data_ptr(), act.data_ptr(),
+                                 h_out.data_ptr(), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b'aligned' in _lib.load().np_last_error()
