@@ -299,6 +299,33 @@ def main():
                 'kernel_avg_ms': ms3, 'steps': k3, 'engagements': E,
                 'note': 'one f16_combat_kernel launch per SingleCombatEnv.step (pairwise reset, 5 x {PID stack, FDM step, '
                         'terminations}, pairwise obs/reward/blood); HIP == oracle bit-exact (tests/test_gpu_combat_parity.py)'}
+        if world == 1 and not args.no_cpu_baseline:
+            # BASELINE.json configs[3] (hierarchical Tracking, a parity-test case reported beside the headline): PlanningEnv.step =
+            # 50 x {low-level obs, frozen PPOActor-architecture controller as ONE fused MFMA kernel, fused env step}, at the batch
+            # size of the reference's own training script (n = 1e4); random-init controller weights of that architecture
+            import numpy as np
+            from neuralplane_amd.actor import FusedActor, NUM_FLOATS
+            from neuralplane_amd.envs.planning_env import PlanningEnv
+            torch.cuda.empty_cache()
+            npl = 10_000
+            ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), str(dev))
+            penv = PlanningEnv(num_envs=npl, config='tracking', model='F16', random_seed=0, device=str(dev), controller=ctrl)
+            ap = torch.rand((npl, 3), generator=g, device=dev) * 2 - 1
+            for i in range(3):
+                penv.step(ap)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            k7 = 20
+            for i in range(k7):
+                penv.step(ap)
+            torch.cuda.synchronize(dev)
+            el7 = time.perf_counter() - t1
+            out.setdefault('optional_modes', {})['planning_tracking_n1e4'] = {
+                'value': 1e3 * el7 / k7, 'unit': 'ms per PlanningEnv.step (50 inner FDM steps + 50 controller calls)', 'steps': k7,
+                'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7,
+                'note': 'controller = np_actor_forward (K=1 fp32 MFMA chains, bit-exact to its oracle: tests/test_gpu_actor.py); '
+                        'the same step with the controller as eager torch modules: 22 ms (tools/microbench/planning_bench.py)'}
+            del penv, ctrl
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
