@@ -5,11 +5,14 @@ through the numpy VecEnv contract the reference's runners use, then with tensors
 
     python examples/drop_in_rollout.py [num_envs] [steps]
 """
+import os
 import sys
 import time
 
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))   # run from a checkout without installing
 
 import neuralplane_amd.envs as npe
 import neuralplane_amd.envs.control_env
@@ -78,6 +81,41 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f'device-resident loop: {n * steps / dt:.3e} env-steps/s (policy included)')
+
+    # a PPO-style collection phase that never leaves the GPU: DeviceVecEnv -> DeviceReplayBuffer (the reference's ReplayBuffer
+    # API on device tensors) -> compute_returns() as one kernel launch -> recurrent mini-batches gathered on the device
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+
+    class Args:
+        buffer_size, n_rollout_threads, gamma, gae_lambda = min(steps, 100), n, 0.99, 0.95
+        use_proper_time_limits, use_gae, recurrent_hidden_size, recurrent_hidden_layers = False, True, 128, 1
+
+    venv = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=1, device=dev)])
+    buf = DeviceReplayBuffer(Args, 1, venv.observation_space, venv.action_space, device=dev)
+    value = torch.nn.Linear(128, 1).to(dev)
+    obs = venv.reset()                                            # torch [E, A, 22] on the device
+    buf.obs[0].copy_(obs)
+    h = torch.zeros(n, 128, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(Args.buffer_size):
+            a, h = policy(obs.reshape(n, -1), h)
+            v = value(h)
+            obs, rew, done, bad, tmo, _ = venv.step(a.reshape(n, 1, -1))
+            ended = (done | bad | tmo).reshape(n, 1)
+            h = h * (~ended)
+            masks = (~ended).float().reshape(n, 1, 1)
+            buf.insert(obs, a.reshape(n, 1, -1), rew, masks, torch.zeros(n, 1, 1, device=dev), v.reshape(n, 1, 1), h.reshape(n, 1, 1, 128),
+                       h.reshape(n, 1, 1, 128), bad_masks=(~bad).float().reshape(n, 1, 1))
+        buf.compute_returns(value(h).reshape(n, 1, 1))
+        nb = sum(batch[0].shape[0] for batch in DeviceReplayBuffer.recurrent_generator(buf, 5, 8))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    buf.after_update()
+    print(f'device-resident collection: {Args.buffer_size} steps x {n} envs into DeviceReplayBuffer + returns + 5 mini-batches ({nb} rows) '
+          f'in {dt * 1e3:.1f} ms = {n * Args.buffer_size / dt:.3e} env-steps/s; mean return-to-go {float(buf.returns[:-1].mean()):.3f}')
 
 
 if __name__ == '__main__':

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 7
+#define NP_ABI_VERSION 8
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -226,6 +226,17 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
 #define NP_ACTOR_NUM_FLOATS 153392
 int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
                      float *actions, float *h_out, int device, void *stream);
+
+/* Returns of one rollout for the device-resident rollout storage — replaces ReplayBuffer.compute_returns
+ * (reference algorithms/utils/buffer.py:139-173; a Python loop over time with numpy array operations there): one launch, a
+ * backward scan per column, the reference's float32 arithmetic operation by operation.  T = buffer_size, N =
+ * n_rollout_threads x num_agents; rewards [T][N]; value_preds, masks, bad_masks, returns [T+1][N] (row-major, device
+ * pointers); next_value [N].  use_gae: value_preds[T] = next_value is written and returns[0..T-1] are the GAE returns
+ * (returns[T] untouched); otherwise returns[T] = next_value and returns[t] are the discounted sums.  bad_masks may be NULL
+ * unless use_proper_time_limits.  gamma / gae_lambda are the Python floats of the reference's argument bag. */
+int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int use_proper_time_limits,
+                       const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,
+                       float *returns, int device, void *stream);
 
 /* np_f16_step has two bit-identical kernel variants: "throughput" (one lane per aircraft, two independent waves per
  * workgroup — large batches) and "latency" (four waves share a tile of 64 aircraft and split the 44 net evaluations of a

@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class NpF16Cfg(C.Structure):
@@ -74,7 +74,7 @@ class NpF16CombatIo(C.Structure):
 
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
            'np_f16_step', 'np_f16_derived', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing',
-           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward')
+           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns')
 KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2}
 
 _lib = None
@@ -110,6 +110,8 @@ def load():
     lib.np_f16_set_kernel_variant.argtypes = [C.c_void_p, C.c_int]
     lib.np_actor_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p]
+    lib.np_rollout_returns.argtypes = [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.np_f16_combat_ctx_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(NpF16CombatCfg), C.c_int, C.POINTER(C.c_void_p)]
     lib.np_f16_combat_reset.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16CombatIo), C.c_void_p]
     lib.np_f16_combat_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16CombatIo), C.c_void_p]

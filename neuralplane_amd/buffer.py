@@ -1,0 +1,161 @@
+"""DeviceReplayBuffer — the reference's rollout storage (algorithms/utils/buffer.py:27-256, `ReplayBuffer`) resident on the GPU.
+
+The reference keeps the rollout in numpy: with `GPUVecEnv` every env.step crosses PCIe six times and `insert()` copies
+each field on the host.  With `DeviceVecEnv` the observations, rewards and masks are already torch
+tensors on the device; this class keeps them there.  Same constructor (`args`, `num_agents`, `obs_space`, `act_space`),
+same field names and shapes, same methods and semantics:
+
+* `insert(obs, actions, rewards, masks, action_log_probs, value_preds, rnn_states_actor, rnn_states_critic, bad_masks=None)`
+  — buffer.py:76-112 (device-to-device copies; numpy inputs are uploaded);
+* `after_update()`, `clear()` — buffer.py:114-135;
+* `compute_returns(next_value)` — buffer.py:137-173: ONE kernel launch (`np_rollout_returns`, csrc/np_rollout.h) instead of a
+  Python loop over `buffer_size` steps of numpy array operations; bit-exact to the reference's float32 arithmetic;
+* `advantages` — buffer.py:68-74 (population std, as numpy's);
+* `recurrent_generator(buffer, num_mini_batch, data_chunk_length)` — buffer.py:175-256: the same chunking and the same
+  `torch.randperm` shuffle (CPU generator, so a seeded run draws the reference's permutation); the batches are gathered on the
+  device and yielded as torch tensors.
+
+There is no CPU fallback: `compute_returns` needs the HIP library and a device tensor.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _shape(space):
+    """get_shape_from_space (algorithms/utils/utils.py:16-28) for the Box spaces of the envs on this path."""
+    if hasattr(space, 'shape') and space.shape is not None and len(space.shape) > 0:
+        return tuple(space.shape)
+    if hasattr(space, 'n'):
+        return (1,)
+    raise NotImplementedError(f"Unsupported action space type: {type(space)}!")
+
+
+class DeviceReplayBuffer:
+
+    @staticmethod
+    def _flatten(T, N, x):
+        return x.reshape(T * N, *x.shape[2:])
+
+    @staticmethod
+    def _cast(x):
+        # [T, threads, agents, ...] -> [threads, agents, T, ...] -> [threads * agents * T, ...]   (buffer.py:33-35)
+        return x.permute(1, 2, 0, *range(3, x.dim())).reshape(-1, *x.shape[3:])
+
+    def __init__(self, args, num_agents, obs_space, act_space, device='cuda:0'):
+        self.device = torch.device(device)
+        self.buffer_size = args.buffer_size
+        self.n_rollout_threads = args.n_rollout_threads
+        self.num_agents = num_agents
+        self.gamma = args.gamma
+        self.use_proper_time_limits = args.use_proper_time_limits
+        self.use_gae = args.use_gae
+        self.gae_lambda = args.gae_lambda
+        self.recurrent_hidden_size = args.recurrent_hidden_size
+        self.recurrent_hidden_layers = args.recurrent_hidden_layers
+        self._obs_shape, self._act_shape = _shape(obs_space), _shape(act_space)
+        self._alloc()
+        self.step = 0
+
+    def _alloc(self):
+        T, N, A = self.buffer_size, self.n_rollout_threads, self.num_agents
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
+        o = lambda *s: torch.ones(s, dtype=torch.float32, device=self.device)
+        self.obs = z(T + 1, N, A, *self._obs_shape)
+        self.actions = z(T, N, A, *self._act_shape)
+        self.rewards = z(T, N, A, 1)
+        self.masks = o(T + 1, N, A, 1)
+        self.bad_masks = o(T + 1, N, A, 1)
+        self.action_log_probs = z(T, N, A, 1)
+        self.value_preds = z(T + 1, N, A, 1)
+        self.returns = z(T + 1, N, A, 1)
+        self.rnn_states_actor = z(T + 1, N, A, self.recurrent_hidden_layers, self.recurrent_hidden_size)
+        self.rnn_states_critic = torch.zeros_like(self.rnn_states_actor)
+
+    def _dev(self, x, like):
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return x.to(device=self.device, dtype=torch.float32).reshape(like.shape)
+
+    @property
+    def advantages(self):
+        adv = self.returns[:-1] - self.value_preds[:-1]
+        return (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-5)
+
+    def insert(self, obs, actions, rewards, masks, action_log_probs, value_preds, rnn_states_actor, rnn_states_critic, bad_masks=None,
+               **kwargs):
+        s = self.step
+        self.obs[s + 1].copy_(self._dev(obs, self.obs[0]))
+        self.actions[s].copy_(self._dev(actions, self.actions[0]))
+        self.rewards[s].copy_(self._dev(rewards, self.rewards[0]))
+        self.masks[s + 1].copy_(self._dev(masks, self.masks[0]))
+        self.action_log_probs[s].copy_(self._dev(action_log_probs, self.action_log_probs[0]))
+        self.value_preds[s].copy_(self._dev(value_preds, self.value_preds[0]))
+        self.rnn_states_actor[s + 1].copy_(self._dev(rnn_states_actor, self.rnn_states_actor[0]))
+        self.rnn_states_critic[s + 1].copy_(self._dev(rnn_states_critic, self.rnn_states_critic[0]))
+        if bad_masks is not None:
+            self.bad_masks[s + 1].copy_(self._dev(bad_masks, self.bad_masks[0]))
+        self.step = (self.step + 1) % self.buffer_size
+
+    def after_update(self):
+        self.obs[0].copy_(self.obs[-1])
+        self.masks[0].copy_(self.masks[-1])
+        self.bad_masks[0].copy_(self.bad_masks[-1])
+        self.rnn_states_actor[0].copy_(self.rnn_states_actor[-1])
+        self.rnn_states_critic[0].copy_(self.rnn_states_critic[-1])
+
+    def clear(self):
+        self.step = 0
+        self._alloc()
+
+    def compute_returns(self, next_value):
+        if self.device.type != 'cuda':
+            raise RuntimeError('DeviceReplayBuffer.compute_returns runs on the GPU (np_rollout_returns); there is no CPU fallback')
+        lib = _lib.load()
+        nv = self._dev(next_value, self.value_preds[0]).contiguous()
+        T, N = self.buffer_size, self.n_rollout_threads * self.num_agents
+        for x in (self.rewards, self.value_preds, self.masks, self.bad_masks, self.returns):
+            assert x.is_contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(lib.np_rollout_returns(T, N, float(self.gamma), float(self.gae_lambda), int(bool(self.use_gae)),
+                                          int(bool(self.use_proper_time_limits)), self.rewards.data_ptr(), self.value_preds.data_ptr(),
+                                          self.masks.data_ptr(), self.bad_masks.data_ptr(), nv.data_ptr(), self.returns.data_ptr(),
+                                          self.device.index or 0, stream))
+
+    @staticmethod
+    def recurrent_generator(buffer, num_mini_batch, data_chunk_length):
+        buffer = [buffer] if isinstance(buffer, DeviceReplayBuffer) else buffer
+        n_rollout_threads, buffer_size, num_agents = buffer[0].n_rollout_threads, buffer[0].buffer_size, buffer[0].num_agents
+        assert all(b.n_rollout_threads == n_rollout_threads and b.buffer_size == buffer_size and b.num_agents == num_agents
+                   and isinstance(b, DeviceReplayBuffer) for b in buffer), "Input buffers must has the same type and shape"
+        buffer_size = buffer_size * len(buffer)
+        assert n_rollout_threads * buffer_size >= data_chunk_length, (
+            "PPO requires the number of processes ({}) * buffer size ({}) * num_agents ({})"
+            "to be greater than or equal to the number of "
+            "data chunk length ({}).".format(n_rollout_threads, buffer_size, num_agents, data_chunk_length))
+        cast, cat = DeviceReplayBuffer._cast, (lambda xs: torch.cat(xs, dim=0))
+        obs = cat([cast(b.obs[:-1]) for b in buffer])
+        actions = cat([cast(b.actions) for b in buffer])
+        masks = cat([cast(b.masks[:-1]) for b in buffer])
+        old_action_log_probs = cat([cast(b.action_log_probs) for b in buffer])
+        advantages = cat([cast(b.advantages) for b in buffer])
+        returns = cat([cast(b.returns[:-1]) for b in buffer])
+        value_preds = cat([cast(b.value_preds[:-1]) for b in buffer])
+        rnn_states_actor = cat([cast(b.rnn_states_actor[:-1]) for b in buffer])
+        rnn_states_critic = cat([cast(b.rnn_states_critic[:-1]) for b in buffer])
+
+        data_chunks = n_rollout_threads * buffer_size // data_chunk_length   # as the reference: agents are not counted here
+        mini_batch_size = data_chunks // num_mini_batch
+        rand = torch.randperm(data_chunks)                                    # CPU generator: the reference's permutation
+        L, N = data_chunk_length, mini_batch_size
+        ar = torch.arange(L, device=obs.device)
+        for i in range(num_mini_batch):
+            indices = rand[i * mini_batch_size:(i + 1) * mini_batch_size].to(obs.device)
+            first = indices * L                                               # [N] first row of every chunk
+            rows = (first[None, :] + ar[:, None]).reshape(-1)                 # [L, N] -> L * N, time-major like np.stack(axis=1)
+            yield (obs[rows], actions[rows], masks[rows], old_action_log_probs[rows], advantages[rows], returns[rows], value_preds[rows],
+                   rnn_states_actor[first].reshape(N, *buffer[0].rnn_states_actor.shape[3:]),
+                   rnn_states_critic[first].reshape(N, *buffer[0].rnn_states_critic.shape[3:]))

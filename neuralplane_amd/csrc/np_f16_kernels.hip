@@ -23,6 +23,7 @@
 #include "np_f16_device.h"
 #include "np_f16_combat.h"
 #include "np_actor.h"
+#include "np_rollout.h"
 
 namespace npf16 {
 
@@ -968,6 +969,40 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     }
     hipLaunchKernelGGL(kernel, grid, block, npact::ACTOR_LDS_BYTES, (hipStream_t)stream, weights, (long long)n, obs, h_in, masks,
                        actions, h_out);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int use_proper_time_limits,
+                       const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,
+                       float *returns, int device, void *stream) {
+    if (!rewards || !value_preds || !masks || !next_value || !returns) return fail("null argument");
+    if (use_proper_time_limits && !bad_masks) return fail("use_proper_time_limits needs bad_masks");
+    if (T < 0 || N < 0) return fail("negative size");
+    if (N == 0) return 0;
+    int ndev = 0;
+    NP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(device));
+    const float g = (float)gamma, gl = (float)(gamma * gae_lambda);
+    const int threads = N >= nproll::MANY_COLUMNS ? nproll::THREADS : 64;
+    const dim3 grid((unsigned)((N + threads - 1) / threads)), block(threads);
+    hipStream_t st = (hipStream_t)stream;
+#define NP_RET(G, P)                                                                                                              \
+    do {                                                                                                                          \
+        if (N >= nproll::MANY_COLUMNS)                                                                                            \
+            hipLaunchKernelGGL((nproll::returns_kernel<G, P, nproll::U_MANY_COLUMNS>), grid, block, 0, st, (long long)T, (long long)N, g, gl, \
+                               rewards, value_preds, masks, bad_masks, next_value, returns);                                      \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((nproll::returns_kernel<G, P, nproll::U_FEW_COLUMNS>), grid, block, 0, st, (long long)T, (long long)N, g, gl,  \
+                               rewards, value_preds, masks, bad_masks, next_value, returns);                                      \
+    } while (0)
+    if (use_gae && use_proper_time_limits) NP_RET(true, true);
+    else if (use_gae) NP_RET(true, false);
+    else if (use_proper_time_limits) NP_RET(false, true);
+    else NP_RET(false, false);
+#undef NP_RET
     NP_HIP(hipGetLastError());
     return 0;
 }

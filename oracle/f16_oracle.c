@@ -908,3 +908,4 @@ int f16o_num_threads(void) {
 
 #include "f16_combat.inc"
 #include "f16_actor.inc"
+#include "f16_rollout.inc"

@@ -169,6 +169,11 @@ int f16o_actor_num_floats(void);
 void f16o_actor_forward(const float *w, int64_t n, const float *obs, const float *h_in, const float *mask, float *act,
                         float *h_out);
 
+/* ReplayBuffer.compute_returns (f16_rollout.inc; reference algorithms/utils/buffer.py:139-173): rewards [T][N], value_preds / masks /
+ * bad_masks / returns [T+1][N], next_value [N]; GAE modes write value_preds[T], the others returns[T] */
+void f16o_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int proper, const float *rewards,
+                          float *value_preds, const float *masks, const float *bad_masks, const float *next_value, float *returns);
+
 int f16o_num_threads(void);
 void f16o_set_threads(int n); /* OpenMP threads used by the batched entry points */
 

@@ -41,7 +41,7 @@ class Cfg(C.Structure):
 
 def build(force=False):
     """Compile oracle/_build/libf16oracle.so with gcc (Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_actor.inc', 'f16_oracle.h', 'Makefile'))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_actor.inc', 'f16_rollout.inc', 'f16_oracle.h', 'Makefile'))
     if os.environ.get('F16O_SO'):      # e.g. the sanitizer build (`make -C oracle asan-test`)
         return os.environ['F16O_SO']
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
@@ -410,3 +410,24 @@ class ActorOracle:
         h_out = np.empty((n, 128), np.float32)
         self.lib.f16o_actor_forward(_p(self.w), C.c_int64(n), _p(obs), _p(h), _p(m), _p(act), _p(h_out))
         return act, h_out
+
+
+# ---------------------------------------------------------------------------------------------
+# Rollout storage: ReplayBuffer.compute_returns (f16_rollout.inc)
+# ---------------------------------------------------------------------------------------------
+def rollout_returns(rewards, value_preds, masks, bad_masks, next_value, gamma, gae_lambda, use_gae, proper):
+    """rewards [T, ...], value_preds / masks / bad_masks [T+1, ...] (trailing dims flattened to N columns), next_value [...].
+    Returns (returns[T+1, ...], value_preds[T+1, ...]) as the reference's buffer holds them after compute_returns()."""
+    lib = C.CDLL(build())
+    shape = np.asarray(value_preds).shape
+    T = shape[0] - 1
+    r = _f32(rewards).reshape(T, -1).copy()
+    N = r.shape[1]
+    v = _f32(value_preds).reshape(T + 1, N).copy()
+    m = _f32(masks).reshape(T + 1, N).copy()
+    b = _f32(bad_masks).reshape(T + 1, N).copy()
+    nv = _f32(next_value).reshape(N).copy()
+    ret = np.zeros((T + 1, N), np.float32)
+    lib.f16o_rollout_returns(C.c_int64(T), C.c_int64(N), C.c_double(gamma), C.c_double(gae_lambda), C.c_int(int(use_gae)), C.c_int(int(proper)),
+                             _p(r), _p(v), _p(m), _p(b), _p(nv), _p(ret))
+    return ret.reshape(shape), v.reshape(shape)

@@ -1,0 +1,73 @@
+"""np_rollout_returns (DeviceReplayBuffer.compute_returns) through the C ABI: equal to the reference's ReplayBuffer bit for bit
+in its four modes (tests/golden/buffer_kat.npz), equal to the CPU oracle bit for bit on larger ragged shapes with terminal
+masks, NaN / inf entries and extreme values, and the argument checks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.f16_oracle import rollout_returns  # noqa: E402  (the checker; test infrastructure)
+from test_buffer_cpu import filled  # noqa: E402
+
+
+def _same(a, b):
+    return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize('proper', [0, 1])
+@pytest.mark.parametrize('gae', [0, 1])
+def test_compute_returns_equals_the_reference_buffer(golden_dir, proper, gae):
+    g = np.load(f'{golden_dir}/buffer_kat.npz')
+    buf = filled(g, proper, gae, 'cuda:0')
+    buf.compute_returns(g['in::next_value'])
+    tag = f'proper{proper}_gae{gae}'
+    assert np.array_equal(buf.returns.cpu().numpy(), g[f'{tag}::returns'])
+    assert np.array_equal(buf.value_preds.cpu().numpy(), g[f'{tag}::value_preds'])
+    assert np.allclose(buf.advantages.cpu().numpy(), g[f'{tag}::advantages'], rtol=0, atol=2e-6)
+    if gae and not proper:
+        torch.manual_seed(int(g['torch_seed']))
+        for b, batch in enumerate(type(buf).recurrent_generator(buf, int(g['num_mini_batch']), int(g['data_chunk_length']))):
+            assert all(x.is_cuda for x in batch)
+            assert np.array_equal(batch[5].cpu().numpy(), g[f'batch{b}::returns']) and np.array_equal(batch[0].cpu().numpy(), g[f'batch{b}::obs'])
+
+
+@pytest.mark.parametrize('T,N', [(1, 1), (7, 63), (37, 1000), (128, 257), (3, 70001)])
+@pytest.mark.parametrize('mode', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_hip_equals_oracle_on_ragged_shapes_and_hostile_values(T, N, mode):
+    from neuralplane_amd import _lib
+    proper, gae = mode
+    rng = np.random.RandomState(T * 131 + N)
+    r = rng.normal(0, 50, (T, N)).astype(np.float32)
+    v = rng.normal(0, 30, (T + 1, N)).astype(np.float32)
+    m = (rng.uniform(0, 1, (T + 1, N)) > 0.1).astype(np.float32)
+    b = (rng.uniform(0, 1, (T + 1, N)) > 0.1).astype(np.float32)
+    nv = rng.normal(0, 30, N).astype(np.float32)
+    if N >= 63:
+        r[0, 3], r[T - 1, 5], v[T // 2, 7], nv[9] = np.nan, np.inf, -np.inf, np.nan
+        r[:, 11], v[:, 12] = 3e38, 1e-42                                         # overflow in the scan, denormal values
+    o_ret, o_v = rollout_returns(r, v, m, b, nv, 0.99, 0.95, gae, proper)
+    lib = _lib.load()
+    d = lambda x: torch.from_numpy(x.copy()).cuda()
+    dr, dv, dm, db, dnv = d(r), d(v), d(m), d(b), d(nv)
+    dret = torch.zeros((T + 1, N), device='cuda')
+    rc = lib.np_rollout_returns(T, N, 0.99, 0.95, gae, proper, dr.data_ptr(), dv.data_ptr(), dm.data_ptr(), db.data_ptr(), dnv.data_ptr(),
+                                dret.data_ptr(), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.np_last_error()
+    assert _same(dret.cpu().numpy(), o_ret), (T, N, mode)
+    assert _same(dv.cpu().numpy(), o_v)
+
+
+def test_argument_checks():
+    from neuralplane_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros((5, 8), device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = x.data_ptr()
+    assert lib.np_rollout_returns(4, 0, 0.99, 0.95, 1, 0, p, p, p, None, p, p, 0, st) == 0           # empty rollout: nothing to do
+    assert lib.np_rollout_returns(4, 8, 0.99, 0.95, 1, 1, p, p, p, None, p, p, 0, st) != 0           # proper time limits need bad_masks
+    assert b'bad_masks' in lib.np_last_error()
+    assert lib.np_rollout_returns(4, 8, 0.99, 0.95, 1, 0, None, p, p, None, p, p, 0, st) != 0
+    assert lib.np_rollout_returns(4, 8, 0.99, 0.95, 1, 0, p, p, p, None, p, p, 99, st) != 0 and b'device' in lib.np_last_error()

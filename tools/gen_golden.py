@@ -779,8 +779,71 @@ def gen_combat_all():
     gen_combat(pin=False)
 
 
+def gen_buffer():
+    """The rollout storage on the policy side of the path: the reference's ReplayBuffer (algorithms/utils/buffer.py:27-256)
+    filled through insert() with seeded random data; compute_returns() in its four modes (GAE x proper time limits),
+    the normalised advantages, and the mini-batches of recurrent_generator() under a fixed torch seed."""
+    if not hasattr(np, 'product'):
+        np.product = np.prod
+    import gym
+    from algorithms.utils.buffer import ReplayBuffer
+    T, NT, NA, H = 12, 5, 2, 8
+    out = {'T': T, 'n_rollout_threads': NT, 'num_agents': NA, 'hidden': H, 'gamma': 0.99, 'gae_lambda': 0.95,
+           'num_mini_batch': 2, 'data_chunk_length': 4, 'torch_seed': 3}
+    obs_space, act_space = gym.spaces.Box(low=-10, high=10, shape=(22,)), gym.spaces.Box(low=-10, high=10, shape=(4,))
+    rng = np.random.RandomState(2718)
+    steps = []
+    for t in range(T):
+        steps.append(dict(obs=rng.normal(0, 1, (NT, NA, 22)).astype(np.float32), actions=rng.uniform(-1, 1, (NT, NA, 4)).astype(np.float32),
+                          rewards=rng.normal(0, 3, (NT, NA, 1)).astype(np.float32),
+                          masks=(rng.uniform(0, 1, (NT, NA, 1)) > 0.2).astype(np.float32),
+                          action_log_probs=rng.normal(-2, 1, (NT, NA, 1)).astype(np.float32),
+                          value_preds=rng.normal(0, 5, (NT, NA, 1)).astype(np.float32),
+                          rnn_states_actor=rng.normal(0, 1, (NT, NA, 1, H)).astype(np.float32),
+                          rnn_states_critic=rng.normal(0, 1, (NT, NA, 1, H)).astype(np.float32),
+                          bad_masks=(rng.uniform(0, 1, (NT, NA, 1)) > 0.15).astype(np.float32)))
+    obs0 = rng.normal(0, 1, (NT, NA, 22)).astype(np.float32)
+    next_value = rng.normal(0, 5, (NT, NA, 1)).astype(np.float32)
+    for k in steps[0]:
+        out['in::' + k] = np.stack([s[k] for s in steps])
+    out['in::obs0'], out['in::next_value'] = obs0, next_value
+    for proper in (False, True):
+        for gae in (False, True):
+            class A:
+                pass
+            a = A()
+            a.buffer_size, a.n_rollout_threads, a.gamma, a.gae_lambda = T, NT, 0.99, 0.95
+            a.use_proper_time_limits, a.use_gae = proper, gae
+            a.recurrent_hidden_size, a.recurrent_hidden_layers = H, 1
+            buf = ReplayBuffer(a, NA, obs_space, act_space)
+            buf.obs[0] = obs0.copy()
+            for s in steps:
+                buf.insert(**s)
+            assert buf.step == 0
+            buf.compute_returns(next_value)
+            tag = f'proper{int(proper)}_gae{int(gae)}'
+            out[f'{tag}::returns'], out[f'{tag}::value_preds'] = buf.returns.copy(), buf.value_preds.copy()
+            out[f'{tag}::advantages'] = buf.advantages.copy()
+            if gae and not proper:          # the shipped configuration: also the stored fields and the generator's batches
+                for f in ('obs', 'actions', 'rewards', 'masks', 'bad_masks', 'action_log_probs', 'rnn_states_actor', 'rnn_states_critic'):
+                    out['stored::' + f] = getattr(buf, f).copy()
+                torch.manual_seed(3)
+                names = ('obs', 'actions', 'masks', 'old_action_log_probs', 'advantages', 'returns', 'value_preds', 'rnn_states_actor',
+                         'rnn_states_critic')
+                for b, batch in enumerate(ReplayBuffer.recurrent_generator(buf, 2, 4)):
+                    for nm, x in zip(names, batch):
+                        out[f'batch{b}::{nm}'] = np.asarray(x)
+                buf.after_update()
+                out['after_update::obs0'], out['after_update::masks0'] = buf.obs[0].copy(), buf.masks[0].copy()
+                out['after_update::rnn_states_actor0'] = buf.rnn_states_actor[0].copy()
+    np.savez_compressed(os.path.join(OUT, 'buffer_kat.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'buffer':
+        gen_buffer()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'planning':
         gen_planning()
         return
@@ -808,6 +871,7 @@ def main():
     gen_combat_all()
     gen_acmi()
     gen_actor()
+    gen_buffer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
