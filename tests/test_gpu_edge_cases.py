@@ -170,3 +170,38 @@ def test_termination_counters_match_per_condition_sums(task, variant):
     assert list(got.values()) == expect.tolist(), (got, expect)
     assert sum(1 for v in got.values() if v > 0) >= 3
     assert b.termination_counts(reset=True) == got and sum(b.termination_counts().values()) == 0
+
+
+def _random_overrides(rng):
+    """Scenario constants drawn far around the shipped YAML values (every key the kernel's constant block is derived from)."""
+    lo_alt = float(rng.uniform(500, 6000))
+    lo_vt = float(rng.uniform(150, 600))
+    return {
+        'dt': float(rng.choice([0.005, 0.01, 0.02, 0.04])), 'airspeed': float(rng.uniform(0, 60)), 'noise_scale': float(rng.choice([0.0, 0.01, 0.3])),
+        'altitude_limit': float(rng.uniform(1000, 9000)), 'acceleration_limit': float(rng.uniform(20, 400)),
+        'max_velocity': float(rng.uniform(1.0, 4.0)), 'min_velocity': float(rng.uniform(0.005, 0.6)),
+        'min_alpha': float(rng.uniform(-30, -3)), 'max_alpha': float(rng.uniform(5, 60)), 'min_beta': float(rng.uniform(-40, -2)),
+        'max_beta': float(rng.uniform(2, 40)), 'max_check_interval': int(rng.randint(8, 60)), 'min_check_interval': int(rng.randint(2, 8)),
+        'min_altitude': lo_alt, 'max_altitude': lo_alt + float(rng.uniform(100, 30000)), 'min_vt': lo_vt, 'max_vt': lo_vt + float(rng.uniform(10, 2000)),
+        'max_heading_increment': float(rng.uniform(0.1, 3.1)), 'max_altitude_increment': float(rng.uniform(10, 5000)),
+        'max_velocities_u_increment': float(rng.uniform(1, 300)), 'max_pitch_increment': float(rng.uniform(0.05, 1.5)),
+        'max_distance': float(rng.uniform(1000, 20000)), 'min_distance': float(rng.uniform(1, 900)),
+        'init_state': {'init_T': float(rng.uniform(0, 20000))},
+    }
+
+
+@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('task', ['heading', 'control', 'tracking'])
+def test_randomised_scenario_constants(task, seed):
+    """A seeded sweep over the whole configuration surface: whatever constants the YAML carries, the kernel's constant block and
+    the oracle's must lead to the same bits (both kernel variants alternate by seed)."""
+    rng = np.random.RandomState(1000 + seed)
+    overrides = _random_overrides(rng)
+    n = 130
+    b, o = _mk(task, n, VARIANTS[seed % 2], overrides=overrides, seed=seed)
+    st = Oracle.new_state(n)
+    for t in range(14):
+        a = rng.uniform(-1.4, 1.4, (n, 4)).astype(np.float32)
+        obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t)
+        _check(b, obs, rew, flags, st, o_obs, o_rew, f'{task} random overrides {seed} step {t}')
