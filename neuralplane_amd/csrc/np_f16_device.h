@@ -513,8 +513,8 @@ __device__ __forceinline__ float eas2tas_of(float alt) {
 // ---------------------------------------------------------------------------------------------
 // reset of one flagged aircraft — F16_model.py:33-45 + task.reset + env_base.py:92
 // ---------------------------------------------------------------------------------------------
-template <int TASK>
-__device__ __forceinline__ void reset_row(const DevCfg &cfg, const float (&ru)[5], float (&s)[12], float (&u)[4],
+template <int TASK, class CFG>  // CFG: DevCfg, or DevCfg in the constant address space (scalar loads)
+__device__ __forceinline__ void reset_row(const CFG &cfg, const float (&ru)[5], float (&s)[12], float (&u)[4],
                                           float (&tgt)[3], long long &step_count) {
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0.0f;
@@ -551,8 +551,8 @@ __device__ __forceinline__ void reset_row(const DevCfg &cfg, const float (&ru)[5
 // ---------------------------------------------------------------------------------------------
 // observation (before noise) — heading_task.py:71-152 / control_task.py:70-152 / tracking_task.py:73-155
 // ---------------------------------------------------------------------------------------------
-template <int TASK>
-__device__ __forceinline__ void observe(const DevCfg &cfg, const float (&s)[12], const float (&u)[4], const float (&tgt)[3],
+template <int TASK, class CFG>  // CFG: DevCfg, or DevCfg in the constant address space (scalar loads)
+__device__ __forceinline__ void observe(const CFG &cfg, const float (&s)[12], const float (&u)[4], const float (&tgt)[3],
                                         const Trig &tr, float (&o)[22]) {
     const float alt = s[2], pitch = s[4], heading = s[5], vt = s[6];
     const float eas2tas = eas2tas_of(alt);
@@ -618,8 +618,8 @@ __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, 
 // terminations + reward at the new state — termination_conditions/*.py, reward_functions/*.py,
 // task_base.py:60-96, env_base.py:70-75
 // ---------------------------------------------------------------------------------------------
-template <int TASK>
-__device__ __forceinline__ void done_and_reward(const DevCfg &cfg, const float (&s)[12], const float (&tgt)[3],
+template <int TASK, class CFG>  // CFG: DevCfg, or DevCfg in the constant address space (scalar loads)
+__device__ __forceinline__ void done_and_reward(const CFG &cfg, const float (&s)[12], const float (&tgt)[3],
                                                 const float (&acc3)[3], long long step_count, bool done_prev, bool bad_prev,
                                                 bool &done, bool &bad, float &reward, unsigned &reasons) {
     // `reasons`: which condition fired at THIS state (NP_TERM_* bits) — what the reference prints per condition

@@ -45,6 +45,10 @@ constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22
 // (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
 constexpr int LDS_FLOATS = (NUM_LDS_SLOTS * BLOCK > BLOCK * OBS_LD) ? NUM_LDS_SLOTS * BLOCK : BLOCK * OBS_LD;
 
+struct KArgs;
+typedef const KArgs __attribute__((address_space(4))) *KArgsC;
+#define NP_REREAD_ARGS(ap) asm volatile("" : "+s"(ap) : : "memory")
+
 struct KArgs {
     float *s, *u, *tgt;
     long long ld;
@@ -90,8 +94,12 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
     const long long i = i0 + t;
     const bool valid = i < a.n;
     const long long ic = valid ? i : a.n - 1;  // tail lanes shadow the last row; their stores are masked
-    const DevCfg &cfg = a.cfg;
-    const bool tables = cfg.aero_1d_tables != 0;
+    // The two MLP phases are asm statements that own s2-s101.  Whatever scalar value is live across them (the ~60 dwords of
+    // scenario constants, the output pointers, ...) would be parked in VGPR lanes and fetched back with v_readlane — ~680 VALU
+    // slots per step.  Instead every phase re-reads what it needs from the kernel-argument segment through `ap`, a pointer the
+    // compiler cannot see through (NP_REREAD_ARGS) — scalar loads, off the VALU's critical path.
+    KArgsC ap = (KArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter: offset 0 of the segment
+    const bool tables = a.cfg.aero_1d_tables != 0;
     const uint64_t call_idx = a.call_idx + (a.call_idx_base ? *a.call_idx_base : 0ull);
 
     // ---- de-phasing -----------------------------------------------------------------------------------
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
             for (int k = 0; k < 4; k++) ru[k] = (float)(w0[k] >> 8) * 5.9604644775390625e-08f;
             ru[4] = (float)(w1[0] >> 8) * 5.9604644775390625e-08f;
         }
-        reset_row<TASK>(cfg, ru, s, u, tgt, sc);
+        reset_row<TASK>(a.cfg, ru, s, u, tgt, sc);
     }
 
     // cache tile of this workgroup: 14 rows of BLOCK floats, contiguous
@@ -168,13 +176,15 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
         u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
         u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
-        const float dt = cfg.dt;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
             xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, part);
+            NP_REREAD_ARGS(ap);
+            const float dt = ap->cfg.dt;
 #pragma unroll
             for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
         } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
+            const float dt = a.cfg.dt;
             const float third = (float)(1.0 / 3.0);
             float y[12], k1[12], k2[12], k3[12];
 #pragma unroll
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
             }
 #pragma unroll
             for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : y[k];
+            NP_REREAD_ARGS(ap);
         }
         sc += 1;  // env_base.py:102
     }
@@ -218,13 +229,14 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
     float tt_unused;
     trig_of(s, tr, tt_unused);
     float o[22];
-    observe<TASK>(cfg, s, u, tgt, tr, o);
-    if (a.noise) {  // obs + randn_like(obs) * noise_scale
+    observe<TASK>(ap->cfg, s, u, tgt, tr, o);
+    if (ap->noise) {  // obs + randn_like(obs) * noise_scale
 #pragma unroll
-        for (int k = 0; k < 22; k++) o[k] = o[k] + a.noise[ic * 22 + k] * cfg.noise_scale;
-    } else if (cfg.noise_scale != 0.0f) {
+        for (int k = 0; k < 22; k++) o[k] = o[k] + ap->noise[ic * 22 + k] * ap->cfg.noise_scale;
+    } else if (ap->cfg.noise_scale != 0.0f) {
 #if !(defined(NPF16_EXP) && (NPF16_EXP & 1))  // timing experiment only: no observation noise
-        add_rng_noise(a.seed, call_idx, a.row0 + ic, cfg.noise_scale, o);
+        const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
+        add_rng_noise(ap->seed, call_idx2, ap->row0 + ic, ap->cfg.noise_scale, o);
 #endif
     }
 
@@ -237,22 +249,26 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
 #if defined(NPF16_EXP) && (NPF16_EXP & 2)  // timing experiment only: no Overload evaluation
         for (int k = 0; k < 12; k++) xd[k] = s[k];
 #else
-        nlplant<false, AB_FORCE, TILE, WPT>(a.wt, s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
+        {
+            const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
+            nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, part);
+        }
 #endif
+        NP_REREAD_ARGS(ap);
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
         // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
-        const bool done_prev = a.inner && a.fin0[ic] != 0, bad_prev = a.inner && a.fin1[ic] != 0;
+        const bool done_prev = ap->inner && ap->fin0[ic] != 0, bad_prev = ap->inner && ap->fin1[ic] != 0;
         unsigned reasons = 0;
-        done_and_reward<TASK>(cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
-        if (a.term_counters) {
+        done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
+        if (ap->term_counters) {
             // the reference prints torch.sum(mask) per termination condition and step (a host sync each); here: one wave
             // ballot per condition, population count, ONE atomic per wave for a condition that fired at all
             const bool counted = valid && part == 0;
 #pragma unroll
             for (int k = 0; k < NP_NUM_TERM_COUNTERS; k++) {
                 const unsigned long long m = __ballot(counted && ((reasons >> k) & 1u));
-                if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(a.term_counters + k, (unsigned)__popcll(m));
+                if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(ap->term_counters + k, (unsigned)__popcll(m));
             }
         }
     }
@@ -263,34 +279,34 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         long long iw = i;
         asm volatile("" : "+v"(iw));
 #pragma unroll
-        for (int k = 0; k < 12; k++) a.s[k * a.ld + iw] = s[k];
+        for (int k = 0; k < 12; k++) ap->s[k * ap->ld + iw] = s[k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) a.u[k * a.ld + iw] = u[k];
+        for (int k = 0; k < 4; k++) ap->u[k * ap->ld + iw] = u[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) a.tgt[k * a.ld + iw] = tgt[k];
-        a.step_count[iw] = sc;
-        a.fout0[iw] = done ? 1 : 0;
-        a.fout1[iw] = bad ? 1 : 0;
-        a.fout2[iw] = tmo_prev ? 1 : 0;
-        if (STEP) a.reward[iw] = reward;
-        if (STEP && a.cache) {
-            float *cache_w = a.cache + ((iw >> 6) * NUM_CACHED) * CACHE_TILE + (iw & (CACHE_TILE - 1));
+        for (int k = 0; k < 3; k++) ap->tgt[k * ap->ld + iw] = tgt[k];
+        ap->step_count[iw] = sc;
+        ap->fout0[iw] = done ? 1 : 0;
+        ap->fout1[iw] = bad ? 1 : 0;
+        ap->fout2[iw] = tmo_prev ? 1 : 0;
+        if (STEP) ap->reward[iw] = reward;
+        if (STEP && ap->cache) {
+            float *cache_w = ap->cache + ((iw >> 6) * NUM_CACHED) * CACHE_TILE + (iw & (CACHE_TILE - 1));
 #pragma unroll
             for (int k = 0; k < NUM_CACHED; k++) cache_w[k * CACHE_TILE] = coef[cached_slot(k) * TILE];
         }
     }
 
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
-    if (a.obs) {
+    if (ap->obs) {
         __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
         if (part == 0) {
 #pragma unroll
             for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
         }
         __syncthreads();
-        const long long rows = (a.n - i0) < TILE ? (a.n - i0) : TILE;
+        const long long rows = (ap->n - i0) < TILE ? (ap->n - i0) : TILE;
         const int total = (int)rows * 22;
-        float *dst = a.obs + i0 * 22;
+        float *dst = ap->obs + i0 * 22;
         constexpr int THREADS = TILE * WPT;
 #pragma unroll
         for (int it = 0; it < (22 * TILE + THREADS - 1) / THREADS; it++) {
