@@ -37,6 +37,12 @@ struct CombatDevCfg {
     int aero_1d_tables;
 };
 
+struct CombatArgs;
+typedef const CombatArgs __attribute__((address_space(4))) *CombatArgsC;
+#ifndef NP_REREAD_ARGS
+#define NP_REREAD_ARGS(ap) asm volatile("" : "+s"(ap) : : "memory")
+#endif
+
 struct CombatArgs {
     float *s, *u, *pid, *blood;
     long long ld;
@@ -66,7 +72,8 @@ __device__ __forceinline__ float partner(float v) { return __shfl_xor(v, 1); }
 
 // {Roll,Pitch,Yaw}Controller.get_rate_out + PID.update_all / update_i (pid.py:18-42).  A row whose target or
 // measurement is non-finite holds its previous output (the reference skips the update of the whole batch).
-__device__ __forceinline__ float rate_out(const PidDev &g, float dt, float desired, float scaler, float eas2tas, float rate,
+template <class PID>  // PidDev, generic or constant address space
+__device__ __forceinline__ float rate_out(const PID &g, float dt, float desired, float scaler, float eas2tas, float rate,
                                           float &err, float &integ, float &last_out, bool strict, bool first) {
     const bool limit = strict ? fabsf(last_out) > 45.0f : fabsf(last_out) >= 45.0f;
     const float target = (desired * scaler) * scaler;
@@ -94,7 +101,8 @@ __device__ __forceinline__ float rate_out(const PidDev &g, float dt, float desir
 }
 
 // Controller.stabilize (controller.py:35-74) for one aircraft; rates = Euler-angle rates xdot[3..5]
-__device__ __forceinline__ void stabilize(const CombatDevCfg &cfg, const float (&s)[12], const Trig &tr, float tt,
+template <class CFG>  // CombatDevCfg, or CombatDevCfg in the constant address space (scalar loads)
+__device__ __forceinline__ void stabilize(const CFG &cfg, const float (&s)[12], const Trig &tr, float tt,
                                           float (&pid)[NUM_PID], bool first, float &el, float &ail, float &rud) {
     const float PI_F = 3.14159265358979323846f;
     const float P = s[9], Q = s[10], R = s[11];
@@ -225,6 +233,9 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
     const long long i = i0 + t;
     const bool valid = i < a.n;
     const long long ic = valid ? i : a.n - 1;  // n is even and B is even: a pair never straddles workgroups
+    // scalars are not kept live across the asm phases (which own s2-s101): every phase re-reads what it needs from the
+    // kernel-argument segment (NP_REREAD_ARGS, see f16_env_kernel)
+    CombatArgsC ap = (CombatArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter
     const CombatDevCfg &cfg = a.cfg;
     const bool tables = cfg.aero_1d_tables != 0;
     const bool is_ego = (t & 1) == 0;
@@ -290,25 +301,30 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             normalise_inputs(a.wt, s[7] * r2d, s[8] * r2d, u[1], xn);
             eval_ab<B, AB_FORCE>(a.wt, xn, coef, tables);
         }
+        NP_REREAD_ARGS(ap);
 #pragma nounroll
-        for (int it = 0; it < cfg.inner_steps; it++) {
+        for (int it = 0; it < ap->cfg.inner_steps; it++) {
             // ---- demand filters (:245-246) and Controller.stabilize ----
             pid[PID_ROLL_DEM] = 0.9f * pid[PID_ROLL_DEM] + (((0.1f * act[1]) * 4.0f) * PI_F) / 9.0f;
             pid[PID_PITCH_DEM] = 0.9f * pid[PID_PITCH_DEM] + ((0.1f * act[2]) * PI_F) / 12.0f;
             float el, ail, rud;
-            stabilize(cfg, s, tr, tt, pid, a.pid_first != 0 && it == 0, el, ail, rud);
+            stabilize(ap->cfg, s, tr, tt, pid, ap->pid_first != 0 && it == 0, el, ail, rud);
             u[0] = 0.9f * u[0] + (((0.1f * act[0]) * 0.225f) * 76300.0f) / 0.3048f;  // :251
             u[1] = -el;                                                                 // :252-255, written straight to u
             u[2] = -ail;
             u[3] = -rud;
             // ---- one integrator step (F16_model.py:64-67) ----
-            const float dt = cfg.dt;
+            const AeroWeights wt1 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
+            const bool tables1 = ap->cfg.aero_1d_tables != 0;
             if (SOLVER == 0) {
                 float k1[12];
-                nlplant<true, AB_REST, B, WPT>(a.wt, s, u, tr, tt, spsi, cpsi, coef, tables, k1, part);
+                nlplant<true, AB_REST, B, WPT>(wt1, s, u, tr, tt, spsi, cpsi, coef, tables1, k1, part);
+                NP_REREAD_ARGS(ap);
+                const float dt = ap->cfg.dt;
 #pragma unroll
                 for (int k = 0; k < 12; k++) s[k] = s[k] + dt * k1[k];
             } else {  // torchdiffeq 0.2.3 rk4_alt_step_func (3/8 rule)
+                const float dt = cfg.dt;
                 const float third = (float)(1.0 / 3.0);
                 float y[12], k1[12], k2[12], k3[12];
 #pragma unroll
@@ -349,36 +365,40 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             trig_of(s, tr, tt);
             np_sincos(s[5], spsi, cpsi);
             float xd[12], acc3[3];
-            nlplant<false, AB_FORCE, B, WPT>(a.wt, s, u, tr, 0.0f, 0.0f, 0.0f, coef, tables, xd, part);
+            {
+                const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
+                nlplant<false, AB_FORCE, B, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, part);
+            }
+            NP_REREAD_ARGS(ap);
             body_acceleration(s, tr, xd, acc3);
             const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
-            const bool r_over = (acc - cfg.acceleration_limit) > 0.0f;   // overload.py:37-42
-            const bool r_low = (s[2] - cfg.altitude_limit) < 0.0f;        // low_altitude.py:29-30
-            const float TAS = s[6] + cfg.airspeed * 1.0f;
+            const bool r_over = (acc - ap->cfg.acceleration_limit) > 0.0f;   // overload.py:37-42
+            const bool r_low = (s[2] - ap->cfg.altitude_limit) < 0.0f;        // low_altitude.py:29-30
+            const float TAS = s[6] + ap->cfg.airspeed * 1.0f;
             const float vel = (TAS * 0.3048f) / 340.0f;
-            const bool r_fast = (vel - cfg.max_velocity) >= 0.0f;         // high_speed.py:29-30
-            const bool r_slow = (vel - cfg.min_velocity) <= 0.0f;         // low_speed.py:29-30
+            const bool r_fast = (vel - ap->cfg.max_velocity) >= 0.0f;         // high_speed.py:29-30
+            const bool r_slow = (vel - ap->cfg.min_velocity) <= 0.0f;         // low_speed.py:29-30
             const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
-            const bool r_ext = ((alpha < cfg.min_alpha) | (alpha > cfg.max_alpha)) | ((beta < cfg.min_beta) | (beta > cfg.max_beta));  // extreme_state.py:32-36
+            const bool r_ext = ((alpha < ap->cfg.min_alpha) | (alpha > ap->cfg.max_alpha)) | ((beta < ap->cfg.min_beta) | (beta > ap->cfg.max_beta));  // extreme_state.py:32-36
             bool b = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
             // crash.py:33-43 (ego - enemy, squared distance in fp32)
             const float on = partner(s[0]), oe = partner(s[1]), oa = partner(s[2]);
             const float dn = is_ego ? s[0] - on : on - s[0], de = is_ego ? s[1] - oe : oe - s[1], da = is_ego ? s[2] - oa : oa - s[2];
-            const bool r_crash = ((dn * dn + de * de) + da * da) <= cfg.dist_limit_sq;
-            const bool r_tmo = (sc - cfg.max_steps) >= 0;           // timeout.py:29
+            const bool r_crash = ((dn * dn + de * de) + da * da) <= ap->cfg.dist_limit_sq;
+            const bool r_tmo = (sc - ap->cfg.max_steps) >= 0;           // timeout.py:29
             b |= r_crash;
             b |= m1;                                               // shutdown.py:36-38
             f_bad |= b;
             f_done |= m2 & !m1;
             f_to |= r_tmo;
-            if (a.term_counters) {  // per-condition sums (the reference prints them per evaluation): ballot + popcount + 1 atomic
+            if (ap->term_counters) {  // per-condition sums (the reference prints them per evaluation): ballot + popcount + 1 atomic
                 const unsigned bits = (r_over ? 1u : 0u) | (r_low ? 2u : 0u) | (r_fast ? 4u : 0u) | (r_slow ? 8u : 0u) | (r_ext ? 16u : 0u) |
                                       (r_crash ? 32u : 0u) | (r_tmo ? 64u : 0u) | (m1 ? 128u : 0u) | ((m2 & !m1) ? 256u : 0u);
                 const bool counted = valid && part == 0;
 #pragma unroll
                 for (int k = 0; k < NP_NUM_COMBAT_TERM_COUNTERS; k++) {
                     const unsigned long long mk = __ballot(counted && ((bits >> k) & 1u));
-                    if (mk != 0 && (threadIdx.x & 63) == 0) atomicAdd(a.term_counters + k, (unsigned)__popcll(mk));
+                    if (mk != 0 && (threadIdx.x & 63) == 0) atomicAdd(ap->term_counters + k, (unsigned)__popcll(mk));
                 }
             }
         }
@@ -439,33 +459,33 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
         long long iw = i;
         asm volatile("" : "+v"(iw));  // re-derive the store addresses here instead of keeping the load addresses alive
 #pragma unroll
-        for (int k = 0; k < 12; k++) a.s[k * a.ld + iw] = s[k];
+        for (int k = 0; k < 12; k++) ap->s[k * ap->ld + iw] = s[k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) a.u[k * a.ld + iw] = u[k];
-        a.u[4 * a.ld + iw] = 0.0f;
-        a.blood[iw] = blood;
-        a.step_count[iw] = sc;
-        a.fout0[iw] = f_done ? 1 : 0;
-        a.fout1[iw] = f_bad ? 1 : 0;
-        a.fout2[iw] = f_to ? 1 : 0;
+        for (int k = 0; k < 4; k++) ap->u[k * ap->ld + iw] = u[k];
+        ap->u[4 * ap->ld + iw] = 0.0f;
+        ap->blood[iw] = blood;
+        ap->step_count[iw] = sc;
+        ap->fout0[iw] = f_done ? 1 : 0;
+        ap->fout1[iw] = f_bad ? 1 : 0;
+        ap->fout2[iw] = f_to ? 1 : 0;
         if (STEP) {
 #pragma unroll
-            for (int k = 0; k < NUM_PID; k++) a.pid[k * a.ld + iw] = pid[k];
-            a.reward[iw] = reward;
+            for (int k = 0; k < NUM_PID; k++) ap->pid[k * ap->ld + iw] = pid[k];
+            ap->reward[iw] = reward;
         }
     }
 
     // ---- [n][15] observation rows: transpose through LDS, store coalesced ----
-    if (a.obs) {
+    if (ap->obs) {
         __syncthreads();
         if (part == 0) {
 #pragma unroll
             for (int k = 0; k < COMBAT_OBS; k++) lds[t * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
         }
         __syncthreads();
-        const long long rows = (a.n - i0) < B ? (a.n - i0) : B;
+        const long long rows = (ap->n - i0) < B ? (ap->n - i0) : B;
         const int total = (int)rows * COMBAT_OBS;
-        float *dst = a.obs + i0 * COMBAT_OBS;
+        float *dst = ap->obs + i0 * COMBAT_OBS;
         constexpr int THREADS = TILE * WPT;
 #pragma unroll
         for (int itr = 0; itr < (COMBAT_OBS * TILE + THREADS - 1) / THREADS; itr++) {

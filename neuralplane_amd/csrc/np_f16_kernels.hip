@@ -47,7 +47,9 @@ constexpr int LDS_FLOATS = (NUM_LDS_SLOTS * BLOCK > BLOCK * OBS_LD) ? NUM_LDS_SL
 
 struct KArgs;
 typedef const KArgs __attribute__((address_space(4))) *KArgsC;
+#ifndef NP_REREAD_ARGS
 #define NP_REREAD_ARGS(ap) asm volatile("" : "+s"(ap) : : "memory")
+#endif
 
 struct KArgs {
     float *s, *u, *tgt;
