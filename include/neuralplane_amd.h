@@ -70,7 +70,7 @@ typedef struct np_f16_io {
     float *s;              /* [12][ld]  F16Model.s            (F16_model.py:19)  in/out */
     float *u;              /* [5][ld]   F16Model.u            (F16_model.py:21)  in/out (row 4 = lef stays 0) */
     float *tgt;            /* [3][ld]   task.target_*         (heading_task.py:26-28) in/out */
-    int64_t ld;            /* leading dimension of s/u/tgt (>= n) */
+    int64_t ld;            /* leading dimension of s/u/tgt (>= n, < 2^30: more rows than fit in 288 GB of HBM) */
     int64_t *step_count;   /* [n]       BaseEnv.step_count    (env_base.py:28) in/out */
     const uint8_t *done_in, *bad_in, *timeout_in;   /* [n] flags left by the previous step (env_base.py:31-33) */
     uint8_t *done_out, *bad_out, *timeout_out;      /* [n] new flags; may NOT alias the *_in buffers */

@@ -45,6 +45,12 @@ constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22
 // (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
 constexpr int LDS_FLOATS = (NUM_LDS_SLOTS * BLOCK > BLOCK * OBS_LD) ? NUM_LDS_SLOTS * BLOCK : BLOCK * OBS_LD;
 
+// row-indexed access as (uniform base) + (32-bit BYTE offset): selects the SGPR-base + VGPR-offset addressing mode
+template <class T>
+__device__ __forceinline__ T &at_off(T *base, unsigned byte_off) {
+    return *reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+
 struct KArgs;
 typedef const KArgs __attribute__((address_space(4))) *KArgsC;
 #ifndef NP_REREAD_ARGS
@@ -120,18 +126,21 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
 
+    // row-indexed arrays are addressed as (uniform 64-bit base in SGPRs) + (32-bit per-lane offset): ld < 2^30 is checked on the
+    // host, so the byte offset of a row fits 32 bits and no per-access 64-bit VALU address arithmetic is left
+    const unsigned r32 = (unsigned)ic, o4 = r32 * 4u, o8 = r32 * 8u;
     float s[12], u[4], tgt[3];
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = a.s[k * a.ld + ic];
+    for (int k = 0; k < 12; k++) s[k] = at_off(a.s + k * a.ld, o4);
 #pragma unroll
-    for (int k = 0; k < 4; k++) u[k] = a.u[k * a.ld + ic];
+    for (int k = 0; k < 4; k++) u[k] = at_off(a.u + k * a.ld, o4);
 #pragma unroll
-    for (int k = 0; k < 3; k++) tgt[k] = a.tgt[k * a.ld + ic];
-    long long sc = a.step_count[ic];
-    const bool flagged = (a.fin0[ic] | a.fin1[ic] | a.fin2[ic]) != 0;
+    for (int k = 0; k < 3; k++) tgt[k] = at_off(a.tgt + k * a.ld, o4);
+    long long sc = at_off(a.step_count, o8);
+    const bool flagged = (at_off(a.fin0, r32) | at_off(a.fin1, r32) | at_off(a.fin2, r32)) != 0;
 
     const bool frozen = a.inner && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
-    const bool tmo_prev = a.inner && a.fin2[ic] != 0;
+    const bool tmo_prev = a.inner && at_off(a.fin2, r32) != 0;
     // ---- self.reset(): re-initialise rows flagged by the previous step (env_base.py:83-95) ----
     if (flagged && !a.inner) {
         float ru[5];
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
         // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
-        const bool done_prev = ap->inner && ap->fin0[ic] != 0, bad_prev = ap->inner && ap->fin1[ic] != 0;
+        const bool done_prev = ap->inner && at_off(ap->fin0, r32) != 0, bad_prev = ap->inner && at_off(ap->fin1, r32) != 0;
         unsigned reasons = 0;
         done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
         if (ap->term_counters) {
@@ -278,21 +287,22 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
     if (valid && part == 0) {
         // re-derive the store addresses from the row index here: without the empty asm the compiler keeps the ~25 64-bit
         // load addresses of the top of the kernel alive across both MLP phases (and spills some of them to scratch)
-        long long iw = i;
+        unsigned iw = (unsigned)i;
         asm volatile("" : "+v"(iw));
+        const unsigned w4 = iw * 4u;
 #pragma unroll
-        for (int k = 0; k < 12; k++) ap->s[k * ap->ld + iw] = s[k];
+        for (int k = 0; k < 12; k++) at_off(ap->s + k * ap->ld, w4) = s[k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) ap->u[k * ap->ld + iw] = u[k];
+        for (int k = 0; k < 4; k++) at_off(ap->u + k * ap->ld, w4) = u[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) ap->tgt[k * ap->ld + iw] = tgt[k];
-        ap->step_count[iw] = sc;
-        ap->fout0[iw] = done ? 1 : 0;
-        ap->fout1[iw] = bad ? 1 : 0;
-        ap->fout2[iw] = tmo_prev ? 1 : 0;
-        if (STEP) ap->reward[iw] = reward;
+        for (int k = 0; k < 3; k++) at_off(ap->tgt + k * ap->ld, w4) = tgt[k];
+        at_off(ap->step_count, iw * 8u) = sc;
+        at_off(ap->fout0, iw) = done ? 1 : 0;
+        at_off(ap->fout1, iw) = bad ? 1 : 0;
+        at_off(ap->fout2, iw) = tmo_prev ? 1 : 0;
+        if (STEP) at_off(ap->reward, w4) = reward;
         if (STEP && ap->cache) {
-            float *cache_w = ap->cache + ((iw >> 6) * NUM_CACHED) * CACHE_TILE + (iw & (CACHE_TILE - 1));
+            float *cache_w = ap->cache + ((long long)(iw >> 6) * NUM_CACHED) * CACHE_TILE + (iw & (CACHE_TILE - 1));
 #pragma unroll
             for (int k = 0; k < NUM_CACHED; k++) cache_w[k * CACHE_TILE] = coef[cached_slot(k) * TILE];
         }
@@ -639,6 +649,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         !io->done_out || !io->bad_out || !io->timeout_out)
         return fail("null state/flag buffer");
     if (io->ld < n) return fail("ld < n");
+    if (io->ld >= (1ll << 30)) return fail("ld must be below 2^30 rows (32-bit byte offsets inside a row-indexed array)");
     if (STEP && (!io->action || !io->obs || !io->reward || io->act_stride < 4))
         return fail("step needs action (>=4 columns), obs and reward buffers");
     if (io->done_out == io->done_in || io->bad_out == io->bad_in || io->timeout_out == io->timeout_in)
