@@ -99,7 +99,10 @@ __device__ __forceinline__ void dense(WS &ws, const float (&x)[IN], float (&y)[O
     }
     if (RELU) {
 #pragma unroll
-        for (int j = 0; j < OUT; j++) y[j] = y[j] > 0.0f ? y[j] : 0.0f;
+        for (int j = 0; j < OUT; j++) {  // ReLU on activations carried / 2^ACT_SHIFT: saturates at 1 (= the asm bodies' clamp modifier)
+            y[j] = y[j] > 0.0f ? y[j] : 0.0f;
+            y[j] = y[j] > 1.0f ? 1.0f : y[j];
+        }
     }
 }
 

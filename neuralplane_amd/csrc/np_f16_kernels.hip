@@ -521,12 +521,22 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vec
             const float *src = par.data() + r.param_offset;
             float *dst = kb.data() + class_base(cl) + (size_t)m * class_stride(cl);
             int in = c.n_in;
+            // Hidden activations are carried divided by 2^ACT_SHIFT (np_nets.h): the ReLU is then the `clamp` output modifier
+            // of the layer's last FMA, which costs no instruction.  Powers of two commute with every rounding, so the first
+            // layer's weights and all hidden biases are stored x 2^-ACT_SHIFT and the output layer's weights x 2^+ACT_SHIFT —
+            // checked here to be exact (normal, finite) for every parameter of the asset.
+            bool exact = true;
+            auto scaled = [&exact](float w, int e) {
+                const float v = std::ldexp(w, e);
+                if (w != 0.0f && !(std::isnormal(v) && std::ldexp(v, -e) == w)) exact = false;
+                return v;
+            };
             for (int l = 0; l < n_hidden; l++) {  // hidden layers: bias row + `in` weight rows, rows padded to even
                 const int out = hid[l], row = pad2(out);
                 const float *W = src, *bias = src + (size_t)in * out;
-                for (int j = 0; j < out; j++) dst[j] = bias[j];
+                for (int j = 0; j < out; j++) dst[j] = scaled(bias[j], -ACT_SHIFT);
                 for (int k = 0; k < in; k++)
-                    for (int j = 0; j < out; j++) dst[row * (k + 1) + j] = W[j * in + k];
+                    for (int j = 0; j < out; j++) dst[row * (k + 1) + j] = l == 0 ? scaled(W[j * in + k], -ACT_SHIFT) : W[j * in + k];
                 src += (size_t)in * out + out;
                 dst += (size_t)row * (in + 1);
                 in = out;
@@ -534,9 +544,10 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vec
             {  // final layer in -> 1: bias, W[0][0..in), padded to even
                 const float *W = src, *bias = src + in;
                 dst[0] = bias[0];
-                for (int k = 0; k < in; k++) dst[1 + k] = W[k];
+                for (int k = 0; k < in; k++) dst[1 + k] = scaled(W[k], ACT_SHIFT);
                 dst += pad2(1 + in);
             }
+            if (!exact) return fail("weights blob: a parameter of net " + nm + " cannot be rescaled by 2^ACT_SHIFT exactly");
             dst[0] = (float)r.out_std;
             dst[1] = (float)r.out_mean;
         }

@@ -48,13 +48,23 @@ typedef struct {
     float out_mean, out_std;
     const float *w[4];
     const float *b[4];
+    const float *ws[4]; /* the parameters as the fp32 evaluation uses them: rescaled by powers of two (ACT_SHIFT below) */
+    const float *bs[4];
     const float *pwl; /* NULL, or t[64], a[64], x0[64], c[64] (blob PWL section) */
 } net_t;
 
 struct f16o_model {
     net_t net[F16O_NUM_NETS];
     float *params;
+    float *scaled;
 };
+
+/* Numerics spec, "ReLU": hidden activations are carried divided by 2^ACT_SHIFT and the ReLU saturates at 1 there, i.e. at
+ * 2^40 in the reference's terms (its own ReLU does not saturate; trained nets on physical inputs stay below 1e4).  The first
+ * layer's weights and every hidden bias are multiplied by 2^-40, the output layer's weights by 2^+40: powers of two commute
+ * with every fp32 rounding, so below the bound — and above 1.3e-26 — each intermediate is the reference-order value times
+ * 2^-40 exactly and the net's output is unchanged.  The load fails if a parameter cannot be rescaled exactly. */
+#define ACT_SHIFT 40
 
 static int g_mode = 0;
 void f16o_set_mode(int mode) { g_mode = mode; }
@@ -104,6 +114,26 @@ f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
         if (used != r.n_params || (off + used) * 4 > pbytes) goto bad;
         if (off + used > n_par_total) n_par_total = off + used;
     }
+    m->scaled = (float *)malloc(n_par_total * sizeof(float));
+    for (uint32_t i = 0; i < nn; i++) {
+        net_t *t = &m->net[i];
+        for (int l = 0; l < t->n_linear; l++) {
+            int in = t->dims[l], out = t->dims[l + 1];
+            const int last = (l + 1 == t->n_linear);
+            const int ew = l == 0 ? -ACT_SHIFT : (last ? ACT_SHIFT : 0), eb = last ? 0 : -ACT_SHIFT;
+            float *ws = m->scaled + (t->w[l] - m->params), *bs = m->scaled + (t->b[l] - m->params);
+            for (int q = 0; q < in * out; q++) {
+                ws[q] = ldexpf(t->w[l][q], ew);
+                if (t->w[l][q] != 0.0f && !(isnormal(ws[q]) && ldexpf(ws[q], -ew) == t->w[l][q])) goto bad;
+            }
+            for (int q = 0; q < out; q++) {
+                bs[q] = ldexpf(t->b[l][q], eb);
+                if (t->b[l][q] != 0.0f && !(isnormal(bs[q]) && ldexpf(bs[q], -eb) == t->b[l][q])) goto bad;
+            }
+            t->ws[l] = ws;
+            t->bs[l] = bs;
+        }
+    }
     if (ver >= 2) { /* PWL section: "PWL1", n_tables, seg_cap, then {net_index, n_segments, t, a, x0, c} */
         const unsigned char *q = p + hdr + n_par_total * 4;
         const unsigned char *end = p + nbytes;
@@ -132,6 +162,7 @@ bad:
 void f16o_model_free(f16o_model *m) {
     if (!m) return;
     free(m->params);
+    free(m->scaled);
     free(m);
 }
 
@@ -420,9 +451,12 @@ static float net_eval(const net_t *t, const float in3[3]) {
     for (int l = 0; l < t->n_linear; l++) {
         int in = t->dims[l], out = t->dims[l + 1];
         for (int j = 0; j < out; j++) {
-            float acc = t->b[l][j];
-            for (int k = 0; k < in; k++) acc = fmaf(t->w[l][j * in + k], x[k], acc);
-            if (l + 1 < t->n_linear) acc = acc > 0.0f ? acc : 0.0f; /* ReLU :19 */
+            float acc = t->bs[l][j];
+            for (int k = 0; k < in; k++) acc = fmaf(t->ws[l][j * in + k], x[k], acc);
+            if (l + 1 < t->n_linear) { /* ReLU :19 on activations carried / 2^ACT_SHIFT; NaN -> 0; saturates at 1 (spec) */
+                acc = acc > 0.0f ? acc : 0.0f;
+                acc = acc > 1.0f ? 1.0f : acc;
+            }
             y[j] = acc;
         }
         for (int j = 0; j < out; j++) x[j] = y[j];

@@ -130,18 +130,22 @@ class Body:
             xr = in_regs[k]
             e = xr & 1
             xp = self.vpair(xr - e)
+            # ReLU = the clamp modifier of the LAST fused multiply-add of every accumulator: activations are carried divided
+            # by 2^ACT_SHIFT (np_nets.h), so clamp's upper bound 1.0 is 2^40 in real terms; no v_max_f32 per neuron
+            relu = ' clamp' if k == n_in - 1 else ''
             for j in range(0, n_out - 1, 2):
                 sp = self.spair(pk + j)
                 acc = self.vpair(out_base + j)
                 if no_bias and k == 0:
                     self.ins.append(f'v_pk_mul_f32 {acc}, {sp}, {xp} op_sel:[0,{e}] op_sel_hi:[1,{e}]')
                     continue
-                self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {xp}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]')
+                self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {xp}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]{relu}')
             if n_out & 1:
                 j = n_out - 1
-                self.ins.append(f'v_fmac_f32 v{out_base + j}, {self.s1(pk + j)}, v{xr}')
-        for j in range(n_out):
-            self.ins.append(f'v_max_f32 v{out_base + j}, 0, v{out_base + j}')
+                if relu:
+                    self.ins.append(f'v_fma_f32 v{out_base + j}, {self.s1(pk + j)}, v{xr}, v{out_base + j} clamp')
+                else:
+                    self.ins.append(f'v_fmac_f32 v{out_base + j}, {self.s1(pk + j)}, v{xr}')
         self.pos = p0 + row * (n_in + 1)
 
     def final(self, n_in, in_regs):
