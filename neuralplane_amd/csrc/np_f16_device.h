@@ -136,7 +136,9 @@ __device__ __forceinline__ float mlp_body(const float *kblob, int w, const float
 }
 
 #ifndef NPF16_ASM_MLP
-#define NPF16_ASM_MLP 1  // 1: hand-scheduled asm class bodies (np_mlp_asm.inc); 0: the C++ bodies above (A/B + reference)
+#define NPF16_ASM_MLP 1  // 1: hand-scheduled asm class bodies (np_mlp_asm.inc).  0 selected the C++ bodies above (the readable statement of
+                         // what the asm computes; A/B reference of the first builds) — since the weights moved from __constant__ to
+                         // per-context buffers hipcc no longer selects scalar loads for them ("illegal VGPR to SGPR copy")
 #endif
 #include "np_mlp_asm.inc"
 
