@@ -41,7 +41,9 @@ V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
 V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
 V_Y = 126        # net output
 V_ADDR = 127     # LDS byte address of the output slot
-V_CLOBBER = list(range(68 if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1' else 70, 128))
+GEN_DUP = os.environ.get('NPF16_GEN_DUP') == '1'   # TIMING EXPERIMENT ONLY: every VALU instruction of a net body is issued twice (second copy on
+                                                    # registers + 58), i.e. two accumulator sets per weight load — what 'two aircraft per lane' would cost
+V_CLOBBER = list(range(68 if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1' else 70, 186 if GEN_DUP else 128))
 S_CLOBBER = list(range(S_W0, S_W0 + 16 * NBUF)) + [S_BASE, S_BASE + 1]
 
 
@@ -175,6 +177,20 @@ class Body:
         # the stream position is exactly one record further when the next net starts
         self.touch(self.len - 1)
         assert self.cur_group == self.len // GROUP - 1
+        if GEN_DUP:
+            import re
+            def shift(m):
+                if m.group(1) is not None:
+                    a, b = int(m.group(1)), int(m.group(2))
+                    return f'v[{a + 58}:{b + 58}]' if a >= 70 else m.group(0)
+                r = int(m.group(3))
+                return f'v{r + 58}' if r >= 70 else m.group(0)
+            out = []
+            for ins in self.ins:
+                out.append(ins)
+                if ins.startswith('v_'):
+                    out.append(re.sub(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', shift, ins))
+            self.ins = out
         return self.ins
 
 
