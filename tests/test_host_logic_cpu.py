@@ -96,3 +96,18 @@ def test_shard_rows_partitions_exactly():
         assert spans[0][0] == 0 and sum(n for _, n in spans) == n_total
         for (r0, n0), (r1, _) in zip(spans, spans[1:]):
             assert r0 + n0 == r1
+
+
+def test_generated_asm_is_up_to_date(tmp_path):
+    """The three generated kernel bodies in csrc/ are exactly what tools/gen_mlp_asm.py emits today (no timing-experiment
+    switch leaked into them, nobody edited them by hand)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith('NPF16_GEN_')}
+    env['NPF16_GEN_OUTDIR'] = str(tmp_path)
+    subprocess.run([sys.executable, os.path.join(root, 'tools', 'gen_mlp_asm.py')], check=True, env=env, stdout=subprocess.DEVNULL)
+    for name in ('np_mlp_asm.inc', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc'):
+        with open(tmp_path / name, 'rb') as f, open(os.path.join(root, 'neuralplane_amd', 'csrc', name), 'rb') as g:
+            assert f.read() == g.read(), f'{name} is stale: run python tools/gen_mlp_asm.py'

@@ -25,7 +25,8 @@ Record layout of one net (floats) — must match np_nets.h::asm_record_len / pac
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_mlp_asm.inc')
+CSRC = os.environ.get('NPF16_GEN_OUTDIR') or os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc')   # tests regenerate into a temp dir
+OUT = os.path.join(CSRC, 'np_mlp_asm.inc')
 
 SHAPES = [(1, 20, 10, 0), (3, 20, 10, 0), (2, 20, 10, 0), (2, 20, 10, 5), (2, 20, 20, 10), (1, 20, 10, 5), (2, 20, 10, 10)]
 
@@ -398,7 +399,7 @@ def phase_checks():
 # together with the loads of their group (one s_waitcnt lgkmcnt(0) retires both).  acc = bias; acc = fma(W[j][k], x[k], acc),
 # k ascending — bit-identical to the C++ loop it replaces.
 # ------------------------------------------------------------------------------------------------
-ACTOR_OUT = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_actor_asm.inc')
+ACTOR_OUT = os.path.join(CSRC, 'np_actor_asm.inc')
 A_ACC = 70        # v[70:85] accumulators
 A_X = [86, 87, 88, 89, 90, 91]   # inputs of the two groups in flight
 A_ADDR = 92       # LDS byte address of x[k = first feature of the iteration] for this lane
@@ -600,7 +601,7 @@ def gen_actor_mfma(lines, LD, LDN, K=128):
 
 
 def gen_actor_mfma_file():
-    out = os.path.join(os.path.dirname(HERE), 'neuralplane_amd', 'csrc', 'np_actor_mfma_asm.inc')
+    out = os.path.join(CSRC, 'np_actor_mfma_asm.inc')
     lines = ['// GENERATED by tools/gen_mlp_asm.py (gen_actor_mfma) — do not edit.', '#pragma once',
              'typedef float f32x32 __attribute__((ext_vector_type(32)));',
              'template <int LD, int LD_NEXT>',
