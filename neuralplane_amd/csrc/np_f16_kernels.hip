@@ -36,6 +36,9 @@ namespace npf16 {
 #ifndef NPF16_STAGGER_CYCLES
 #define NPF16_STAGGER_CYCLES 20000  // ~10 us at 2 GHz per phase step; 0 disables the de-phasing
 #endif
+#ifndef NPF16_STAGGER_CYCLES_LONG
+#define NPF16_STAGGER_CYCLES_LONG 30000  // grids of 8 generations and more (N >= 1.6e6 on 256 CUs), see the kernel
+#endif
 constexpr int BLOCK = NPF16_BLOCK;
 // workgroups resident at once: 256 CUs x 4 SIMDs x NPF16_MINWAVES wave slots / waves per workgroup
 constexpr int FIRST_GENERATION = 256 * 4 * NPF16_MINWAVES / (BLOCK / 64);
@@ -121,7 +124,11 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
     if (WPT == 1 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
-        const long long wait = (long long)(blockIdx.x % 3) * NPF16_STAGGER_CYCLES;
+        // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
+        // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
+        // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
+        const long long unit = gridDim.x >= 8 * FIRST_GENERATION ? NPF16_STAGGER_CYCLES_LONG : NPF16_STAGGER_CYCLES;
+        const long long wait = (long long)(blockIdx.x % 3) * unit;
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
