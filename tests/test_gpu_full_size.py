@@ -152,3 +152,15 @@ def test_soak_long_horizon_block_stays_bit_exact(task):
     assert np.array_equal(obs.cpu().numpy()[rows], o_obs) and np.array_equal(rew.cpu().numpy()[rows], o_rew)
     assert resets > cnt       # every aircraft of the block went through at least one episode boundary on average
     assert torch.isfinite(b.s).all()
+
+
+def test_drop_in_example_runs():
+    """examples/drop_in_rollout.py — host code written against the reference's import paths (numpy VecEnv loop, device-resident
+    loop, device-resident collection into DeviceReplayBuffer + returns + mini-batches) runs end to end."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'drop_in_rollout.py'), '512', '24'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'numpy VecEnv loop' in out.stdout and 'device-resident loop' in out.stdout and 'device-resident collection' in out.stdout
