@@ -242,7 +242,7 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
  * workgroup — large batches) and "latency" (four waves share a tile of 64 aircraft and split the 44 net evaluations of a
  * step — a step takes about half of a lone wave's 44 us; chosen automatically for n <= 65536 (the measured
  * crossover), Euler solver).  This call pins the choice for a context (tests, tuning). */
-enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2 };
+enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
 /* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context,

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libneuralplane_hip.so')
 SOURCES = ['np_f16_kernels.hip']
-HEADERS = ['np_f16_device.h', 'np_f16_combat.h', 'np_actor.h', 'np_rollout.h', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc', 'np_math.h', 'np_nets.h', 'np_mlp_asm.inc', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
+HEADERS = ['np_f16_device.h', 'np_f16_combat.h', 'np_actor.h', 'np_rollout.h', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc', 'np_math.h', 'np_nets.h', 'np_mlp_asm.inc', 'np_mlp_asm_dual.inc', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared']
 
 

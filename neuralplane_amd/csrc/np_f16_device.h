@@ -141,6 +141,7 @@ __device__ __forceinline__ float mlp_body(const float *kblob, int w, const float
                          // per-context buffers hipcc no longer selects scalar loads for them ("illegal VGPR to SGPR copy")
 #endif
 #include "np_mlp_asm.inc"
+#include "np_mlp_asm_dual.inc"
 
 // All nets of one class (np_nets.h): same shape, same inputs, KBLOB records back to back.  ONE
 // compact loop body per class keeps the instruction footprint of a full aero evaluation at a few
@@ -304,6 +305,70 @@ __device__ __forceinline__ void eval_plan_wave(const AeroWeights &wt, const floa
 #undef NPF16_ITEM
 }
 
+// ---- pair variant (WPT == 2): the two waves of a 128-aircraft workgroup split the nets of an evaluation between them, and each
+// evaluates its half for BOTH waves' aircraft (dual class bodies, np_mlp_asm_dual.inc: set A = the lane's own aircraft, set
+// B = the same lane of the other wave).  Every scalar weight load then feeds two accumulator sets: half the scalar-cache traffic
+// per aircraft, twice the arithmetic behind every wait.  The normalised inputs of the partner come through LDS columns
+// NUM_LIVE_NETS.. of the same matrix.  Plans balanced by FLOPs as above.
+constexpr int PAIR_MAX = 7;
+struct PairPlan {
+    SplitItem it[2][PAIR_MAX];
+};
+constexpr PairPlan PAIR_REST = {{{{CL_DAMP, 4, 8}, {CL_DLEF, 2, 5}, {CL_E_RUD, 1, 3}, NO_ITEM, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 {{CL_D_RUD, 1, 1}, {CL_D_LEF, 1, 1}, {CL_E_LEF, 2, 2}, {CL_F, 1, 2}, {CL_C, 0, 5}, {CL_ETA, 0, 1}, NO_ITEM}}};
+constexpr PairPlan PAIR_ALL = {{{{CL_DAMP, 0, 12}, {CL_DLEF, 0, 7}, {CL_E_LEF, 0, 4}, {CL_YPLEF, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                {{CL_D_RUD, 0, 2}, {CL_D_LEF, 0, 2}, {CL_E_RUD, 0, 4}, {CL_F, 0, 3}, {CL_YA20, 0, 1}, {CL_C, 0, 5}, {CL_ETA, 0, 1}}}};
+constexpr PairPlan PAIR_FORCE2 = {{{{CL_DAMP, 0, 4}, {CL_DLEF, 0, 2}, {CL_E_LEF, 0, 2}, {CL_E_RUD, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                   {{CL_D_RUD, 0, 1}, {CL_D_LEF, 0, 1}, {CL_F, 0, 1}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}, {CL_C, 0, 2}, NO_ITEM}}};
+constexpr bool pair_plan_covers(const PairPlan &p, int part, int n_c, int n_eta) {
+    for (int cl = 0; cl < NUM_CLASSES; cl++) {
+        int lo = 0, hi = 0;
+        if (cl < NUM_AB_CLASSES) {
+            lo = part == AB_REST ? CLASSES[cl].n_force : 0;
+            hi = part == AB_FORCE ? CLASSES[cl].n_force : CLASSES[cl].count;
+        } else {
+            hi = cl == CL_C ? n_c : n_eta;
+        }
+        for (int net = 0; net < CLASSES[cl].count; net++) {
+            int hits = 0;
+            for (int w = 0; w < 2; w++)
+                for (int k = 0; k < PAIR_MAX; k++)
+                    if (p.it[w][k].cl == cl && net >= p.it[w][k].first && net < p.it[w][k].first + p.it[w][k].cnt) hits++;
+            if (hits != ((net >= lo && net < hi) ? 1 : 0)) return false;
+        }
+    }
+    return true;
+}
+static_assert(pair_plan_covers(PAIR_REST, AB_REST, 5, 1) && pair_plan_covers(PAIR_ALL, AB_ALL, 5, 1) && pair_plan_covers(PAIR_FORCE2, AB_FORCE, 2, 0),
+              "pair plans must cover each net of their phase exactly once");
+
+template <int CL, int N, int LD, int FIRST>
+__device__ __forceinline__ void eval_class_dual(const AeroWeights &wt, const float (&xa)[NUM_NORM_GROUPS], const float (&xb)[NUM_NORM_GROUPS],
+                                                float *__restrict__ out_a, float *__restrict__ out_b) {
+    constexpr NetClass c = CLASSES[CL];
+    const unsigned addr_a = (unsigned)(unsigned long long)(out_a + (class_slot(CL) + FIRST) * LD);
+    const unsigned addr_b = (unsigned)(unsigned long long)(out_b + (class_slot(CL) + FIRST) * LD);
+    constexpr int g0 = c.grp[0], g1 = c.grp[c.n_in > 1 ? 1 : 0], g2 = c.grp[c.n_in > 2 ? 2 : 0];
+    mlp_class_asm_dual<c.n_in, c.h1, c.h2, c.h3, N, (int)(LD * sizeof(float))>(wt.kblob + class_base(CL) + FIRST * class_stride(CL), addr_a, addr_b, xa[g0],
+                                                                              c.n_in > 1 ? xa[g1] : 0.0f, c.n_in > 2 ? xa[g2] : 0.0f, xb[g0],
+                                                                              c.n_in > 1 ? xb[g1] : 0.0f, c.n_in > 2 ? xb[g2] : 0.0f);
+}
+
+template <const PairPlan &P, int W, int LD>
+__device__ __forceinline__ void eval_pair_wave(const AeroWeights &wt, const float (&xa)[NUM_NORM_GROUPS], const float (&xb)[NUM_NORM_GROUPS],
+                                               float *__restrict__ out_a, float *__restrict__ out_b) {
+#define NPF16_ITEM(K) \
+    if constexpr (P.it[W][K].cnt > 0) eval_class_dual<P.it[W][K].cl, P.it[W][K].cnt, LD, P.it[W][K].first>(wt, xa, xb, out_a, out_b)
+    NPF16_ITEM(0);
+    NPF16_ITEM(1);
+    NPF16_ITEM(2);
+    NPF16_ITEM(3);
+    NPF16_ITEM(4);
+    NPF16_ITEM(5);
+    NPF16_ITEM(6);
+#undef NPF16_ITEM
+}
+
 // All nets of one nlplant evaluation.  With the asm bodies and the default numerics the whole sequence of classes is ONE
 // asm statement (tools/gen_mlp_asm.py, "phase functions"): the weight stream keeps running across class boundaries.
 // WPT = 4: the latency variant above; `part` is the wave's index within its workgroup (wave-uniform).
@@ -313,7 +378,25 @@ __device__ __forceinline__ void eval_plan_wave(const AeroWeights &wt, const floa
 template <int LD, int PART, bool FULL, int WPT = 1>
 __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables, int part = 0) {
     constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
-    if constexpr (WPT == 4) {
+    if constexpr (WPT == 2) {  // pair variant: `part` = this wave's index in its 128-aircraft workgroup; never used with `tables`
+        static_assert(has_phase, "no pair plan for this evaluation");
+        float *out_b = out + 64 - 128 * part;  // the same lane's column in the other wave's half of the matrix
+#pragma unroll
+        for (int g = 0; g < NUM_NORM_GROUPS; g++) out[(NUM_LIVE_NETS + g) * LD] = xn[g];
+        __syncthreads();  // inputs are visible; both waves have finished reading the coefficients of the previous evaluation
+        float xb[NUM_NORM_GROUPS];
+#pragma unroll
+        for (int g = 0; g < NUM_NORM_GROUPS; g++) xb[g] = out_b[(NUM_LIVE_NETS + g) * LD];
+#define NPF16_WAVE(W)                                                                                    \
+    if constexpr (FULL && PART == AB_ALL) eval_pair_wave<PAIR_ALL, W, LD>(wt, xn, xb, out, out_b);           \
+    else if constexpr (FULL && PART == AB_REST) eval_pair_wave<PAIR_REST, W, LD>(wt, xn, xb, out, out_b);    \
+    else eval_pair_wave<PAIR_FORCE2, W, LD>(wt, xn, xb, out, out_b)
+        if (part == 0) { NPF16_WAVE(0); }
+        else { NPF16_WAVE(1); }
+#undef NPF16_WAVE
+        __syncthreads();  // all coefficient columns of both waves are complete
+        return;
+    } else if constexpr (WPT == 4) {
         static_assert(has_phase, "no split plan for this evaluation");
         __syncthreads();  // every wave has finished reading the coefficients of the previous evaluation
 #define NPF16_WAVE(W)                                                                                          \

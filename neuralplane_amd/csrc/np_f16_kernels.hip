@@ -94,12 +94,16 @@ struct KArgs {
 //             net evaluations (eval_nets<.., 4>, np_f16_device.h) and redo the cheap non-MLP arithmetic redundantly, so a
 //             step takes ~1/2 of a lone wave's time; wave 0 stores.  Results are bit-identical between the variants.
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1>
-__global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(const KArgs a) {
-    constexpr int TILE_LDS = (NUM_LDS_SLOTS * TILE > TILE * OBS_LD) ? NUM_LDS_SLOTS * TILE : TILE * OBS_LD;
+__global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
+    // pair variant (WPT == 2): nine more columns carry the normalised MLP inputs to the other wave of the workgroup
+    constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0);
+    constexpr int TILE_LDS = (COLS * TILE > TILE * OBS_LD) ? COLS * TILE : TILE * OBS_LD;
     __shared__ float lds[TILE_LDS];
     float *obs_tile = lds;
-    const int t = WPT == 1 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
-    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform
+    const int t = WPT != 4 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
+    const int part = WPT != 4 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform; 0 = the wave that stores
+    // what the net evaluation calls `part`: latency variant = which quarter of the nets, pair variant = which wave of the pair
+    const int pw = WPT == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)) : part;
     float *coef = lds + t;  // this lane's coefficient column, stride TILE
     const long long i0 = (long long)blockIdx.x * TILE;
     const long long i = i0 + t;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
     // worse: 0.45 ms); later workgroups inherit the phase of the workgroup whose slot they take.  Only done
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
-    if (WPT == 1 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
+    if (WPT != 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
-            xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, part);
+            xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
             NP_REREAD_ARGS(ap);
             const float dt = ap->cfg.dt;
 #pragma unroll
@@ -210,8 +214,8 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
 #pragma nounroll
             for (int stage = 0; stage < 4; stage++) {
                 float kk[12];
-                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(a.wt, y, u, coef, tables, kk, part);  // y == s: cached coefficients apply
-                else xdot_full<AB_ALL, TILE, WPT>(a.wt, y, u, coef, tables, kk, part);
+                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(a.wt, y, u, coef, tables, kk, pw);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, TILE, WPT>(a.wt, y, u, coef, tables, kk, pw);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
 #else
         {
             const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
-            nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, part);
+            nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
         }
 #endif
         NP_REREAD_ARGS(ap);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_MINWAVES) void f16_env_kernel(con
         const long long rows = (ap->n - i0) < TILE ? (ap->n - i0) : TILE;
         const int total = (int)rows * 22;
         float *dst = ap->obs + i0 * 22;
-        constexpr int THREADS = TILE * WPT;
+        constexpr int THREADS = TILE * (WPT == 4 ? 4 : 1);
 #pragma unroll
         for (int it = 0; it < (22 * TILE + THREADS - 1) / THREADS; it++) {
             const int L = it * THREADS + (int)threadIdx.x;
@@ -657,6 +661,15 @@ bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
     if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY;
     return n <= LAT_MAX_N;
 }
+// pair variant (two waves split the nets and evaluate them for each other's aircraft): Euler, MLP numerics (no 1-D tables)
+bool use_pair_kernel(const np_f16_ctx *ctx, int64_t n) {
+    static const bool forced = [] {  // NPF16_KERNEL=pair
+        const char *e = std::getenv("NPF16_KERNEL");
+        return e && std::strcmp(e, "pair") == 0;
+    }();
+    (void)n;
+    return ctx->variant == NP_KERNEL_PAIR || (ctx->variant == NP_KERNEL_AUTO && forced);
+}
 
 template <bool STEP>
 int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
@@ -687,7 +700,8 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.reset_coef = ctx->d_reset_coef;
     a.wt = ctx->wt;
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
-    const bool latency = STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
+    const bool pair = STEP && ctx->solver == 0 && !ctx->cfg.aero_1d_tables && !io->inner_step && use_pair_kernel(ctx, n);
+    const bool latency = !pair && STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)), block(latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -706,7 +720,10 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
 #define NP_LAUNCH(T, S)                                                                                           \
     do {                                                                                                          \
-        if (latency && S == 0) {                                                                                  \
+        if (pair && S == 0) {                                                                                     \
+            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, BLOCK, 2>), grid, block, 0, st, a);      \
+            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, BLOCK, 2>), grid, block, 0, st, a);            \
+        } else if (latency && S == 0) {                                                                           \
             if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4>), grid, block, 0, st, a);   \
             else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4>), grid, block, 0, st, a);         \
         } else if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP>), grid, block, 0, st, a);         \
@@ -1056,7 +1073,8 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
     if (!ctx) return fail("null ctx");
-    if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT) return fail("unknown kernel variant");
+    if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR)
+        return fail("unknown kernel variant");
     ctx->variant = variant;
     return 0;
 }

@@ -179,20 +179,107 @@ class Body:
         self.touch(self.len - 1)
         assert self.cur_group == self.len // GROUP - 1
         if GEN_DUP:
-            import re
-            def shift(m):
-                if m.group(1) is not None:
-                    a, b = int(m.group(1)), int(m.group(2))
-                    return f'v[{a + 58}:{b + 58}]' if a >= 70 else m.group(0)
-                r = int(m.group(3))
-                return f'v{r + 58}' if r >= 70 else m.group(0)
-            out = []
-            for ins in self.ins:
-                out.append(ins)
-                if ins.startswith('v_'):
-                    out.append(re.sub(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', shift, ins))
-            self.ins = out
+            self.ins = second_set(self.ins)
         return self.ins
+
+
+SET_B = 58   # the second accumulator set of the dual bodies lives SET_B registers above the first (v128-v185)
+
+
+def second_set(ins_list):
+    """every VALU instruction once more, on the registers of the second set (same SGPR weight operands)"""
+    import re
+
+    def shift(m):
+        if m.group(1) is not None:
+            a, b = int(m.group(1)), int(m.group(2))
+            return f'v[{a + SET_B}:{b + SET_B}]' if a >= 70 else m.group(0)
+        r = int(m.group(3))
+        return f'v{r + SET_B}' if r >= 70 else m.group(0)
+    out = []
+    for ins in ins_list:
+        out.append(ins)
+        if ins.startswith('v_'):
+            out.append(re.sub(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', shift, ins))
+    return out
+
+
+def gen_function_dual(shape):
+    """The class body for TWO aircraft per lane ("pair" kernel variant): one weight stream, two accumulator sets.  Set A = the
+    lane's own aircraft, set B = the aircraft of the same lane in the other wave of the workgroup (inputs and output column
+    come from / go to LDS); every s_load_dwordx16 now feeds 16 instead of 8 v_pk_fma_f32."""
+    IN, H1, H2, H3 = shape
+    ln = record_len(*shape)
+    ngroups = ln // GROUP
+    two_parities = ngroups % 2 == 1
+    name = f'mlp_class_asm_dual_{IN}_{H1}_{H2}_{H3}'
+    lines = []
+    A = lines.append
+    A('template <int COUNT, int LDS_STEP>')
+    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_addr_a, unsigned lds_addr_b, float x0a, float x1a, float x2a,')
+    A('                                                     float x0b, float x1b, float x2b) {')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
+    emit(f's_mov_b32 {S_CNT}, %[cnt]')
+    for sfx, off in (('a', 0), ('b', SET_B)):
+        emit(f'v_mov_b32 v{V_X + off}, %[x0{sfx}]')
+        if IN > 1:
+            emit(f'v_mov_b32 v{V_X + 2 + off}, %[x1{sfx}]')
+        if IN > 2:
+            emit(f'v_mov_b32 v{V_X + 4 + off}, %[x2{sfx}]')
+        emit(f'v_mov_b32 v{V_ADDR + off}, %[addr{sfx}]')
+    for c in range(CPG):
+        emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
+    emit('.LNP_LOOP_%=:')
+    for parity in ([0, 1] if two_parities else [0]):
+        for ins in second_set(Body(shape, parity).build()):
+            emit(ins)
+        emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
+        emit(f'ds_write_b32 v{V_ADDR + SET_B}, v{V_Y + SET_B}')
+        emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
+        emit(f'v_add_u32 v{V_ADDR + SET_B}, %[step], v{V_ADDR + SET_B}')
+        emit(f's_add_u32 s{S_BASE}, s{S_BASE}, 0x{ln * 4:x}')
+        emit(f's_addc_u32 s{S_BASE + 1}, s{S_BASE + 1}, 0')
+        emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
+        emit(f's_cmp_lg_u32 {S_CNT}, 0')
+        if two_parities and parity == 0:
+            emit('s_cbranch_scc0 .LNP_DONE_%=')
+        else:
+            emit('s_cbranch_scc1 .LNP_LOOP_%=')
+    emit('.LNP_DONE_%=:')
+    emit('s_waitcnt lgkmcnt(0)')
+    A('        :')
+    A('        : [w] "s"(w), [cnt] "n"(COUNT), [addra] "v"(lds_addr_a), [addrb] "v"(lds_addr_b), [step] "n"(LDS_STEP), [x0a] "v"(x0a), [x1a] "v"(x1a),')
+    A('          [x2a] "v"(x2a), [x0b] "v"(x0b), [x1b] "v"(x1b), [x2b] "v"(x2b)')
+    regs = list(range(70, 128 + SET_B))
+    clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in S_CLOBBER] + ['"vcc"', '"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+    A('')
+    return lines, name
+
+
+def gen_dual_file():
+    out = ['// GENERATED by tools/gen_mlp_asm.py (gen_function_dual) — do not edit.',
+           '// Class bodies with two accumulator sets per weight stream (the "pair" kernel variant, np_f16_device.h).', '#pragma once', '']
+    for shape in SHAPES:
+        lines, _ = gen_function_dual(shape)
+        out += lines
+    out.append('template <int IN, int H1, int H2, int H3, int COUNT, int LDS_STEP>')
+    out.append('__device__ __forceinline__ void mlp_class_asm_dual(const float *w, unsigned addr_a, unsigned addr_b, float x0a, float x1a, float x2a, float x0b,')
+    out.append('                                                   float x1b, float x2b) {')
+    for i, (IN, H1, H2, H3) in enumerate(SHAPES):
+        kw = 'if' if i == 0 else 'else if'
+        out.append(f'    {kw} constexpr (IN == {IN} && H1 == {H1} && H2 == {H2} && H3 == {H3}) mlp_class_asm_dual_{IN}_{H1}_{H2}_{H3}<COUNT, LDS_STEP>(w, addr_a, addr_b, x0a, x1a, x2a, x0b, x1b, x2b);')
+    out.append('    else static_assert(IN < 0, "no generated dual body for this shape");')
+    out.append('}')
+    with open(os.path.join(CSRC, 'np_mlp_asm_dual.inc'), 'w') as f:
+        f.write('\n'.join(out) + '\n')
+    print('wrote np_mlp_asm_dual.inc')
 
 
 def gen_function(shape):
@@ -650,5 +737,6 @@ def main():
 
 if __name__ == '__main__':
     main()
+    gen_dual_file()
     gen_actor_dense()
     gen_actor_mfma_file()
