@@ -341,6 +341,9 @@ constexpr bool pair_plan_covers(const PairPlan &p, int part, int n_c, int n_eta)
 }
 static_assert(pair_plan_covers(PAIR_REST, AB_REST, 5, 1) && pair_plan_covers(PAIR_ALL, AB_ALL, 5, 1) && pair_plan_covers(PAIR_FORCE2, AB_FORCE, 2, 0),
               "pair plans must cover each net of their phase exactly once");
+static_assert(NPF16_PAIR_PLAN_CHECK_REST_0 && NPF16_PAIR_PLAN_CHECK_REST_1 && NPF16_PAIR_PLAN_CHECK_ALL_0 && NPF16_PAIR_PLAN_CHECK_ALL_1 &&
+                  NPF16_PAIR_PLAN_CHECK_FORCE2_0 && NPF16_PAIR_PLAN_CHECK_FORCE2_1,
+              "the dual phase statements were generated from other plans (tools/gen_mlp_asm.py::PAIR_PLANS)");
 
 template <int CL, int N, int LD, int FIRST>
 __device__ __forceinline__ void eval_class_dual(const AeroWeights &wt, const float (&xa)[NUM_NORM_GROUPS], const float (&xb)[NUM_NORM_GROUPS],
@@ -387,10 +390,19 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
         float xb[NUM_NORM_GROUPS];
 #pragma unroll
         for (int g = 0; g < NUM_NORM_GROUPS; g++) xb[g] = out_b[(NUM_LIVE_NETS + g) * LD];
+#if NPF16_PHASE_ASM  // one asm statement per wave and phase: the weight stream runs across the class boundaries of the wave's plan
+        const unsigned base_a = (unsigned)(unsigned long long)out, base_b = (unsigned)(unsigned long long)out_b;
+        constexpr int STEP_BYTES = (int)(LD * sizeof(float));
+#define NPF16_WAVE(W)                                                                                                                  \
+    if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_dual_ALL_##W<STEP_BYTES>(wt.kblob + MLP_PAIR_ALL_##W##_START, base_a, base_b, xn, xb);          \
+    else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_dual_REST_##W<STEP_BYTES>(wt.kblob + MLP_PAIR_REST_##W##_START, base_a, base_b, xn, xb);  \
+    else mlp_phase_asm_dual_FORCE2_##W<STEP_BYTES>(wt.kblob + MLP_PAIR_FORCE2_##W##_START, base_a, base_b, xn, xb)
+#else
 #define NPF16_WAVE(W)                                                                                    \
     if constexpr (FULL && PART == AB_ALL) eval_pair_wave<PAIR_ALL, W, LD>(wt, xn, xb, out, out_b);           \
     else if constexpr (FULL && PART == AB_REST) eval_pair_wave<PAIR_REST, W, LD>(wt, xn, xb, out, out_b);    \
     else eval_pair_wave<PAIR_FORCE2, W, LD>(wt, xn, xb, out, out_b)
+#endif
         if (part == 0) { NPF16_WAVE(0); }
         else { NPF16_WAVE(1); }
 #undef NPF16_WAVE

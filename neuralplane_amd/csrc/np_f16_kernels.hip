@@ -30,6 +30,12 @@ namespace npf16 {
 #ifndef NPF16_BLOCK
 #define NPF16_BLOCK 128
 #endif
+#ifndef NPF16_PAIR_STAGGER
+#define NPF16_PAIR_STAGGER 20000
+#endif
+#ifndef NPF16_PAIR_GROUPS
+#define NPF16_PAIR_GROUPS 3
+#endif
 #ifndef NPF16_MINWAVES
 #define NPF16_MINWAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
@@ -127,12 +133,14 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
     // worse: 0.45 ms); later workgroups inherit the phase of the workgroup whose slot they take.  Only done
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
-    if (WPT != 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GENERATION && blockIdx.x < FIRST_GENERATION) {
+    constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * 2 / (BLOCK / 64) : FIRST_GENERATION;  // pair variant: two waves per SIMD
+    if (WPT != 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GEN && blockIdx.x < FIRST_GEN) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
         const long long unit = gridDim.x >= 8 * FIRST_GENERATION ? NPF16_STAGGER_CYCLES_LONG : NPF16_STAGGER_CYCLES;
-        const long long wait = (long long)(blockIdx.x % 3) * unit;
+        // pair variant: two waves per SIMD -> two phase groups (NPF16_PAIR_STAGGER cycles apart)
+        const long long wait = WPT == 2 ? (long long)(blockIdx.x % NPF16_PAIR_GROUPS) * NPF16_PAIR_STAGGER : (long long)(blockIdx.x % 3) * unit;
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
@@ -667,8 +675,14 @@ bool use_pair_kernel(const np_f16_ctx *ctx, int64_t n) {
         const char *e = std::getenv("NPF16_KERNEL");
         return e && std::strcmp(e, "pair") == 0;
     }();
-    (void)n;
-    return ctx->variant == NP_KERNEL_PAIR || (ctx->variant == NP_KERNEL_AUTO && forced);
+    // measured against the throughput variant (tools/microbench/ab_pair.sh, one session): N = 1e5 0.060 / 0.062 ms, 2e5 0.112 /
+    // 0.170, 4e5 0.180 / 0.187, 1e6 0.384 / 0.402, 1e7 3.31 / 3.37 — the default above the latency variant's range
+    if (ctx->variant != NP_KERNEL_AUTO) return ctx->variant == NP_KERNEL_PAIR;
+    static const bool off = [] {  // NPF16_KERNEL=throughput|latency pins the others process-wide
+        const char *e = std::getenv("NPF16_KERNEL");
+        return e && (std::strcmp(e, "throughput") == 0 || std::strcmp(e, "latency") == 0);
+    }();
+    return forced || (!off && n > LAT_MAX_N);
 }
 
 template <bool STEP>

@@ -263,6 +263,107 @@ def gen_function_dual(shape):
     return lines, name
 
 
+# ------------------------------------------------------------------------------------------------
+# Pair variant: phase statements with two accumulator sets.  PAIR_PLANS mirrors np_f16_device.h::PAIR_* (checked by
+# static_asserts in the generated file): per phase and per wave of the pair, the (class, first, count) runs it evaluates.
+# ------------------------------------------------------------------------------------------------
+PAIR_PLANS = {
+    'REST': ([('CL_DAMP', 4, 8), ('CL_DLEF', 2, 5), ('CL_E_RUD', 1, 3)],
+             [('CL_D_RUD', 1, 1), ('CL_D_LEF', 1, 1), ('CL_E_LEF', 2, 2), ('CL_F', 1, 2), ('CL_C', 0, 5), ('CL_ETA', 0, 1)]),
+    'ALL': ([('CL_DAMP', 0, 12), ('CL_DLEF', 0, 7), ('CL_E_LEF', 0, 4), ('CL_YPLEF', 0, 1)],
+            [('CL_D_RUD', 0, 2), ('CL_D_LEF', 0, 2), ('CL_E_RUD', 0, 4), ('CL_F', 0, 3), ('CL_YA20', 0, 1), ('CL_C', 0, 5), ('CL_ETA', 0, 1)]),
+    'FORCE2': ([('CL_DAMP', 0, 4), ('CL_DLEF', 0, 2), ('CL_E_LEF', 0, 2), ('CL_E_RUD', 0, 1)],
+               [('CL_D_RUD', 0, 1), ('CL_D_LEF', 0, 1), ('CL_F', 0, 1), ('CL_YPLEF', 0, 1), ('CL_YA20', 0, 1), ('CL_C', 0, 2)]),
+}
+
+
+def gen_phase_dual(kind, wave):
+    CI = {c[0]: i for i, c in enumerate(CLASSES)}
+    items = [(CI[c], first, n) for c, first, n in PAIR_PLANS[kind][wave]]
+    name = f'mlp_phase_asm_dual_{kind}_{wave}'
+    lines = []
+    A = lines.append
+    A(f'// pair phase {kind}, wave {wave}: ' + ', '.join(f'{CLASSES[ci][0]}[{first}:{first + n}]' for ci, first, n in items))
+    A('template <int LDS_STEP>')
+    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base_a, unsigned lds_base_b, const float (&xa)[{len(G)}],')
+    A(f'                                       const float (&xb)[{len(G)}]) {{')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    used_x = sorted({G[g] for ci, _, _ in items for g in CLASSES[ci][2]})
+    emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
+    for c in range(CPG):
+        emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
+    parity = 0
+    for idx, (ci, first, n) in enumerate(items):
+        cname, shape, grps, _, _ = CLASSES[ci]
+        ln = record_len(*shape)
+        ngroups = ln // GROUP
+        start = class_base(ci) + first * ln
+        has_next = idx + 1 < len(items)
+        if has_next:
+            nci, nfirst, _ = items[idx + 1]
+            nstart = class_base(nci) + nfirst * record_len(*CLASSES[nci][1])
+            delta = nstart - (start + (n - 1) * ln)
+            assert delta > 0, (kind, cname, delta)
+        emit(f's_mov_b32 {S_CNT}, {n}')
+        for k, g in enumerate(grps):
+            emit(f'v_mov_b32 v{V_X + 2 * k}, %[xa{G[g]}]')
+            emit(f'v_mov_b32 v{V_X + 2 * k + SET_B}, %[xb{G[g]}]')
+        emit(f'v_add_u32 v{V_ADDR}, %[step]*{class_slot(ci) + first}, %[addra]')
+        emit(f'v_add_u32 v{V_ADDR + SET_B}, %[step]*{class_slot(ci) + first}, %[addrb]')
+        emit(f'.LNP_L{idx}_%=:')
+        pars = [parity, 1 - parity] if (ngroups % 2 == 1 and n > 1) else [parity]
+        for pi, par in enumerate(pars):
+            emit(f's_mov_b32 s{S_NEXT}, 0x{ln * 4:x}')
+            if has_next:
+                emit(f's_cmp_eq_u32 {S_CNT}, 1')
+                emit(f's_cmov_b32 s{S_NEXT}, 0x{delta * 4:x}')
+            emit(f's_add_u32 s{S_NEXT}, s{S_BASE}, s{S_NEXT}')
+            emit(f's_addc_u32 s{S_NEXT + 1}, s{S_BASE + 1}, 0')
+            for ins in second_set(Body(shape, par, use_next=True).build()):
+                emit(ins)
+            emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
+            emit(f'ds_write_b32 v{V_ADDR + SET_B}, v{V_Y + SET_B}')
+            emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
+            emit(f'v_add_u32 v{V_ADDR + SET_B}, %[step], v{V_ADDR + SET_B}')
+            emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], s[{S_NEXT}:{S_NEXT + 1}]')
+            emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
+            emit(f's_cmp_lg_u32 {S_CNT}, 0')
+            if len(pars) == 2 and pi == 0:
+                emit(f's_cbranch_scc0 .LNP_D{idx}_%=')
+            else:
+                emit(f's_cbranch_scc1 .LNP_L{idx}_%=')
+        emit(f'.LNP_D{idx}_%=:')
+        parity = (parity + n * ngroups) % 2
+    emit('s_waitcnt lgkmcnt(0)')
+    A('        :')
+    ops = '[w] "s"(w), [addra] "v"(lds_base_a), [addrb] "v"(lds_base_b), [step] "n"(LDS_STEP)'
+    ops += ', ' + ', '.join(f'[xa{k}] "v"(xa[{k}])' for k in used_x) + ', ' + ', '.join(f'[xb{k}] "v"(xb[{k}])' for k in used_x)
+    A(f'        : {ops}')
+    regs = list(range(70, 128 + SET_B))
+    clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in S_CLOBBER + [S_NEXT, S_NEXT + 1]] + ['"vcc"', '"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+    first_off = class_base(items[0][0]) + items[0][1] * record_len(*CLASSES[items[0][0]][1])
+    A(f'constexpr int MLP_PAIR_{kind}_{wave}_START = {first_off};  // KBLOB offset of the first record')
+    A('')
+    return lines
+
+
+def pair_plan_checks():
+    out = ['// the pair plans the dual phase statements were generated from (checked against np_f16_device.h::PAIR_*)']
+    for kind, waves in PAIR_PLANS.items():
+        for w, items in enumerate(waves):
+            conds = [f'PAIR_{kind}.it[{w}][{k}].cl == {c} && PAIR_{kind}.it[{w}][{k}].first == {f} && PAIR_{kind}.it[{w}][{k}].cnt == {n}'
+                     for k, (c, f, n) in enumerate(items)]
+            conds += [f'PAIR_{kind}.it[{w}][{k}].cnt == 0' for k in range(len(items), 7)]
+            out.append(f'#define NPF16_PAIR_PLAN_CHECK_{kind}_{w} ({" && ".join(conds)})')
+    return out + ['']
+
+
 def gen_dual_file():
     out = ['// GENERATED by tools/gen_mlp_asm.py (gen_function_dual) — do not edit.',
            '// Class bodies with two accumulator sets per weight stream (the "pair" kernel variant, np_f16_device.h).', '#pragma once', '']
@@ -277,6 +378,11 @@ def gen_dual_file():
         out.append(f'    {kw} constexpr (IN == {IN} && H1 == {H1} && H2 == {H2} && H3 == {H3}) mlp_class_asm_dual_{IN}_{H1}_{H2}_{H3}<COUNT, LDS_STEP>(w, addr_a, addr_b, x0a, x1a, x2a, x0b, x1b, x2b);')
     out.append('    else static_assert(IN < 0, "no generated dual body for this shape");')
     out.append('}')
+    out.append('')
+    for kind in PAIR_PLANS:
+        for wave in (0, 1):
+            out += gen_phase_dual(kind, wave)
+    out += pair_plan_checks()
     with open(os.path.join(CSRC, 'np_mlp_asm_dual.inc'), 'w') as f:
         f.write('\n'.join(out) + '\n')
     print('wrote np_mlp_asm_dual.inc')
