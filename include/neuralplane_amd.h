@@ -238,10 +238,11 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
                        const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,
                        float *returns, int device, void *stream);
 
-/* np_f16_step has two bit-identical kernel variants: "throughput" (one lane per aircraft, two independent waves per
- * workgroup — large batches) and "latency" (four waves share a tile of 64 aircraft and split the 44 net evaluations of a
- * step — a step takes about half of a lone wave's 44 us; chosen automatically for n <= 65536 (the measured
- * crossover), Euler solver).  This call pins the choice for a context (tests, tuning). */
+/* np_f16_step has three bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
+ * evaluations of a step — about half of a lone wave's 44 us; chosen automatically for n <= 65536, Euler solver), "pair" (the
+ * two waves of a 128-aircraft workgroup split the nets and evaluate them for each other's aircraft: half the scalar weight
+ * traffic per aircraft; the default above that size for the Euler solver and MLP numerics) and "throughput" (two independent
+ * waves per workgroup; rk4, the 1-D table mode).  This call pins the choice for a context (tests, tuning). */
 enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
