@@ -241,8 +241,8 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 /* np_f16_step has three bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
  * evaluations of a step — about half of a lone wave's 44 us; chosen automatically for n <= 65536, Euler solver), "pair" (the
  * two waves of a 128-aircraft workgroup split the nets and evaluate them for each other's aircraft: half the scalar weight
- * traffic per aircraft; the default above that size for the Euler solver and MLP numerics) and "throughput" (two independent
- * waves per workgroup; rk4, the 1-D table mode).  This call pins the choice for a context (tests, tuning). */
+ * traffic per aircraft; the default above that size with the MLP numerics) and "throughput" (two independent
+ * waves per workgroup; the 1-D table mode).  This call pins the choice for a context (tests, tuning). */
 enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
