@@ -1,11 +1,11 @@
-"""Latency regime: microseconds per env.step for small batches, both kernel variants (bit-identical results)."""
+"""Latency regime: microseconds per env.step for small batches, the three kernel variants (bit-identical results)."""
 import sys, time, torch
 sys.path.insert(0, '.')
 from neuralplane_amd.envs.control_env import ControlEnv
 sizes = [int(x) for x in sys.argv[1:]] or [256, 4096, 16384, 32768, 49152, 65536, 98304, 131072]
 for n in sizes:
     row = []
-    for variant in ('latency', 'throughput'):
+    for variant in ('latency', 'throughput', 'pair'):
         env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=0, device='cuda:0')
         env._batch.set_kernel_variant(variant)
         env.reset()
