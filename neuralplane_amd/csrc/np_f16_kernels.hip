@@ -714,7 +714,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.reset_coef = ctx->d_reset_coef;
     a.wt = ctx->wt;
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
-    const bool pair = STEP && !ctx->cfg.aero_1d_tables && !io->inner_step && use_pair_kernel(ctx, n);
+    const bool pair = STEP && !ctx->cfg.aero_1d_tables && use_pair_kernel(ctx, n);
     const bool latency = !pair && STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)), block(latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;

@@ -216,9 +216,11 @@ def test_checkpoint_resume_is_bit_exact_and_device_vec_env_keeps_tensors_on_gpu(
     assert bool(ref[-1][3].any()) or bool(a_env.env.step_count.min() < 40)   # the resumed stretch really contained resets
 
 
-def test_planning_env_bit_exact_vs_oracle_and_close_to_reference(golden_dir):
+@pytest.mark.parametrize('variant', ['auto'] + VARIANTS)
+def test_planning_env_bit_exact_vs_oracle_and_close_to_reference(golden_dir, variant):
     """PlanningEnv mirror (reset + 50 x {low-level obs kernel, controller, inner fused step}) with the reference's
-    recorded low-level actions replayed as the controller: == oracle bit for bit, masks == reference."""
+    recorded low-level actions replayed as the controller: == oracle bit for bit, masks == reference — whichever kernel
+    variant runs the inner steps."""
     from neuralplane_amd.envs.planning_env import PlanningEnv
     g = np.load(f'{golden_dir}/planning_kat.npz')
     hi = g['hi_actions']
@@ -236,6 +238,7 @@ def test_planning_env_bit_exact_vs_oracle_and_close_to_reference(golden_dir):
 
     ctrl = Replay()
     env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cuda:0', controller=ctrl)
+    env._batch.set_kernel_variant(variant)
     o = Oracle('tracking')
     st = Oracle.new_state(n)
     for k in range(hi.shape[0]):
