@@ -74,6 +74,10 @@ class Body:
         self.ins = []
         self.pos = 0
         self.cur_group = -1
+        # for the dual bodies (second_set): instructions that set B does not repeat (bias moves) and instructions whose set-B
+        # version is special and goes FIRST (the first FMA of a chain takes the bias from set A's freshly initialised register)
+        self.skip_dup = set()
+        self.b_first = {}
 
     def sreg(self, pos):
         c, l = divmod(pos, 16)
@@ -123,11 +127,14 @@ class Body:
         if not no_bias:                                        # getting the bias moves off the VALU could gain
             for j in range(0, n_out - 1, 2):
                 sp = self.spair(p0 + j)
+                self.skip_dup.add(len(self.ins))
                 self.ins.append(f'v_pk_mov_b32 {self.vpair(out_base + j)}, {sp}, {sp} op_sel:[0,1]')
                 if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1':   # TIMING EXPERIMENT ONLY: what one bias move costs
                     self.ins.append(f'v_pk_mov_b32 v[68:69], {sp}, {sp} op_sel:[0,1]')
             if n_out & 1:
-                self.ins.append(f'v_mov_b32 v{out_base + n_out - 1}, {self.s1(p0 + n_out - 1)}')
+                s_b = self.s1(p0 + n_out - 1)
+                self.skip_dup.add(len(self.ins))
+                self.ins.append(f'v_mov_b32 v{out_base + n_out - 1}, {s_b}')
         for k in range(n_in):
             pk = p0 + row * (k + 1)
             xr = in_regs[k]
@@ -142,20 +149,30 @@ class Body:
                 if no_bias and k == 0:
                     self.ins.append(f'v_pk_mul_f32 {acc}, {sp}, {xp} op_sel:[0,{e}] op_sel_hi:[1,{e}]')
                     continue
+                if k == 0 and not no_bias:   # set B: acc_B = fma(w, x_B, bias) with the bias read from set A's register
+                    xpb, accb = self.vpair(xr - e + SET_B), self.vpair(out_base + j + SET_B)
+                    self.b_first[len(self.ins)] = f'v_pk_fma_f32 {accb}, {sp}, {xpb}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]{relu}'
                 self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {xp}, {acc} op_sel:[0,{e},0] op_sel_hi:[1,{e},1]{relu}')
             if n_out & 1:
                 j = n_out - 1
+                s_w = self.s1(pk + j)
+                if k == 0 and not no_bias:
+                    self.b_first[len(self.ins)] = f'v_fma_f32 v{out_base + j + SET_B}, {s_w}, v{xr + SET_B}, v{out_base + j}' + (' clamp' if relu else '')
                 if relu:
-                    self.ins.append(f'v_fma_f32 v{out_base + j}, {self.s1(pk + j)}, v{xr}, v{out_base + j} clamp')
+                    self.ins.append(f'v_fma_f32 v{out_base + j}, {s_w}, v{xr}, v{out_base + j} clamp')
                 else:
-                    self.ins.append(f'v_fmac_f32 v{out_base + j}, {self.s1(pk + j)}, v{xr}')
+                    self.ins.append(f'v_fmac_f32 v{out_base + j}, {s_w}, v{xr}')
         self.pos = p0 + row * (n_in + 1)
 
     def final(self, n_in, in_regs):
         p0 = self.pos
+        self.skip_dup.add(len(self.ins))
         self.ins.append(f'v_mov_b32 v{V_Y}, {self.s1(p0)}')
         for k in range(n_in):
-            self.ins.append(f'v_fmac_f32 v{V_Y}, {self.s1(p0 + 1 + k)}, v{in_regs[k]}')
+            s_w = self.s1(p0 + 1 + k)
+            if k == 0:
+                self.b_first[len(self.ins)] = f'v_fma_f32 v{V_Y + SET_B}, {s_w}, v{in_regs[k] + SET_B}, v{V_Y}'
+            self.ins.append(f'v_fmac_f32 v{V_Y}, {s_w}, v{in_regs[k]}')
         self.pos = p0 + pad2(1 + n_in)
         # unnormalize: X * std + mean, two roundings (hifi_F16_AeroData.py:36-37)
         self.ins.append(f'v_mul_f32 v{V_Y}, {self.s1(self.pos)}, v{V_Y}')
@@ -179,16 +196,20 @@ class Body:
         self.touch(self.len - 1)
         assert self.cur_group == self.len // GROUP - 1
         if GEN_DUP:
-            self.ins = second_set(self.ins)
+            self.ins = second_set(self.ins)   # the experiment duplicates everything, bias moves included
         return self.ins
 
 
 SET_B = 58   # the second accumulator set of the dual bodies lives SET_B registers above the first (v128-v185)
 
 
-def second_set(ins_list):
-    """every VALU instruction once more, on the registers of the second set (same SGPR weight operands)"""
+def second_set(ins_list, body=None):
+    """every VALU instruction once more, on the registers of the second set (same SGPR weight operands) — except the bias
+    moves: set B's first FMA of every chain reads the bias out of set A's register (before set A's own first FMA overwrites
+    it), so acc_B = fma(w0, x0_B, bias) needs no move of its own.  The chains stay acc = bias; acc = fma(w_k, x_k, acc)."""
     import re
+    skip = body.skip_dup if body is not None else set()
+    first = body.b_first if body is not None else {}
 
     def shift(m):
         if m.group(1) is not None:
@@ -197,9 +218,13 @@ def second_set(ins_list):
         r = int(m.group(3))
         return f'v{r + SET_B}' if r >= 70 else m.group(0)
     out = []
-    for ins in ins_list:
+    for i, ins in enumerate(ins_list):
+        if i in first:
+            out.append(first[i])
+            out.append(ins)
+            continue
         out.append(ins)
-        if ins.startswith('v_'):
+        if ins.startswith('v_') and i not in skip:
             out.append(re.sub(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', shift, ins))
     return out
 
@@ -236,7 +261,8 @@ def gen_function_dual(shape):
         emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
     emit('.LNP_LOOP_%=:')
     for parity in ([0, 1] if two_parities else [0]):
-        for ins in second_set(Body(shape, parity).build()):
+        body = Body(shape, parity)
+        for ins in second_set(body.build(), body):
             emit(ins)
         emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
         emit(f'ds_write_b32 v{V_ADDR + SET_B}, v{V_Y + SET_B}')
@@ -323,7 +349,8 @@ def gen_phase_dual(kind, wave):
                 emit(f's_cmov_b32 s{S_NEXT}, 0x{delta * 4:x}')
             emit(f's_add_u32 s{S_NEXT}, s{S_BASE}, s{S_NEXT}')
             emit(f's_addc_u32 s{S_NEXT + 1}, s{S_BASE + 1}, 0')
-            for ins in second_set(Body(shape, par, use_next=True).build()):
+            body = Body(shape, par, use_next=True)
+            for ins in second_set(body.build(), body):
                 emit(ins)
             emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
             emit(f'ds_write_b32 v{V_ADDR + SET_B}, v{V_Y + SET_B}')
