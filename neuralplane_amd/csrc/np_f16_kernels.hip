@@ -95,10 +95,14 @@ struct KArgs {
 // STEP=false: BaseEnv.reset (env_base.py:83-97)
 // CACHED    : a.cache holds, for every row, the 14 force-side alpha/beta-only coefficients of its CURRENT
 //             state (written by the previous step's Overload evaluation) -> the integrator skips them.
-// TILE, WPT : aircraft per workgroup and waves that share them.  Throughput variant: TILE = 128, WPT = 1 (2 independent
-//             waves).  Latency variant (small batches): TILE = 64, WPT = 4 — four waves hold the SAME 64 aircraft, split the
-//             net evaluations (eval_nets<.., 4>, np_f16_device.h) and redo the cheap non-MLP arithmetic redundantly, so a
-//             step takes ~1/2 of a lone wave's time; wave 0 stores.  Results are bit-identical between the variants.
+// TILE, WPT : aircraft per workgroup and how its waves cooperate.  Results are bit-identical between the variants.
+//             WPT = 1, TILE = 128  throughput variant: two independent waves (rk4 fallbacks, the 1-D table mode).
+//             WPT = 2, TILE = 128  pair variant (default for large batches): each wave owns 64 aircraft, but the two waves split
+//                                  the NETS of every evaluation and evaluate their half for both waves' aircraft (dual asm
+//                                  bodies, eval_nets in np_f16_device.h); inputs and coefficients cross through LDS.
+//             WPT = 4, TILE = 64   latency variant (small batches): four waves hold the SAME 64 aircraft, split the net
+//                                  evaluations and redo the cheap non-MLP arithmetic redundantly, so a step takes ~1/2 of a
+//                                  lone wave's time; wave 0 stores.
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1>
 __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
     // pair variant (WPT == 2): nine more columns carry the normalised MLP inputs to the other wave of the workgroup
