@@ -111,3 +111,23 @@ def test_generated_asm_is_up_to_date(tmp_path):
     for name in ('np_mlp_asm.inc', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc'):
         with open(tmp_path / name, 'rb') as f, open(os.path.join(root, 'neuralplane_amd', 'csrc', name), 'rb') as g:
             assert f.read() == g.read(), f'{name} is stale: run python tools/gen_mlp_asm.py'
+
+
+def test_pair_plans_are_balanced_and_complete():
+    """tools/gen_mlp_asm.py::PAIR_PLANS (mirrored by np_f16_device.h::PAIR_*, tied by static_asserts in the generated file): the
+    two waves of a pair get the same number of VALU instructions within 3 %, and together they cover every net of the phase
+    exactly once."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'tools', 'gen_mlp_asm.py')).read().replace("if __name__ == '__main__':", 'if False:')
+    g = {'__file__': os.path.join(root, 'tools', 'gen_mlp_asm.py')}
+    exec(compile(src, 'gen_mlp_asm', 'exec'), g)
+    cost = {shape: sum(1 for i in g['Body'](shape, 0).build() if i.startswith('v_')) for shape in g['SHAPES']}
+    classes = {c[0]: c for c in g['CLASSES']}
+    for kind, waves in g['PAIR_PLANS'].items():
+        loads = [sum(cost[classes[c][1]] * n for c, _, n in w) for w in waves]
+        assert abs(loads[0] - loads[1]) <= 0.03 * max(loads), (kind, loads)
+        want = {(classes_name, k) for ci, first, n in g['phase_items'](kind) for classes_name in [g['CLASSES'][ci][0]] for k in range(first, first + n)}
+        got = [(c, k) for w in waves for c, first, n in w for k in range(first, first + n)]
+        assert len(got) == len(set(got)) and set(got) == want, kind
