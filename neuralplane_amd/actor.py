@@ -76,7 +76,9 @@ class FusedActor:
     def eval(self):
         return self
 
-    def __call__(self, obs, rnn_states, masks, deterministic=True):
+    def __call__(self, obs, rnn_states, masks, deterministic=True, out=None):
+        """PPOActor.forward.  `out=(actions[n,4], rnn_states[n,1,128])`: write into caller-owned buffers (distinct from the
+        inputs) instead of allocating — PlanningEnv ping-pongs two recurrent-state buffers through its 50 inner iterations."""
         if not deterministic:
             raise NotImplementedError('the frozen low-level controller acts deterministically (planning_env.py:158)')
         n = obs.shape[0]
@@ -85,8 +87,17 @@ class FusedActor:
         if h.data_ptr() % 16:  # a view at an odd storage offset: the kernel reads the state 16 bytes at a time
             h = h.clone()
         m = masks.to(device=self.device, dtype=torch.float32).reshape(n).contiguous()
-        act = torch.empty((n, ACT), dtype=torch.float32, device=self.device)
-        h_out = torch.empty((n, 1, HID), dtype=torch.float32, device=self.device)
+        if out is None:
+            act = torch.empty((n, ACT), dtype=torch.float32, device=self.device)
+            h_out = torch.empty((n, 1, HID), dtype=torch.float32, device=self.device)
+        else:
+            act, h_out = out
+            ok = (act.is_contiguous() and h_out.is_contiguous() and act.dtype == torch.float32 and h_out.dtype == torch.float32 and
+                  act.numel() == n * ACT and h_out.numel() == n * HID and act.device == self.device and h_out.device == self.device and
+                  h_out.data_ptr() != h.data_ptr() and h_out.data_ptr() % 16 == 0)
+            if not ok:
+                raise ValueError('out = (actions[n,4], rnn_states[n,1,128]): contiguous float32 device tensors, the state buffer 16-byte aligned '
+                                 'and different from the input state')
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self.lib.np_actor_forward(self.weights.data_ptr(), NUM_FLOATS, n, obs.data_ptr(), h.data_ptr(), m.data_ptr(),
                                              act.data_ptr(), h_out.data_ptr(), self.device.index, stream))

@@ -17,6 +17,7 @@ import os
 import numpy as np
 import torch
 
+from ..actor import FusedActor
 from .env_base import BaseEnv
 from .models.F16_model import F16Model
 from .spaces import Box
@@ -114,11 +115,17 @@ class PlanningEnv(BaseEnv):
         action = torch.clamp(g['action'], -1, 1)
         tgt3 = torch.stack((b.s[4] + action[:, 0] * 0.3, b.s[5] + action[:, 1] * 0.3, b.s[6] + action[:, 2] * 30))
         fin, fout = g['fb'], g['fa']
+        fused = isinstance(self.controller, FusedActor)   # writes into caller-owned buffers: no allocation, no state copy
+        rnn_a, rnn_b = g['rnn'], g.get('rnn2')
         for k in range(INNER_STEPS):
             b.lowlevel_obs_into(tgt3, g['ll_obs'])
-            ego_actions, _, rnn = self.controller(g['ll_obs'], g['rnn'], g['masks'], deterministic=True)
-            g['rnn'].copy_(rnn)
-            ego_actions = ego_actions.to(torch.float32).contiguous()
+            if fused:
+                ego_actions, _, _ = self.controller(g['ll_obs'], rnn_a, g['masks'], deterministic=True, out=(g['ll_act'], rnn_b))
+                rnn_a, rnn_b = rnn_b, rnn_a          # INNER_STEPS is even: the state ends up in g['rnn'] again
+            else:
+                ego_actions, _, rnn = self.controller(g['ll_obs'], g['rnn'], g['masks'], deterministic=True)
+                g['rnn'].copy_(rnn)
+                ego_actions = ego_actions.to(torch.float32).contiguous()
             # the first inner step re-evaluates the cached coefficients: the caller may have edited `s` between steps
             b.launch_static(fin, fout, 1 + k, action=ego_actions, obs=g['obs'], reward=g['reward'], inner=True, cache_valid=(k > 0))
             fin, fout = fout, fin
@@ -132,6 +139,10 @@ class PlanningEnv(BaseEnv):
              'll_obs': torch.empty((n, 22), dtype=torch.float32, device=d), 'obs': torch.empty((n, 22), dtype=torch.float32, device=d),
              'reward': torch.empty(n, dtype=torch.float32, device=d), 'masks': torch.ones((n, 1), device=d),
              'rnn': self.ego_rnn_states.detach().clone()}
+        if isinstance(self.controller, FusedActor):   # second recurrent-state buffer and the low-level actions, written in place
+            g['rnn2'] = torch.empty_like(g['rnn'])
+            g['ll_act'] = torch.empty((n, 4), dtype=torch.float32, device=d)
+        assert INNER_STEPS % 2 == 0
         # warm-up on a side stream (library handles, autotuning) with the env state saved and restored around it
         saved = (b.state_dict(), b.coef_cache.clone(), g['rnn'].clone())
         g['fa'].copy_(b.flags)
