@@ -31,7 +31,7 @@ namespace npf16 {
 #define NPF16_BLOCK 128
 #endif
 #ifndef NPF16_PAIR_STAGGER
-#define NPF16_PAIR_STAGGER 20000
+#define NPF16_PAIR_STAGGER 14000  // 10 000 / 14 000 / 20 000 / 26 000 cycles: N = 1e6 0.38 ms all; 3e6 1.02 / 1.02 / 1.05 / -; 1e7 3.21 / 3.19 / 3.49 / 3.51 ms
 #endif
 #ifndef NPF16_PAIR_GROUPS
 #define NPF16_PAIR_GROUPS 3
