@@ -73,6 +73,14 @@ class FusedActor:
         self.packed = w
         self.weights = torch.from_numpy(w).to(self.device)
 
+    @classmethod
+    def from_checkpoint(cls, path, device='cuda:0'):
+        """The reference's `actor_latest.pt` (a PPOActor state_dict saved by its runner, runner/F16sim_runner.py:223-229)."""
+        sd = torch.load(path, map_location='cpu')
+        if not isinstance(sd, dict):
+            raise ValueError(f'{path}: expected a PPOActor state_dict')
+        return cls({k: v for k, v in sd.items()}, device)
+
     def eval(self):
         return self
 

@@ -45,6 +45,14 @@ class PlanningEnv(BaseEnv):
                  controller_checkpoint=None, row0=0, aero_1d_tables=None):
         super().__init__(num_envs, config, model, random_seed, device, row0=row0, aero_1d_tables=aero_1d_tables)
         self.low_level_action_space = Box(low=-np.inf, high=np.inf, shape=(4,))
+        if isinstance(controller, str):
+            if controller != 'fused':
+                raise ValueError("controller: a callable with the PPOActor signature, None (the host repo's PPOActor) or 'fused'")
+            # the reference's checkpoint (planning_env.py:16,43) run by the fused MFMA kernel instead of ~15 torch kernels per call
+            ckpt = controller_checkpoint or self._default_checkpoint()
+            if not os.path.exists(ckpt):
+                raise RuntimeError(f'low-level controller checkpoint {ckpt} not found (it is not part of the reference snapshot)')
+            controller = FusedActor.from_checkpoint(ckpt, self.device)
         self.controller = controller if controller is not None else self._load_reference_actor(controller_checkpoint)
         self.ego_rnn_states = torch.zeros((self.n, 1, 128), device=self.device)
         self._graph_enabled = False
@@ -59,14 +67,17 @@ class PlanningEnv(BaseEnv):
         self.model = F16Model(self.config, self.n, self.device, random_seed, batch)
         self.task = TrackingTask(self.config, self.n, self.device, random_seed, batch)
 
+    @staticmethod
+    def _default_checkpoint():
+        return os.path.join(os.getcwd(), '..', 'scripts', 'runs', '2024-05-26_02-14-24_Control_control_ppo_v1', 'episode_249', 'actor_latest.pt')
+
     def _load_reference_actor(self, checkpoint):
         try:
             from algorithms.ppo.ppo_actor import PPOActor  # the host repo's own actor (out of the accelerated path)
         except Exception as e:  # pragma: no cover
             raise RuntimeError('PlanningEnv needs a low-level controller: pass controller=..., or run inside the '
                                'NeuralPlane repo so that algorithms.ppo.ppo_actor.PPOActor is importable') from e
-        ckpt = checkpoint or os.path.join(os.getcwd(), '..', 'scripts', 'runs',
-                                          '2024-05-26_02-14-24_Control_control_ppo_v1', 'episode_249', 'actor_latest.pt')
+        ckpt = checkpoint or self._default_checkpoint()
         if not os.path.exists(ckpt):
             raise RuntimeError(f'low-level controller checkpoint {ckpt} not found (it is not part of the reference snapshot)')
         actor = PPOActor(_ActorArgs(self.device), self.observation_space, self.low_level_action_space, device=self.device)

@@ -106,3 +106,23 @@ def test_misaligned_recurrent_state(golden_dir):
     rc = fa.lib.np_actor_forward(fa.weights.data_ptr(), NUM_FLOATS, n, obs.data_ptr(), h_view.data_ptr(), m.data_ptr(), act.data_ptr(),
                                  h_out.data_ptr(), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0 and b'aligned' in _lib.load().np_last_error()
+
+
+def test_planning_env_loads_a_checkpoint_into_the_fused_controller(golden_dir, tmp_path):
+    """PlanningEnv(controller='fused', controller_checkpoint=path): the reference's actor_latest.pt format (a PPOActor
+    state_dict) runs through the fused kernel; same results as handing the state_dict over directly; a missing file fails loudly."""
+    from neuralplane_amd.actor import FusedActor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    sd = {k: torch.from_numpy(v) for k, v in _sd(d).items()}
+    path = tmp_path / 'actor_latest.pt'
+    torch.save(sd, path)
+    n = 200
+    a = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=2, device='cuda:0', controller='fused', controller_checkpoint=str(path))
+    b = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=2, device='cuda:0', controller=FusedActor(sd, 'cuda:0'))
+    act = torch.rand(n, 3, device='cuda') * 2 - 1
+    for _ in range(2):
+        ra, rb = a.step(act), b.step(act)
+        assert all(torch.equal(x, y) for x, y in zip(ra[:5], rb[:5]))
+    with pytest.raises(RuntimeError, match='not found'):
+        PlanningEnv(num_envs=4, config='tracking', model='F16', random_seed=0, device='cuda:0', controller='fused', controller_checkpoint=str(tmp_path / 'nope.pt'))
