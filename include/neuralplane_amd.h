@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 8
+#define NP_ABI_VERSION 9
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -251,6 +251,18 @@ int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
  * enable with np_f16_set_timing(ctx, 1)).  Synchronises on the recorded events. */
 int np_f16_set_timing(np_f16_ctx *ctx, int enable);
 int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count);
+/* The individual durations (ms, launch order) behind np_f16_get_timing since timing was enabled: the first
+ * min(capacity, *count) of them are copied to ms_out; *count = launches timed.  For the median / first-launch
+ * numbers bench.py reports beside the mean (the reference's own benchmark, envs/measure_env.py:65-78, reports a mean only). */
+int np_f16_get_timing_samples(np_f16_ctx *ctx, float *ms_out, int64_t capacity, int64_t *count);
+
+/* Profiling hook: while a device buffer of capacity_workgroups x NP_TRACE_WORDS uint64 is set (NULL clears), every
+ * np_f16_step launch on this context writes one record per workgroup: [0] shader-clock counter at entry, [1] after the
+ * de-phasing delay, [2] at exit, [3] / [4] the constant-rate (100 MHz) counter at entry / exit, [5] XCC id << 32 | HW_ID.
+ * capacity must cover ceil(n / 64) workgroups.  tools/wg_timeline.py turns the records into the per-CU occupancy timeline
+ * (start-up, tail, effective shader clock) quoted in DESIGN.md. */
+#define NP_TRACE_WORDS 6
+int np_f16_set_trace(np_f16_ctx *ctx, uint64_t *dev_buf, int64_t capacity_workgroups);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,8 @@ class DeviceReplayBuffer:
 
     def __init__(self, args, num_agents, obs_space, act_space, device='cuda:0'):
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:   # 'cuda' = the CURRENT device (a torchrun rank after set_device)
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.buffer_size = args.buffer_size
         self.n_rollout_threads = args.n_rollout_threads
         self.num_agents = num_agents
@@ -123,19 +125,20 @@ class DeviceReplayBuffer:
         _lib.check(lib.np_rollout_returns(T, N, float(self.gamma), float(self.gae_lambda), int(bool(self.use_gae)),
                                           int(bool(self.use_proper_time_limits)), self.rewards.data_ptr(), self.value_preds.data_ptr(),
                                           self.masks.data_ptr(), self.bad_masks.data_ptr(), nv.data_ptr(), self.returns.data_ptr(),
-                                          self.device.index or 0, stream))
+                                          self.device.index, stream))
 
     @staticmethod
     def recurrent_generator(buffer, num_mini_batch, data_chunk_length):
         buffer = [buffer] if isinstance(buffer, DeviceReplayBuffer) else buffer
         n_rollout_threads, buffer_size, num_agents = buffer[0].n_rollout_threads, buffer[0].buffer_size, buffer[0].num_agents
-        assert all(b.n_rollout_threads == n_rollout_threads and b.buffer_size == buffer_size and b.num_agents == num_agents
-                   and isinstance(b, DeviceReplayBuffer) for b in buffer), "Input buffers must has the same type and shape"
+        for b in buffer:
+            if not isinstance(b, DeviceReplayBuffer) or (b.n_rollout_threads, b.buffer_size, b.num_agents) != (n_rollout_threads, buffer_size, num_agents):
+                raise AssertionError('recurrent_generator: every buffer must be a DeviceReplayBuffer of the same '
+                                     '(n_rollout_threads, buffer_size, num_agents)')
         buffer_size = buffer_size * len(buffer)
-        assert n_rollout_threads * buffer_size >= data_chunk_length, (
-            "PPO requires the number of processes ({}) * buffer size ({}) * num_agents ({})"
-            "to be greater than or equal to the number of "
-            "data chunk length ({}).".format(n_rollout_threads, buffer_size, num_agents, data_chunk_length))
+        if n_rollout_threads * buffer_size < data_chunk_length:
+            raise AssertionError(f'recurrent_generator: {n_rollout_threads} rollout threads x {buffer_size} steps hold fewer than one '
+                                 f'chunk of data_chunk_length={data_chunk_length} (num_agents={num_agents})')
         cast, cat = DeviceReplayBuffer._cast, (lambda xs: torch.cat(xs, dim=0))
         obs = cat([cast(b.obs[:-1]) for b in buffer])
         actions = cat([cast(b.actions) for b in buffer])

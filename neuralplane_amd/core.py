@@ -260,6 +260,14 @@ class F16Batch:
         _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def get_timing_samples(self):
+        """Durations (ms) of the individual launches timed since set_timing(True), in launch order."""
+        cnt = C.c_int64()
+        _lib.check(self.lib.np_f16_get_timing_samples(self._ctx, None, 0, C.byref(cnt)))
+        buf = (C.c_float * max(1, cnt.value))()
+        _lib.check(self.lib.np_f16_get_timing_samples(self._ctx, buf, cnt.value, C.byref(cnt)))
+        return [float(buf[i]) for i in range(cnt.value)]
+
     TERM_NAMES = ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'unreach', 'reached')
 
     def termination_counts(self, reset=False):
@@ -448,6 +456,14 @@ class F16CombatBatch:
         ms, cnt = C.c_double(), C.c_int64()
         _lib.check(self.lib.np_f16_get_timing(self._ctx, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def get_timing_samples(self):
+        """Durations (ms) of the individual launches timed since set_timing(True), in launch order."""
+        cnt = C.c_int64()
+        _lib.check(self.lib.np_f16_get_timing_samples(self._ctx, None, 0, C.byref(cnt)))
+        buf = (C.c_float * max(1, cnt.value))()
+        _lib.check(self.lib.np_f16_get_timing_samples(self._ctx, buf, cnt.value, C.byref(cnt)))
+        return [float(buf[i]) for i in range(cnt.value)]
 
     def set_kernel_variant(self, variant):
         """'auto' (default: latency kernel while n <= 49152 aircraft), 'latency', 'throughput' — bit-identical results."""

@@ -89,6 +89,9 @@ struct KArgs {
     // device; read only inside the `flagged` branches
     const float *reset_coef;
     AeroWeights wt;
+    // profiling hook (np_f16_set_trace; null otherwise): per workgroup NP_TRACE_WORDS 64-bit words — shader-clock counter at
+    // entry, after the de-phasing delay and at exit, the constant 100 MHz counter at entry and exit, XCC / CU / SIMD ids
+    unsigned long long *trace;
 };
 
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
@@ -126,6 +129,11 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
     KArgsC ap = (KArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter: offset 0 of the segment
     const bool tables = a.cfg.aero_1d_tables != 0;
     const uint64_t call_idx = a.call_idx + (a.call_idx_base ? *a.call_idx_base : 0ull);
+    unsigned long long tr_c0 = 0, tr_r0 = 0, tr_c1 = 0;
+    if (a.trace) {  // wave-uniform, null outside profiling runs
+        tr_c0 = __builtin_readcyclecounter();
+        tr_r0 = wall_clock64();
+    }
 
     // ---- de-phasing -----------------------------------------------------------------------------------
     // Every workgroup does identical work: load state (HBM) -> ~45 K VALU cycles -> store.  Launched
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
+    if (a.trace) tr_c1 = __builtin_readcyclecounter();
 
     // row-indexed arrays are addressed as (uniform 64-bit base in SGPRs) + (32-bit per-lane offset): ld < 2^30 is checked on the
     // host, so the byte offset of a row fits 32 bits and no per-access 64-bit VALU address arithmetic is left
@@ -352,6 +361,18 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
             }
         }
     }
+    if (ap->trace && threadIdx.x == 0) {
+        unsigned long long *rec = ap->trace + (unsigned long long)blockIdx.x * NP_TRACE_WORDS;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        rec[0] = tr_c0;
+        rec[1] = tr_c1;
+        rec[2] = __builtin_readcyclecounter();
+        rec[3] = tr_r0;
+        rec[4] = wall_clock64();
+        rec[5] = ((unsigned long long)xcc << 32) | hw;
+    }
 }
 
 // F16Model getters that need the dynamics (F16_model.py:47-49, 132-181): out[20][ld_out]
@@ -477,6 +498,9 @@ struct np_f16_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double t_sum_ms;
     int64_t t_count;
+    std::vector<float> samples;  // per-launch durations in launch order since np_f16_set_timing(ctx, 1)
+    unsigned long long *trace;   // np_f16_set_trace
+    int64_t trace_cap;
 };
 
 namespace {
@@ -717,11 +741,19 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
     a.wt = ctx->wt;
+    a.trace = nullptr;
+    if (STEP && ctx->trace) {
+        const int64_t wgs = (n + 63) / 64;  // upper bound over the variants' grids
+        if (wgs > ctx->trace_cap) return fail("np_f16_set_trace: buffer too small for this launch");
+        a.trace = ctx->trace;
+    }
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
     const bool pair = STEP && !ctx->cfg.aero_1d_tables && use_pair_kernel(ctx, n);
     const bool latency = !pair && STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)), block(latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
+    if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
+    const bool cached = STEP && io->coef_cache && io->cache_valid;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = STEP && ctx->timing;
     if (timed) {
@@ -734,8 +766,6 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         }
         NP_HIP(hipEventRecord(ev.first, st));
     }
-    const bool cached = STEP && io->coef_cache && io->cache_valid;
-    if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
 #define NP_LAUNCH(T, S)                                                                                           \
     do {                                                                                                          \
         if (pair) {                                                                                               \
@@ -933,6 +963,8 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     ctx->timing = false;
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
+    ctx->trace = nullptr;
+    ctx->trace_cap = 0;
     *out = ctx;
     return 0;
 }
@@ -1102,6 +1134,7 @@ int np_f16_set_timing(np_f16_ctx *ctx, int enable) {
     ctx->timing = enable != 0;
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
+    ctx->samples.clear();
     for (auto &e : ctx->events) ctx->pool.push_back(e);
     ctx->events.clear();
     return 0;
@@ -1117,11 +1150,30 @@ int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count) {
         NP_HIP(hipEventElapsedTime(&ms, e.first, e.second));
         ctx->t_sum_ms += ms;
         ctx->t_count += 1;
+        ctx->samples.push_back(ms);
         ctx->pool.push_back(e);
     }
     ctx->events.clear();
     if (avg_ms) *avg_ms = ctx->t_count ? ctx->t_sum_ms / (double)ctx->t_count : 0.0;
     if (count) *count = ctx->t_count;
+    return 0;
+}
+
+int np_f16_set_trace(np_f16_ctx *ctx, uint64_t *dev_buf, int64_t capacity_workgroups) {
+    if (!ctx) return fail("null ctx");
+    if (dev_buf && capacity_workgroups <= 0) return fail("np_f16_set_trace: capacity must be positive");
+    ctx->trace = (unsigned long long *)dev_buf;
+    ctx->trace_cap = dev_buf ? capacity_workgroups : 0;
+    return 0;
+}
+
+int np_f16_get_timing_samples(np_f16_ctx *ctx, float *ms_out, int64_t capacity, int64_t *count) {
+    if (!ctx) return fail("null ctx");
+    if (capacity < 0 || (capacity > 0 && !ms_out)) return fail("bad sample buffer");
+    if (np_f16_get_timing(ctx, nullptr, nullptr)) return 1;  // resolves the events still pending
+    const int64_t n = (int64_t)ctx->samples.size(), m = n < capacity ? n : capacity;
+    for (int64_t k = 0; k < m; k++) ms_out[k] = ctx->samples[(size_t)k];
+    if (count) *count = n;
     return 0;
 }
 

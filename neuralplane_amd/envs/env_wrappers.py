@@ -18,6 +18,8 @@ class GPUVecEnv:
         self.device = self.env.device
         self.observation_space = self.env.observation_space
         self.action_space = self.env.action_space
+        self.closed = False
+        self._pending = None
 
     def _shape(self, x, k):
         return x.reshape(self.num_envs, self.num_agents, k)
@@ -27,13 +29,35 @@ class GPUVecEnv:
         return _t2n(self._shape(obs, obs.shape[-1]))
 
     def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    # The reference's VecEnv protocol (envs/env_wrappers.py:40-82,113-123) splits a step into step_async / step_wait; its
+    # GPUVecEnv leaves both empty.  Here they are the natural halves of a GPU step: step_async enqueues the H2D copy and the
+    # fused kernel on the current stream and returns at once, step_wait brings the results to the host (the synchronising part).
+    def step_async(self, actions):
+        if self.closed:
+            raise RuntimeError('step_async on a closed GPUVecEnv')
         a = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device).reshape(self.n, -1)
-        obs, reward, done, bad_done, exceed_time_limit, info = self.env.step(a)
+        self._pending = self.env.step(a)
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError('step_wait without a step_async in flight')
+        obs, reward, done, bad_done, exceed_time_limit, info = self._pending
+        self._pending = None
         return (_t2n(self._shape(obs, obs.shape[-1])), _t2n(self._shape(reward, 1)), _t2n(self._shape(done, 1)),
                 _t2n(self._shape(bad_done, 1)), _t2n(self._shape(exceed_time_limit, 1)), info)
 
-    def close(self):
+    def close_extras(self):
         pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.close_extras()
+        self._pending = None
+        self.closed = True
 
 
 class PinnedVecEnv(GPUVecEnv):
@@ -70,6 +94,12 @@ class PinnedVecEnv(GPUVecEnv):
         return self._shape(h, h.shape[-1]).numpy()
 
     def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_async(self, actions):
+        if self.closed:
+            raise RuntimeError('step_async on a closed PinnedVecEnv')
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, -1)
         if self._act_host is None or self._act_host.shape != a.shape:
             self._act_host = torch.empty(a.shape, dtype=torch.float32, pin_memory=True)
@@ -80,6 +110,13 @@ class PinnedVecEnv(GPUVecEnv):
         bufs = self._next()
         h = [self._to_host(bufs, k, v) for k, v in (('obs', obs), ('reward', reward), ('done', done), ('bad', bad_done),
                                                     ('tmo', exceed_time_limit))]
+        self._pending = (h, info)                                   # kernel and the five D2H copies are in flight
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError('step_wait without a step_async in flight')
+        h, info = self._pending
+        self._pending = None
         torch.cuda.current_stream(self.device).synchronize()       # the only host<->device synchronisation of the step
         return (self._shape(h[0], h[0].shape[-1]).numpy(), self._shape(h[1], 1).numpy(), self._shape(h[2], 1).numpy(),
                 self._shape(h[3], 1).numpy(), self._shape(h[4], 1).numpy(), info)
@@ -95,8 +132,16 @@ class DeviceVecEnv(GPUVecEnv):
         obs = self.env.reset()
         return self._shape(obs, obs.shape[-1])
 
-    def step(self, actions):
+    def step_async(self, actions):
+        if self.closed:
+            raise RuntimeError('step_async on a closed DeviceVecEnv')
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(self.n, -1)
-        obs, reward, done, bad_done, exceed_time_limit, info = self.env.step(a)
+        self._pending = self.env.step(a)
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError('step_wait without a step_async in flight')
+        obs, reward, done, bad_done, exceed_time_limit, info = self._pending
+        self._pending = None
         return (self._shape(obs, obs.shape[-1]), self._shape(reward, 1), self._shape(done, 1),
                 self._shape(bad_done, 1), self._shape(exceed_time_limit, 1), info)

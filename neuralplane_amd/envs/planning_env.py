@@ -106,6 +106,7 @@ class PlanningEnv(BaseEnv):
             obs, reward, flags = b.step(ego_actions, inner=True)
             if render:
                 self.render(count=count)
+                count += 1                                             # :171-173: one frame per inner iteration
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
 
@@ -155,7 +156,7 @@ class PlanningEnv(BaseEnv):
             g['ll_act'] = torch.empty((n, 4), dtype=torch.float32, device=d)
         assert INNER_STEPS % 2 == 0
         # warm-up on a side stream (library handles, autotuning) with the env state saved and restored around it
-        saved = (b.state_dict(), b.coef_cache.clone(), g['rnn'].clone())
+        saved = (b.state_dict(), b.coef_cache.clone(), g['rnn'].clone(), b.term_counters.clone())
         g['fa'].copy_(b.flags)
         b.call_base.fill_(b.call_idx)
         side = torch.cuda.Stream(device=d)
@@ -166,6 +167,7 @@ class PlanningEnv(BaseEnv):
         b.load_state_dict(saved[0])
         b.coef_cache.copy_(saved[1])
         g['rnn'].copy_(saved[2])
+        b.term_counters.copy_(saved[3])          # the warm-up's terminations were counted by device atomics: not part of the run
         graph = torch.cuda.CUDAGraph()
         g['fa'].copy_(b.flags)
         b.call_base.fill_(b.call_idx)
@@ -197,3 +199,19 @@ class PlanningEnv(BaseEnv):
         self.ego_rnn_states = g['rnn']
         f = g['fa'].clone().view(torch.bool)
         return g['obs'].clone(), g['reward'].clone(), f[0], f[1], f[2], self.info()
+
+    # -- checkpoint: the batch state plus the low-level controller's recurrent state (without it a restored env diverges) -----
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['ego_rnn_states'] = self.ego_rnn_states.detach().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        if 'ego_rnn_states' not in sd:
+            raise KeyError("PlanningEnv checkpoint without 'ego_rnn_states': the controller's recurrent state is part of the env state")
+        rnn = sd['ego_rnn_states'].to(self.device)
+        if tuple(rnn.shape) != tuple(self.ego_rnn_states.shape):
+            raise ValueError(f'ego_rnn_states: checkpoint {tuple(rnn.shape)} vs env {tuple(self.ego_rnn_states.shape)}')
+        super().load_state_dict(sd)
+        # a fresh tensor: the graph path notices that it is not its own buffer and copies it in before the next replay
+        self.ego_rnn_states = rnn.clone()

@@ -11,22 +11,47 @@ import torch
 import yaml
 
 
+CONFIG_DIR = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir, 'configs'))
+
+
+class ScenarioConfig:
+    """Attribute bag of one scenario YAML.  The env surface reads it the way the reference's callers do —
+    `getattr(config, key, default)` and `config.init_state['init_T']` — so every top-level YAML key is an attribute."""
+
+    def __init__(self, name, entries):
+        self.__dict__.update(entries)
+        self._scenario = name
+
+    def __repr__(self):
+        keys = sorted(k for k in self.__dict__ if not k.startswith('_'))
+        return f'ScenarioConfig({self._scenario!r}: {", ".join(keys)})'
+
+
 def get_root_dir():
-    return os.path.join(os.path.split(os.path.realpath(__file__))[0], '..')
+    """Directory that holds `configs/` (the reference's contract: envs/)."""
+    return os.path.dirname(CONFIG_DIR)
 
 
 def parse_config(filename):
-    """Parse envs/configs/<filename>.yaml into an attribute bag (same contract as the reference)."""
-    filepath = os.path.join(get_root_dir(), 'configs', f'{filename}.yaml')
-    assert os.path.exists(filepath), \
-        f'config path {filepath} does not exist. Please pass in a string that represents the file path to the config yaml.'
-    with open(filepath, 'r', encoding='utf-8') as f:
-        config_data = yaml.load(f, Loader=yaml.FullLoader)
-    return type('EnvConfig', (object,), config_data)
+    """envs/configs/<filename>.yaml -> ScenarioConfig.  A scenario that does not exist is an AssertionError, as in the
+    reference (envs/utils/utils.py:22-23), so callers that catch it keep working."""
+    path = os.path.join(CONFIG_DIR, filename + '.yaml')
+    if not os.path.isfile(path):
+        raise AssertionError(f"no scenario '{filename}': {path} is missing (scenarios shipped: {sorted(available_configs())})")
+    with open(path, encoding='utf-8') as fh:
+        entries = yaml.safe_load(fh) or {}
+    if not isinstance(entries, dict):
+        raise AssertionError(f'{path}: a scenario file must be a YAML mapping')
+    return ScenarioConfig(filename, entries)
 
 
-def _t2n(x):
-    return x.detach().cpu().numpy()
+def available_configs():
+    return [os.path.splitext(f)[0] for f in os.listdir(CONFIG_DIR) if f.endswith('.yaml')]
+
+
+def _t2n(tensor):
+    """torch tensor -> numpy array on the host (the adapter GPUVecEnv uses)."""
+    return tensor.detach().to('cpu').numpy()
 
 
 def wrap_2PI(angle):

@@ -65,6 +65,9 @@ def all_gather_opponent(x_local, dist, envs_per_rank=None):
     x_local = x_local.contiguous()
     if dist is None:
         return x_local
+    if x_local.is_cuda and dist.get_backend() == 'gloo':
+        # functional-check path only (ranks sharing one GPU in the tests): gloo has no all_gather for device tensors
+        return all_gather_opponent(x_local.cpu(), dist, envs_per_rank).to(x_local.device)
     world = dist.get_world_size()
     if envs_per_rank is None:
         sizes = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device)

@@ -280,3 +280,73 @@ def test_opponent_exchange_runs_over_rccl():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and 'RCCL_OK (128, 15)' in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the sharded self-play loop of bench.py --task combat on the real kernels: two gloo ranks sharing this GPU
+# ---------------------------------------------------------------------------------------------------
+def _hip_selfplay_loop(e_loc, env0, e_total, d, steps, lag):
+    from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+    from neuralplane_amd.selfplay import OpponentExchange
+    dev = torch.device('cuda', 0)
+    env = SingleCombatEnv(num_envs=e_loc, config='selfplay', random_seed=21, device='cuda:0', env0=env0)
+    W_ego = torch.linspace(-1, 1, 15 * 4, device=dev).reshape(15, 4)
+    W_opp = torch.linspace(1, -1, 15 * 4, device=dev).reshape(15, 4)
+
+    def opp_policy(obs, env_ids):       # elementwise in the env dimension and keyed by the GLOBAL env index
+        return torch.tanh((obs[:, :, None] * W_opp[None]).sum(1) + (env_ids.to(obs.dtype) % 7)[:, None] * 0.01)
+
+    ex = OpponentExchange(e_loc, env0, e_total, d, dev, opponent_policy=opp_policy, lag=lag)
+    obs = env.reset()
+    for _ in range(steps):
+        a = ex.actions(obs, lambda x: torch.tanh((x[:, :, None] * W_ego[None]).sum(1)))
+        obs, rew = env.step(a)[:2]
+    torch.cuda.synchronize()
+    return env.s.cpu().numpy(), obs.cpu().numpy(), rew.cpu().numpy(), env.blood.cpu().numpy()
+
+
+def _hip_selfplay_worker(rank, world, port, e_total, steps, lag, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from neuralplane_amd import sharding
+    torch.cuda.set_device(0)
+    d = sharding.init_distributed('gloo')
+    env0, e_loc = sharding.shard_rows(e_total, world, rank)
+    res = _hip_selfplay_loop(e_loc, env0, e_total, d, steps, lag)
+    parts = [None] * world
+    d.all_gather_object(parts, (env0,) + res)
+    if rank == 0:
+        q.put(parts)
+    d.barrier()
+    d.destroy_process_group()
+
+
+@pytest.mark.parametrize('lag', [0, 1])
+def test_two_rank_hip_selfplay_loop_equals_single_process_run(lag):
+    """OpponentExchange (two all-gathers per step on a side stream) around the HIP combat kernel, 2 ranks x ragged env shards,
+    against the unsharded run in this process: states, observations, rewards and blood bit for bit after 8 env.steps."""
+    import socket
+    import torch.multiprocessing as mp
+    e_total, steps, world = 301, 8, 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_selfplay_worker, args=(r, world, port, e_total, steps, lag, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    parts.sort(key=lambda x: x[0])
+    got = [np.concatenate([p[k] for p in parts]) for k in (1, 2, 3, 4)]
+    want = _hip_selfplay_loop(e_total, 0, e_total, None, steps, lag)
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)

@@ -99,31 +99,55 @@ def test_same_seed_same_trajectory_and_flagged_rows_are_reinitialised():
     assert bool(((alt0 > 18000) & (alt0 < 21000)).all())
 
 
-def test_bench_multi_rank_path_on_one_gpu():
-    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank) — with
-    the gloo backend so that two ranks can share this box's single GPU: sharding, barrier, max-over-ranks and the rank-0
-    JSON line of the weak-scaling path are exercised on real hardware (RCCL itself is not)."""
+def _bench_json(args, timeout=900):
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '3',
-           '--aircraft', '200000', '--backend', 'gloo']
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
-    d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 20 and d['scaling'] == 'weak' and d['state_finite'] is True
+    return json.loads(lines[0])
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """`python bench.py --gpus 2 ...` as a PLAIN command (no launcher environment): the script re-executes itself under
+    torch.distributed.run, one process per rank — here with the gloo backend so that two ranks can share this box's single GPU:
+    sharding, barrier, max-over-ranks and the rank-0 JSON line of the weak-scaling path are exercised on real hardware (RCCL
+    itself is not)."""
+    d = _bench_json(['--gpus', '2', '--steps', '20', '--warmup', '3', '--n', '200000', '--backend', 'gloo', '--prelude-ms', '50'])
+    assert d['n_gpus'] == 2 and d['world_size'] == 2 and d['steps'] == 20 and d['scaling'] == 'weak' and d['state_finite'] is True
+    assert d['backend'] == 'gloo' and d['rccl_ranks'] == 0
     assert d['value'] == pytest.approx(2 * 200000 * 20 / (d['ms_per_step'] * 1e-3 * 20), rel=1e-6)
-    assert 'cpu_baseline' not in d and d['roofline']['frac'] > 0
+    assert 'cpu_baseline' not in d and d['roofline']['frac'] > 0 and d['roofline']['bound'] == 'valu'
+    assert d['prelude']['steps'] > 0 and d['cold_start']['launches_timed'] == 20 and d['roofline']['launches_timed'] == 20
+
+
+def test_bench_single_gpu_line_has_the_contract_fields():
+    d = _bench_json(['--steps', '20', '--warmup', '5', '--n', '100000', '--headline-only', '--prelude-ms', '50'])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline'):
+        assert k in d, k
+    r = d['roofline']
+    assert r['bound'] == 'valu' and r['unit'] == 'TFLOP/s' and r['frac'] == pytest.approx(r['achieved'] / r['peak'])
+    assert r['executed_flop_per_aircraft_step'] < r['algorithmic_flop_per_aircraft_step'] and r['executed_frac'] < r['frac']
+    assert r['traffic'] is None or r['traffic_source'].startswith('profiles/')
+    assert 1500 < r['effective_shader_mhz'] < 2600
+    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 0 and d['steps'] == 20 and d['warmup'] == 5
+
+
+@pytest.mark.parametrize('task', ['tracking', 'combat'])
+def test_bench_other_configs_multi_rank(task):
+    """BASELINE.json configs[3] (Tracking, rows sharded) and configs[4] (SingleCombat, envs sharded, the opponent exchange inside
+    the stepped loop) through the same plain command, two gloo ranks on this GPU."""
+    extra = ['--n', '100000'] if task == 'tracking' else ['--engagements', '20001']     # odd: ragged shards
+    d = _bench_json(['--gpus', '2', '--task', task, '--steps', '10', '--warmup', '2', '--backend', 'gloo', '--prelude-ms', '20'] + extra)
+    assert d['n_gpus'] == 2 and d['state_finite'] is True and d['value'] > 0
+    if task == 'combat':
+        assert d['scaling'] == 'strong' and d['exchange']['collectives_per_step'] == 2 and d['unit'] == 'engagement-steps/s'
 
 
 @pytest.mark.parametrize('task', ['heading', 'tracking'])

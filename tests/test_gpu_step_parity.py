@@ -351,55 +351,52 @@ def test_planning_env_hip_graph_replay_equals_eager():
         assert torch.equal(envs[0].step_count, envs[1].step_count) and torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
         terminated += int(outs[0][3].sum())
     assert envs[0]._batch.call_idx == envs[1]._batch.call_idx == 6 * 51
-    # restore a checkpoint into the graph-mode env and continue: still identical
+    # the capture's warm-up macro-step must not leak into the per-condition termination statistics
+    assert envs[0].termination_counts() == envs[1].termination_counts() and sum(envs[0].termination_counts().values()) > 0
+    # a checkpoint carries the controller's recurrent state: restored into the graph-mode env AND into a fresh eager env,
+    # the run continues bit for bit (two macro-steps, so that the restored GRU state has been consumed and re-written)
     sd = envs[0].state_dict()
-    rnn = envs[0].ego_rnn_states.clone()
-    ref = envs[0].step(acts[0])
-    envs[1].load_state_dict(sd)
-    envs[1].ego_rnn_states.copy_(rnn)
-    got = envs[1].step(acts[0])
-    for x, y in zip(ref[:5], got[:5]):
-        assert torch.equal(x, y)
+    assert 'ego_rnn_states' in sd
+    ref = [envs[0].step(a) for a in acts[:2]]
+    fresh = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=4, device='cuda:0', controller=ctrl)
+    for e in (envs[1], fresh):
+        e.load_state_dict(sd)
+        got = [e.step(a) for a in acts[:2]]
+        for r, g_ in zip(ref, got):
+            for x, y in zip(r[:5], g_[:5]):
+                assert torch.equal(x, y)
+        assert torch.equal(e.ego_rnn_states, envs[0].ego_rnn_states) and torch.equal(e.model.s, envs[0].model.s)
+    with pytest.raises(KeyError):
+        fresh.load_state_dict(envs[0]._batch.state_dict())      # a bare batch checkpoint lacks the controller state
 
 
-@pytest.mark.parametrize('task,n,T', [('heading', 128, 1000), ('control', 64, 300), ('tracking', 64, 300)])
-def test_hip_free_running_trajectory_vs_reference_recording(task, n, T, golden_dir):
-    """The headline parity claim, directly: the HIP env stepped freely for 1000 steps (Heading; 300 for Control /
-    Tracking) from a fresh env, with the reference's reset draws injected, against the trajectory the REFERENCE
-    recorded (tests/golden/traj_*.npz; plain ATen arithmetic).  Same acceptance rule as the oracle's CPU test: rows that
-    still follow the reference's episode schedule stay within 1e-4 relative (median; p90 5e-4 — the reference's own
-    fp32-vs-fp64 noise is p99 3e-4 after 1000 steps), max 1e-4 over the first 100 steps, and a mask may differ
-    first only on a handful of threshold-grazing rows."""
-    from test_oracle_golden import STATE_FLOORS, _traj_actions
-    from neuralplane_amd.core import F16Batch
-    from neuralplane_amd.envs.utils.utils import parse_config
-    g = np.load(f'{golden_dir}/traj_{task}_N{n}_T{T}.npz')
-    acts = _traj_actions(T, n)
-    cfg = parse_config(task)
-    cfg.noise_scale = 0
-    b = F16Batch(n, cfg, task, 'cuda:0', seed=0)
-    rec = {int(t): i for i, t in enumerate(g['rec_steps'])}
-    diverged = np.zeros(n, bool)
-    errs, n_mask_diff = [], 0
-    for t in range(T):
-        obs, rew, flags = b.step(torch.from_numpy(acts[t]).cuda(), rand_u=g['rand_u'][t])
-        f = flags.cpu().numpy().astype(bool)
-        fl = g['flags'][t].astype(bool)
-        diff = (f[0] != fl[:, 0]) | (f[1] != fl[:, 1]) | (f[2] != fl[:, 2])
-        n_mask_diff += int((diff & ~diverged).sum())
-        diverged |= diff
-        if t in rec:
-            ref = g['state'][rec[t]]
-            e = np.abs(b.s.cpu().numpy().T - ref[:, :12]) / np.maximum(np.abs(ref[:, :12]), STATE_FLOORS)
-            errs.append((t, np.nanmax(e, axis=1)))
-    ok_rows = ~diverged
-    assert ok_rows.mean() > 0.9
-    assert n_mask_diff <= max(2, n // 32), f'{n_mask_diff} first-time mask differences'
-    for t, e in errs:
-        e = e[ok_rows]
-        if t < 100:
-            assert np.max(e) < 1e-4, (t, np.max(e))
-        assert np.median(e) < 1e-4 and np.percentile(e, 90) < 5e-4, (t, np.median(e), np.percentile(e, 90))
+def test_hip_parity_report_vs_reference_recordings():
+    """The headline parity claim, directly, and the artefact SURVEY.md §8(d) asks for: the HIP env against what the REFERENCE
+    recorded (tests/golden/traj_*.npz, plain ATen arithmetic; the authors' CUDA episode) — tools/parity_report.py with the HIP
+    engine.  Heading N = 256 x 1000 steps open loop (7254 resets: the episode schedule) and closed loop (no reset: 1000
+    uninterrupted steps), Control / Tracking 300 steps.  Bounds are the measured ones: MAX over aircraft < 1e-4 at every
+    reported step, p99 < 5e-5.  The report is written to gpurun_out/ (copied to profiles/ by the builder)."""
+    import json
+    import os
+    from test_oracle_golden import check_parity_rows
+    from tools.parity_report import build
+    rep = build('hip')
+    for tr in rep['trajectories']:
+        check_parity_rows(tr, tr['n'])
+    cl = rep['closed_loop']
+    assert cl['resets_in_reference'] == 0
+    check_parity_rows(cl, cl['n'])
+    assert cl['at'][-1]['t'] == 1000 and cl['at'][-1]['max'] < 2e-5
+    ep = {r['t']: r for r in rep['recorded_episode']['at']}
+    assert ep[200]['max_so_far'] < 1e-5 and ep[426]['max_so_far'] < 1e-3      # the recording ends in a departure (DESIGN.md §5)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_hip.json'), 'w') as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass
 
 
 def test_pinned_vec_env_equals_gpu_vec_env():

@@ -75,6 +75,37 @@ def test_gpuvecenv_reshapes_like_the_reference():
     assert rew.dtype == np.float32 and done.dtype == np.bool_ and bad.all() and not done.any() and info == {}
     with pytest.raises(AssertionError):
         GPUVecEnv([Stub, Stub])
+    # VecEnv protocol of the reference (env_wrappers.py:40-82,113-123): step == step_async + step_wait, close() is idempotent
+    assert v.closed is False
+    v.step_async(np.ones((6, 1, 4), np.float32))
+    obs2 = v.step_wait()[0]
+    assert np.array_equal(obs2, obs)
+    with pytest.raises(RuntimeError):
+        v.step_wait()
+    v.close()
+    v.close()
+    assert v.closed is True
+    with pytest.raises(RuntimeError):
+        v.step_async(np.ones((6, 1, 4), np.float32))
+
+
+def test_shipped_yaml_constants_equal_the_reference():
+    """neuralplane_amd/envs/configs/*.yaml are re-written files; their key/value sets must equal the reference's
+    (envs/configs/*.yaml, algorithms/pid/config/*.yaml), recorded by tools/gen_yaml_fixture.py in the build container."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, 'tests', 'golden', 'ref_yaml_configs.json')))
+    cfg = os.path.join(root, 'neuralplane_amd', 'envs', 'configs')
+    assert set(ref['scenarios']) == {'heading', 'control', 'tracking', 'selfplay'}
+    for name, want in ref['scenarios'].items():
+        got = yaml.safe_load(open(os.path.join(cfg, name + '.yaml')))
+        assert got == want, (name, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)})
+        bag = parse_config(name)
+        for k, v in want.items():
+            assert getattr(bag, k) == v
+    for name, want in ref['pid'].items():
+        assert yaml.safe_load(open(os.path.join(cfg, 'pid', name + '.yaml'))) == want, name
 
 
 def test_spaces_are_boxes_with_shape():

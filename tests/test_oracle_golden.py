@@ -183,49 +183,41 @@ def test_step_plain_mode_within_tolerance_masks_exact(task, fixture, solver, pre
 # free-running trajectories and the authors' recorded episode
 # ---------------------------------------------------------------------------------------------------
 def _traj_actions(T, n, seed=123):
-    """Same formula as tools/gen_golden.py:traj_actions (numpy RandomState is version-stable)."""
-    rng = np.random.RandomState(seed)
-    t = np.arange(T, dtype=np.float64)[:, None, None]
-    phase = rng.uniform(0, 2 * np.pi, (1, n, 4))
-    freq = rng.uniform(0.002, 0.02, (1, n, 4))
-    a = 0.3 * np.sin(2 * np.pi * freq * t + phase) + rng.uniform(-1, 1, (T, n, 4)) * np.array([1.0, 0.3, 0.3, 0.3])
-    a[..., 0] = 0.5 + 0.5 * a[..., 0]
-    return np.clip(a, -1, 1).astype(np.float32)
+    """The fixtures' action sequence (one definition: tools/parity_report.py, shared with tools/gen_golden.py's formula)."""
+    from tools.parity_report import traj_actions
+    return traj_actions(T, n, seed)
 
 
-@pytest.mark.parametrize('task,n,T', [('heading', 128, 1000), ('control', 64, 300), ('tracking', 64, 300)])
-def test_free_running_trajectory_vs_reference(task, n, T, golden_dir):
-    """Free-running env.step from a fresh env for T steps with the reference's reset draws injected.
-    fp32 trajectories separate chaotically (the reference's own fp32-vs-fp64 noise is p99 3e-4 after
-    1000 steps), so: the bulk (median / p90) must stay within 1e-4, and a mask may
-    differ from the reference only on a row that has already drifted or sits within 1e-3 of a
-    threshold — never on a row that still tracks the reference."""
-    g = np.load(f'{golden_dir}/traj_{task}_N{n}_T{T}.npz')
-    acts = _traj_actions(T, n)
-    o = Oracle(task, overrides={'noise_scale': 0})
-    st = Oracle.new_state(n)
-    rec = {int(t): i for i, t in enumerate(g['rec_steps'])}
-    diverged = np.zeros(n, bool)   # rows whose episode boundary differed from the reference once
-    errs = []
-    n_mask_diff = 0
-    for t in range(T):
-        obs, rew, d, b, tm = o.step(st, acts[t], rand_u=g['rand_u'][t])
-        fl = g['flags'][t]
-        diff = (d != fl[:, 0]) | (b != fl[:, 1]) | (tm != fl[:, 2])
-        n_mask_diff += int((diff & ~diverged).sum())
-        diverged |= diff
-        if t in rec:
-            ref = g['state'][rec[t]]
-            e = np.abs(st['s'] - ref[:, :12]) / np.maximum(np.abs(ref[:, :12]), STATE_FLOORS)
-            errs.append((t, np.nanmax(e, axis=1)))
-    ok_rows = ~diverged
-    assert ok_rows.mean() > 0.9, 'more than 10% of the rows left the reference episode schedule'
-    assert n_mask_diff <= max(2, n // 32), f'{n_mask_diff} first-time mask differences'
-    for t, e in errs:
-        e = e[ok_rows]
-        if t < 100:
-            assert np.max(e) < 1e-4, (t, np.max(e))
-        assert np.median(e) < 1e-4 and np.percentile(e, 90) < 5e-4, (t, np.median(e), np.percentile(e, 90))
+def check_parity_rows(rep, n):
+    """Acceptance of SURVEY.md §8(d) on one trajectory report of tools/parity_report.py, as measured (not a loose envelope):
+    every aircraft that still follows the reference's episode schedule is within 1e-4 relative at every reported step (MAX, not
+    a percentile), p99 within 5e-5, and at most n/64 aircraft may ever leave the schedule through a threshold-grazing mask."""
+    assert rep['first_mask_differences'] <= n // 64 and rep['rows_diverged_final'] <= n // 64, rep
+    for r in rep['at']:
+        assert r['rows_compared'] >= n - n // 64
+        assert r['max'] < 1e-4 and r['p99'] < 5e-5 and r['median'] < 1e-5, r
+
+
+@pytest.mark.parametrize('task,n,T,at', [('heading', 256, 1000, (1, 10, 100, 426, 1000)), ('control', 64, 300, (1, 10, 100, 300)),
+                                         ('tracking', 64, 300, (1, 10, 100, 300))])
+def test_free_running_trajectory_vs_reference(task, n, T, at):
+    """Free-running env.step from a fresh env for T steps with the reference's reset draws injected, against the trajectory
+    the reference recorded (random open-loop actions: every aircraft goes through ~28 episodes in 1000 steps, so this is the
+    reset / termination schedule test: 7254 resets, every mask of every step compared)."""
+    from tools.parity_report import OracleEngine, trajectory_report
+    rep = trajectory_report(OracleEngine, task, n, T, at)
+    assert rep['resets_in_reference'] > 4 * n
+    check_parity_rows(rep, n)
+
+
+def test_closed_loop_1000_uninterrupted_steps_vs_reference():
+    """BASELINE.json's acceptance sentence, literally: 'trajectories within 1e-4 rel-err of reference over 1000 steps' — N = 256
+    (configs[0]), a policy in the loop on both sides, no aircraft resets in 1000 steps, MAX error over all aircraft and states."""
+    from tools.parity_report import OracleEngine, closed_loop_report
+    rep = closed_loop_report(OracleEngine)
+    assert rep['resets_in_reference'] == 0 and rep['longest_episode_in_reference'] == 1000
+    check_parity_rows(rep, 256)
+    assert rep['at'][-1]['t'] == 1000 and rep['at'][-1]['max'] < 2e-5      # measured 1.45e-5
 
 
 def test_recorded_cuda_episode_replay(golden_dir):

@@ -147,3 +147,67 @@ def test_two_rank_combat_shards_with_opponent_exchange_equal_single_process_run(
         o_np, o_rew, _, _, _ = o.combat_step(st, a.numpy(), pid_first=(t == 0), seed=21, call_idx=t + 1, env0=0)
         ob = torch.from_numpy(o_np)
     assert np.array_equal(s, st['s']) and np.array_equal(obs, o_np) and np.array_equal(rew, o_rew) and np.array_equal(blood, st['blood'])
+
+
+# ---------------------------------------------------------------------------------------------------
+# The self-play loop bench.py --task combat steps (neuralplane_amd/selfplay.py::OpponentExchange): opponent
+# observations all-gathered to the rank hosting the opponent policy, opponent actions all-gathered back
+# ---------------------------------------------------------------------------------------------------
+def _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag):
+    from neuralplane_amd.selfplay import OpponentExchange
+    W_ego = torch.linspace(-1, 1, 15 * 4).reshape(15, 4)
+    W_opp = torch.linspace(1, -1, 15 * 4).reshape(15, 4)
+
+    def opp_policy(obs, env_ids):     # depends on the GLOBAL env index: a misrouted slice cannot go unnoticed
+        return torch.tanh(obs @ W_opp + (env_ids.to(obs.dtype) % 7)[:, None] * 0.01)
+
+    ex = OpponentExchange(e_loc, env0, e_total, d, 'cpu', opponent_policy=opp_policy, lag=lag)
+    obs = torch.from_numpy(o.combat_reset(st, seed=21, call_idx=0, env0=env0))
+    for t in range(steps):
+        a = ex.actions(obs, lambda x: torch.tanh(x @ W_ego))
+        o_np, rew, dn, bd, tm = o.combat_step(st, a.numpy(), pid_first=(t == 0), seed=21, call_idx=t + 1, env0=env0)
+        obs = torch.from_numpy(o_np)
+    return o_np, rew
+
+
+def _selfplay_worker(rank, world, port, e_total, steps, lag, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    from neuralplane_amd import sharding
+    from oracle.f16_oracle import CombatOracle
+    d = sharding.init_distributed('gloo')
+    env0, e_loc = sharding.shard_rows(e_total, world, rank)
+    o = CombatOracle()
+    st = o.new_state(e_loc)
+    o_np, rew = _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag)
+    parts = [None] * world
+    d.all_gather_object(parts, (env0, st['s'], o_np, rew, st['blood']))
+    if rank == 0:
+        q.put(parts)
+    d.barrier()
+    d.destroy_process_group()
+
+
+@pytest.mark.parametrize('e_total,lag', [(21, 0), (20, 0), (20, 1), (21, 1)], ids=['ragged_lag0', 'equal_lag0', 'equal_lag1', 'ragged_lag1'])
+def test_two_rank_selfplay_exchange_equals_single_process_run(e_total, lag):
+    steps, world = 6, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_selfplay_worker, args=(r, world, port, e_total, steps, lag, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    parts.sort(key=lambda x: x[0])
+    s, obs, rew, blood = (np.concatenate([p[k] for p in parts]) for k in (1, 2, 3, 4))
+
+    sys.path.insert(0, ROOT)
+    from oracle.f16_oracle import CombatOracle
+    o = CombatOracle()
+    st = o.new_state(e_total)
+    o_np, o_rew = _selfplay_loop(o, st, e_total, 0, e_total, None, steps, lag)
+    assert np.array_equal(s, st['s']) and np.array_equal(obs, o_np) and np.array_equal(rew, o_rew) and np.array_equal(blood, st['blood'])

@@ -393,7 +393,7 @@ def traj_actions(T, n, seed=123):
     return np.clip(a, -1, 1).astype(np.float32)
 
 
-def gen_traj(task='heading', n=128, T=1000):
+def gen_traj(task='heading', n=256, T=1000):
     env = make_env(task, n, seed=0)
     env.task.noise_scale = 0  # keeps the fixture small; noise parity is covered by step_kat
     acts = traj_actions(T, n)
@@ -412,16 +412,46 @@ def gen_traj(task='heading', n=128, T=1000):
         flags[t, :, 0] = done.numpy()
         flags[t, :, 1] = bad.numpy()
         flags[t, :, 2] = tmo.numpy()
-        if (t + 1) % 10 == 0 or t < 3:
+        if (t + 1) % 10 == 0 or t < 3 or t + 1 == 426:   # 426 = the length of the authors' recorded episode
             states.append(np.hstack([env.model.s.numpy(), env.model.u.numpy()[:, :4], get_tgt(env, task)]))
             obs_l.append(obs.numpy().copy())
             rew_l.append(rew.numpy().copy())
-    rec_steps = np.array([t for t in range(T) if (t + 1) % 10 == 0 or t < 3], np.int64)
+    rec_steps = np.array([t for t in range(T) if (t + 1) % 10 == 0 or t < 3 or t + 1 == 426], np.int64)
     np.savez_compressed(os.path.join(OUT, f'traj_{task}_N{n}_T{T}.npz'), action_seed=np.int64(123),
                         rec_steps=rec_steps, state=np.stack(states).astype(np.float32),
                         obs=np.stack(obs_l).astype(np.float32), reward=np.stack(rew_l).astype(np.float32),
                         flags=flags, rand_u=rand_u, step_count_final=env.step_count.numpy())
     print(f'traj {task}: done={int(flags[:, :, 0].sum())} bad={int(flags[:, :, 1].sum())}')
+
+
+def gen_traj_closed(n=256, T=1000):
+    """Heading with a policy in the loop (tools/parity_report.py::closed_loop_action on the reference's own state): every
+    aircraft flies the whole 1000 steps, so round-off has 1000 uninterrupted steps to grow."""
+    sys.path.insert(0, REPO)
+    from tools.parity_report import closed_loop_action, closed_loop_setup
+    env = make_env('heading', n, seed=0)
+    env.task.noise_scale = 0
+    th_cmd, phi_cmd, rng = closed_loop_setup(n)
+    states = []
+    flags = np.zeros((T, n, 3), np.uint8)
+    rand_u = np.zeros((T, n, 5), np.float32)
+    s = np.zeros((n, 12), np.float32)
+    for t in range(T):
+        dither = rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32)
+        a = closed_loop_action(s, th_cmd, phi_cmd, dither)
+        prev = (env.is_done | env.bad_done | env.exceed_time_limit).numpy().astype(bool)
+        with Recorder() as rec, quiet():
+            obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(a))
+            log = rec.take()
+        rand_u[t], _ = draws_to_arrays(log, prev, n, 0, which_randn=1)
+        flags[t, :, 0], flags[t, :, 1], flags[t, :, 2] = done.numpy(), bad.numpy(), tmo.numpy()
+        s = env.model.s.numpy().astype(np.float32).copy()
+        if (t + 1) % 10 == 0 or t < 3 or t + 1 == 426:
+            states.append(np.hstack([s, env.model.u.numpy()[:, :4], get_tgt(env, 'heading')]))
+    rec_steps = np.array([t for t in range(T) if (t + 1) % 10 == 0 or t < 3 or t + 1 == 426], np.int64)
+    np.savez_compressed(os.path.join(OUT, f'traj_heading_closed_N{n}_T{T}.npz'), rec_steps=rec_steps, state=np.stack(states).astype(np.float32),
+                        flags=flags, rand_u=rand_u, step_count_final=env.step_count.numpy())
+    print(f'traj closed: done={int(flags[:, :, 0].sum())} bad={int(flags[:, :, 1].sum())} longest episode {int(env.step_count.max())}')
 
 
 def gen_recorded_episode():
@@ -856,6 +886,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'actor':
         gen_actor()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'traj':
+        gen_traj('heading', 256, 1000)     # BASELINE.json configs[0] / SURVEY.md App. D.3 #5: N = 256
+        gen_traj('control', 64, 300)
+        gen_traj('tracking', 64, 300)
+        gen_traj_closed(256, 1000)
+        return
     env = make_env('heading', 4)
     gen_aero(env)
     gen_nlplant(env)
@@ -863,9 +899,10 @@ def main():
     for task in ('heading', 'control', 'tracking'):
         gen_step_kat(task)
     gen_step_kat('heading', solver='rk4', tag='step_kat_heading_rk4')
-    gen_traj('heading', 128, 1000)
+    gen_traj('heading', 256, 1000)
     gen_traj('control', 64, 300)
     gen_traj('tracking', 64, 300)
+    gen_traj_closed(256, 1000)
     gen_recorded_episode()
     gen_planning()
     gen_combat_all()

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""SURVEY.md §8(d) parity report: an engine (the HIP env on a GPU box, or the CPU oracle) against what the REFERENCE recorded.
+
+    python tools/parity_report.py --engine hip    [--out profiles/r02_parity.json]      # GPU box
+    python tools/parity_report.py --engine oracle [--out ...]                            # anywhere
+
+Inputs are committed data only (tests/golden/traj_*.npz — trajectories of the imported reference, plain ATen arithmetic,
+its reset draws recorded; tests/golden/recorded_episode0.npz — the authors' own CUDA recording, renders/result/*.npy).
+Metric: per state k  err = |x - x_ref| / max(|x_ref|, floor_k), floors (npos, epos, alt: 100 ft; angles:
+0.1 rad; vt: 10 ft/s; P, Q, R: 0.1 rad/s); per aircraft the max over the 12 states; reported as median / p90 / p99 / max over
+the aircraft that still follow the reference's episode schedule at step t (an aircraft whose done/bad_done mask differed once
+has reset at a different time and is counted in `rows_diverged` from then on), at t in {1, 10, 100, 426, 1000} (Heading) or
+{1, 10, 100, 300}.  tests/test_gpu_step_parity.py asserts the bounds on the same numbers and writes this report.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+STATE_FLOORS = np.array([100, 100, 100, 0.1, 0.1, 0.1, 10, 0.1, 0.1, 0.1, 0.1, 0.1], np.float32)
+TRAJ = (('heading', 256, 1000, (1, 10, 100, 426, 1000)), ('control', 64, 300, (1, 10, 100, 300)), ('tracking', 64, 300, (1, 10, 100, 300)))
+
+
+def traj_actions(T, n, seed=123):
+    """The action sequence of the fixtures (tools/gen_golden.py::traj_actions; numpy RandomState is version-stable)."""
+    rng = np.random.RandomState(seed)
+    t = np.arange(T, dtype=np.float64)[:, None, None]
+    phase = rng.uniform(0, 2 * np.pi, (1, n, 4))
+    freq = rng.uniform(0.002, 0.02, (1, n, 4))
+    a = 0.3 * np.sin(2 * np.pi * freq * t + phase) + rng.uniform(-1, 1, (T, n, 4)) * np.array([1.0, 0.3, 0.3, 0.3])
+    a[..., 0] = 0.5 + 0.5 * a[..., 0]
+    return np.clip(a, -1, 1).astype(np.float32)
+
+
+def closed_loop_setup(n, seed=321):
+    """Per-aircraft attitude commands and the per-step dither of the closed-loop fixture (numpy RandomState: version-stable)."""
+    rng = np.random.RandomState(seed)
+    th_cmd = rng.uniform(-0.05, 0.10, n).astype(np.float32)
+    phi_cmd = rng.uniform(-0.3, 0.3, n).astype(np.float32)
+    return th_cmd, phi_cmd, rng
+
+
+def closed_loop_action(s, th_cmd, phi_cmd, dither):
+    """A deterministic attitude-hold policy, a pure float32 function of the CURRENT state s[n, 12]: pitch and roll PD loops on
+    elevator / aileron, a yaw damper, fixed throttle, plus a small recorded-seed dither.  It keeps every aircraft flying for the
+    whole 1000 steps, so the fixture measures how an engine's round-off grows over LONG uninterrupted episodes with the policy
+    in the loop (the open-loop random-action fixture resets each aircraft every ~35 steps)."""
+    f = np.float32
+    a = np.empty((s.shape[0], 4), np.float32)
+    a[:, 0] = f(0.3)
+    a[:, 1] = f(2.0) * (s[:, 4] - th_cmd) + f(1.0) * s[:, 10]
+    a[:, 2] = f(1.0) * (s[:, 3] - phi_cmd) + f(0.5) * s[:, 9]
+    a[:, 3] = f(0.2) * s[:, 11]
+    a[:, 1:] += dither
+    return np.clip(a, f(-1), f(1)).astype(np.float32)
+
+
+class OracleEngine:
+    name = 'oracle (oracle/f16_oracle.c, CPU)'
+
+    def __init__(self, task, n):
+        from oracle.f16_oracle import Oracle
+        self.o = Oracle(task, overrides={'noise_scale': 0})
+        self.st = Oracle.new_state(n)
+
+    def step(self, action, rand_u):
+        _, _, d, b, tm = self.o.step(self.st, action, rand_u=rand_u)
+        return self.st['s'], np.stack([d, b, tm], 1).astype(bool)
+
+    @staticmethod
+    def xdot(s, u):
+        from oracle.f16_oracle import Oracle
+        return Oracle('heading').nlplant(np.hstack([s, u]).astype(np.float32))
+
+
+class HipEngine:
+    name = 'hip (libneuralplane_hip.so on cuda:0)'
+
+    def __init__(self, task, n):
+        import torch
+        from neuralplane_amd.core import F16Batch
+        from neuralplane_amd.envs.utils.utils import parse_config
+        cfg = parse_config(task)
+        cfg.noise_scale = 0
+        self.torch = torch
+        self.b = F16Batch(n, cfg, task, 'cuda:0', seed=0)
+
+    def step(self, action, rand_u):
+        _, _, flags = self.b.step(self.torch.from_numpy(action).cuda(), rand_u=rand_u)
+        return self.b.s.cpu().numpy().T, flags.cpu().numpy().astype(bool).T
+
+    @staticmethod
+    def xdot(s, u):
+        import torch
+        from neuralplane_amd.core import F16Batch
+        from neuralplane_amd.envs.utils.utils import parse_config
+        b = HipEngine._xb = getattr(HipEngine, '_xb', None) or F16Batch(1, parse_config('heading'), 'heading', 'cuda:0', seed=0)
+        b.s.copy_(torch.from_numpy(np.ascontiguousarray(s.T)).cuda())
+        b.u.copy_(torch.from_numpy(np.ascontiguousarray(u.T)).cuda())
+        return b.derived()[:12].cpu().numpy().T
+
+
+def trajectory_report(engine_cls, task, n, T, at):
+    g = np.load(os.path.join(GOLDEN, f'traj_{task}_N{n}_T{T}.npz'))
+    acts = traj_actions(T, n)
+    eng = engine_cls(task, n)
+    rec = {int(t): i for i, t in enumerate(g['rec_steps'])}
+    diverged = np.zeros(n, bool)
+    first_mask_diff, rows = 0, []
+    for t in range(T):
+        s, f = eng.step(acts[t], g['rand_u'][t])
+        diff = (f != g['flags'][t].astype(bool)).any(axis=1)
+        first_mask_diff += int((diff & ~diverged).sum())
+        diverged |= diff
+        if (t + 1) in at:
+            ref = g['state'][rec[t]][:, :12]
+            e = np.nanmax(np.abs(s - ref) / np.maximum(np.abs(ref), STATE_FLOORS), axis=1)[~diverged]
+            rows.append({'t': t + 1, 'rows_compared': int(e.size), 'rows_diverged': int(diverged.sum()), 'median': float(np.median(e)),
+                         'p90': float(np.percentile(e, 90)), 'p99': float(np.percentile(e, 99)), 'max': float(e.max())})
+    return {'task': task, 'n': n, 'T': T, 'first_mask_differences': first_mask_diff, 'rows_diverged_final': int(diverged.sum()),
+            'resets_in_reference': int(g['flags'].any(axis=2).sum()), 'at': rows}
+
+
+def closed_loop_report(engine_cls, n=256, T=1000, at=(1, 10, 100, 426, 1000)):
+    """Policy in the loop on both sides: the engine computes its actions from ITS OWN state with the same float32 policy the
+    reference run used on its state (tools/gen_golden.py::gen_traj_closed)."""
+    g = np.load(os.path.join(GOLDEN, f'traj_heading_closed_N{n}_T{T}.npz'))
+    th_cmd, phi_cmd, rng = closed_loop_setup(n)
+    eng = engine_cls('heading', n)
+    rec = {int(t): i for i, t in enumerate(g['rec_steps'])}
+    diverged = np.zeros(n, bool)
+    first_mask_diff, rows = 0, []
+    s = np.zeros((n, 12), np.float32)      # the policy sees the state BEFORE the step; the first step resets every row anyway
+    for t in range(T):
+        dither = rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32)
+        a = closed_loop_action(s, th_cmd, phi_cmd, dither)
+        s, f = eng.step(a, g['rand_u'][t])
+        s = np.array(s, np.float32)
+        diff = (f != g['flags'][t].astype(bool)).any(axis=1)
+        first_mask_diff += int((diff & ~diverged).sum())
+        diverged |= diff
+        if (t + 1) in at:
+            ref = g['state'][rec[t]][:, :12]
+            e = np.nanmax(np.abs(s - ref) / np.maximum(np.abs(ref), STATE_FLOORS), axis=1)[~diverged]
+            rows.append({'t': t + 1, 'rows_compared': int(e.size), 'rows_diverged': int(diverged.sum()), 'median': float(np.median(e)),
+                         'p90': float(np.percentile(e, 90)), 'p99': float(np.percentile(e, 99)), 'max': float(e.max())})
+    return {'task': 'heading (closed loop: attitude-hold policy on the engine\'s own state)', 'n': n, 'T': T, 'first_mask_differences': first_mask_diff,
+            'rows_diverged_final': int(diverged.sum()), 'resets_in_reference': int(g['flags'][1:].any(axis=2).sum()),
+            'longest_episode_in_reference': int(g['step_count_final'].max()), 'at': rows}
+
+
+def recorded_episode_report(engine_cls):
+    """The authors' CUDA recording replayed: x_{t+1} = x_t + dt * xdot(x_t, recorded controls) with the engine's nlplant."""
+    g = np.load(os.path.join(GOLDEN, 'recorded_episode0.npz'))
+    rows, cols = g['rows'], list(g['columns'])
+    ix = {c: cols.index(c) for c in cols}
+    s = np.zeros((1, 12), np.float32)
+    s[0, 2], s[0, 6] = rows[0, ix['altitude']], rows[0, ix['vt']]
+    dt = np.float32(0.02)
+    floors = STATE_FLOORS[:9]
+    out, worst = [], 0.0
+    for t in range(426):
+        u = np.array([[rows[t + 1, ix['T']], rows[t + 1, ix['el']], rows[t + 1, ix['ail']], rows[t + 1, ix['rud']], 0]], np.float32)
+        s = (s + dt * engine_cls.xdot(s, u)[:, :12]).astype(np.float32)
+        ref = rows[t + 1, :9]
+        e = float(np.max(np.abs(s[0, :9] - ref) / np.maximum(np.abs(ref), floors)))
+        worst = max(worst, e)
+        if (t + 1) in (1, 10, 100, 200, 400, 426):
+            out.append({'t': t + 1, 'err': e, 'max_so_far': worst})
+    return {'source': 'renders/result/*.npy rows 0..426 (the authors\' CUDA run of the reference), 9 recorded states', 'at': out}
+
+
+def build(engine):
+    cls = HipEngine if engine == 'hip' else OracleEngine
+    return {'engine': cls.name, 'reference': 'tests/golden/traj_*.npz: free-running trajectories of the imported reference (tools/gen_golden.py), '
+                                             'reset draws injected, observation noise off',
+            'metric': 'per aircraft max_k |x_k - ref_k| / max(|ref_k|, floor_k); aircraft that left the reference episode schedule excluded',
+            'trajectories': [trajectory_report(cls, *t) for t in TRAJ], 'closed_loop': closed_loop_report(cls), 'recorded_episode': recorded_episode_report(cls)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--engine', default='hip', choices=['hip', 'oracle'])
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    rep = build(args.engine)
+    txt = json.dumps(rep, indent=1)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, 'w') as f:
+            f.write(txt + '\n')
+    print(txt)
+
+
+if __name__ == '__main__':
+    main()
