@@ -81,7 +81,8 @@ _lib = None
 
 
 def so_path():
-    return _build.SO
+    # NPF16_LIB: A/B timing of experimental builds inside one gpurun session (tools/microbench/ab_libs.py); never set in production
+    return os.environ.get('NPF16_LIB') or _build.SO
 
 
 def load():

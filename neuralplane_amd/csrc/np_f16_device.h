@@ -116,19 +116,27 @@ __device__ __forceinline__ float mlp_body(const float *kblob, int w, const float
     float h1[H1], h2[H2];
     dense<IN, H1, true>(ws, x, h1);
     dense<H1, H2, true>(ws, h1, h2);
+    // output layer: two interleaved partial chains from (bias, 0), even inputs to the first, odd to the second; an odd last
+    // input joins the first; y = lo + hi (numerics spec, DESIGN.md §4 — one packed FMA per input pair in the asm bodies)
+    auto out_layer = [&ws](const float *h, int n) {
+        float lo = ws.next(), hi = ws.next();
+        for (int k = 0; k + 1 < n; k += 2) {
+            lo = fmaf(ws.next(), h[k], lo);
+            hi = fmaf(ws.next(), h[k + 1], hi);
+        }
+        if (n & 1) {
+            lo = fmaf(ws.next(), h[n - 1], lo);
+            (void)ws.next();
+        }
+        return lo + hi;
+    };
     float y;
     if constexpr (H3 > 0) {
         float h3[H3];
         dense<H2, H3, true>(ws, h2, h3);
-        y = ws.next();  // final layer: bias, W[0][0..H3), padded to even
-#pragma unroll
-        for (int k = 0; k < H3; k++) y = fmaf(ws.next(), h3[k], y);
-        if (((1 + H3) & 1) != 0) (void)ws.next();
+        y = out_layer(h3, H3);
     } else {
-        y = ws.next();
-#pragma unroll
-        for (int k = 0; k < H2; k++) y = fmaf(ws.next(), h2[k], y);
-        if (((1 + H2) & 1) != 0) (void)ws.next();
+        y = out_layer(h2, H2);
     }
     const float out_std = ws.next();
     const float out_mean = ws.next();
@@ -452,7 +460,8 @@ __device__ __forceinline__ void normalise_inputs(const AeroWeights &wt, float al
 #pragma unroll
     for (int g = 0; g < NUM_NORM_GROUPS; g++) {
         const float v = (g <= G_A_RUD) ? alpha_deg : (g <= G_B_O ? beta_deg : el);
-        xn[g] = (v - NPF16_CONST(wt.kblob)[2 * g]) / NPF16_CONST(wt.kblob)[2 * g + 1];
+        const cf32_ptr h = NPF16_CONST(wt.kblob) + KBLOB_NORM_STRIDE * g;  // (mean, sigma, RN(1 / sigma))
+        xn[g] = np_divc(v - h[0], h[1], h[2]);
     }
 }
 
@@ -492,7 +501,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     vt = (vt <= 0.01f ? 1.0f : 0.0f) * 0.01f + (vt > 0.01f ? 1.0f : 0.0f) * vt;  // :104
 
     const float T = u[0], el = u[1], ail = u[2], rud = u[3];
-    const float dail = ail / 21.5f, drud = rud / 30.0f;  // lef == 0 -> dlef == 1 (exact)
+    const float dail = NP_DIVC(ail, 21.5f), drud = NP_DIVC(rud, 30.0f);  // lef == 0 -> dlef == 1 (exact)
 
     const float tfac = 1.0f - 0.703e-5f * alt;
     const float rho = 2.377e-3f * np_pow(tfac, 4.14f);
@@ -536,9 +545,9 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     const float Cy_tot =
         ((((NPF16_NET(N_Cy) + NPF16_NET(N_dCy_lef)) + dYdail * dail) + NPF16_NET(N_dCy_r30) * drud) + dYdR * R) + dYdP * P;
 
-    const float Udot = (((R * V - Q * W) - g * st) + ((qbar * S) * Cx_tot) / mass) + T / mass;
-    const float Vdot = ((P * W - R * U) + (g * ct) * sphi) + ((qbar * S) * Cy_tot) / mass;
-    const float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + ((qbar * S) * Cz_tot) / mass;
+    const float Udot = (((R * V - Q * W) - g * st) + NP_DIVC((qbar * S) * Cx_tot, mass)) + NP_DIVC(T, mass);
+    const float Vdot = ((P * W - R * U) + (g * ct) * sphi) + NP_DIVC((qbar * S) * Cy_tot, mass);
+    const float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + NP_DIVC((qbar * S) * Cz_tot, mass);
     xd[6] = ((U * Udot + V * Vdot) + W * Wdot) / vt;
     xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
     xd[8] = (Vdot * vt - V * xd[6]) / ((vt * vt) * cb);
@@ -565,9 +574,9 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         const float L_tot = ((Cl_tot * qbar) * S) * B;
         const float M_tot = ((Cm_tot * qbar) * S) * cbar;
         const float N_tot = ((Cn_tot * qbar) * S) * B;
-        xd[9] = ((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng) / denom;
-        xd[10] = (((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng) / Jy;
-        xd[11] = ((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng) / denom;
+        xd[9] = NP_DIVC((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng, denom);
+        xd[10] = NP_DIVC(((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng, Jy);
+        xd[11] = NP_DIVC((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom);
     }
 #undef NPF16_NET
 }
@@ -659,24 +668,24 @@ __device__ __forceinline__ void observe(const CFG &cfg, const float (&s)[12], co
     const float TAS = vt + cfg.airspeed * 1.0f;
     const float EAS = TAS / eas2tas;
     if (TASK == 0) {
-        o[0] = ((alt - tgt[0]) * 0.3048f) / 1000.0f;
+        o[0] = NP_DIVC((alt - tgt[0]) * 0.3048f, 1000.0f);
         o[1] = np_wrap_pi(heading - tgt[1]);
-        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+        o[2] = NP_DIVC((vt - tgt[2]) * 0.3048f, 340.0f);
     } else if (TASK == 1) {
         o[0] = np_wrap_pi(pitch - tgt[0]);
         o[1] = np_wrap_pi(heading - tgt[1]);
-        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+        o[2] = NP_DIVC((vt - tgt[2]) * 0.3048f, 340.0f);
     } else {
-        o[0] = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
-        o[1] = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
-        o[2] = ((alt - tgt[2]) * 0.3048f) / 1000.0f;
+        o[0] = NP_DIVC((s[0] - tgt[0]) * 0.3048f, 1000.0f);
+        o[1] = NP_DIVC((s[1] - tgt[1]) * 0.3048f, 1000.0f);
+        o[2] = NP_DIVC((alt - tgt[2]) * 0.3048f, 1000.0f);
     }
-    o[3] = (alt * 0.3048f) / 5000.0f;
+    o[3] = NP_DIVC(alt * 0.3048f, 5000.0f);
     o[4] = tr.sphi;
     o[5] = tr.cphi;
     o[6] = tr.st;
     o[7] = tr.ct;
-    o[8] = (EAS * 0.3048f) / 340.0f;
+    o[8] = NP_DIVC(EAS * 0.3048f, 340.0f);
     o[9] = tr.sa;
     o[10] = tr.ca;
     o[11] = tr.sb;
@@ -684,33 +693,44 @@ __device__ __forceinline__ void observe(const CFG &cfg, const float (&s)[12], co
     o[13] = s[9];
     o[14] = s[10];
     o[15] = s[11];
-    o[16] = ((u[0] / 0.225f) / 76300.0f) * 0.3048f;
-    o[17] = u[1] / 45.0f;
-    o[18] = u[2] / 45.0f;
-    o[19] = u[3] / 45.0f;
+    o[16] = NP_DIVC(NP_DIVC(u[0], 0.225f), 76300.0f) * 0.3048f;
+    o[17] = NP_DIVC(u[1], 45.0f);
+    o[18] = NP_DIVC(u[2], 45.0f);
+    o[19] = NP_DIVC(u[3], 45.0f);
     o[20] = 0.0f / 45.0f;  // lef
     o[21] = eas2tas;
 }
 
-// 22 standard normals of (seed, call_idx, row): Philox blocks 2..7, Box-Muller per pair
+// Observation noise (numerics spec): 22 normals of (seed, call_idx, global row) from FOUR Philox4x32-10 blocks
+// (counter blocks 2..5) by Box-Muller on 11 pairs.  Every pair takes a 21-bit radius index K1 and a 21-bit direction index K2:
+// pairs 0..7 the top 21 bits of two words, pairs 8..10 are assembled from the low 11 bits of the 16 words.
+//   u = (K1 + 0.5) * 2^-21;  o[2i], o[2i+1] += (sqrt(-2 ln u) * scale) * (cos, sin)(direction K2), one fma each
 __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, int64_t row, float scale, float (&o)[22]) {
+    uint32_t w[16];
 #pragma unroll
-    for (uint32_t b = 0; b < 6; b++) {
-        uint32_t w[4];
-        rng_block(seed, call_idx, row, 2 + b, w);
+    for (uint32_t b = 0; b < 4; b++) {
+        uint32_t blk[4];
+        rng_block(seed, call_idx, row, 2 + b, blk);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int pair = 2 * (int)b + h;
-            if (pair < 11) {
-                const float u1 = ((float)(w[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-07f;
-                const float u2 = (float)(w[2 * h + 1] >> 8) * 5.9604644775390625e-08f;
-                const float rad = sqrtf(-2.0f * logf_spec(u1));
-                float sn, cs;
-                sincos2pi_spec(u2, sn, cs);
-                o[2 * pair] = o[2 * pair] + (rad * cs) * scale;
-                o[2 * pair + 1] = o[2 * pair + 1] + (rad * sn) * scale;
-            }
+        for (int k = 0; k < 4; k++) w[4 * b + k] = blk[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        uint32_t k1, k2;
+        if (i < 8) {
+            k1 = w[2 * i] >> 11;
+            k2 = w[2 * i + 1] >> 11;
+        } else {
+            const int j = i - 8;
+            k1 = ((w[4 * j] & 0x7FFu) << 10) | ((w[4 * j + 1] >> 1) & 0x3FFu);
+            k2 = ((w[4 * j + 2] & 0x7FFu) << 10) | ((w[4 * j + 3] >> 1) & 0x3FFu);
         }
+        const float u = fmaf((float)k1, 4.76837158203125e-07f, 2.384185791015625e-07f);  // (K1 + 0.5) * 2^-21, exact
+        const float rs = sqrt_spec(neg2ln_spec(u)) * scale;
+        float cs, sn;
+        unit_vector_spec(k2, cs, sn);
+        o[2 * i] = fmaf(rs, cs, o[2 * i]);
+        o[2 * i + 1] = fmaf(rs, sn, o[2 * i + 1]);
     }
 }
 
@@ -728,10 +748,10 @@ __device__ __forceinline__ void done_and_reward(const CFG &cfg, const float (&s)
     const bool r_over = (acc - cfg.acceleration_limit) > 0.0f;        // overload.py:37-42
     const bool r_low = (s[2] - cfg.altitude_limit) < 0.0f;             // low_altitude.py:29-30
     const float TAS = s[6] + cfg.airspeed * 1.0f;
-    const float vel = (TAS * 0.3048f) / 340.0f;
+    const float vel = NP_DIVC(TAS * 0.3048f, 340.0f);
     const bool r_fast = (vel - cfg.max_velocity) >= 0.0f;              // high_speed.py:29-30
     const bool r_slow = (vel - cfg.min_velocity) <= 0.0f;              // low_speed.py:29-30
-    const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
+    const float alpha = NP_DIVC(s[7] * 180.0f, PI_F), beta = NP_DIVC(s[8] * 180.0f, PI_F);
     const bool r_ext = ((alpha < cfg.min_alpha) | (alpha > cfg.max_alpha)) | ((beta < cfg.min_beta) | (beta > cfg.max_beta));  // extreme_state.py:32-36
     bool b = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
     const float pi36 = (float)(3.141592653589793 / 36.0);
@@ -744,26 +764,26 @@ __device__ __forceinline__ void done_and_reward(const CFG &cfg, const float (&s)
         m3 = fabsf(dpsi) >= pi36;
         m4 = fabsf(s[2] - tgt[0]) >= 100.0f;
         m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
-        const float da = ((s[2] - tgt[0]) * 0.3048f) / 1000.0f;
-        const float dh = dpsi / PI_F;
-        const float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        const float da = NP_DIVC((s[2] - tgt[0]) * 0.3048f, 1000.0f);
+        const float dh = NP_DIVC(dpsi, PI_F);
+        const float dv = NP_DIVC((s[6] - tgt[2]) * 0.3048f, 340.0f);
         rew = (-(da * da) + -(dh * dh)) + -(dv * dv);
     } else if (TASK == 1) {  // unreach_posture.py:40-55, posture_reward.py:26-35
         const float dpsi = np_wrap_pi(s[5] - tgt[1]);
         m3 = fabsf(dpsi) >= pi36;
         m4 = fabsf(s[4] - tgt[0]) >= pi36;
         m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
-        const float dp = np_wrap_pi(s[4] - tgt[0]) / PI_F;
-        const float dh = dpsi / PI_F;
-        const float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        const float dp = NP_DIVC(np_wrap_pi(s[4] - tgt[0]), PI_F);
+        const float dh = NP_DIVC(dpsi, PI_F);
+        const float dv = NP_DIVC((s[6] - tgt[2]) * 0.3048f, 340.0f);
         rew = (-(dp * dp) + -(dh * dh)) + -(dv * dv);
     } else {  // unreach_target.py:38-47, position_reward.py:26-34
         m3 = fabsf(s[0] - tgt[0]) >= 100.0f;
         m4 = fabsf(s[1] - tgt[1]) >= 100.0f;
         m5 = fabsf(s[2] - tgt[2]) >= 100.0f;
-        const float dn = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
-        const float de = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
-        const float da = ((s[2] - tgt[2]) * 0.3048f) / 1000.0f;
+        const float dn = NP_DIVC((s[0] - tgt[0]) * 0.3048f, 1000.0f);
+        const float de = NP_DIVC((s[1] - tgt[1]) * 0.3048f, 1000.0f);
+        const float da = NP_DIVC((s[2] - tgt[2]) * 0.3048f, 1000.0f);
         rew = 0.1f * ((-(dn * dn) + -(de * de)) + -(da * da));
     }
     const bool off = (m3 | m4) | m5;

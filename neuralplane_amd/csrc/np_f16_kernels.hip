@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
             v = v > 1.0f ? 1.0f : v;
             act[k] = v;
         }
-        u[0] = 0.9f * u[0] + (((0.1f * act[0]) * 0.225f) * 76300.0f) / 0.3048f;
+        u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);
         u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
         u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
         u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
@@ -356,8 +356,11 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
         for (int it = 0; it < (22 * TILE + THREADS - 1) / THREADS; it++) {
             const int L = it * THREADS + (int)threadIdx.x;
             if (L < total) {
-                const int r = L / 22, c = L - r * 22;
-                dst[L] = obs_tile[r * OBS_LD + c];
+                // row r = L / 22 of the tile, padded pitch 23: element r * 23 + (L - 22 r) = L + r; L * 2979 >> 16 == L / 22 for
+                // every L < 22 * 256 (24-bit product: one v_mul_u32_u24)
+                static_assert(OBS_LD == 23 && TILE <= 256, "index arithmetic of the observation transpose");
+                const unsigned r = ((unsigned)L * 2979u) >> 16;
+                dst[L] = obs_tile[(unsigned)L + r];
             }
         }
     }
@@ -557,10 +560,11 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vec
                 if (!kind_ok) return fail("weights blob: input kind of net " + nm + " does not match its class");
                 const float mean = (float)r.in_mean[k], sd = (float)r.in_std[k];  // torch rounds the CSV doubles to fp32
                 if (!grp_set[g]) {
-                    kb[2 * g] = mean;
-                    kb[2 * g + 1] = sd;
+                    kb[KBLOB_NORM_STRIDE * g] = mean;
+                    kb[KBLOB_NORM_STRIDE * g + 1] = sd;
+                    kb[KBLOB_NORM_STRIDE * g + 2] = (float)(1.0 / (double)sd);  // np_divc: the normalisation divides by a per-context constant
                     grp_set[g] = true;
-                } else if (kb[2 * g] != mean || kb[2 * g + 1] != sd) {
+                } else if (kb[KBLOB_NORM_STRIDE * g] != mean || kb[KBLOB_NORM_STRIDE * g + 1] != sd) {
                     return fail("weights blob: normalisation of net " + nm + " differs from its class");
                 }
             }
@@ -588,11 +592,12 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vec
                 dst += (size_t)row * (in + 1);
                 in = out;
             }
-            {  // final layer in -> 1: bias, W[0][0..in), padded to even
+            {  // output layer in -> 1: (bias, 0), then W[0][0..in) padded to even (two interleaved partial chains, np_nets.h)
                 const float *W = src, *bias = src + in;
                 dst[0] = bias[0];
-                for (int k = 0; k < in; k++) dst[1 + k] = scaled(W[k], ACT_SHIFT);
-                dst += pad2(1 + in);
+                dst[1] = 0.0f;
+                for (int k = 0; k < in; k++) dst[2 + k] = scaled(W[k], ACT_SHIFT);
+                dst += 2 + pad2(in);
             }
             if (!exact) return fail("weights blob: a parameter of net " + nm + " cannot be rescaled by 2^ACT_SHIFT exactly");
             dst[0] = (float)r.out_std;

@@ -32,6 +32,35 @@ namespace npf16 {
 #define NPM_PIO2_3T (8.47842766036889956997e-32)
 #define NPM_TWO_PI (6.283185307179586476925)
 
+// ---------------------------------------------------------------------------------------------
+// Division by a constant c (a literal of the reference, or a per-context constant such as a normalisation sigma):
+//     q = x * rc;  r = fma(-q, c, x);  q' = fma(r, rc, q)        with rc = RN(1 / c) prepared once
+// Markstein's correction step: q' is the correctly rounded IEEE quotient x / c.  That is a property of the constant (it can
+// fail for a few significands of x for unlucky c): the CPU test suite proves it for every constant on the path over ALL
+// 2^24 significands (tests/test_oracle_golden.py::test_constant_divisors_*), exponent-independent as long as nothing under- or
+// overflows: |x| >= 2^-100 and q normal.  Zero, infinite, NaN and denormal q are returned as q = x * rc, which is the exact
+// IEEE result for 0 / inf / NaN; denormal quotients and |x| < 2^-100 (unreachable for physical quantities) may differ from IEEE
+// in the last place — the oracle evaluates the same sequence, so HIP == oracle holds there too (numerics spec).
+// 5 VALU instructions instead of the 12 of the IEEE division sequence; ~50 such divisions per aircraft-step.
+// ---------------------------------------------------------------------------------------------
+#ifndef NPF16_DIVC
+#define NPF16_DIVC 1  // 0: plain IEEE division (A/B reference); 9: x * rc, TIMING EXPERIMENT ONLY (wrong last bits)
+#endif
+__device__ __forceinline__ float np_divc(float x, float c, float rc) {
+#if NPF16_DIVC == 0
+    return x / c;
+#elif NPF16_DIVC == 9
+    return x * rc;
+#else
+    const float q = x * rc;
+    const float r = fmaf(-q, c, x);
+    const float f = fmaf(r, rc, q);
+    return __builtin_isnormal(q) ? f : q;
+#endif
+}
+#define NP_RCP_CONST(c) ((float)(1.0 / (double)(c)))
+#define NP_DIVC(x, c) np_divc((x), (c), NP_RCP_CONST(c))
+
 __device__ __forceinline__ void sincos_d(double x, double &sn, double &cs) {
     if (!(fabs(x) < 1073741824.0)) x = fmod(x, NPM_TWO_PI);  // exact remainder; inf/NaN -> NaN (cold path)
     const double k = rint(x * NPM_INVPIO2);
@@ -260,47 +289,55 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t call_idx, int6
                   out);
 }
 
-// fp32 log of u in (0,1) and sin/cos of 2*pi*a, a in [0,1): only feed the observation noise
-// (Box-Muller); explicit fmaf sequences so that host and device agree bit-for-bit.
-__device__ __forceinline__ float logf_spec(float u) {
-    uint32_t bits = __float_as_uint(u);
-    int e = (int)(bits >> 23) - 127;
-    bits = (bits & 0x007FFFFFu) | 0x3F800000u;
-    float m = __uint_as_float(bits);
-    if (m > 1.41421356f) {
-        m = m * 0.5f;
-        e += 1;
-    }
-    const float s = (m - 1.0f) / (m + 1.0f);
-    const float z = s * s;
-    float p = fmaf(z, 0.111111111f, 0.142857143f);
-    p = fmaf(z, p, 0.2f);
-    p = fmaf(z, p, 0.333333333f);
-    p = fmaf(z, p, 1.0f);
-    return fmaf((float)e, 0.693147181f, (2.0f * s) * p);
+// Observation noise of the numerics spec: explicit fp32 sequences — fma polynomials accurate to ~1e-7
+// relative — so that host and device agree bit for bit.  They only feed the Box-Muller transform of add_rng_noise.
+// -2 ln(u), u in (0, 1) normal: exponent + degree-7 polynomial on [sqrt(1/2), sqrt(2)) (no division)
+__device__ __forceinline__ float neg2ln_spec(float u) {
+    const uint32_t ix = __float_as_uint(u) + 0x004AFB0Du;  // 0x3F800000 - 0x3F3504F3
+    const int e = (int)(ix >> 23) - 127;
+    const float m = __uint_as_float((ix & 0x007FFFFFu) + 0x3F3504F3u);
+    const float f = m - 1.0f;
+    float p = fmaf(f, 0.2026811391115188f, -0.3246837854385376f);  // -2 x the coefficients of ln(1 + f) / f
+    p = fmaf(f, p, 0.34494027495384216f);
+    p = fmaf(f, p, -0.3979713022708893f);
+    p = fmaf(f, p, 0.49940142035484314f);
+    p = fmaf(f, p, -0.6667022705078125f);
+    p = fmaf(f, p, 1.0000072717666626f);
+    p = fmaf(f, p, -1.9999998807907104f);
+    return fmaf((float)e, -1.3862943649291992f, f * p);
 }
 
-__device__ __forceinline__ void sincos2pi_spec(float a, float &sn, float &cs) {
-    const float q = rintf(a * 4.0f);
-    const float f = fmaf(q, -0.25f, a);
-    const float th = f * 6.28318531f;
+// sqrt(w), w in [1e-7, 40]: w * rsqrt(w), the reciprocal square root by two Newton steps from an exponent-halving seed
+// (8e-7 relative; the IEEE sqrt sequence costs 17 instructions on gfx950, this one 11)
+__device__ __forceinline__ float sqrt_spec(float w) {
+    float y = __uint_as_float(0x5F1FFFF9u - (__float_as_uint(w) >> 1));
+    float t = w * y;
+    t = fmaf(-t, y, 2.38924456f);
+    y = y * (0.703952253f * t);
+    const float h = 0.5f * w;
+    t = h * y;
+    t = fmaf(-t, y, 1.5f);
+    y = y * t;
+    return w * y;
+}
+
+// uniformly distributed unit vector from 21 random bits: 18 bits of angle inside one octant, 3 bits of symmetry
+__device__ __forceinline__ void unit_vector_spec(uint32_t k2, float &cs, float &sn) {
+    const float th = fmaf((float)(k2 & 0x3FFFFu), 2.9960562e-06f, 1.4980281e-06f);  // (k + 0.5) * (pi / 4) / 2^18
     const float z = th * th;
-    float ps = fmaf(z, 2.75573192e-6f, -1.98412698e-4f);
-    ps = fmaf(z, ps, 8.33333333e-3f);
-    ps = fmaf(z, ps, -1.66666667e-1f);
-    ps = fmaf(z, ps, 1.0f);
-    const float sr = th * ps;
-    float pc = fmaf(z, -2.75573192e-7f, 2.48015873e-5f);
-    pc = fmaf(z, pc, -1.38888889e-3f);
-    pc = fmaf(z, pc, 4.16666667e-2f);
-    pc = fmaf(z, pc, -0.5f);
-    const float cr = fmaf(z, pc, 1.0f);
-    const int n = (int)q & 3;
-    const bool swap = n & 1;
-    const float s_ = swap ? cr : sr;
-    const float c_ = swap ? sr : cr;
-    sn = (n & 2) ? -s_ : s_;
-    cs = ((n + 1) & 2) ? -c_ : c_;
+    float p = fmaf(z, -0.00019587951828725636f, 0.008332748897373676f);
+    p = fmaf(z, p, -0.166666641831398f);
+    p = z * p;
+    const float s = fmaf(th, p, th);
+    float q = fmaf(z, 2.4463830413878895e-05f, -0.001388759003020823f);
+    q = fmaf(z, q, 0.04166664928197861f);
+    q = fmaf(z, q, -0.5f);
+    const float c = fmaf(z, q, 1.0f);
+    const bool swap = (k2 & 0x40000u) != 0;
+    const float a = swap ? s : c, b = swap ? c : s;
+    // a, b > 0: the sign bits come straight from bits 19 / 20 of k2 (v_bfi_b32)
+    cs = __uint_as_float((__float_as_uint(a) & 0x7FFFFFFFu) | ((k2 << 12) & 0x80000000u));
+    sn = __uint_as_float((__float_as_uint(b) & 0x7FFFFFFFu) | ((k2 << 11) & 0x80000000u));
 }
 
 }  // namespace npf16

@@ -14,10 +14,12 @@
 // reference but its value is never used (F16_dynamics.py:167-175 skips temp[3]); it is not stored.
 //
 // KBLOB layout (floats):
-//   [0 .. 2*NUM_NORM_GROUPS)   (mean, std) of the 9 distinct input normalisations
-//   per class, per net:        per Linear layer: bias[out] then W^T[in][out] (k-major: the order
-//                              the FMA chains consume them; every row padded to an even length),
-//                              then out_std, out_mean, zero padding to a multiple of 32 floats
+//   [0 .. KBLOB_HEADER)        (mean, sigma, RN(1/sigma)) of the 9 distinct input normalisations (+1 pad)
+//   per class, per net:        per hidden Linear layer: bias[out] then W^T[in][out] (k-major: the order
+//                              the FMA chains consume them; every row padded to an even length);
+//                              output layer: (bias, 0), W[0][0..in) padded to even — its two interleaved
+//                              partial chains start from that pair (numerics spec);
+//                              then out_std, out_mean, zero padding to whole weight-stream groups
 // np_pack_kblob (np_f16_kernels.hip) also verifies that every net of a class has the fp32
 // normalisation constants of the class, so this static grouping cannot silently disagree with the
 // data.
@@ -135,15 +137,16 @@ constexpr int ASM_GROUP = 48;  // floats per weight-stream group (3 x s_load_dwo
 constexpr int pad2(int n) { return n + (n & 1); }
 constexpr int asm_record_len(int n_in, int h1, int h2, int h3) {
     int n = pad2(h1) + n_in * pad2(h1) + pad2(h2) + h1 * pad2(h2);
-    if (h3 > 0) n += pad2(h3) + h2 * pad2(h3) + pad2(1 + h3);
-    else n += pad2(1 + h2);
+    if (h3 > 0) n += pad2(h3) + h2 * pad2(h3) + 2 + pad2(h3);
+    else n += 2 + pad2(h2);  // output layer: (bias, 0) pair, then W[0][0..in) padded to even
     n += 2;  // out_std, out_mean
     return (n + ASM_GROUP - 1) / ASM_GROUP * ASM_GROUP;
 }
 // KBLOB stride of one net of a class
 constexpr int class_stride(int cl) { return asm_record_len(CLASSES[cl].n_in, CLASSES[cl].h1, CLASSES[cl].h2, CLASSES[cl].h3); }
 
-constexpr int KBLOB_HEADER = 2 * NUM_NORM_GROUPS;
+constexpr int KBLOB_NORM_STRIDE = 3;  // (mean, sigma, RN(1 / sigma)) per normalisation group
+constexpr int KBLOB_HEADER = KBLOB_NORM_STRIDE * NUM_NORM_GROUPS + 1;  // padded to an even number of floats
 
 constexpr int class_base(int cl) {  // KBLOB offset of the first net of class cl
     int off = KBLOB_HEADER;

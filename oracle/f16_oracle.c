@@ -45,6 +45,7 @@ typedef struct {
     int dims[6];
     int sel[3];           /* which of (alpha, beta, el) feeds input slot i */
     float in_mean[3], in_std[3]; /* per input slot, rounded double->float like torch does */
+    float in_rstd[3];            /* RN(1 / in_std): the normalisation divides by a per-model constant (divc_rc) */
     float out_mean, out_std;
     const float *w[4];
     const float *b[4];
@@ -69,6 +70,35 @@ struct f16o_model {
 static int g_mode = 0;
 void f16o_set_mode(int mode) { g_mode = mode; }
 int f16o_get_mode(void) { return g_mode; }
+
+/* Division by a constant (numerics spec; device twin: csrc/np_math.h::np_divc).  The reference writes
+ * `x / c`; for a constant c with rc = RN(1/c) the sequence q = x*rc, r = fma(-q, c, x), q' = fma(r, rc, q) (Markstein's
+ * correction) IS that IEEE quotient — a property of c that f16o_divc_check proves over all significands for every constant
+ * used below.  Non-normal q (0, inf, NaN, denormal) is returned as q: exact for 0 / inf / NaN. */
+static inline float divc_rc(float x, float c, float rc) {
+    if (g_mode & F16O_MODE_DIV_IEEE) return x / c;
+    const float q = x * rc;
+    const float r = fmaf(-q, c, x);
+    const float f = fmaf(r, rc, q);
+    return isnormal(q) ? f : q;
+}
+#define DIVC(x, c) divc_rc((x), (c), (float)(1.0 / (double)(c)))
+float f16o_divc(float x, float c) { return DIVC(x, c); }
+
+long f16o_divc_check(float c) {
+    const float rc = (float)(1.0 / (double)c);
+    long bad = 0;
+    for (int binade = 0; binade < 2; binade++) {
+        for (uint32_t m = 0; m < (1u << 23); m++) {
+            uint32_t bits = ((127u + (uint32_t)binade) << 23) | m;
+            float x;
+            memcpy(&x, &bits, 4);
+            const float q = x * rc, r = fmaf(-q, c, x), f = fmaf(r, rc, q), want = x / c;
+            if (memcmp(&f, &want, 4) != 0) bad++;
+        }
+    }
+    return bad;
+}
 
 f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
     const unsigned char *p = (const unsigned char *)blob;
@@ -97,6 +127,7 @@ f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
                 t->sel[slot] = k;
                 t->in_mean[slot] = (float)r.in_mean[k];
                 t->in_std[slot] = (float)r.in_std[k];
+                t->in_rstd[slot] = (float)(1.0 / (double)t->in_std[slot]);
                 slot++;
             }
         if (slot != t->n_in) goto bad;
@@ -354,65 +385,100 @@ void f16o_rng_uniforms(uint64_t seed, uint64_t call_idx, int64_t row, float u8[8
     }
 }
 
-static float logf_spec(float u) { /* u in (0,1), normal */
-    uint32_t bits;
-    memcpy(&bits, &u, 4);
-    int e = (int)(bits >> 23) - 127;
-    bits = (bits & 0x007FFFFFu) | 0x3F800000u;
-    float m;
-    memcpy(&m, &bits, 4);
-    if (m > 1.41421356f) {
-        m = m * 0.5f;
-        e += 1;
-    }
-    float s = (m - 1.0f) / (m + 1.0f);
-    float z = s * s;
-    float p = fmaf(z, 0.111111111f, 0.142857143f);
-    p = fmaf(z, p, 0.2f);
-    p = fmaf(z, p, 0.333333333f);
-    p = fmaf(z, p, 1.0f);
-    return fmaf((float)e, 0.693147181f, (2.0f * s) * p);
+/* Observation noise (numerics spec; device twin: csrc/np_f16_device.h::add_rng_noise).  The reference
+ * adds torch.randn_like(obs) * noise_scale (heading_task.py:150-152) from torch's device-specific global generator; the
+ * spec's stream is its own: 22 standard normals per (seed, call, global row) from FOUR Philox4x32-10 blocks (counter blocks
+ * 2..5) by Box-Muller on 11 pairs.  Every pair takes a 21-bit radius index K1 and a 21-bit direction index K2: pairs 0..7 the
+ * top 21 bits of two words, pairs 8..10 are assembled from the low 11 bits of the 16 words (all 512 bits are independent).
+ *   u  = (K1 + 0.5) * 2^-21                          in (0, 1): radius^2 = -2 ln u, at most 5.5 sigma
+ *   th = ((K2 & 0x3FFFF) + 0.5) * (pi/4) * 2^-18     in (0, pi/4); bits 18, 19, 20 of K2: swap sin/cos, sign of cos, sign of sin
+ * -2 ln u, sqrt and sin/cos are explicit fp32 sequences (fma polynomials, ~1e-7 relative) so that host and device agree bit for
+ * bit; z = (sqrt(w) * noise_scale) * (cos, sin) is added to the observation with one fma. */
+static inline uint32_t f2u(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    return b;
+}
+static inline float u2f(uint32_t b) {
+    float x;
+    memcpy(&x, &b, 4);
+    return x;
 }
 
-static void sincos2pi_spec(float a, float *sn, float *cs) { /* a in [0,1) */
-    float q = rintf(a * 4.0f);
-    float f = fmaf(q, -0.25f, a);
-    float th = f * 6.28318531f;
-    float z = th * th;
-    float ps = fmaf(z, 2.75573192e-6f, -1.98412698e-4f);
-    ps = fmaf(z, ps, 8.33333333e-3f);
-    ps = fmaf(z, ps, -1.66666667e-1f);
-    ps = fmaf(z, ps, 1.0f);
-    float sr = th * ps;
-    float pc = fmaf(z, -2.75573192e-7f, 2.48015873e-5f);
-    pc = fmaf(z, pc, -1.38888889e-3f);
-    pc = fmaf(z, pc, 4.16666667e-2f);
-    pc = fmaf(z, pc, -0.5f);
-    float cr = fmaf(z, pc, 1.0f);
-    switch ((int)q & 3) {
-    case 0: *sn = sr; *cs = cr; break;
-    case 1: *sn = cr; *cs = -sr; break;
-    case 2: *sn = -sr; *cs = -cr; break;
-    default: *sn = -cr; *cs = sr; break;
+static float neg2ln_spec(float u) { /* -2 ln(u), u in (0, 1) normal: exponent + degree-7 polynomial on [sqrt(1/2), sqrt(2)) */
+    const uint32_t ix = f2u(u) + 0x004AFB0Du; /* 0x3F800000 - 0x3F3504F3 */
+    const int e = (int)(ix >> 23) - 127;
+    const float m = u2f((ix & 0x007FFFFFu) + 0x3F3504F3u);
+    const float f = m - 1.0f;
+    float p = fmaf(f, 0.2026811391115188f, -0.3246837854385376f); /* -2 x the coefficients of ln(1 + f) / f */
+    p = fmaf(f, p, 0.34494027495384216f);
+    p = fmaf(f, p, -0.3979713022708893f);
+    p = fmaf(f, p, 0.49940142035484314f);
+    p = fmaf(f, p, -0.6667022705078125f);
+    p = fmaf(f, p, 1.0000072717666626f);
+    p = fmaf(f, p, -1.9999998807907104f);
+    return fmaf((float)e, -1.3862943649291992f, f * p);
+}
+
+static float sqrt_spec(float w) { /* w in [1e-7, 40]: reciprocal square root by two Newton steps from an exponent-halving seed */
+    float y = u2f(0x5F1FFFF9u - (f2u(w) >> 1));
+    float t = w * y;
+    t = fmaf(-t, y, 2.38924456f);
+    y = y * (0.703952253f * t);
+    const float h = 0.5f * w;
+    t = h * y;
+    t = fmaf(-t, y, 1.5f);
+    y = y * t;
+    return w * y;
+}
+
+static void unit_vector_spec(uint32_t k2, float *cs, float *sn) { /* k2: 21 bits */
+    const float th = fmaf((float)(k2 & 0x3FFFFu), 2.9960562e-06f, 1.4980281e-06f); /* (k + 0.5) * (pi / 4) / 2^18 */
+    const float z = th * th;
+    float p = fmaf(z, -0.00019587951828725636f, 0.008332748897373676f);
+    p = fmaf(z, p, -0.166666641831398f);
+    p = z * p;
+    const float s = fmaf(th, p, th);
+    float q = fmaf(z, 2.4463830413878895e-05f, -0.001388759003020823f);
+    q = fmaf(z, q, 0.04166664928197861f);
+    q = fmaf(z, q, -0.5f);
+    const float c = fmaf(z, q, 1.0f);
+    const float a = (k2 & 0x40000u) ? s : c, b = (k2 & 0x40000u) ? c : s;
+    *cs = (k2 & 0x80000u) ? -a : a;
+    *sn = (k2 & 0x100000u) ? -b : b;
+}
+
+/* 22 index pairs (K1, K2) of one row: four Philox blocks -> 11 x (21 + 21) bits */
+static void noise_indices(uint64_t seed, uint64_t call_idx, int64_t row, uint32_t k1[11], uint32_t k2[11]) {
+    uint32_t w[16];
+    for (uint32_t b = 0; b < 4; b++) rng_block(seed, call_idx, row, 2 + b, w + 4 * b);
+    for (int i = 0; i < 8; i++) {
+        k1[i] = w[2 * i] >> 11;
+        k2[i] = w[2 * i + 1] >> 11;
+    }
+    for (int j = 0; j < 3; j++) { /* low 11 bits of words 4j .. 4j+3: (11 + 10) bits each */
+        k1[8 + j] = ((w[4 * j] & 0x7FFu) << 10) | ((w[4 * j + 1] >> 1) & 0x3FFu);
+        k2[8 + j] = ((w[4 * j + 2] & 0x7FFu) << 10) | ((w[4 * j + 3] >> 1) & 0x3FFu);
+    }
+}
+
+/* o[2i], o[2i+1] += (sqrt(-2 ln u_i) * scale) * (cos, sin)(direction_i), one fma each */
+static void add_rng_noise(uint64_t seed, uint64_t call_idx, int64_t row, float scale, float o[F16O_NOBS]) {
+    uint32_t k1[11], k2[11];
+    noise_indices(seed, call_idx, row, k1, k2);
+    for (int i = 0; i < 11; i++) {
+        const float u = fmaf((float)k1[i], 4.76837158203125e-07f, 2.384185791015625e-07f); /* (K1 + 0.5) * 2^-21, exact */
+        const float rs = sqrt_spec(neg2ln_spec(u)) * scale;
+        float cs, sn;
+        unit_vector_spec(k2[i], &cs, &sn);
+        o[2 * i] = fmaf(rs, cs, o[2 * i]);
+        o[2 * i + 1] = fmaf(rs, sn, o[2 * i + 1]);
     }
 }
 
 void f16o_rng_normals(uint64_t seed, uint64_t call_idx, int64_t row, float z22[F16O_NOBS]) {
-    uint32_t w[4];
-    for (uint32_t b = 0; b < 6; b++) {
-        rng_block(seed, call_idx, row, 2 + b, w);
-        for (int h = 0; h < 2; h++) {
-            int pair = 2 * (int)b + h;
-            if (pair >= 11) break;
-            float u1 = ((float)(w[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-07f; /* 2^-23 */
-            float u2 = (float)(w[2 * h + 1] >> 8) * 5.9604644775390625e-08f;
-            float rad = sqrtf(-2.0f * logf_spec(u1));
-            float sn, cs;
-            sincos2pi_spec(u2, &sn, &cs);
-            z22[2 * pair] = rad * cs;
-            z22[2 * pair + 1] = rad * sn;
-        }
-    }
+    for (int k = 0; k < F16O_NOBS; k++) z22[k] = 0.0f;
+    add_rng_noise(seed, call_idx, row, 1.0f, z22);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -422,7 +488,7 @@ void f16o_rng_normals(uint64_t seed, uint64_t call_idx, int64_t row, float z22[F
 
 static float net_eval(const net_t *t, const float in3[3]) {
     float x[20], y[20];
-    for (int i = 0; i < t->n_in; i++) x[i] = (in3[t->sel[i]] - t->in_mean[i]) / t->in_std[i]; /* normalize :32-33 */
+    for (int i = 0; i < t->n_in; i++) x[i] = divc_rc(in3[t->sel[i]] - t->in_mean[i], t->in_std[i], t->in_rstd[i]); /* normalize :32-33; sigma is a per-model constant */
     if ((g_mode & F16O_MODE_PWL) && t->pwl) {
         /* numerics spec, "aero_1d_tables": a ReLU MLP of one input is exactly piecewise linear; binary search
          * over the sorted breakpoints, then y = fma(a, x - x0, c) on the segment */
@@ -448,18 +514,28 @@ static float net_eval(const net_t *t, const float in3[3]) {
         }
         return (float)xd[0] * t->out_std + t->out_mean; /* unnormalize :36-37 */
     }
-    for (int l = 0; l < t->n_linear; l++) {
+    for (int l = 0; l + 1 < t->n_linear; l++) { /* hidden layers: acc = bias; acc = fma(W[j][k], x[k], acc), k ascending (spec) */
         int in = t->dims[l], out = t->dims[l + 1];
         for (int j = 0; j < out; j++) {
             float acc = t->bs[l][j];
             for (int k = 0; k < in; k++) acc = fmaf(t->ws[l][j * in + k], x[k], acc);
-            if (l + 1 < t->n_linear) { /* ReLU :19 on activations carried / 2^ACT_SHIFT; NaN -> 0; saturates at 1 (spec) */
-                acc = acc > 0.0f ? acc : 0.0f;
-                acc = acc > 1.0f ? 1.0f : acc;
-            }
+            acc = acc > 0.0f ? acc : 0.0f; /* ReLU :19 on activations carried / 2^ACT_SHIFT; NaN -> 0; saturates at 1 (spec) */
+            acc = acc > 1.0f ? 1.0f : acc;
             y[j] = acc;
         }
         for (int j = 0; j < out; j++) x[j] = y[j];
+    }
+    { /* output layer in -> 1 (spec): two interleaved partial chains — lo starts at the bias and takes the even inputs (and an
+       * odd last one), hi starts at 0 and takes the odd inputs; y = lo + hi.  The reference's order is ATen sgemm's,
+       * implementation-defined; this one is a single packed FMA per input pair on gfx950 */
+        int l = t->n_linear - 1, in = t->dims[l];
+        float lo = t->bs[l][0], hi = 0.0f;
+        for (int k = 0; k + 1 < in; k += 2) {
+            lo = fmaf(t->ws[l][k], x[k], lo);
+            hi = fmaf(t->ws[l][k + 1], x[k + 1], hi);
+        }
+        if (in & 1) lo = fmaf(t->ws[l][in - 1], x[in - 1], lo);
+        x[0] = lo + hi;
     }
     return x[0] * t->out_std + t->out_mean; /* unnormalize :36-37 */
 }
@@ -521,7 +597,7 @@ static void nlplant_row(const f16o_model *m, const float x[17], float xd[12]) {
 
     float T = x[12], el = x[13], ail = x[14], rud = x[15];
     /* lef = x[16] is identically 0 (F16_model.py:57): dlef = 1 - lef/25 = 1 and `* dlef` is exact */
-    float dail = ail / 21.5f, drud = rud / 30.0f; /* :114-115 */
+    float dail = DIVC(ail, 21.5f), drud = DIVC(rud, 30.0f); /* :114-115 */
 
     /* atmos :22-35 (mach, ps are dead) */
     float tfac = 1.0f - 0.703e-5f * alt;
@@ -565,18 +641,18 @@ static void nlplant_row(const f16o_model *m, const float x[17], float xd[12]) {
     float Cl_tot = (((((c[N_Cl] + c[N_dCl_lef]) + dLdail * dail) + c[N_dCl_r30] * drud) + dLdR * R) + dLdP * P) +
                    c[N_dClbeta] * beta;
 
-    float Udot = (((R * V - Q * W) - g * st) + ((qbar * S) * Cx_tot) / mass) + T / mass;
-    float Vdot = ((P * W - R * U) + (g * ct) * sphi) + ((qbar * S) * Cy_tot) / mass;
-    float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + ((qbar * S) * Cz_tot) / mass;
+    float Udot = (((R * V - Q * W) - g * st) + DIVC((qbar * S) * Cx_tot, mass)) + DIVC(T, mass);
+    float Vdot = ((P * W - R * U) + (g * ct) * sphi) + DIVC((qbar * S) * Cy_tot, mass);
+    float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + DIVC((qbar * S) * Cz_tot, mass);
     xd[6] = ((U * Udot + V * Vdot) + W * Wdot) / vt;
     xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
     xd[8] = (Vdot * vt - V * xd[6]) / ((vt * vt) * cb);
     float L_tot = ((Cl_tot * qbar) * S) * B;
     float M_tot = ((Cm_tot * qbar) * S) * cbar;
     float N_tot = ((Cn_tot * qbar) * S) * B;
-    xd[9] = ((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng) / denom;
-    xd[10] = (((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng) / Jy;
-    xd[11] = ((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng) / denom;
+    xd[9] = DIVC((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng, denom);
+    xd[10] = DIVC(((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng, Jy);
+    xd[11] = DIVC((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom);
 }
 
 void f16o_nlplant(const f16o_model *m, int64_t n, const float *x17, float *xdot12) {
@@ -684,31 +760,31 @@ static void obs_row(const f16o_cfg *cfg, const float *s, const float *u, const f
     float TAS = vt + (float)cfg->airspeed * 1.0f; /* get_TAS :96-97 */
     float EAS = TAS / eas2tas;                    /* get_EAS :99-103 */
     if (cfg->task == F16O_TASK_HEADING) {
-        o[0] = ((alt - tgt[0]) * 0.3048f) / 1000.0f;
+        o[0] = DIVC((alt - tgt[0]) * 0.3048f, 1000.0f);
         o[1] = f16o_wrap_pi(heading - tgt[1]);
-        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+        o[2] = DIVC((vt - tgt[2]) * 0.3048f, 340.0f);
     } else if (cfg->task == F16O_TASK_CONTROL) {
         o[0] = f16o_wrap_pi(pitch - tgt[0]);
         o[1] = f16o_wrap_pi(heading - tgt[1]);
-        o[2] = ((vt - tgt[2]) * 0.3048f) / 340.0f;
+        o[2] = DIVC((vt - tgt[2]) * 0.3048f, 340.0f);
     } else {
-        o[0] = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
-        o[1] = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
-        o[2] = ((alt - tgt[2]) * 0.3048f) / 1000.0f;
+        o[0] = DIVC((s[0] - tgt[0]) * 0.3048f, 1000.0f);
+        o[1] = DIVC((s[1] - tgt[1]) * 0.3048f, 1000.0f);
+        o[2] = DIVC((alt - tgt[2]) * 0.3048f, 1000.0f);
     }
-    o[3] = (alt * 0.3048f) / 5000.0f;
+    o[3] = DIVC(alt * 0.3048f, 5000.0f);
     f16o_sincos(roll, &o[4], &o[5]);
     f16o_sincos(pitch, &o[6], &o[7]);
-    o[8] = (EAS * 0.3048f) / 340.0f;
+    o[8] = DIVC(EAS * 0.3048f, 340.0f);
     f16o_sincos(s[7], &o[9], &o[10]);
     f16o_sincos(s[8], &o[11], &o[12]);
     o[13] = s[9];
     o[14] = s[10];
     o[15] = s[11];
-    o[16] = ((u[0] / 0.225f) / 76300.0f) * 0.3048f;
-    o[17] = u[1] / 45.0f;
-    o[18] = u[2] / 45.0f;
-    o[19] = u[3] / 45.0f;
+    o[16] = DIVC(DIVC(u[0], 0.225f), 76300.0f) * 0.3048f;
+    o[17] = DIVC(u[1], 45.0f);
+    o[18] = DIVC(u[2], 45.0f);
+    o[19] = DIVC(u[3], 45.0f);
     o[20] = u[4] / 45.0f;
     o[21] = eas2tas;
 }
@@ -719,9 +795,7 @@ static void add_noise(const f16o_cfg *cfg, float *o, const float *noise_row, uin
     if (noise_row) { /* obs + randn_like(obs) * noise_scale */
         for (int k = 0; k < F16O_NOBS; k++) o[k] = o[k] + noise_row[k] * scale;
     } else if (scale != 0.0f) {
-        float z[F16O_NOBS];
-        f16o_rng_normals(seed, call_idx, grow, z);
-        for (int k = 0; k < F16O_NOBS; k++) o[k] = o[k] + z[k] * scale;
+        add_rng_noise(seed, call_idx, grow, scale, o);
     }
 }
 
@@ -778,7 +852,7 @@ static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float
     }
     float x[17];
     memcpy(x, s, 12 * sizeof(float));
-    x[12] = 0.9f * u[0] + (((0.1f * a[0]) * 0.225f) * 76300.0f) / 0.3048f;
+    x[12] = 0.9f * u[0] + DIVC(((0.1f * a[0]) * 0.225f) * 76300.0f, 0.3048f);
     x[13] = 0.9f * u[1] + (0.1f * a[1]) * 45.0f;
     x[14] = 0.9f * u[2] + (0.1f * a[2]) * 45.0f;
     x[15] = 0.9f * u[3] + (0.1f * a[3]) * 45.0f;
@@ -800,11 +874,11 @@ static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const floa
     int r_low = (s[2] - (float)cfg->altitude_limit) < 0.0f;
     /* HighSpeed / LowSpeed — high_speed.py:29-30, low_speed.py:29-30 */
     float TAS = s[6] + (float)cfg->airspeed * 1.0f;
-    float vel = (TAS * 0.3048f) / 340.0f;
+    float vel = DIVC(TAS * 0.3048f, 340.0f);
     int r_fast = (vel - (float)cfg->max_velocity) >= 0.0f;
     int r_slow = (vel - (float)cfg->min_velocity) <= 0.0f;
     /* ExtremeState — extreme_state.py:32-36 */
-    float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
+    float alpha = DIVC(s[7] * 180.0f, PI_F), beta = DIVC(s[8] * 180.0f, PI_F);
     int r_ext = ((alpha < (float)cfg->min_alpha) | (alpha > (float)cfg->max_alpha)) |
                 ((beta < (float)cfg->min_beta) | (beta > (float)cfg->max_beta));
     int bad = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
@@ -818,27 +892,27 @@ static void done_reward_row(const f16o_model *m, const f16o_cfg *cfg, const floa
         m4 = fabsf(s[2] - tgt[0]) >= 100.0f;
         m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
         /* HeadingReward — heading_reward.py:26-36 */
-        float da = ((s[2] - tgt[0]) * 0.3048f) / 1000.0f;
-        float dh = f16o_wrap_pi(s[5] - tgt[1]) / PI_F;
-        float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        float da = DIVC((s[2] - tgt[0]) * 0.3048f, 1000.0f);
+        float dh = DIVC(f16o_wrap_pi(s[5] - tgt[1]), PI_F);
+        float dv = DIVC((s[6] - tgt[2]) * 0.3048f, 340.0f);
         rew = (-(da * da) + -(dh * dh)) + -(dv * dv);
     } else if (cfg->task == F16O_TASK_CONTROL) {
         m3 = fabsf(f16o_wrap_pi(s[5] - tgt[1])) >= pi36;
         m4 = fabsf(s[4] - tgt[0]) >= pi36;
         m5 = fabsf(s[6] - tgt[2]) >= 20.0f;
         /* PostureReward — posture_reward.py:26-35 */
-        float dp = f16o_wrap_pi(s[4] - tgt[0]) / PI_F;
-        float dh = f16o_wrap_pi(s[5] - tgt[1]) / PI_F;
-        float dv = ((s[6] - tgt[2]) * 0.3048f) / 340.0f;
+        float dp = DIVC(f16o_wrap_pi(s[4] - tgt[0]), PI_F);
+        float dh = DIVC(f16o_wrap_pi(s[5] - tgt[1]), PI_F);
+        float dv = DIVC((s[6] - tgt[2]) * 0.3048f, 340.0f);
         rew = (-(dp * dp) + -(dh * dh)) + -(dv * dv);
     } else {
         m3 = fabsf(s[0] - tgt[0]) >= 100.0f;
         m4 = fabsf(s[1] - tgt[1]) >= 100.0f;
         m5 = fabsf(s[2] - tgt[2]) >= 100.0f;
         /* PositionReward — position_reward.py:26-34 */
-        float dn = ((s[0] - tgt[0]) * 0.3048f) / 1000.0f;
-        float de = ((s[1] - tgt[1]) * 0.3048f) / 1000.0f;
-        float da = ((s[2] - tgt[2]) * 0.3048f) / 1000.0f;
+        float dn = DIVC((s[0] - tgt[0]) * 0.3048f, 1000.0f);
+        float de = DIVC((s[1] - tgt[1]) * 0.3048f, 1000.0f);
+        float da = DIVC((s[2] - tgt[2]) * 0.3048f, 1000.0f);
         rew = 0.1f * ((-(dn * dn) + -(de * de)) + -(da * da));
     }
     int off = (m3 | m4) | m5;

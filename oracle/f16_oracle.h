@@ -56,6 +56,8 @@ void f16o_model_free(f16o_model *m);
 #define F16O_MODE_MLP_F64 1  /* pin mode: MLPs evaluated in fp64 from fp32 inputs, rounded once */
 #define F16O_MODE_LIBM 2     /* transcendental functions from the host libm (sinf/cosf/tanf/powf) */
 #define F16O_MODE_PWL 4      /* single-input nets through their exact piecewise-linear tables (blob PWL section) */
+#define F16O_MODE_DIV_IEEE 8 /* divisions by constants as plain IEEE `x / c` (the reference's operator) instead of the spec's
+                              * Markstein sequence f16o_divc — identical results wherever f16o_divc_check holds (tests run both) */
 void f16o_set_mode(int mode);
 int f16o_get_mode(void);
 

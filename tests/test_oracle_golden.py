@@ -327,3 +327,71 @@ def test_step_with_tables_within_tolerance_masks_exact(task, fixture, solver, go
     assert relerr(st['s'], g['out_s'], STATE_FLOORS) < (2e-4 if solver == 'rk4' else 1e-4)
     assert relerr(obs, g['out_obs'], 0.1) < 1e-4 and relerr(rew, g['out_reward'], 1.0) < 1e-4
     assert np.array_equal(d, g['out_done']) and np.array_equal(b, g['out_bad']) and np.array_equal(t, g['out_timeout'])
+
+
+# ---------------------------------------------------------------------------------------------------
+# numerics spec: division by a constant as Markstein's multiply / correct sequence (f16o_divc == csrc/np_math.h::np_divc)
+# ---------------------------------------------------------------------------------------------------
+def _divisor_constants():
+    """Every constant the path divides by through the sequence: the reference's literals (F16_dynamics.py:114-115,215-227,
+    the task / reward / termination files' unit conversions) and the 9 distinct normalisation sigmas of mean_std.csv."""
+    import struct
+    from oracle.f16_oracle import DEFAULT_BLOB
+    blob = open(DEFAULT_BLOB, 'rb').read()
+    sig = set()
+    for i in range(struct.unpack_from('<I', blob, 12)[0]):
+        rec = blob[16 + 128 * i:16 + 128 * (i + 1)]
+        mask = struct.unpack_from('<I', rec, 24)[0]
+        stds = struct.unpack_from('<3d', rec, 24 + 8 + 24 + 24)
+        sig |= {float(np.float32(stds[k])) for k in range(3) if mask & (1 << k)}
+    assert len(sig) == 9
+    lit = [21.5, 30.0, 636.94, float(np.float32(9496.0 * 63100.0 - 982.0 * 982.0)), 55814.0, 0.3048, 1000.0, 340.0, 5000.0, 0.225,
+           76300.0, 45.0, float(np.float32(np.pi))]
+    return lit + sorted(sig)
+
+
+def test_constant_divisors_markstein_sequence_is_the_ieee_quotient_for_every_significand():
+    """The proof obligation behind np_divc / f16o_divc: for each constant c on the path, q' = fma(fma(-q, c, x), rc, q) with
+    q = x * rc equals x / c for ALL 2^23 significands of x in two adjacent binades (the sequence is exponent-independent
+    while nothing under- or overflows)."""
+    import ctypes as C
+    from oracle.f16_oracle import build
+    lib = C.CDLL(build())
+    lib.f16o_divc_check.restype = C.c_long
+    lib.f16o_divc_check.argtypes = [C.c_float]
+    lib.f16o_divc.restype = C.c_float
+    lib.f16o_divc.argtypes = [C.c_float, C.c_float]
+    for c in _divisor_constants():
+        assert lib.f16o_divc_check(C.c_float(c)) == 0, c
+    # specials: zero keeps its sign, inf and NaN propagate as in IEEE division
+    assert np.signbit(lib.f16o_divc(C.c_float(-0.0), C.c_float(45.0))) and lib.f16o_divc(C.c_float(-0.0), C.c_float(45.0)) == 0.0
+    assert lib.f16o_divc(C.c_float(float('inf')), C.c_float(340.0)) == float('inf')
+    assert np.isnan(lib.f16o_divc(C.c_float(float('nan')), C.c_float(340.0)))
+    rng = np.random.RandomState(0)
+    x = (rng.standard_normal(200000) * 10.0 ** rng.uniform(-25, 25, 200000)).astype(np.float32)
+    for c in (636.94, 0.3048, 45.0):
+        got = np.array([lib.f16o_divc(C.c_float(float(v)), C.c_float(c)) for v in x[:20000]], np.float32)
+        assert np.array_equal(got, x[:20000] / np.float32(c))
+
+
+@pytest.mark.parametrize('task', ['heading', 'control', 'tracking'])
+def test_constant_division_sequence_changes_no_bit_of_a_run(task):
+    """The same 400 free-running steps (production RNG, noise on, random actions, hundreds of resets) with the spec's
+    sequence and with plain IEEE `x / c` (MODE_DIV_IEEE, the reference's operator): every output identical bit for bit."""
+    from oracle.f16_oracle import MODE_DIV_IEEE
+    n, T = 192, 400
+    acts = np.random.RandomState(4).uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    outs = []
+    for mode in (0, MODE_DIV_IEEE):
+        o = Oracle(task, mode=mode)
+        st = Oracle.new_state(n)
+        o.reset(st, seed=5, call_idx=0)
+        acc = []
+        for t in range(T):
+            obs, rew, d, b, tm = o.step(st, acts[t], seed=5, call_idx=t + 1)
+            if t % 50 == 49 or t < 3:
+                acc.append((obs.copy(), rew.copy(), d.copy(), b.copy(), st['s'].copy(), st['u'].copy()))
+        outs.append(acc)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)

@@ -40,8 +40,8 @@ S_CNT = 'vcc_lo' # remaining nets
 S_NEXT = 2       # s[2:3] (phase functions only): pointer of the record that follows the current one in the SEQUENCE
 V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
 V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
-V_Y = 126        # net output
-V_ADDR = 127     # LDS byte address of the output slot
+V_Y = 126        # v[126:127] the two partial sums of the output layer; v126 = net output
+V_ADDR = 121     # LDS byte address of the output slot (the odd register between the input pairs: never read as an input)
 GEN_DUP = os.environ.get('NPF16_GEN_DUP') == '1'   # TIMING EXPERIMENT ONLY: every VALU instruction of a net body is issued twice (second copy on
                                                     # registers + 58), i.e. two accumulator sets per weight load — what 'two aircraft per lane' would cost
 V_CLOBBER = list(range(68 if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1' else 70, 186 if GEN_DUP else 128))
@@ -58,7 +58,7 @@ def record_len(IN, H1, H2, H3):
     for h in hid:
         n += pad2(h) + prev * pad2(h)
         prev = h
-    n += pad2(1 + prev) + 2
+    n += 2 + pad2(prev) + 2    # final layer: (bias, 0) pair, W[0][0..in) padded to even; then out_std, out_mean
     return (n + GROUP - 1) // GROUP * GROUP
 
 
@@ -165,15 +165,27 @@ class Body:
         self.pos = p0 + row * (n_in + 1)
 
     def final(self, n_in, in_regs):
+        """output layer in -> 1 as TWO interleaved partial chains in one packed accumulator (numerics spec):
+        acc = (bias, 0); acc = (fma(w[2i], x[2i], acc.lo), fma(w[2i+1], x[2i+1], acc.hi)) for i ascending; an odd last input goes to
+        the low chain; y = acc.lo + acc.hi.  Half the instructions of the serial chain (5 + 1 instead of 10 for the 10-wide layers)."""
         p0 = self.pos
+        assert in_regs[0] % 2 == 0 and all(in_regs[k] == in_regs[0] + k for k in range(n_in))
+        sp = self.spair(p0)
         self.skip_dup.add(len(self.ins))
-        self.ins.append(f'v_mov_b32 v{V_Y}, {self.s1(p0)}')
-        for k in range(n_in):
-            s_w = self.s1(p0 + 1 + k)
-            if k == 0:
-                self.b_first[len(self.ins)] = f'v_fma_f32 v{V_Y + SET_B}, {s_w}, v{in_regs[k] + SET_B}, v{V_Y}'
-            self.ins.append(f'v_fmac_f32 v{V_Y}, {s_w}, v{in_regs[k]}')
-        self.pos = p0 + pad2(1 + n_in)
+        self.ins.append(f'v_pk_mov_b32 {self.vpair(V_Y)}, {sp}, {sp} op_sel:[0,1]')
+        for k in range(0, n_in - 1, 2):
+            sw = self.spair(p0 + 2 + k)
+            xp = self.vpair(in_regs[k])
+            acc = self.vpair(V_Y)
+            if k == 0:   # set B takes (bias, 0) from set A's freshly initialised pair
+                self.b_first[len(self.ins)] = f'v_pk_fma_f32 {self.vpair(V_Y + SET_B)}, {sw}, {self.vpair(in_regs[k] + SET_B)}, {acc}'
+            self.ins.append(f'v_pk_fma_f32 {acc}, {sw}, {xp}, {acc}')
+        if n_in & 1:
+            k = n_in - 1
+            assert k > 0
+            self.ins.append(f'v_fmac_f32 v{V_Y}, {self.s1(p0 + 2 + k)}, v{in_regs[k]}')
+        self.ins.append(f'v_add_f32 v{V_Y}, v{V_Y}, v{V_Y + 1}')
+        self.pos = p0 + 2 + pad2(n_in)
         # unnormalize: X * std + mean, two roundings (hifi_F16_AeroData.py:36-37)
         self.ins.append(f'v_mul_f32 v{V_Y}, {self.s1(self.pos)}, v{V_Y}')
         self.ins.append(f'v_add_f32 v{V_Y}, {self.s1(self.pos + 1)}, v{V_Y}')
@@ -478,7 +490,7 @@ def gen_function(shape):
 # one epilogue per PHASE instead of per class (19 -> 3 exposed scalar-load latencies per env.step).
 # ------------------------------------------------------------------------------------------------
 G = {'G_A_C': 0, 'G_A_DAMP': 1, 'G_A_LEF': 2, 'G_A_DLEF': 3, 'G_A_RUD': 4, 'G_B_C': 5, 'G_B_O': 6, 'G_E_C': 7, 'G_E_ETA': 8}
-KBLOB_HEADER = 2 * len(G)
+KBLOB_HEADER = 3 * len(G) + 1   # np_nets.h: (mean, sigma, 1/sigma) per normalisation group, padded to even
 X_IN_LDS = False  # True: the phase statements read their inputs from LDS slots NUM_LIVE.. (51 slots/lane: only 5 workgroups per CU)
 NUM_LIVE = 42    # output slots; the normalised inputs live in LDS slots NUM_LIVE .. NUM_LIVE + 8 (np_nets.h::NUM_LDS_SLOTS)
 # (name, shape, input groups, count, n_force) — mirror of np_nets.h::CLASSES, cross-checked by static_asserts in the output
