@@ -93,7 +93,7 @@ __device__ __forceinline__ float rate_out(const PID &g, float dt, float desired,
     }
     const float ff = (target * g.Kff) / (scaler * eas2tas + 1e-8f);
     float out = ((ff + e * g.Kp) + in) + deriv * g.Kd;
-    out = (180.0f * out) / 3.14159265358979323846f;
+    out = NP_DIVC(180.0f * out, 3.14159265358979323846f);
     err = ok ? e : err;
     integ = ok ? in : integ;
     last_out = ok ? out : last_out;
@@ -186,11 +186,11 @@ __device__ __forceinline__ void ao_ta_r(const float (&ep)[3], const float (&mp)[
 
 __device__ __forceinline__ float orientation_reward_v2(float AO, float TA) {  // utils.py:207-218
     const float PI_F = 3.14159265358979323846f;
-    const float a = (1.0f / ((AO * 50.0f) / PI_F + 2.0f)) * 1.0f + 0.5f;
-    float m = (TA * 1.9f) / PI_F;
+    const float a = (1.0f / (NP_DIVC(AO * 50.0f, PI_F) + 2.0f)) * 1.0f + 0.5f;
+    float m = NP_DIVC(TA * 1.9f, PI_F);
     const float floor_ = 1e-4f * 1.0f;
     m = (m != m) ? m : (m > floor_ ? m : floor_);
-    float t = np_atanh(1.0f - m) / (float)(2.0 * 3.141592653589793);
+    float t = NP_DIVC(np_atanh(1.0f - m), (float)(2.0 * 3.141592653589793));
     t = (t != t) ? t : (t < 0.0f ? t : 0.0f);
     return (a + t) + 0.5f;
 }
@@ -204,7 +204,7 @@ __device__ __forceinline__ float orientation_fn(float AO) {  // utils.py:235-243
     const float PI_F = 3.14159265358979323846f;
     const float pi6 = (float)(3.141592653589793 / 6.0);
     const float m3 = ((AO >= 0.0f) & (AO <= pi6)) ? 1.0f : 0.0f, m4 = ((AO <= 0.0f) & (AO >= -pi6)) ? 1.0f : 0.0f;
-    const float q = (6.0f * AO) / PI_F;
+    const float q = NP_DIVC(6.0f * AO, PI_F);
     return (1.0f - q) * m3 + (1.0f + q) * m4;
 }
 __device__ __forceinline__ float distance_fn(float R) {  // utils.py:245-249
@@ -220,14 +220,20 @@ constexpr int COMBAT_BLOCK = 128;
 static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as the observation transpose tile");
 
 // STEP=true: SingleCombatEnv.step; STEP=false: reset_done_envs + obs
-// TILE, WPT: as f16_env_kernel — (128, 1) throughput variant, (64, 4) latency variant: four waves hold the same 64 aircraft
-// (32 engagements), split the net evaluations and repeat the rest; the pair exchange stays inside each wave.
+// TILE, WPT: as f16_env_kernel — (128, 1) throughput variant; (128, 2) pair variant: the two waves of the workgroup split the nets
+// of every evaluation and evaluate their half for both waves' aircraft (dual asm bodies, half the scalar weight traffic);
+// (64, 4) latency variant: four waves hold the same 64 aircraft (32 engagements), split the net evaluations and repeat the
+// rest.  The engagement's pair exchange stays inside each wave in every variant.
 template <int SOLVER, bool STEP, int TILE = COMBAT_BLOCK, int WPT = 1>
-__global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_kernel(const CombatArgs a) {
+__global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), NPF16_COMBAT_MINWAVES) void f16_combat_kernel(const CombatArgs a) {
     constexpr int B = TILE;
-    __shared__ float lds[NUM_LDS_SLOTS * TILE];  // > TILE * COMBAT_OBS
-    const int t = WPT == 1 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
-    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform
+    constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0);  // pair variant: nine more columns carry the inputs to the partner wave
+    __shared__ float lds[COLS * TILE];  // > TILE * COMBAT_OBS
+    const int t = WPT != 4 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
+    // latency variant: which quarter of the nets / pair variant: which wave of the pair (wave-uniform); stores are done by part 0
+    // in the latency variant and by every wave otherwise
+    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)) % (WPT == 4 ? 4 : 2);
+    const bool storer = WPT != 4 || part == 0;
     float *coef = lds + t;
     const long long i0 = (long long)blockIdx.x * B;
     const long long i = i0 + t;
@@ -299,17 +305,19 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             const float r2d = (float)(180.0 / 3.141592653589793);
             float xn[NUM_NORM_GROUPS];
             normalise_inputs(a.wt, s[7] * r2d, s[8] * r2d, u[1], xn);
-            eval_ab<B, AB_FORCE>(a.wt, xn, coef, tables);
+            // pair variant: the Overload phase (the 14 nets + the force-side Cx, Cz, whose values are simply not used here)
+            if constexpr (WPT == 2) eval_nets<B, AB_FORCE, false, 2>(a.wt, xn, coef, tables, part);
+            else eval_ab<B, AB_FORCE>(a.wt, xn, coef, tables);
         }
         NP_REREAD_ARGS(ap);
 #pragma nounroll
         for (int it = 0; it < ap->cfg.inner_steps; it++) {
             // ---- demand filters (:245-246) and Controller.stabilize ----
-            pid[PID_ROLL_DEM] = 0.9f * pid[PID_ROLL_DEM] + (((0.1f * act[1]) * 4.0f) * PI_F) / 9.0f;
-            pid[PID_PITCH_DEM] = 0.9f * pid[PID_PITCH_DEM] + ((0.1f * act[2]) * PI_F) / 12.0f;
+            pid[PID_ROLL_DEM] = 0.9f * pid[PID_ROLL_DEM] + NP_DIVC(((0.1f * act[1]) * 4.0f) * PI_F, 9.0f);
+            pid[PID_PITCH_DEM] = 0.9f * pid[PID_PITCH_DEM] + NP_DIVC((0.1f * act[2]) * PI_F, 12.0f);
             float el, ail, rud;
             stabilize(ap->cfg, s, tr, tt, pid, ap->pid_first != 0 && it == 0, el, ail, rud);
-            u[0] = 0.9f * u[0] + (((0.1f * act[0]) * 0.225f) * 76300.0f) / 0.3048f;  // :251
+            u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);  // :251
             u[1] = -el;                                                                 // :252-255, written straight to u
             u[2] = -ail;
             u[3] = -rud;
@@ -375,10 +383,10 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             const bool r_over = (acc - ap->cfg.acceleration_limit) > 0.0f;   // overload.py:37-42
             const bool r_low = (s[2] - ap->cfg.altitude_limit) < 0.0f;        // low_altitude.py:29-30
             const float TAS = s[6] + ap->cfg.airspeed * 1.0f;
-            const float vel = (TAS * 0.3048f) / 340.0f;
+            const float vel = NP_DIVC(TAS * 0.3048f, 340.0f);
             const bool r_fast = (vel - ap->cfg.max_velocity) >= 0.0f;         // high_speed.py:29-30
             const bool r_slow = (vel - ap->cfg.min_velocity) <= 0.0f;         // low_speed.py:29-30
-            const float alpha = (s[7] * 180.0f) / PI_F, beta = (s[8] * 180.0f) / PI_F;
+            const float alpha = NP_DIVC(s[7] * 180.0f, PI_F), beta = NP_DIVC(s[8] * 180.0f, PI_F);
             const bool r_ext = ((alpha < ap->cfg.min_alpha) | (alpha > ap->cfg.max_alpha)) | ((beta < ap->cfg.min_beta) | (beta > ap->cfg.max_beta));  // extreme_state.py:32-36
             bool b = (((r_over | r_low) | r_fast) | r_slow) | r_ext;
             // crash.py:33-43 (ego - enemy, squared distance in fp32)
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
             if (ap->term_counters) {  // per-condition sums (the reference prints them per evaluation): ballot + popcount + 1 atomic
                 const unsigned bits = (r_over ? 1u : 0u) | (r_low ? 2u : 0u) | (r_fast ? 4u : 0u) | (r_slow ? 8u : 0u) | (r_ext ? 16u : 0u) |
                                       (r_crash ? 32u : 0u) | (r_tmo ? 64u : 0u) | (m1 ? 128u : 0u) | ((m2 & !m1) ? 256u : 0u);
-                const bool counted = valid && part == 0;
+                const bool counted = valid && storer;
 #pragma unroll
                 for (int k = 0; k < NP_NUM_COMBAT_TERM_COUNTERS; k++) {
                     const unsigned long long mk = __ballot(counted && ((bits >> k) & 1u));
@@ -426,27 +434,27 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
     float AO2, TA2, R2, side;
     ao_ta_r<2>(ep, mp, ev, mv, AO2, TA2, R2, side);
     float o[COMBAT_OBS];
-    o[0] = (s[2] * 0.3048f) / 5000.0f;
+    o[0] = NP_DIVC(s[2] * 0.3048f, 5000.0f);
     o[1] = tr.sphi;
     o[2] = tr.cphi;
     o[3] = tr.st;
     o[4] = tr.ct;
-    o[5] = (vel_u * 0.3048f) / 340.0f;
-    o[6] = (vel_v * 0.3048f) / 340.0f;
-    o[7] = (vel_w * 0.3048f) / 340.0f;
-    o[8] = (s[6] * 0.3048f) / 340.0f;
-    o[9] = ((o_vel_u - vel_u) * 0.3048f) / 340.0f;
-    o[10] = ((op[2] - s[2]) * 0.3048f) / 1000.0f;
+    o[5] = NP_DIVC(vel_u * 0.3048f, 340.0f);
+    o[6] = NP_DIVC(vel_v * 0.3048f, 340.0f);
+    o[7] = NP_DIVC(vel_w * 0.3048f, 340.0f);
+    o[8] = NP_DIVC(s[6] * 0.3048f, 340.0f);
+    o[9] = NP_DIVC((o_vel_u - vel_u) * 0.3048f, 340.0f);
+    o[10] = NP_DIVC((op[2] - s[2]) * 0.3048f, 1000.0f);
     o[11] = is_ego ? AO2 : PI_F - TA2;
     o[12] = is_ego ? TA2 : PI_F - AO2;
-    o[13] = (R2 * 0.3048f) / 10000.0f;
+    o[13] = NP_DIVC(R2 * 0.3048f, 10000.0f);
     o[14] = is_ego ? side : -side;
 
     float reward = 0.0f;
     if (STEP) {
         float AO, TA, R, side3;
         ao_ta_r<3>(ep, mp, ev, mv, AO, TA, R, side3);
-        const float Rkm = (R * 0.3048f) / 1000.0f;
+        const float Rkm = NP_DIVC(R * 0.3048f, 1000.0f);
         const float rr = range_reward_v3(Rkm);
         const float orient = is_ego ? orientation_reward_v2(AO, TA) : orientation_reward_v2(PI_F - TA, PI_F - AO);
         reward = 0.01f * (orient * rr);
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
         blood = blood - (is_ego ? orientation_fn(PI_F - TA) : orientation_fn(AO)) * dfn;
     }
 
-    if (valid && part == 0) {
+    if (valid && storer) {
         long long iw = i;
         asm volatile("" : "+v"(iw));  // re-derive the store addresses here instead of keeping the load addresses alive
 #pragma unroll
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
     // ---- [n][15] observation rows: transpose through LDS, store coalesced ----
     if (ap->obs) {
         __syncthreads();
-        if (part == 0) {
+        if (storer) {
 #pragma unroll
             for (int k = 0; k < COMBAT_OBS; k++) lds[t * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
         }
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(TILE * WPT, NPF16_COMBAT_MINWAVES) void f16_combat_
         const long long rows = (ap->n - i0) < B ? (ap->n - i0) : B;
         const int total = (int)rows * COMBAT_OBS;
         float *dst = ap->obs + i0 * COMBAT_OBS;
-        constexpr int THREADS = TILE * WPT;
+        constexpr int THREADS = TILE * (WPT == 4 ? 4 : 1);
 #pragma unroll
         for (int itr = 0; itr < (COMBAT_OBS * TILE + THREADS - 1) / THREADS; itr++) {
             const int L = itr * THREADS + (int)threadIdx.x;

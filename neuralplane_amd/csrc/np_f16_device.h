@@ -598,7 +598,6 @@ __device__ __forceinline__ void xdot_full(const AeroWeights &wt, const float (&s
     np_sincos(s[5], spsi, cpsi);
     nlplant<true, PART, LD, WPT>(wt, s, u, tr, tt, spsi, cpsi, coef, tables, xd, part);
 }
-
 // F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)
 __device__ __forceinline__ void body_acceleration(const float (&s)[12], const Trig &tr, const float (&xd)[12], float (&a)[3]) {
     const float sina = tr.sa, cosa = tr.ca, sinb = tr.sb, cosb = tr.cb;

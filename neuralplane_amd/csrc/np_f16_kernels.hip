@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
     // pair variant (WPT == 2): nine more columns carry the normalised MLP inputs to the other wave of the workgroup
     constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0);
     constexpr int TILE_LDS = (COLS * TILE > TILE * OBS_LD) ? COLS * TILE : TILE * OBS_LD;
-    __shared__ float lds[TILE_LDS];
+    __shared__ __attribute__((aligned(16))) float lds[TILE_LDS];
     float *obs_tile = lds;
     const int t = WPT != 4 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
     const int part = WPT != 4 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform; 0 = the wave that stores
@@ -343,24 +343,45 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
     if (ap->obs) {
         __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
-        if (part == 0) {
-#pragma unroll
-            for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
-        }
-        __syncthreads();
         const long long rows = (ap->n - i0) < TILE ? (ap->n - i0) : TILE;
-        const int total = (int)rows * 22;
         float *dst = ap->obs + i0 * 22;
         constexpr int THREADS = TILE * (WPT == 4 ? 4 : 1);
+        if (rows == TILE && ((uintptr_t)dst & 15) == 0) {  // workgroup-uniform: a full tile and a 16-byte aligned destination
+            // unpadded rows (pitch 22 floats): 11 ds_write_b64 per lane, then the tile leaves as 16-byte vectors — 6 (2)
+            // ds_read_b128 + global_store_dwordx4 per thread instead of 22 dword pairs; the LDS bank conflicts of the unpadded
+            // pitch cost LDS cycles, which this VALU-bound kernel has to spare, and no VALU index arithmetic is left
+            if (part == 0) {
+                float2 *row = reinterpret_cast<float2 *>(obs_tile + t * 22);
 #pragma unroll
-        for (int it = 0; it < (22 * TILE + THREADS - 1) / THREADS; it++) {
-            const int L = it * THREADS + (int)threadIdx.x;
-            if (L < total) {
-                // row r = L / 22 of the tile, padded pitch 23: element r * 23 + (L - 22 r) = L + r; L * 2979 >> 16 == L / 22 for
-                // every L < 22 * 256 (24-bit product: one v_mul_u32_u24)
-                static_assert(OBS_LD == 23 && TILE <= 256, "index arithmetic of the observation transpose");
-                const unsigned r = ((unsigned)L * 2979u) >> 16;
-                dst[L] = obs_tile[(unsigned)L + r];
+                for (int k = 0; k < 11; k++) row[k] = make_float2(o[2 * k], o[2 * k + 1]);
+            }
+            __syncthreads();
+            constexpr int VECS = TILE * 22 / 4;
+            static_assert((TILE * 22) % 4 == 0, "a tile is a whole number of 16-byte vectors");
+            const float4 *src4 = reinterpret_cast<const float4 *>(obs_tile);
+            float4 *dst4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+            for (int it = 0; it < (VECS + THREADS - 1) / THREADS; it++) {
+                const int L = it * THREADS + (int)threadIdx.x;
+                if ((it + 1) * THREADS <= VECS || L < VECS) dst4[L] = src4[L];
+            }
+        } else {  // the last, partial tile of a batch (or an unaligned caller buffer): dword by dword through the padded pitch
+            if (part == 0) {
+#pragma unroll
+                for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
+            }
+            __syncthreads();
+            const int total = (int)rows * 22;
+#pragma nounroll
+            for (int it = 0; it < (22 * TILE + THREADS - 1) / THREADS; it++) {
+                const int L = it * THREADS + (int)threadIdx.x;
+                if (L < total) {
+                    // row r = L / 22 of the tile, padded pitch 23: element r * 23 + (L - 22 r) = L + r; L * 2979 >> 16 == L / 22
+                    // for every L < 22 * 256 (24-bit product: one v_mul_u32_u24)
+                    static_assert(OBS_LD == 23 && TILE <= 256, "index arithmetic of the observation transpose");
+                    const unsigned r = ((unsigned)L * 2979u) >> 16;
+                    dst[L] = obs_tile[(unsigned)L + r];
+                }
             }
         }
     }
@@ -897,7 +918,10 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
         }
         NP_HIP(hipEventRecord(ev.first, st));
     }
+    // pair variant (Euler, MLP numerics): the default above the latency variant's range; NP_KERNEL_THROUGHPUT pins the single-set kernel
+    const bool pair = STEP && !latency && ctx->solver == 0 && !ctx->ccfg.aero_1d_tables && ctx->variant != NP_KERNEL_THROUGHPUT;
     if (latency) hipLaunchKernelGGL((f16_combat_kernel<0, STEP, LAT_TILE, 4>), grid, block, 0, st, a);
+    else if (pair) hipLaunchKernelGGL((f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>), grid, block, 0, st, a);
     else if (STEP && ctx->solver == 1) hipLaunchKernelGGL((f16_combat_kernel<1, STEP>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((f16_combat_kernel<0, STEP>), grid, block, 0, st, a);
     NP_HIP(hipGetLastError());

@@ -63,9 +63,11 @@ def _fixture_state(o, d, n):
     return st
 
 
-@pytest.mark.parametrize('variant', ['latency', 'throughput'])
+@pytest.mark.parametrize('variant', ['latency', 'throughput', 'pair'])
 @pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
 def test_combat_fixture_free_running_bit_exact_vs_oracle(golden_dir, tables, variant):
+    if tables and variant == 'pair':
+        pytest.skip('the pair variant evaluates the MLP numerics only (the table mode falls back to the single-set kernel)')
     """The 48 recorded env.steps (Crash, Timeout, both Shutdown outcomes, pairwise auto-resets with injected draws)."""
     d = np.load(f'{golden_dir}/combat_kat.npz')
     K, n = d['actions'].shape[:2]
@@ -104,7 +106,7 @@ def test_combat_fixture_vs_reference_teacher_forced(golden_dir):
                   done=d[f'flags_{k}'][0], bad=d[f'flags_{k}'][1], timeout=d[f'flags_{k}'][2])
 
 
-@pytest.mark.parametrize('solver,variant', [('euler', 'latency'), ('euler', 'throughput'), ('rk4', 'auto')])
+@pytest.mark.parametrize('solver,variant', [('euler', 'latency'), ('euler', 'throughput'), ('euler', 'pair'), ('rk4', 'auto')])
 def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver, variant):
     """reset + 40 env.steps (200 FDM steps) with the in-kernel Philox reset draws, hazard-rich demands, a ragged last
     workgroup and a non-zero first env (shard offset)."""
@@ -217,7 +219,7 @@ def test_combat_full_size_sampled_blocks_vs_oracle():
         _check(b, outs[-1][0], outs[-1][1], outs[-1][2], st, o_obs, o_rew, f'block at env {e0}', rows=rows)
 
 
-@pytest.mark.parametrize('variant', ['latency', 'throughput'])
+@pytest.mark.parametrize('variant', ['latency', 'throughput', 'pair'])
 def test_combat_hostile_inputs(variant):
     """NaN / inf demands and poisoned states: the per-row "non-finite target or measurement holds the previous PID output" rule,
     NaN-compares-false in Crash / Shutdown / Timeout and the pair exchange must agree with the oracle lane by lane."""

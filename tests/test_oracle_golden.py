@@ -346,7 +346,8 @@ def _divisor_constants():
         sig |= {float(np.float32(stds[k])) for k in range(3) if mask & (1 << k)}
     assert len(sig) == 9
     lit = [21.5, 30.0, 636.94, float(np.float32(9496.0 * 63100.0 - 982.0 * 982.0)), 55814.0, 0.3048, 1000.0, 340.0, 5000.0, 0.225,
-           76300.0, 45.0, float(np.float32(np.pi))]
+           76300.0, 45.0, float(np.float32(np.pi)),
+           9.0, 12.0, 10000.0, float(np.float32(2.0 * np.pi))]      # SingleCombat: demand filters, obs / reward unit conversions
     return lit + sorted(sig)
 
 

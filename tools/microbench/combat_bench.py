@@ -5,12 +5,15 @@ from neuralplane_amd.core import F16CombatBatch
 from neuralplane_amd.envs.utils.utils import parse_config
 sizes = [int(x) for x in sys.argv[1:]] or [100_000, 500_000]
 for E in sizes:
-    for variant in (('latency', 'throughput') if E <= 65536 else ('auto',)):
+    for variant in (('latency', 'throughput', 'pair') if E <= 65536 else ('throughput', 'pair')):
         b = F16CombatBatch(E, parse_config('selfplay'), 'cuda:0', seed=1)
         b.set_kernel_variant(variant)
         b.reset()
         a = torch.rand(2 * E, 4, device='cuda') * 2 - 1
-        for _ in range(5): b.step(a)
+        t0 = time.time()
+        while time.time() - t0 < 0.3:     # clock-governor ramp (bench.py's prelude)
+            for _ in range(8): b.step(a)
+            torch.cuda.synchronize()
         b.set_timing(True)
         torch.cuda.synchronize(); t0 = time.time()
         K = 50 if E > 65536 else 300
