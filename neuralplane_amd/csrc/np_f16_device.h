@@ -478,9 +478,21 @@ struct Trig {  // sines/cosines of the attitude and flow angles of one state
 // PART: which alpha/beta-only nets are evaluated here — AB_ALL, AB_FORCE (FULL=false), or AB_REST
 // when the 14 force-side slots of `coef` already hold the values of THIS state (carried over from
 // the Overload evaluation of the previous step).
-template <bool FULL, int PART, int LD, int WPT = 1>
-__device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
-                                        float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
+// SHARE (latency variant, WPT == 4, Euler): the serial fp64 chains of the state — sin / cos of alpha, beta, theta, phi (+ tan theta,
+// sin / cos psi when FULL) and tfac^4.14 — are evaluated ONCE per tile instead of once per wave: wave w computes its share
+// before the barrier that opens the net evaluation and publishes it in LDS columns NUM_LDS_SLOTS + 12 * SET .. (SET alternates
+// between the two evaluations of a step, so a fast wave never overwrites what a slow one still reads); after the evaluation every
+// wave reads all twelve values back.  `sc` is then an OUTPUT (the caller's observation / Overload code uses it).  Same operations on
+// the same inputs: bit-identical to every wave computing everything (12 of a lone wave's ~23 us were these chains).
+struct StateScalars {
+    Trig tr;
+    float tt, spsi, cpsi, powv;  // tan(theta), sin / cos(psi), (1 - 0.703e-5 alt)^4.14
+};
+constexpr int NUM_SHARED_SCALARS = 12;
+template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0>
+__device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], StateScalars &sc,
+                                        float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
+    static_assert(!SHARE || WPT == 4, "shared state scalars belong to the latency variant");
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
     const float xc = (float)(0.35 - 0.30);
@@ -496,15 +508,71 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     float vt = s[6];
     const float alpha = s[7] * r2d, beta = s[8] * r2d;
     const float P = s[9], Q = s[10], R = s[11];
+    const float T = u[0], el = u[1], ail = u[2], rud = u[3];
+    const float tfac = 1.0f - 0.703e-5f * alt;
+
+    if constexpr (SHARE) {  // this wave's share of the state's serial chains -> LDS (published by the barrier inside eval_nets)
+        float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
+        if (part == 0) {
+            float a_, b_;
+            np_sincos(s[7], a_, b_);
+            shr[0 * LD] = a_;
+            shr[1 * LD] = b_;
+            if (FULL) {
+                np_sincos(s[5], a_, b_);
+                shr[9 * LD] = a_;
+                shr[10 * LD] = b_;
+            }
+        } else if (part == 1) {
+            float a_, b_;
+            np_sincos(s[8], a_, b_);
+            shr[2 * LD] = a_;
+            shr[3 * LD] = b_;
+            shr[11 * LD] = np_pow(tfac, 4.14f);
+        } else if (part == 2) {
+            float a_, b_, c_ = 0.0f;
+            if (FULL) np_sincostan(s[4], a_, b_, c_);
+            else np_sincos(s[4], a_, b_);
+            shr[4 * LD] = a_;
+            shr[5 * LD] = b_;
+            shr[8 * LD] = c_;
+        } else {
+            float a_, b_;
+            np_sincos(s[3], a_, b_);
+            shr[6 * LD] = a_;
+            shr[7 * LD] = b_;
+        }
+    }
+
+    float xn[NUM_NORM_GROUPS];
+    normalise_inputs(wt, alpha, beta, el, xn);
+    // non-finite inputs poison every coefficient (numerics spec, "non-finite inputs")
+    const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
+    const bool ok = (chk == chk);
+    const float qnan = __builtin_nanf("");
+    eval_nets<LD, PART, FULL, WPT>(wt, xn, coef, tables, part);
+#define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
+
+    if constexpr (SHARE) {
+        const float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
+        sc.tr.sa = shr[0 * LD]; sc.tr.ca = shr[1 * LD]; sc.tr.sb = shr[2 * LD]; sc.tr.cb = shr[3 * LD];
+        sc.tr.st = shr[4 * LD]; sc.tr.ct = shr[5 * LD]; sc.tr.sphi = shr[6 * LD]; sc.tr.cphi = shr[7 * LD];
+        sc.tt = shr[8 * LD];
+        sc.spsi = FULL ? shr[9 * LD] : 0.0f;
+        sc.cpsi = FULL ? shr[10 * LD] : 0.0f;
+        sc.powv = shr[11 * LD];
+    } else {
+        sc.powv = np_pow(tfac, 4.14f);
+    }
+    const Trig &tr = sc.tr;
+    const float tt = sc.tt, spsi = sc.spsi, cpsi = sc.cpsi;
     const float sa = tr.sa, ca = tr.ca, sb = tr.sb, cb = tr.cb, st = tr.st, ct = tr.ct, sphi = tr.sphi, cphi = tr.cphi;
 
     vt = (vt <= 0.01f ? 1.0f : 0.0f) * 0.01f + (vt > 0.01f ? 1.0f : 0.0f) * vt;  // :104
 
-    const float T = u[0], el = u[1], ail = u[2], rud = u[3];
     const float dail = NP_DIVC(ail, 21.5f), drud = NP_DIVC(rud, 30.0f);  // lef == 0 -> dlef == 1 (exact)
 
-    const float tfac = 1.0f - 0.703e-5f * alt;
-    const float rho = 2.377e-3f * np_pow(tfac, 4.14f);
+    const float rho = 2.377e-3f * sc.powv;
     const float qbar = (0.5f * rho) * (vt * vt);
 
     const float U = (vt * ca) * cb, V = vt * sb, W = (vt * sa) * cb;
@@ -517,15 +585,6 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         xd[4] = Q * cphi - R * sphi;
         xd[5] = (Q * sphi + R * cphi) / ct;
     }
-
-    float xn[NUM_NORM_GROUPS];
-    normalise_inputs(wt, alpha, beta, el, xn);
-    // non-finite inputs poison every coefficient (numerics spec, "non-finite inputs")
-    const float chk = ((alpha - alpha) + (beta - beta)) + (el - el);
-    const bool ok = (chk == chk);
-    const float qnan = __builtin_nanf("");
-    eval_nets<LD, PART, FULL, WPT>(wt, xn, coef, tables, part);
-#define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
 
     const float inv2vt = 1.0f / (2.0f * vt);
     const float c2v = inv2vt * cbar;
@@ -579,6 +638,18 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         xd[11] = NP_DIVC((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom);
     }
 #undef NPF16_NET
+}
+
+// the state's trigonometry computed by the caller (every variant but the latency one)
+template <bool FULL, int PART, int LD, int WPT = 1>
+__device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
+                                        float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
+    StateScalars sc;
+    sc.tr = tr;
+    sc.tt = tt;
+    sc.spsi = spsi;
+    sc.cpsi = cpsi;
+    nlplant<FULL, PART, LD, WPT, false, 0>(wt, s, u, sc, coef, tables, xd, part);
 }
 
 __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &tt) {
@@ -659,11 +730,12 @@ __device__ __forceinline__ void reset_row(const CFG &cfg, const float (&ru)[5], 
 // ---------------------------------------------------------------------------------------------
 // observation (before noise) — heading_task.py:71-152 / control_task.py:70-152 / tracking_task.py:73-155
 // ---------------------------------------------------------------------------------------------
-template <int TASK, class CFG>  // CFG: DevCfg, or DevCfg in the constant address space (scalar loads)
+template <int TASK, bool HAVE_POW = false, class CFG>  // CFG: DevCfg, or DevCfg in the constant address space (scalar loads)
 __device__ __forceinline__ void observe(const CFG &cfg, const float (&s)[12], const float (&u)[4], const float (&tgt)[3],
-                                        const Trig &tr, float (&o)[22]) {
+                                        const Trig &tr, float (&o)[22], float powv = 0.0f) {
     const float alt = s[2], pitch = s[4], heading = s[5], vt = s[6];
-    const float eas2tas = eas2tas_of(alt);
+    // F16Model.get_EAS2TAS (F16_model.py:156-162); powv = (1 - 0.703e-5 alt)^4.14 when the caller already has it (latency variant)
+    const float eas2tas = HAVE_POW ? sqrtf((1.0f / powv) * 1.0f) : eas2tas_of(alt);
     const float TAS = vt + cfg.airspeed * 1.0f;
     const float EAS = TAS / eas2tas;
     if (TASK == 0) {
@@ -704,32 +776,38 @@ __device__ __forceinline__ void observe(const CFG &cfg, const float (&s)[12], co
 // (counter blocks 2..5) by Box-Muller on 11 pairs.  Every pair takes a 21-bit radius index K1 and a 21-bit direction index K2:
 // pairs 0..7 the top 21 bits of two words, pairs 8..10 are assembled from the low 11 bits of the 16 words.
 //   u = (K1 + 0.5) * 2^-21;  o[2i], o[2i+1] += (sqrt(-2 ln u) * scale) * (cos, sin)(direction K2), one fma each
+// one Box-Muller pair from its two 21-bit indices: radius x scale, and the direction
+__device__ __forceinline__ void noise_pair(uint32_t k1, uint32_t k2, float scale, float &rs, float &cs, float &sn) {
+    const float u = fmaf((float)k1, 4.76837158203125e-07f, 2.384185791015625e-07f);  // (K1 + 0.5) * 2^-21, exact
+    rs = sqrt_spec(neg2ln_spec(u)) * scale;
+    unit_vector_spec(k2, cs, sn);
+}
+// the index pairs one Philox block contributes: pairs 2b and 2b+1 from the top 21 bits of its words and (b < 3) pair 8+b from
+// their low 11 bits
+__device__ __forceinline__ void noise_block_indices(const uint32_t (&w)[4], uint32_t (&k1)[3], uint32_t (&k2)[3]) {
+    k1[0] = w[0] >> 11;
+    k2[0] = w[1] >> 11;
+    k1[1] = w[2] >> 11;
+    k2[1] = w[3] >> 11;
+    k1[2] = ((w[0] & 0x7FFu) << 10) | ((w[1] >> 1) & 0x3FFu);
+    k2[2] = ((w[2] & 0x7FFu) << 10) | ((w[3] >> 1) & 0x3FFu);
+}
 __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, int64_t row, float scale, float (&o)[22]) {
-    uint32_t w[16];
 #pragma unroll
     for (uint32_t b = 0; b < 4; b++) {
-        uint32_t blk[4];
+        uint32_t blk[4], k1[3], k2[3];
         rng_block(seed, call_idx, row, 2 + b, blk);
+        noise_block_indices(blk, k1, k2);
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[4 * b + k] = blk[k];
-    }
-#pragma unroll
-    for (int i = 0; i < 11; i++) {
-        uint32_t k1, k2;
-        if (i < 8) {
-            k1 = w[2 * i] >> 11;
-            k2 = w[2 * i + 1] >> 11;
-        } else {
-            const int j = i - 8;
-            k1 = ((w[4 * j] & 0x7FFu) << 10) | ((w[4 * j + 1] >> 1) & 0x3FFu);
-            k2 = ((w[4 * j + 2] & 0x7FFu) << 10) | ((w[4 * j + 3] >> 1) & 0x3FFu);
+        for (int j = 0; j < 3; j++) {
+            const int pair = j < 2 ? 2 * (int)b + j : 8 + (int)b;
+            if (pair < 11) {
+                float rs, cs, sn;
+                noise_pair(k1[j], k2[j], scale, rs, cs, sn);
+                o[2 * pair] = fmaf(rs, cs, o[2 * pair]);
+                o[2 * pair + 1] = fmaf(rs, sn, o[2 * pair + 1]);
+            }
         }
-        const float u = fmaf((float)k1, 4.76837158203125e-07f, 2.384185791015625e-07f);  // (K1 + 0.5) * 2^-21, exact
-        const float rs = sqrt_spec(neg2ln_spec(u)) * scale;
-        float cs, sn;
-        unit_vector_spec(k2, cs, sn);
-        o[2 * i] = fmaf(rs, cs, o[2 * i]);
-        o[2 * i + 1] = fmaf(rs, sn, o[2 * i + 1]);
     }
 }
 

@@ -108,8 +108,14 @@ struct KArgs {
 //                                  lone wave's time; wave 0 stores.
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1>
 __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
+    // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
+    // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
+    // terminations / reward / state stores
+    constexpr bool SHARED = WPT == 4 && STEP && SOLVER == 0;
+    constexpr int NOISE_COL0 = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS;  // 11 pairs x (radius x scale, cos, sin)
+    constexpr int STATE_WAVE = SHARED ? 1 : 0;  // which wave of the latency variant stores state / flags / reward
     // pair variant (WPT == 2): nine more columns carry the normalised MLP inputs to the other wave of the workgroup
-    constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0);
+    constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0) + (SHARED ? 2 * NUM_SHARED_SCALARS + 33 : 0);
     constexpr int TILE_LDS = (COLS * TILE > TILE * OBS_LD) ? COLS * TILE : TILE * OBS_LD;
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS];
     float *obs_tile = lds;
@@ -221,7 +227,12 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
         u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
-            xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
+            if constexpr (SHARED) {
+                StateScalars sc0;
+                nlplant<true, (CACHED ? AB_REST : AB_ALL), TILE, WPT, true, 0>(a.wt, s, u, sc0, coef, tables, k1, pw);
+            } else {
+                xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
+            }
             NP_REREAD_ARGS(ap);
             const float dt = ap->cfg.dt;
 #pragma unroll
@@ -269,18 +280,42 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
 
     // ---- observation at the new state (task.get_obs) ----
     Trig tr;
-    float tt_unused;
-    trig_of(s, tr, tt_unused);
     float o[22];
-    observe<TASK>(ap->cfg, s, u, tgt, tr, o);
-    if (ap->noise) {  // obs + randn_like(obs) * noise_scale
+    StateScalars sc1;  // SHARED: filled by the Overload evaluation below
+    const bool gen_noise = !ap->noise && ap->cfg.noise_scale != 0.0f;
+    if constexpr (!SHARED) {
+        float tt_unused;
+        trig_of(s, tr, tt_unused);
+        observe<TASK>(ap->cfg, s, u, tgt, tr, o);
+        if (ap->noise) {  // obs + randn_like(obs) * noise_scale
 #pragma unroll
-        for (int k = 0; k < 22; k++) o[k] = o[k] + ap->noise[ic * 22 + k] * ap->cfg.noise_scale;
-    } else if (ap->cfg.noise_scale != 0.0f) {
+            for (int k = 0; k < 22; k++) o[k] = o[k] + ap->noise[ic * 22 + k] * ap->cfg.noise_scale;
+        } else if (gen_noise) {
 #if !(defined(NPF16_EXP) && (NPF16_EXP & 1))  // timing experiment only: no observation noise
-        const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
-        add_rng_noise(ap->seed, call_idx2, ap->row0 + ic, ap->cfg.noise_scale, o);
+            const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
+            add_rng_noise(ap->seed, call_idx2, ap->row0 + ic, ap->cfg.noise_scale, o);
 #endif
+        }
+    } else if (gen_noise) {
+        // this wave's Philox block of the row -> its two or three Box-Muller pairs -> LDS (published by the barrier that opens the
+        // Overload evaluation; wave 0 adds them to the observation afterwards: same values, same fma as add_rng_noise)
+        const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
+        uint32_t blk[4], k1[3], k2[3];
+        rng_block(ap->seed, call_idx2, ap->row0 + ic, 2u + (uint32_t)part, blk);
+        noise_block_indices(blk, k1, k2);
+        float *nz = coef + NOISE_COL0 * TILE;
+        const float scale = ap->cfg.noise_scale;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j < 2 || part < 3) {
+                const int pair = j < 2 ? 2 * part + j : 8 + part;  // wave-uniform
+                float rs, cs, sn;
+                noise_pair(k1[j], k2[j], scale, rs, cs, sn);
+                nz[(3 * pair) * TILE] = rs;
+                nz[(3 * pair + 1) * TILE] = cs;
+                nz[(3 * pair + 2) * TILE] = sn;
+            }
+        }
     }
 
     bool done = false, bad = false;
@@ -294,29 +329,53 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
 #else
         {
             const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
-            nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+            if constexpr (SHARED) {
+                nlplant<false, AB_FORCE, TILE, WPT, true, 1>(wt2, s, u, sc1, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                tr = sc1.tr;
+            } else {
+                nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+            }
         }
 #endif
         NP_REREAD_ARGS(ap);
-        float acc3[3];
-        body_acceleration(s, tr, xd, acc3);
-        // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
-        const bool done_prev = ap->inner && at_off(ap->fin0, r32) != 0, bad_prev = ap->inner && at_off(ap->fin1, r32) != 0;
-        unsigned reasons = 0;
-        done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
-        if (ap->term_counters) {
-            // the reference prints torch.sum(mask) per termination condition and step (a host sync each); here: one wave
-            // ballot per condition, population count, ONE atomic per wave for a condition that fired at all
-            const bool counted = valid && part == 0;
+        if (!SHARED || part == STATE_WAVE) {
+            float acc3[3];
+            body_acceleration(s, tr, xd, acc3);
+            // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
+            const bool done_prev = ap->inner && at_off(ap->fin0, r32) != 0, bad_prev = ap->inner && at_off(ap->fin1, r32) != 0;
+            unsigned reasons = 0;
+            done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
+            if (ap->term_counters) {
+                // the reference prints torch.sum(mask) per termination condition and step (a host sync each); here: one wave
+                // ballot per condition, population count, ONE atomic per wave for a condition that fired at all
+                const bool counted = valid && part == STATE_WAVE;
 #pragma unroll
-            for (int k = 0; k < NP_NUM_TERM_COUNTERS; k++) {
-                const unsigned long long m = __ballot(counted && ((reasons >> k) & 1u));
-                if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(ap->term_counters + k, (unsigned)__popcll(m));
+                for (int k = 0; k < NP_NUM_TERM_COUNTERS; k++) {
+                    const unsigned long long m = __ballot(counted && ((reasons >> k) & 1u));
+                    if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(ap->term_counters + k, (unsigned)__popcll(m));
+                }
+            }
+        }
+    }
+    if constexpr (SHARED) {
+        if (part == 0) {  // the wave that owns the observation: base values, then the noise the four waves prepared
+            observe<TASK, true>(ap->cfg, s, u, tgt, tr, o, sc1.powv);
+            if (ap->noise) {
+#pragma unroll
+                for (int k = 0; k < 22; k++) o[k] = o[k] + ap->noise[ic * 22 + k] * ap->cfg.noise_scale;
+            } else if (gen_noise) {
+                const float *nz = coef + NOISE_COL0 * TILE;
+#pragma unroll
+                for (int pair = 0; pair < 11; pair++) {
+                    const float rs = nz[(3 * pair) * TILE], cs = nz[(3 * pair + 1) * TILE], sn = nz[(3 * pair + 2) * TILE];
+                    o[2 * pair] = fmaf(rs, cs, o[2 * pair]);
+                    o[2 * pair + 1] = fmaf(rs, sn, o[2 * pair + 1]);
+                }
             }
         }
     }
 
-    if (valid && part == 0) {
+    if (valid && part == STATE_WAVE) {
         // re-derive the store addresses from the row index here: without the empty asm the compiler keeps the ~25 64-bit
         // load addresses of the top of the kernel alive across both MLP phases (and spills some of them to scratch)
         unsigned iw = (unsigned)i;

@@ -205,3 +205,38 @@ def test_randomised_scenario_constants(task, seed):
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
         o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t)
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'{task} random overrides {seed} step {t}')
+
+
+@pytest.mark.parametrize('task', ['heading', 'control'])
+def test_heading_wrap_is_the_exact_remainder_for_every_magnitude(task):
+    """np_wrap_pi (torch.remainder semantics, envs/utils/utils.py:144-154) on the device against the oracle's: yaw and pitch errors
+    that are exact multiples of fp32(2 pi), one ulp around them, around +-pi, signed zeros, denormals, huge, infinite and NaN —
+    observation, reward and masks bit for bit.  (A hand-written remainder replacing the library fmodf was built and measured:
+    no gain, dropped.)"""
+    n = 4096
+    b, o = _mk(task, n, 'pair', seed=3, overrides={'noise_scale': 0.0})
+    st = Oracle.new_state(n)
+    o.reset(st, seed=3, call_idx=0)
+    b.reset()
+    c = np.float32(6.28318530717958647692)
+    rng = np.random.RandomState(2)
+    k = rng.randint(-160000, 160000, n).astype(np.float64)
+    x = (k * np.float64(c)).astype(np.float32)                                # near-multiples of 2 pi up to ~1e6
+    x[0::4] = np.nextafter(x[0::4], np.float32(np.inf))
+    x[1::4] = np.nextafter(x[1::4], np.float32(-np.inf))
+    x[2::8] += np.float32(np.pi)
+    special = np.array([0.0, -0.0, c, -c, 2 * c, np.pi, -np.pi, np.nextafter(np.float32(np.pi), np.float32(4)), 1e-42, -1e-42, 1048575.94,
+                        1048576.0, 1048576.1, -1048576.0, 3e7, -3e7, 1e30, -1e30, np.inf, -np.inf, np.nan, 1.17549435e-38], np.float32)
+    x[:special.size] = special
+    x[special.size:special.size + 1000] = rng.uniform(-20, 20, 1000).astype(np.float32)
+    st['s'][:, 5] = x                      # yaw
+    st['tgt'][:, 1] = 0.0                  # target heading 0: the wrapped error is the wrapped yaw (after one Euler step of yaw rate)
+    if task == 'control':
+        st['s'][:, 4] = np.roll(x, 7) * np.float32(1e-3)   # pitch error through the same wrap, small enough to keep cos(theta) sane
+        st['tgt'][:, 0] = 0.0
+    _load(b, st)
+    for t in range(2):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        obs, rew, flags = b.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _, _, _ = o.step(st, a, seed=3, call_idx=t + 1)
+        _check(b, obs, rew, flags, st, o_obs, o_rew, f'{task} wrap step {t}')

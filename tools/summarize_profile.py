@@ -37,6 +37,9 @@ def main(tag):
                 w = csv.writer(f)
                 for r in rows:
                     w.writerow([c[:100] for c in r])
+    for extra in ('wg_timeline_n1e6.json', 'bench_driver_cmd.json', 'cold_start.json'):
+        if os.path.exists(os.path.join(src, extra)):
+            shutil.copy(os.path.join(src, extra), os.path.join(dst, f'{tag}_{extra}'))
     # PMC passes: mean per launch / per wave for the dominant kernel
     summary, traffic = [], {}
     for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
@@ -70,7 +73,7 @@ def main(tag):
                 w.writerow([row[0], row[1], f'{row[2]:.6g}', f'{row[3]:.4g}'])
     if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
         n = json.load(open(os.path.join(dst, f'{tag}_bench.json')))['config']['aircraft_per_gpu'] if os.path.exists(os.path.join(dst, f'{tag}_bench.json')) else 1000000
-        json.dump({'round': 1, 'kernel': 'f16_env_kernel<0, 0, true, true>', 'n': n, 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
+        json.dump({'round': int(tag[1:3]) if tag[1:3].isdigit() else None, 'kernel': 'f16_env_kernel<0, 0, true, true, 128, 2>', 'n': n, 'task': 'heading', 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
                    'WRITE_SIZE_KB': traffic['WRITE_SIZE'],
                    'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), mean over the '
                            'cached-kernel launches. MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at '
