@@ -238,12 +238,14 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
                        const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,
                        float *returns, int device, void *stream);
 
-/* np_f16_step has three bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
- * evaluations of a step — about half of a lone wave's 44 us; chosen automatically for n <= 65536, Euler solver), "pair" (the
- * two waves of a 128-aircraft workgroup split the nets and evaluate them for each other's aircraft: half the scalar weight
- * traffic per aircraft; the default above that size with the MLP numerics) and "throughput" (two independent
- * waves per workgroup; the 1-D table mode).  This call pins the choice for a context (tests, tuning). */
-enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3 };
+/* np_f16_step has four bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
+ * evaluations of a step, the serial fp64 chains of the state and the observation noise; chosen automatically for n <= 65536,
+ * Euler solver), "latency8" (eight waves per tile — two per SIMD, so one wave's scalar-load latency is the other's FMA time;
+ * chosen automatically for n <= 16384, where every tile still has a CU of its own), "pair" (the two waves of a 128-aircraft
+ * workgroup split the nets and evaluate them for each other's aircraft: half the scalar weight traffic per aircraft; the default
+ * above that size with the MLP numerics) and "throughput" (two independent waves per workgroup; the 1-D table mode).  This call
+ * pins the choice for a context (tests, tuning); np_f16_combat_step has latency, pair and throughput. */
+enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
 /* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context,

@@ -259,26 +259,57 @@ __device__ __forceinline__ void eval_el(const AeroWeights &wt, const float (&xn)
 struct SplitItem {
     int cl, first, cnt;
 };
-constexpr int SPLIT_WAVES = 4, SPLIT_MAX = 4;
+constexpr int SPLIT_WAVES = 8, SPLIT_MAX = 4;  // rows 4..7 stay empty in the four-wave plans
 struct SplitPlan {
     SplitItem it[SPLIT_WAVES][SPLIT_MAX];
 };
 constexpr SplitItem NO_ITEM = {-1, 0, 0};
+#define NPF16_NO_WAVE {NO_ITEM, NO_ITEM, NO_ITEM, NO_ITEM}
 // AB_REST + C[0:5] + ETA (cached integrator evaluation, 28 nets)
 constexpr SplitPlan PLAN_REST = {{{{CL_DAMP, 4, 8}, NO_ITEM, NO_ITEM, NO_ITEM},
                                   {{CL_DLEF, 2, 5}, {CL_D_RUD, 1, 1}, {CL_D_LEF, 1, 1}, {CL_ETA, 0, 1}},
                                   {{CL_E_LEF, 2, 2}, {CL_F, 1, 2}, NO_ITEM, NO_ITEM},
-                                  {{CL_E_RUD, 1, 3}, {CL_C, 0, 5}, NO_ITEM, NO_ITEM}}};
+                                  {{CL_E_RUD, 1, 3}, {CL_C, 0, 5}, NO_ITEM, NO_ITEM},
+                                  NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
 // AB_ALL + C[0:5] + ETA (un-cached evaluation, 42 nets)
 constexpr SplitPlan PLAN_ALL = {{{{CL_DAMP, 0, 12}, {CL_ETA, 0, 1}, NO_ITEM, NO_ITEM},
                                  {{CL_DLEF, 0, 7}, {CL_C, 0, 5}, NO_ITEM, NO_ITEM},
                                  {{CL_F, 0, 3}, {CL_D_RUD, 0, 2}, {CL_D_LEF, 0, 2}, NO_ITEM},
-                                 {{CL_E_LEF, 0, 4}, {CL_E_RUD, 0, 4}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}}}};
+                                 {{CL_E_LEF, 0, 4}, {CL_E_RUD, 0, 4}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}},
+                                 NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
 // AB_FORCE + C[0:2] (Overload re-evaluation, 16 nets)
 constexpr SplitPlan PLAN_FORCE2 = {{{{CL_DAMP, 0, 4}, {CL_D_RUD, 0, 1}, NO_ITEM, NO_ITEM},
                                     {{CL_DLEF, 0, 2}, {CL_E_LEF, 0, 2}, NO_ITEM, NO_ITEM},
                                     {{CL_F, 0, 1}, {CL_C, 0, 2}, NO_ITEM, NO_ITEM},
-                                    {{CL_D_LEF, 0, 1}, {CL_E_RUD, 0, 1}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}}}};
+                                    {{CL_D_LEF, 0, 1}, {CL_E_RUD, 0, 1}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}},
+                                    NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
+// ---- eight waves per tile (batches up to one workgroup per CU): two waves per SIMD, so one wave's scalar-load latency is the
+// other's FMA time, and half as many nets on each wave's serial path.  Balanced by VALU instructions per net (1-in 20-10: 138,
+// 2-in: 148, 3-in: 158, 2-in 20-10-5: 178, 2-in 20-20-10: 345, 1-in 20-10-5: 168, 2-in 20-10-10: 213).
+constexpr SplitPlan PLAN8_REST = {{{{CL_DAMP, 4, 4}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                   {{CL_DAMP, 8, 4}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                   {{CL_DLEF, 2, 4}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                   {{CL_DLEF, 6, 1}, {CL_D_RUD, 1, 1}, {CL_D_LEF, 1, 1}, {CL_ETA, 0, 1}},
+                                   {{CL_E_LEF, 2, 2}, {CL_E_RUD, 1, 1}, NO_ITEM, NO_ITEM},
+                                   {{CL_E_RUD, 2, 2}, {CL_C, 0, 2}, NO_ITEM, NO_ITEM},
+                                   {{CL_F, 1, 1}, {CL_C, 2, 1}, NO_ITEM, NO_ITEM},
+                                   {{CL_F, 2, 1}, {CL_C, 3, 2}, NO_ITEM, NO_ITEM}}};
+constexpr SplitPlan PLAN8_ALL = {{{{CL_DAMP, 0, 6}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                  {{CL_DAMP, 6, 6}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                  {{CL_DLEF, 0, 6}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                  {{CL_DLEF, 6, 1}, {CL_D_RUD, 0, 2}, {CL_D_LEF, 0, 2}, {CL_ETA, 0, 1}},
+                                  {{CL_E_LEF, 0, 4}, {CL_YPLEF, 0, 1}, NO_ITEM, NO_ITEM},
+                                  {{CL_E_RUD, 0, 4}, {CL_YA20, 0, 1}, NO_ITEM, NO_ITEM},
+                                  {{CL_F, 0, 2}, {CL_C, 0, 1}, NO_ITEM, NO_ITEM},
+                                  {{CL_F, 2, 1}, {CL_C, 1, 4}, NO_ITEM, NO_ITEM}}};
+constexpr SplitPlan PLAN8_FORCE2 = {{{{CL_DAMP, 0, 3}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                     {{CL_DAMP, 3, 1}, {CL_DLEF, 0, 2}, NO_ITEM, NO_ITEM},
+                                     {{CL_D_RUD, 0, 1}, {CL_D_LEF, 0, 1}, {CL_C, 0, 1}, NO_ITEM},
+                                     {{CL_E_LEF, 0, 2}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                     {{CL_F, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                     {{CL_E_RUD, 0, 1}, {CL_YA20, 0, 1}, NO_ITEM, NO_ITEM},
+                                     {{CL_YPLEF, 0, 1}, {CL_C, 1, 1}, NO_ITEM, NO_ITEM},
+                                     NPF16_NO_WAVE}};
 // a plan must cover exactly the nets eval_ab<PART> + eval_el<N_C, N_ETA> evaluate, each once
 constexpr bool plan_covers(const SplitPlan &p, int part, int n_c, int n_eta) {
     for (int cl = 0; cl < NUM_CLASSES; cl++) {
@@ -301,6 +332,8 @@ constexpr bool plan_covers(const SplitPlan &p, int part, int n_c, int n_eta) {
 }
 static_assert(plan_covers(PLAN_REST, AB_REST, 5, 1) && plan_covers(PLAN_ALL, AB_ALL, 5, 1) && plan_covers(PLAN_FORCE2, AB_FORCE, 2, 0),
               "split plans must cover each net of their phase exactly once");
+static_assert(plan_covers(PLAN8_REST, AB_REST, 5, 1) && plan_covers(PLAN8_ALL, AB_ALL, 5, 1) && plan_covers(PLAN8_FORCE2, AB_FORCE, 2, 0),
+              "eight-wave split plans must cover each net of their phase exactly once");
 
 template <const SplitPlan &P, int W, int LD>
 __device__ __forceinline__ void eval_plan_wave(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
@@ -416,17 +449,29 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
 #undef NPF16_WAVE
         __syncthreads();  // all coefficient columns of both waves are complete
         return;
-    } else if constexpr (WPT == 4) {
+    } else if constexpr (WPT == 4 || WPT == 8) {
         static_assert(has_phase, "no split plan for this evaluation");
         __syncthreads();  // every wave has finished reading the coefficients of the previous evaluation
-#define NPF16_WAVE(W)                                                                                          \
-    if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN_ALL, W, LD>(wt, xn, out, tables);                  \
-    else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN_REST, W, LD>(wt, xn, out, tables);           \
-    else eval_plan_wave<PLAN_FORCE2, W, LD>(wt, xn, out, tables)
+#define NPF16_WAVE(W)                                                                                                    \
+    if constexpr (WPT == 8) {                                                                                            \
+        if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN8_ALL, W, LD>(wt, xn, out, tables);                     \
+        else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN8_REST, W, LD>(wt, xn, out, tables);              \
+        else eval_plan_wave<PLAN8_FORCE2, W, LD>(wt, xn, out, tables);                                                   \
+    } else {                                                                                                             \
+        if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN_ALL, W, LD>(wt, xn, out, tables);                      \
+        else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN_REST, W, LD>(wt, xn, out, tables);               \
+        else eval_plan_wave<PLAN_FORCE2, W, LD>(wt, xn, out, tables);                                                    \
+    }
         if (part == 0) { NPF16_WAVE(0); }
         else if (part == 1) { NPF16_WAVE(1); }
         else if (part == 2) { NPF16_WAVE(2); }
-        else { NPF16_WAVE(3); }
+        else if (part == 3) { NPF16_WAVE(3); }
+        else if constexpr (WPT == 8) {
+            if (part == 4) { NPF16_WAVE(4); }
+            else if (part == 5) { NPF16_WAVE(5); }
+            else if (part == 6) { NPF16_WAVE(6); }
+            else { NPF16_WAVE(7); }
+        }
 #undef NPF16_WAVE
         __syncthreads();  // all 42 / 16 coefficient columns are complete
         return;
@@ -492,7 +537,7 @@ constexpr int NUM_SHARED_SCALARS = 12;
 template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0>
 __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], StateScalars &sc,
                                         float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
-    static_assert(!SHARE || WPT == 4, "shared state scalars belong to the latency variant");
+    static_assert(!SHARE || WPT == 4 || WPT == 8, "shared state scalars belong to the latency variants");
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
     const float xc = (float)(0.35 - 0.30);
@@ -513,12 +558,14 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
 
     if constexpr (SHARE) {  // this wave's share of the state's serial chains -> LDS (published by the barrier inside eval_nets)
         float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
-        if (part == 0) {
+        if (part == 0 || (WPT == 8 && part == 4)) {  // four waves: wave 0 takes alpha and psi; eight: wave 4 takes psi
             float a_, b_;
-            np_sincos(s[7], a_, b_);
-            shr[0 * LD] = a_;
-            shr[1 * LD] = b_;
-            if (FULL) {
+            if (part == 0) {
+                np_sincos(s[7], a_, b_);
+                shr[0 * LD] = a_;
+                shr[1 * LD] = b_;
+            }
+            if (FULL && (WPT == 4 || part == 4)) {
                 np_sincos(s[5], a_, b_);
                 shr[9 * LD] = a_;
                 shr[10 * LD] = b_;
@@ -536,7 +583,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
             shr[4 * LD] = a_;
             shr[5 * LD] = b_;
             shr[8 * LD] = c_;
-        } else {
+        } else if (part == 3) {
             float a_, b_;
             np_sincos(s[3], a_, b_);
             shr[6 * LD] = a_;

@@ -107,11 +107,11 @@ struct KArgs {
 //                                  evaluations and redo the cheap non-MLP arithmetic redundantly, so a step takes ~1/2 of a
 //                                  lone wave's time; wave 0 stores.
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1>
-__global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
+__global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
     // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
     // terminations / reward / state stores
-    constexpr bool SHARED = WPT == 4 && STEP && SOLVER == 0;
+    constexpr bool SHARED = WPT >= 4 && STEP && SOLVER == 0;
     constexpr int NOISE_COL0 = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS;  // 11 pairs x (radius x scale, cos, sin)
     constexpr int STATE_WAVE = SHARED ? 1 : 0;  // which wave of the latency variant stores state / flags / reward
     // pair variant (WPT == 2): nine more columns carry the normalised MLP inputs to the other wave of the workgroup
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
     constexpr int TILE_LDS = (COLS * TILE > TILE * OBS_LD) ? COLS * TILE : TILE * OBS_LD;
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS];
     float *obs_tile = lds;
-    const int t = WPT != 4 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
-    const int part = WPT != 4 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform; 0 = the wave that stores
+    const int t = WPT < 4 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
+    const int part = WPT < 4 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));  // wave-uniform: which of the tile's 4 / 8 waves
     // what the net evaluation calls `part`: latency variant = which quarter of the nets, pair variant = which wave of the pair
     const int pw = WPT == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)) : part;
     float *coef = lds + t;  // this lane's coefficient column, stride TILE
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
     constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * 2 / (BLOCK / 64) : FIRST_GENERATION;  // pair variant: two waves per SIMD
-    if (WPT != 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GEN && blockIdx.x < FIRST_GEN) {
+    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GEN && blockIdx.x < FIRST_GEN) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
@@ -300,21 +300,24 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
         // this wave's Philox block of the row -> its two or three Box-Muller pairs -> LDS (published by the barrier that opens the
         // Overload evaluation; wave 0 adds them to the observation afterwards: same values, same fma as add_rng_noise)
         const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
+        const int nb = WPT == 8 ? part - 4 : part;  // eight waves: 0..3 are computing the state's trigonometry meanwhile
+        if (nb >= 0) {
         uint32_t blk[4], k1[3], k2[3];
-        rng_block(ap->seed, call_idx2, ap->row0 + ic, 2u + (uint32_t)part, blk);
+        rng_block(ap->seed, call_idx2, ap->row0 + ic, 2u + (uint32_t)nb, blk);
         noise_block_indices(blk, k1, k2);
         float *nz = coef + NOISE_COL0 * TILE;
         const float scale = ap->cfg.noise_scale;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            if (j < 2 || part < 3) {
-                const int pair = j < 2 ? 2 * part + j : 8 + part;  // wave-uniform
+            if (j < 2 || nb < 3) {
+                const int pair = j < 2 ? 2 * nb + j : 8 + nb;  // wave-uniform
                 float rs, cs, sn;
                 noise_pair(k1[j], k2[j], scale, rs, cs, sn);
                 nz[(3 * pair) * TILE] = rs;
                 nz[(3 * pair + 1) * TILE] = cs;
                 nz[(3 * pair + 2) * TILE] = sn;
             }
+        }
         }
     }
 
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), (WPT == 2 ? 2 : NPF16_MI
         __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
         const long long rows = (ap->n - i0) < TILE ? (ap->n - i0) : TILE;
         float *dst = ap->obs + i0 * 22;
-        constexpr int THREADS = TILE * (WPT == 4 ? 4 : 1);
+        constexpr int THREADS = TILE * (WPT >= 4 ? WPT : 1);
         if (rows == TILE && ((uintptr_t)dst & 15) == 0) {  // workgroup-uniform: a full tile and a 16-byte aligned destination
             // unpadded rows (pitch 22 floats): 11 ds_write_b64 per lane, then the tile leaves as 16-byte vectors — 6 (2)
             // ds_read_b128 + global_store_dwordx4 per thread instead of 22 dword pairs; the LDS bank conflicts of the unpadded
@@ -573,7 +576,7 @@ struct np_f16_ctx {
     float *d_reset_coef;  // [NUM_CACHED] device buffer owned by the context
     float *d_weights;     // KBLOB | PWL tables | PWL un-normalisation, one device allocation owned by the context
     AeroWeights wt;
-    int variant;          // NP_KERNEL_AUTO / _LATENCY / _THROUGHPUT
+    int variant;          // NP_KERNEL_AUTO / _LATENCY / _THROUGHPUT / _PAIR / _LATENCY8
     bool combat;  // created by np_f16_combat_ctx_create: only the combat entry points accept it
     CombatDevCfg ccfg;
     bool timing;
@@ -770,6 +773,7 @@ struct DeviceGuard {
 };
 
 constexpr int LAT_TILE = 64;
+constexpr int64_t LAT8_MAX_N = 16384;  // eight waves per tile while every tile still gets a CU of its own (256 tiles)
 constexpr int64_t COMBAT_LAT_MAX_N = 49152;  // aircraft (24576 engagements: 0.211 vs 0.258 ms; 32768 engagements: a tie)
 constexpr int64_t LAT_MAX_N = 65536;  // measured crossover (tools/microbench/small_n.py): 65536: 53.6 vs 58.9 us, 98304: 73.5 vs 59.2 us
 bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
@@ -779,7 +783,7 @@ bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
         return std::strcmp(e, "latency") == 0 ? (int)NP_KERNEL_LATENCY : std::strcmp(e, "throughput") == 0 ? (int)NP_KERNEL_THROUGHPUT : (int)NP_KERNEL_AUTO;
     }();
     const int v = ctx->variant != NP_KERNEL_AUTO ? ctx->variant : forced;
-    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY;
+    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY || v == NP_KERNEL_LATENCY8;
     return n <= LAT_MAX_N;
 }
 // pair variant (two waves split the nets and evaluate them for each other's aircraft): Euler, MLP numerics (no 1-D tables)
@@ -835,7 +839,11 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
     const bool pair = STEP && !ctx->cfg.aero_1d_tables && use_pair_kernel(ctx, n);
     const bool latency = !pair && STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
-    const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)), block(latency ? LAT_TILE * 4 : BLOCK);
+    // eight waves per tile: small batches of the MLP numerics (the table mode's classes are too short to split further)
+    const bool latency8 = latency && !ctx->cfg.aero_1d_tables &&
+                          (ctx->variant == NP_KERNEL_LATENCY8 || (ctx->variant == NP_KERNEL_AUTO && n <= LAT8_MAX_N));
+    const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)),
+        block(latency8 ? LAT_TILE * 8 : latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
@@ -856,6 +864,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         if (pair) {                                                                                               \
             if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP, BLOCK, 2>), grid, block, 0, st, a);      \
             else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false, BLOCK, 2>), grid, block, 0, st, a);            \
+        } else if (latency8 && S == 0) {                                                                          \
+            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 8>), grid, block, 0, st, a);   \
+            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 8>), grid, block, 0, st, a);         \
         } else if (latency && S == 0) {                                                                           \
             if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4>), grid, block, 0, st, a);   \
             else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4>), grid, block, 0, st, a);         \
@@ -1211,7 +1222,8 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
     if (!ctx) return fail("null ctx");
-    if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR)
+    if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR &&
+        variant != NP_KERNEL_LATENCY8)
         return fail("unknown kernel variant");
     ctx->variant = variant;
     return 0;

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle.f16_oracle import Oracle  # noqa: E402  (the checker; test infrastructure)
 
-VARIANTS = ['latency', 'throughput', 'pair']
+VARIANTS = ['latency', 'latency8', 'throughput', 'pair']
 
 
 def _same(a, b):
@@ -198,7 +198,7 @@ def test_randomised_scenario_constants(task, seed):
     rng = np.random.RandomState(1000 + seed)
     overrides = _random_overrides(rng)
     n = 130
-    b, o = _mk(task, n, VARIANTS[seed % 2], overrides=overrides, seed=seed)
+    b, o = _mk(task, n, VARIANTS[seed % 4], overrides=overrides, seed=seed)
     st = Oracle.new_state(n)
     for t in range(14):
         a = rng.uniform(-1.4, 1.4, (n, 4)).astype(np.float32)

@@ -5,7 +5,7 @@ from neuralplane_amd.envs.control_env import ControlEnv
 sizes = [int(x) for x in sys.argv[1:]] or [256, 4096, 16384, 32768, 49152, 65536, 98304, 131072]
 for n in sizes:
     row = []
-    for variant in ('latency', 'throughput', 'pair'):
+    for variant in ('latency8', 'latency', 'throughput', 'pair'):
         env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=0, device='cuda:0')
         env._batch.set_kernel_variant(variant)
         env.reset()
