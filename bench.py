@@ -334,7 +334,7 @@ def run_env(args, rank, local_rank, world, dev, dist):
     modes['latency_n256'] = {'value': 1e6 * el6 / k6, 'unit': 'us per env.step (wall, back-to-back launches, no timing events)', 'steps': k6,
                              'kernel_avg_us': 1e3 * stats(s6)['kernel_avg_ms'], 'kernel_median_us': 1e3 * stats(s6)['kernel_median_ms'],
                              'aircraft_steps_per_s': 256 * k6 / el6,
-                             'note': 'latency variant: four waves share a tile of 64 aircraft, split the net evaluations, the serial fp64 '
+                             'note': 'latency8 variant: eight waves share a tile of 64 aircraft (two per SIMD), split the net evaluations, the serial fp64 '
                                      'chains and the observation noise; the GPU is otherwise idle (reference training sizes: 3 000-10 000 '
                                      'envs, scripts/train_heading.sh)'}
     del envs, tm6
