@@ -136,6 +136,13 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
     const bool tables = a.cfg.aero_1d_tables != 0;
     const uint64_t call_idx = a.call_idx + (a.call_idx_base ? *a.call_idx_base : 0ull);
     unsigned long long tr_c0 = 0, tr_r0 = 0, tr_c1 = 0;
+#ifdef NPF16_LAT_TRACE  // experiment builds only (tools/microbench/lat_trace.py): 100 MHz stamps at the phase boundaries of every wave
+    unsigned long long lt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NP_LT(k) lt[k] = wall_clock64()
+#else
+#define NP_LT(k)
+#endif
+    NP_LT(0);
     if (a.trace) {  // wave-uniform, null outside profiling runs
         tr_c0 = __builtin_readcyclecounter();
         tr_r0 = wall_clock64();
@@ -227,9 +234,11 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
         u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
+            NP_LT(1);
             if constexpr (SHARED) {
                 StateScalars sc0;
                 nlplant<true, (CACHED ? AB_REST : AB_ALL), TILE, WPT, true, 0>(a.wt, s, u, sc0, coef, tables, k1, pw);
+                NP_LT(2);
             } else {
                 xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
             }
@@ -333,7 +342,9 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
         {
             const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
             if constexpr (SHARED) {
+                NP_LT(3);
                 nlplant<false, AB_FORCE, TILE, WPT, true, 1>(wt2, s, u, sc1, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                NP_LT(4);
                 tr = sc1.tr;
             } else {
                 nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
         }
     }
 
+    NP_LT(5);
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
     if (ap->obs) {
         __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
@@ -447,7 +459,14 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
             }
         }
     }
-    if (ap->trace && threadIdx.x == 0) {
+#ifdef NPF16_LAT_TRACE
+    NP_LT(6);
+    if (ap->trace && WPT >= 4 && (threadIdx.x & 63) == 0) {  // 8 words per wave, WPT waves per tile (the caller sizes the buffer)
+        unsigned long long *rec = ap->trace + ((unsigned long long)blockIdx.x * WPT + part) * 8;
+        for (int k = 0; k < 7; k++) rec[k] = lt[k];
+    }
+#endif
+    if (ap->trace && threadIdx.x == 0 && WPT < 4) {
         unsigned long long *rec = ap->trace + (unsigned long long)blockIdx.x * NP_TRACE_WORDS;
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
