@@ -154,19 +154,23 @@ class Timer:
         elapsed = sharding.max_over_ranks(elapsed, self.dist, self.dev if self.backend == 'nccl' else 'cpu')
         return elapsed, samples, i
 
-    def prelude(self, seconds, i0=0, max_steps=20000):
-        """Untimed steps for `seconds` of GPU load (the clock governor's ramp).  -> (steps run, wall seconds, next index)"""
+    def prelude(self, seconds, i0=0, est_step_s=None, max_steps=20000):
+        """Untimed steps for about `seconds` of GPU load (the clock governor's ramp).  The COUNT is fixed up front from a step-time
+        estimate that is identical on every rank (the cold window's max-over-ranks time): a step may contain collectives (--task
+        combat), so all ranks must run the same number of them.  -> (steps run, wall seconds, next index)"""
         import torch
         i, t0 = i0, time.perf_counter()
         if seconds <= 0:
             return 0, 0.0, i
-        while i - i0 < max_steps:
-            for _ in range(8):
-                self.step(i)
-                i += 1
-            torch.cuda.synchronize(self.dev)   # bounds the launch queue; ~10 us of idle per 8 launches
-            if time.perf_counter() - t0 >= seconds:
+        n = max_steps if not est_step_s else max(8, min(max_steps, int(seconds / est_step_s + 0.999)))
+        for k in range(n):
+            self.step(i)
+            i += 1
+            if k % 8 == 7:
+                torch.cuda.synchronize(self.dev)   # bounds the launch queue; ~10 us of idle per 8 launches
+            if not est_step_s and time.perf_counter() - t0 >= seconds:   # single-process callers without an estimate: time-based
                 break
+        torch.cuda.synchronize(self.dev)
         return i - i0, time.perf_counter() - t0, i
 
 
@@ -230,7 +234,7 @@ def run_env(args, rank, local_rank, world, dev, dist):
 
     env.reset()
     cold_el, cold_samples, i = tm.window(args.warmup, args.steps)            # 1. the requested protocol from an idle GPU
-    p_steps, p_sec, i = tm.prelude(args.prelude_ms * 1e-3, i)                # 2. clock-governor ramp, untimed, reported
+    p_steps, p_sec, i = tm.prelude(args.prelude_ms * 1e-3, i, est_step_s=cold_el / max(1, args.steps))   # 2. clock-governor ramp, untimed, reported
     elapsed, samples, i = tm.window(args.warmup, args.steps, i)              # 3. W warm-up + EXACTLY K timed steps -> value
     mhz = shader_mhz(b, lambda k: env.step(pool[0]), n, dev) if rank == 0 else None
     mem_mb = torch.cuda.max_memory_allocated(dev) / 2 ** 20   # env state + cache + outputs of one step + the 8-entry action pool
@@ -424,7 +428,7 @@ def run_combat(args, rank, local_rank, world, dev, dist):
 
     tm = Timer(step, cenv._batch, dev, dist, args.backend)
     cold_el, cold_samples, i = tm.window(args.warmup, args.steps)
-    p_steps, p_sec, i = tm.prelude(args.prelude_ms * 1e-3, i)
+    p_steps, p_sec, i = tm.prelude(args.prelude_ms * 1e-3, i, est_step_s=cold_el / max(1, args.steps))   # same count on every rank: steps hold collectives
     elapsed, samples, i = tm.window(args.warmup, args.steps, i)
     fin = bool(torch.isfinite(cenv.s).all().item())
     if rank != 0:

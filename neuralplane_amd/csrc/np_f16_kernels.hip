@@ -106,7 +106,9 @@ struct KArgs {
 //             WPT = 4, TILE = 64   latency variant (small batches): four waves hold the SAME 64 aircraft, split the net
 //                                  evaluations and redo the cheap non-MLP arithmetic redundantly, so a step takes ~1/2 of a
 //                                  lone wave's time; wave 0 stores.
-template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1>
+// INNER     : one low-level iteration of PlanningEnv.step (np_f16_io.inner_step): no auto-reset, flagged rows keep their state, flags
+//             accumulate.  A template parameter so that the plain env.step carries none of its selects (~30 VALU instructions).
+template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1, bool INNER = false>
 __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
     // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
     long long sc = at_off(a.step_count, o8);
     const bool flagged = (at_off(a.fin0, r32) | at_off(a.fin1, r32) | at_off(a.fin2, r32)) != 0;
 
-    const bool frozen = a.inner && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
-    const bool tmo_prev = a.inner && at_off(a.fin2, r32) != 0;
+    const bool frozen = INNER && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
+    const bool tmo_prev = INNER && at_off(a.fin2, r32) != 0;
     // ---- self.reset(): re-initialise rows flagged by the previous step (env_base.py:83-95) ----
-    if (flagged && !a.inner) {
+    if (flagged && !INNER) {
         float ru[5];
         if (a.rand_u) {
 #pragma unroll
@@ -209,11 +211,14 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
     if (STEP && CACHED) {  // coefficient columns <- cache (a reset aircraft sits at alpha = beta = 0)
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) {
-            const float c = cache_blk[k * CACHE_TILE];
-            coef[cached_slot(k) * TILE] = (flagged && !a.inner) ? a.reset_coef[k] : c;
+            coef[cached_slot(k) * TILE] = cache_blk[k * CACHE_TILE];
+        }
+        if (flagged && !INNER) {  // a re-initialised aircraft: overwrite its column (LDS writes of the few flagged lanes instead of 14 selects for all)
+#pragma unroll
+            for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * TILE] = a.reset_coef[k];
         }
     }
-    if (!STEP && a.cache && flagged && valid && !a.inner && part == 0) {  // reset(): keep the cache consistent for re-initialised rows
+    if (!STEP && a.cache && flagged && valid && !INNER && part == 0) {  // reset(): keep the cache consistent for re-initialised rows
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * CACHE_TILE] = a.reset_coef[k];
     }
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
             float acc3[3];
             body_acceleration(s, tr, xd, acc3);
             // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
-            const bool done_prev = ap->inner && at_off(ap->fin0, r32) != 0, bad_prev = ap->inner && at_off(ap->fin1, r32) != 0;
+            const bool done_prev = INNER && at_off(ap->fin0, r32) != 0, bad_prev = INNER && at_off(ap->fin1, r32) != 0;
             unsigned reasons = 0;
             done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
             if (ap->term_counters) {
@@ -831,6 +836,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         return fail("null state/flag buffer");
     if (io->ld < n) return fail("ld < n");
     if (io->ld >= (1ll << 30)) return fail("ld must be below 2^30 rows (32-bit byte offsets inside a row-indexed array)");
+    if (!STEP && io->inner_step) return fail("inner_step applies to np_f16_step only");
     if (STEP && (!io->action || !io->obs || !io->reward || io->act_stride < 4))
         return fail("step needs action (>=4 columns), obs and reward buffers");
     if (io->done_out == io->done_in || io->bad_out == io->bad_in || io->timeout_out == io->timeout_in)
@@ -878,19 +884,24 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         }
         NP_HIP(hipEventRecord(ev.first, st));
     }
-#define NP_LAUNCH(T, S)                                                                                           \
-    do {                                                                                                          \
-        if (pair) {                                                                                               \
-            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP, BLOCK, 2>), grid, block, 0, st, a);      \
-            else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false, BLOCK, 2>), grid, block, 0, st, a);            \
-        } else if (latency8 && S == 0) {                                                                          \
-            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 8>), grid, block, 0, st, a);   \
-            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 8>), grid, block, 0, st, a);         \
-        } else if (latency && S == 0) {                                                                           \
-            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4>), grid, block, 0, st, a);   \
-            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4>), grid, block, 0, st, a);         \
-        } else if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP>), grid, block, 0, st, a);         \
-        else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false>), grid, block, 0, st, a);                      \
+#define NP_LAUNCH_I(T, S, I)                                                                                          \
+    do {                                                                                                              \
+        if (pair) {                                                                                                   \
+            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, I>), grid, block, 0, st, a);       \
+            else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false, BLOCK, 2, I>), grid, block, 0, st, a);             \
+        } else if (latency8 && S == 0) {                                                                              \
+            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 8, I>), grid, block, 0, st, a);    \
+            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 8, I>), grid, block, 0, st, a);          \
+        } else if (latency && S == 0) {                                                                               \
+            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4, I>), grid, block, 0, st, a);    \
+            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4, I>), grid, block, 0, st, a);          \
+        } else if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP, BLOCK, 1, I>), grid, block, 0, st, a);    \
+        else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false, BLOCK, 1, I>), grid, block, 0, st, a);                 \
+    } while (0)
+#define NP_LAUNCH(T, S)                                         \
+    do {                                                        \
+        if (STEP && a.inner) NP_LAUNCH_I(T, S, STEP);           \
+        else NP_LAUNCH_I(T, S, false);                          \
     } while (0)
     const int key = ctx->task * 2 + (STEP ? ctx->solver : 0);
     switch (key) {
@@ -903,6 +914,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     default: return fail("bad task/solver");
     }
 #undef NP_LAUNCH
+#undef NP_LAUNCH_I
     NP_HIP(hipGetLastError());
     if (timed) {
         NP_HIP(hipEventRecord(ev.second, st));

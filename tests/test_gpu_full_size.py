@@ -99,7 +99,7 @@ def test_same_seed_same_trajectory_and_flagged_rows_are_reinitialised():
     assert bool(((alt0 > 18000) & (alt0 < 21000)).all())
 
 
-def _bench_json(args, timeout=900):
+def _bench_json(args, timeout=300):
     import json
     import os
     import subprocess
