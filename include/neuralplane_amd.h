@@ -248,9 +248,10 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
-/* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context,
- * measured with HIP events recorded on the launch stream around each launch (0 disables;
- * enable with np_f16_set_timing(ctx, 1)).  Synchronises on the recorded events. */
+/* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context, measured with
+ * HIP events on the launch stream: a start / stop pair attached to each kernel's own dispatch (hipExtLaunchKernelGGL — the
+ * timestamps of the kernel's packet, no extra barrier packets between back-to-back launches; 0 disables, enable with
+ * np_f16_set_timing(ctx, 1)).  Synchronises on the recorded events. */
 int np_f16_set_timing(np_f16_ctx *ctx, int enable);
 int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count);
 /* The individual durations (ms, launch order) behind np_f16_get_timing since timing was enabled: the first

@@ -9,6 +9,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see neuralplane_amd/build.py).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -826,6 +827,15 @@ bool use_pair_kernel(const np_f16_ctx *ctx, int64_t n) {
     return forced || (!off && n > LAT_MAX_N);
 }
 
+// One kernel launch; when the context is being timed, the start / stop events are attached to the dispatch itself
+// (hipExtLaunchKernelGGL: the timestamps of the kernel's own packet — no extra barrier packets between consecutive launches,
+// and the duration is the kernel's execution time, as rocprofv3 reports it)
+#define NP_DISPATCH(ARGS, ...)                                                                                       \
+    do {                                                                                                             \
+        if (timed) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, ev.first, ev.second, 0, ARGS);            \
+        else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, ARGS);                                             \
+    } while (0)
+
 template <bool STEP>
 int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     if (!ctx || !io) return fail("null ctx/io");
@@ -882,21 +892,20 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
             NP_HIP(hipEventCreate(&ev.first));
             NP_HIP(hipEventCreate(&ev.second));
         }
-        NP_HIP(hipEventRecord(ev.first, st));
     }
 #define NP_LAUNCH_I(T, S, I)                                                                                          \
     do {                                                                                                              \
         if (pair) {                                                                                                   \
-            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, I>), grid, block, 0, st, a);       \
-            else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false, BLOCK, 2, I>), grid, block, 0, st, a);             \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, I>);       \
+            else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, I>);             \
         } else if (latency8 && S == 0) {                                                                              \
-            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 8, I>), grid, block, 0, st, a);    \
-            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 8, I>), grid, block, 0, st, a);          \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 8, I>);    \
+            else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, 8, I>);          \
         } else if (latency && S == 0) {                                                                               \
-            if (cached) hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4, I>), grid, block, 0, st, a);    \
-            else hipLaunchKernelGGL((f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4, I>), grid, block, 0, st, a);          \
-        } else if (cached) hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, STEP, BLOCK, 1, I>), grid, block, 0, st, a);    \
-        else hipLaunchKernelGGL((f16_env_kernel<T, S, STEP, false, BLOCK, 1, I>), grid, block, 0, st, a);                 \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4, I>);    \
+            else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4, I>);          \
+        } else if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 1, I>);    \
+        else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 1, I>);                 \
     } while (0)
 #define NP_LAUNCH(T, S)                                         \
     do {                                                        \
@@ -916,10 +925,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
 #undef NP_LAUNCH
 #undef NP_LAUNCH_I
     NP_HIP(hipGetLastError());
-    if (timed) {
-        NP_HIP(hipEventRecord(ev.second, st));
-        ctx->events.push_back(ev);
-    }
+    if (timed) ctx->events.push_back(ev);
     return 0;
 }
 
@@ -1017,19 +1023,15 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
             NP_HIP(hipEventCreate(&ev.first));
             NP_HIP(hipEventCreate(&ev.second));
         }
-        NP_HIP(hipEventRecord(ev.first, st));
     }
     // pair variant (Euler, MLP numerics): the default above the latency variant's range; NP_KERNEL_THROUGHPUT pins the single-set kernel
     const bool pair = STEP && !latency && ctx->solver == 0 && !ctx->ccfg.aero_1d_tables && ctx->variant != NP_KERNEL_THROUGHPUT;
-    if (latency) hipLaunchKernelGGL((f16_combat_kernel<0, STEP, LAT_TILE, 4>), grid, block, 0, st, a);
-    else if (pair) hipLaunchKernelGGL((f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>), grid, block, 0, st, a);
-    else if (STEP && ctx->solver == 1) hipLaunchKernelGGL((f16_combat_kernel<1, STEP>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((f16_combat_kernel<0, STEP>), grid, block, 0, st, a);
+    if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
+    else if (pair) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>);
+    else if (STEP && ctx->solver == 1) NP_DISPATCH(a, f16_combat_kernel<1, STEP>);
+    else NP_DISPATCH(a, f16_combat_kernel<0, STEP>);
     NP_HIP(hipGetLastError());
-    if (timed) {
-        NP_HIP(hipEventRecord(ev.second, st));
-        ctx->events.push_back(ev);
-    }
+    if (timed) ctx->events.push_back(ev);
     return 0;
 }
 
