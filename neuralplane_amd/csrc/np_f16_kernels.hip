@@ -247,6 +247,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
                 NP_LT(2);
             } else {
                 xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
+                NP_LT(2);
             }
             NP_REREAD_ARGS(ap);
             const float dt = ap->cfg.dt;
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
                 NP_LT(4);
                 tr = sc1.tr;
             } else {
+                NP_LT(3);
                 nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                NP_LT(4);
             }
         }
 #endif
@@ -467,12 +470,15 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
     }
 #ifdef NPF16_LAT_TRACE
     NP_LT(6);
-    if (ap->trace && WPT >= 4 && (threadIdx.x & 63) == 0) {  // 8 words per wave, WPT waves per tile (the caller sizes the buffer)
-        unsigned long long *rec = ap->trace + ((unsigned long long)blockIdx.x * WPT + part) * 8;
+    if (ap->trace && (threadIdx.x & 63) == 0) {  // 8 words per wave (the caller sizes the buffer)
+        constexpr int NW = TILE * (WPT >= 4 ? WPT : 1) / 64;
+        unsigned long long *rec = ap->trace + ((unsigned long long)blockIdx.x * NW + threadIdx.x / 64) * 8;
         for (int k = 0; k < 7; k++) rec[k] = lt[k];
     }
+    if (0) {
+#else
+    if (ap->trace && threadIdx.x == 0) {
 #endif
-    if (ap->trace && threadIdx.x == 0 && WPT < 4) {
         unsigned long long *rec = ap->trace + (unsigned long long)blockIdx.x * NP_TRACE_WORDS;
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
