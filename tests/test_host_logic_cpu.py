@@ -162,3 +162,36 @@ def test_pair_plans_are_balanced_and_complete():
         want = {(classes_name, k) for ci, first, n in g['phase_items'](kind) for classes_name in [g['CLASSES'][ci][0]] for k in range(first, first + n)}
         got = [(c, k) for w in waves for c, first, n in w for k in range(first, first + n)]
         assert len(got) == len(set(got)) and set(got) == want, kind
+
+
+def test_bench_self_launch_and_prelude_count(monkeypatch):
+    """bench.py without a launcher environment: `--gpus N` re-executes under torch.distributed.run (127.0.0.1, one rank per GPU,
+    `--n` spelled `--aircraft` for the launcher's parser); the prelude's step count is a pure function of an estimate that is
+    identical on every rank (steps may hold collectives: a time-based count diverges between ranks and deadlocks)."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--n', '1000', '--steps', '7'])
+    args = type('A', (), {'gpus': 4})()
+    assert bench.self_launch(args) == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and '--aircraft' in cmd and '--n' not in cmd
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+    class Dev:
+        pass
+    calls = []
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda dev=None: None)
+    tm = bench.Timer(lambda i: calls.append(i), None, Dev(), None, 'gloo')
+    n1, _, nxt = tm.prelude(0.3, i0=5, est_step_s=0.004)
+    assert n1 == 75 and nxt == 80 and calls == list(range(5, 80))
+    assert tm.prelude(0.0, i0=0, est_step_s=0.004)[0] == 0
+    st = bench.stats([0.3, 0.1, 0.2])
+    assert st['kernel_median_ms'] == 0.2 and st['kernel_min_ms'] == 0.1 and st['launches_timed'] == 3
