@@ -259,6 +259,13 @@ int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count);
  * numbers bench.py reports beside the mean (the reference's own benchmark, envs/measure_env.py:65-78, reports a mean only). */
 int np_f16_get_timing_samples(np_f16_ctx *ctx, float *ms_out, int64_t capacity, int64_t *count);
 
+/* Self-check of the numerics spec on the device at hand: divisions by a constant c run as q = x*rc; r = fma(-q, c, x);
+ * q' = fma(r, rc, q) instead of the 12-instruction IEEE sequence.  This sweeps ALL 2^32 bit patterns of x
+ * and compares with the IEEE quotient: counts3[0] = mismatches with a normal quotient and |x| >= 2^-100 (the spec promises 0),
+ * counts3[1] = mismatches with a denormal / underflowing quotient or |x| < 2^-100 (last place only), counts3[2] = inputs compared
+ * (2^32).  Blocking; about 10 ms per constant. */
+int np_selfcheck_divc(float c, uint64_t *counts3, int device);
+
 /* Profiling hook: while a device buffer of capacity_workgroups x NP_TRACE_WORDS uint64 is set (NULL clears), every
  * np_f16_step launch on this context writes one record per workgroup: [0] shader-clock counter at entry, [1] after the
  * de-phasing delay, [2] at exit, [3] / [4] the constant-rate (100 MHz) counter at entry / exit, [5] XCC id << 32 | HW_ID.

@@ -73,7 +73,7 @@ class NpF16CombatIo(C.Structure):
 
 
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
-           'np_f16_step', 'np_f16_derived', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace',
+           'np_f16_step', 'np_f16_derived', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace', 'np_selfcheck_divc',
            'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns')
 KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4}
 
@@ -118,6 +118,7 @@ def load():
     lib.np_f16_combat_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16CombatIo), C.c_void_p]
     lib.np_f16_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.np_f16_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.np_selfcheck_divc.argtypes = [C.c_float, C.POINTER(C.c_uint64), C.c_int]
     lib.np_f16_get_timing_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     if lib.np_abi_version() != ABI_VERSION:
         raise RuntimeError('libneuralplane_hip.so ABI version mismatch')

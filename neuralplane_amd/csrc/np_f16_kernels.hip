@@ -582,6 +582,36 @@ __global__ __launch_bounds__(BLOCK) void f16_reset_coef_kernel(float *out, int t
     }
 }
 
+// Self-check of the numerics spec's constant division on THIS device: np_divc(x, c) against the IEEE x / c for every one of the
+// 2^32 bit patterns of x.  counts[0]: mismatches whose IEEE quotient is a normal number with |x| >= 2^-100 (the spec promises
+// none), counts[1]: mismatches with a denormal / underflowing quotient or |x| < 2^-100 (allowed: the last place may differ),
+// counts[2]: inputs compared.
+__global__ __launch_bounds__(256) void divc_sweep_kernel(float c, float rc, unsigned long long *counts) {
+    unsigned long long bad = 0, soft = 0, seen = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((unsigned)b);
+        const float got = np_divc(x, c, rc), want = x / c;
+        seen++;
+        const bool same = (__float_as_uint(got) == __float_as_uint(want)) || (got != got && want != want);
+        if (!same) {
+            const float aw = fabsf(want), ax = fabsf(x);
+            if (aw >= 1.17549435e-38f && aw <= 3.402823466e38f && ax >= 7.888609052e-31f) bad++;  // 2^-100
+            else soft++;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_down(bad, off);
+        soft += __shfl_down(soft, off);
+        seen += __shfl_down(seen, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counts + 0, bad);
+        atomicAdd(counts + 1, soft);
+        atomicAdd(counts + 2, seen);
+    }
+}
+
 }  // namespace npf16
 
 // =================================================================================================
@@ -1295,6 +1325,29 @@ int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count) {
     ctx->events.clear();
     if (avg_ms) *avg_ms = ctx->t_count ? ctx->t_sum_ms / (double)ctx->t_count : 0.0;
     if (count) *count = ctx->t_count;
+    return 0;
+}
+
+int np_selfcheck_divc(float c, uint64_t *counts3, int device) {
+    if (!counts3) return fail("null argument");
+    if (!(c == c) || c == 0.0f || std::isinf(c)) return fail("np_selfcheck_divc: the divisor must be a finite non-zero constant");
+    int ndev = 0;
+    NP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(device));
+    unsigned long long *d = nullptr;
+    NP_HIP(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(divc_sweep_kernel, dim3(256 * 64), dim3(256), 0, 0, c, (float)(1.0 / (double)c), d);
+        e = hipGetLastError();
+    }
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    NP_HIP(e);
+    for (int k = 0; k < 3; k++) counts3[k] = h[k];
     return 0;
 }
 

@@ -240,3 +240,29 @@ def test_heading_wrap_is_the_exact_remainder_for_every_magnitude(task):
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
         o_obs, o_rew, _, _, _ = o.step(st, a, seed=3, call_idx=t + 1)
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'{task} wrap step {t}')
+
+
+def test_constant_division_sequence_equals_ieee_division_on_this_device_for_all_floats():
+    """np_selfcheck_divc: for every constant the path divides by (the same list the CPU proof uses), all 2^32 bit patterns of x —
+    the device's np_divc equals the IEEE quotient wherever the quotient is a normal number and |x| >= 2^-100; what differs
+    (denormal quotients, tiny x) is counted separately and stays a vanishing fraction."""
+    from neuralplane_amd import _lib
+    from test_oracle_golden import _divisor_constants
+    lib = _lib.load()
+    total_soft, rows = 0, []
+    for c in _divisor_constants():
+        cnt = (C.c_uint64 * 3)()
+        _lib.check(lib.np_selfcheck_divc(C.c_float(c), cnt, 0))
+        assert cnt[2] == 2 ** 32, c
+        assert cnt[0] == 0, (c, cnt[0])
+        total_soft += cnt[1]
+        rows.append({'c': c, 'mismatch_normal_range': int(cnt[0]), 'mismatch_tiny_or_denormal': int(cnt[1]), 'inputs': int(cnt[2])})
+        assert cnt[1] < 2 ** 32 // 50, (c, cnt[1])     # only sub-2^-100 inputs / denormal quotients (< 2 % of all bit patterns)
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(rows, open(os.path.join(out, 'divc_selfcheck.json'), 'w'), indent=1)
+    except OSError:
+        pass
