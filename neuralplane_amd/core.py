@@ -467,7 +467,7 @@ class F16CombatBatch:
         return [float(buf[i]) for i in range(cnt.value)]
 
     def set_kernel_variant(self, variant):
-        """'auto' (default: latency kernel while n <= 49152 aircraft), 'latency', 'throughput' — bit-identical results."""
+        """'auto' (default: latency kernel while n <= 40000 aircraft, then 'pair'), 'latency', 'throughput', 'pair' — bit-identical results."""
         _lib.check(self.lib.np_f16_set_kernel_variant(self._ctx, _lib.KERNEL_VARIANTS[variant]))
 
     TERM_NAMES = ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'crash', 'timeout', 'shutdown_bad',

@@ -835,7 +835,7 @@ struct DeviceGuard {
 
 constexpr int LAT_TILE = 64;
 constexpr int64_t LAT8_MAX_N = 16384;  // eight waves per tile while every tile still gets a CU of its own (256 tiles)
-constexpr int64_t COMBAT_LAT_MAX_N = 49152;  // aircraft (24576 engagements: 0.211 vs 0.258 ms; 32768 engagements: a tie)
+constexpr int64_t COMBAT_LAT_MAX_N = 40000;  // aircraft; against the pair variant (round 2): 16 384 engagements 0.116 vs 0.127 ms, 20 000 a tie (0.197), 24 576 0.213 vs 0.198
 constexpr int64_t LAT_MAX_N = 65536;  // measured crossover (tools/microbench/small_n.py): 65536: 53.6 vs 58.9 us, 98304: 73.5 vs 59.2 us
 bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
     static const int forced = [] {  // process-wide override for experiments: NPF16_KERNEL=latency|throughput
