@@ -833,6 +833,59 @@ struct DeviceGuard {
     }
 };
 
+// Turn the pending event pairs into durations (waits for the launches they belong to).  The sample list is for short
+// measurement windows: beyond MAX_TIMING_SAMPLES only the running sum / count keep growing.
+constexpr size_t MAX_TIMING_SAMPLES = 1u << 20, MAX_PENDING_EVENTS = 8192;
+int resolve_events(np_f16_ctx *ctx) {
+    size_t k = 0;
+    for (; k < ctx->events.size(); k++) {
+        auto &e = ctx->events[k];
+        hipError_t err = hipEventSynchronize(e.second);
+        float ms = 0.0f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e.first, e.second);
+        if (err != hipSuccess) {
+            ctx->events.erase(ctx->events.begin(), ctx->events.begin() + (long)k);
+            return fail(std::string("timing events: ") + hipGetErrorString(err));
+        }
+        ctx->t_sum_ms += ms;
+        ctx->t_count += 1;
+        if (ctx->samples.size() < MAX_TIMING_SAMPLES) ctx->samples.push_back(ms);
+        ctx->pool.push_back(e);
+    }
+    ctx->events.clear();
+    return 0;
+}
+
+// A start / stop event pair taken from the context's pool for one timed launch; goes back to the pool unless the launch was
+// enqueued (commit() hands it to ctx->events, where np_f16_get_timing resolves it)
+struct EventLease {
+    np_f16_ctx *ctx;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    explicit EventLease(np_f16_ctx *c) : ctx(c) {}
+    hipError_t take() {
+        if (!ctx->pool.empty()) {
+            ev = ctx->pool.back();
+            ctx->pool.pop_back();
+            return hipSuccess;
+        }
+        hipError_t e = hipEventCreate(&ev.first);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&ev.second);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(ev.first);
+            ev = {nullptr, nullptr};
+        }
+        return e;
+    }
+    void commit() {
+        ctx->events.push_back(ev);
+        ev = {nullptr, nullptr};
+    }
+    ~EventLease() {
+        if (ev.first) ctx->pool.push_back(ev);
+    }
+};
+
 constexpr int LAT_TILE = 64;
 constexpr int64_t LAT8_MAX_N = 16384;  // eight waves per tile while every tile still gets a CU of its own (256 tiles)
 constexpr int64_t COMBAT_LAT_MAX_N = 40000;  // aircraft; against the pair variant (round 2): 16 384 engagements 0.116 vs 0.127 ms, 20 000 a tie (0.197), 24 576 0.213 vs 0.198
@@ -918,17 +971,11 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = STEP && ctx->timing;
-    if (timed) {
-        if (!ctx->pool.empty()) {
-            ev = ctx->pool.back();
-            ctx->pool.pop_back();
-        } else {
-            NP_HIP(hipEventCreate(&ev.first));
-            NP_HIP(hipEventCreate(&ev.second));
-        }
-    }
+    EventLease lease(ctx);
+    if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;  // a caller that never polls
+    if (timed) NP_HIP(lease.take());
+    const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
 #define NP_LAUNCH_I(T, S, I)                                                                                          \
     do {                                                                                                              \
         if (pair) {                                                                                                   \
@@ -961,7 +1008,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
 #undef NP_LAUNCH
 #undef NP_LAUNCH_I
     NP_HIP(hipGetLastError());
-    if (timed) ctx->events.push_back(ev);
+    if (timed) lease.commit();
     return 0;
 }
 
@@ -1049,17 +1096,11 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)),
         block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = STEP && ctx->timing;
-    if (timed) {
-        if (!ctx->pool.empty()) {
-            ev = ctx->pool.back();
-            ctx->pool.pop_back();
-        } else {
-            NP_HIP(hipEventCreate(&ev.first));
-            NP_HIP(hipEventCreate(&ev.second));
-        }
-    }
+    EventLease lease(ctx);
+    if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;  // a caller that never polls
+    if (timed) NP_HIP(lease.take());
+    const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
     // pair variant (Euler, MLP numerics): the default above the latency variant's range; NP_KERNEL_THROUGHPUT pins the single-set kernel
     const bool pair = STEP && !latency && ctx->solver == 0 && !ctx->ccfg.aero_1d_tables && ctx->variant != NP_KERNEL_THROUGHPUT;
     if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
@@ -1067,7 +1108,7 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     else if (STEP && ctx->solver == 1) NP_DISPATCH(a, f16_combat_kernel<1, STEP>);
     else NP_DISPATCH(a, f16_combat_kernel<0, STEP>);
     NP_HIP(hipGetLastError());
-    if (timed) ctx->events.push_back(ev);
+    if (timed) lease.commit();
     return 0;
 }
 
@@ -1313,16 +1354,7 @@ int np_f16_get_timing(np_f16_ctx *ctx, double *avg_ms, int64_t *count) {
     if (!ctx) return fail("null ctx");
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
-    for (auto &e : ctx->events) {
-        NP_HIP(hipEventSynchronize(e.second));
-        float ms = 0.0f;
-        NP_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-        ctx->t_sum_ms += ms;
-        ctx->t_count += 1;
-        ctx->samples.push_back(ms);
-        ctx->pool.push_back(e);
-    }
-    ctx->events.clear();
+    if (resolve_events(ctx)) return 1;
     if (avg_ms) *avg_ms = ctx->t_count ? ctx->t_sum_ms / (double)ctx->t_count : 0.0;
     if (count) *count = ctx->t_count;
     return 0;
