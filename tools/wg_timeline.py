@@ -61,6 +61,8 @@ def analyse(t, wgs_per_slotset=None):
         'cus_seen': int(len(per_cu)), 'wgs_per_cu_min': int(per_cu.min()), 'wgs_per_cu_max': int(per_cu.max()),
         'wgs_per_xcc': per_xcc.tolist(), 'simd_hist_of_wave0': np.bincount(simd.astype(np.int64), minlength=4).tolist(),
         'last_start_us': float(start.max()), 'first_end_us': float(end.min()),
+        'wgs_per_cu_hist': np.bincount(per_cu.astype(np.int64)).tolist() if per_cu.max() < 64 else None,
+        'idle_cus': int(256 - len(per_cu)),
     }
 
 
@@ -71,6 +73,7 @@ def main():
     ap.add_argument('--task', default='heading')
     ap.add_argument('--out', default=None)
     ap.add_argument('--raw', default=None)
+    ap.add_argument('--variant', default=None, help='pin a kernel variant (auto when omitted)')
     args = ap.parse_args()
     from neuralplane_amd import _lib
     from neuralplane_amd.envs.control_env import ControlEnv
@@ -81,6 +84,8 @@ def main():
     g.manual_seed(1234)
     pool = [torch.rand((n, 4), generator=g, device=dev) * 2 - 1 for _ in range(8)]
     b = env._batch
+    if args.variant:
+        b.set_kernel_variant(args.variant)
     env.reset()
     for i in range(args.prelude):
         env.step(pool[i % 8])
@@ -96,7 +101,7 @@ def main():
     t = trace.cpu().numpy()
     t = t[t[:, 3] != 0]
     out = analyse(t)
-    out.update({'n': n, 'task': args.task, 'prelude_steps': args.prelude, 'kernel_ms_traced_launches': ms})
+    out.update({'n': n, 'task': args.task, 'variant': args.variant or 'auto', 'prelude_steps': args.prelude, 'kernel_ms_traced_launches': ms})
     if args.raw:
         np.save(args.raw, t)
     txt = json.dumps(out)
