@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 9
+#define NP_ABI_VERSION 10
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
 #define NP_NUM_TARGETS 3   /* task targets (heading: alt,heading,vt | control: pitch,heading,vt | tracking: n,e,alt) */
 #define NP_NUM_OBS 22      /* envs/tasks/heading_task.py:71-152                                                   */
 #define NP_NUM_DERIVED 20  /* rows written by np_f16_derived()                                                    */
+#define NP_NUM_NETS 43     /* rows written by np_f16_aero_coefficients(): the aero surrogates, hifi_F16_AeroData.py    */
 #define NP_NUM_TERM_COUNTERS 7 /* per-condition termination counters (np_f16_io.term_counters)                      */
 #define NP_NUM_CACHED 14   /* values per aircraft in the cross-step coefficient cache (np_f16_io.coef_cache)      */
 
@@ -143,6 +144,21 @@ int np_f16_step(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream);
  *   row  19     get_EAS()                                                                  */
 int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, int64_t ld, float *out,
                    int64_t ld_out, void *stream);
+
+/* The aero coefficient surrogates on their own — hifi_F16.hifi_C(alpha, beta, el), hifi_damping(alpha), hifi_C_lef(alpha, beta),
+ * hifi_damping_lef(alpha), hifi_rudder(alpha, beta), hifi_ailerons(alpha, beta), hifi_other_coeffs(alpha, el)
+ * (envs/models/F16/hifi_F16_AeroData.py:745-822; inputs in DEGREES as F16_dynamics.py:135-137 passes them): out[43][ld_out],
+ * rows in the reference's evaluation order
+ *   0-5 Cx Cz Cm Cy Cn Cl | 6-14 Cxq Cyr Cyp Czq Clr Clp Cmq Cnr Cnp | 15-20 delta_{Cx,Cz,Cm,Cy,Cn,Cl}_lef |
+ *   21-29 delta_{Cxq,Cyr,Cyp,Czq,Clr,Clp,Cmq,Cnr,Cnp}_lef | 30-32 delta_{Cy,Cn,Cl}_r30 |
+ *   33-38 delta_Cy_a20, delta_Cy_a20_lef, delta_Cn_a20, delta_Cn_a20_lef, delta_Cl_a20, delta_Cl_a20_lef |
+ *   39-42 delta_Cnbeta, delta_Clbeta, delta_Cm, eta_el
+ * evaluated by the same device code (normalisation + net bodies, or the 1-D tables when the context has them on) that the
+ * step kernels run.  Row 24 (delta_Czq_lef) is returned as 0: F16Dynamics.nlplant never reads it (F16_dynamics.py:199 uses
+ * delta_Cz_lef) and the device weights do not carry it.  This is the entry the reference's surrogate check
+ * (envs/models/F16/model/test_model.py:58-338: MLPs against the table values of model/coefs.csv) binds to. */
+int np_f16_aero_coefficients(np_f16_ctx *ctx, int64_t n, const float *alpha_deg, const float *beta_deg, const float *el, float *out,
+                             int64_t ld_out, void *stream);
 
 /* PlanningEnv.low_level_obs(target_pitch, target_heading, target_vt) — envs/planning_env.py:60-142: the 22-float
  * observation of the low-level controller (same layout as ControlTask.get_obs, no noise) for caller-supplied

@@ -15,6 +15,7 @@ from . import _lib
 
 ASSET_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'f16_aero_mlp.bin')
 NUM_DERIVED = 20
+NUM_NETS = 43
 NUM_CACHED = 14
 
 
@@ -222,6 +223,19 @@ class F16Batch:
         _lib.check(self.lib.np_f16_lowlevel_obs(self._ctx, self.n, self.s.data_ptr(), self.u.data_ptr(), tgt3.data_ptr(), self.n,
                                                 obs.data_ptr(), self._stream()))
         return obs
+
+    def aero_coefficients(self, alpha_deg, beta_deg, el):
+        """The 43 aero coefficient surrogates at arbitrary inputs in degrees (hifi_F16_AeroData.py:745-822) -> [43, m] in the
+        reference's evaluation order, through the same device code the step kernels run (np_f16_aero_coefficients).  Row 24
+        (delta_Czq_lef, never read by nlplant) is 0."""
+        a, b, e = (torch.as_tensor(v, dtype=torch.float32, device=self.device).reshape(-1).contiguous() for v in (alpha_deg, beta_deg, el))
+        if not (a.numel() == b.numel() == e.numel()):
+            raise ValueError('alpha, beta and el must have the same number of elements')
+        m = a.numel()
+        out = torch.empty((NUM_NETS, m), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.np_f16_aero_coefficients(self._ctx, m, a.data_ptr(), b.data_ptr(), e.data_ptr(), out.data_ptr(), m,
+                                                     self._stream()))
+        return out
 
     def derived(self):
         """[20,n] derived quantities at the current (s,u) (np_f16_derived), cached per state version."""

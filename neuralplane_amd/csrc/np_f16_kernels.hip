@@ -532,6 +532,33 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     out[19 * ld_out + i] = eas;
 }
 
+// hifi_F16.hifi_C / hifi_damping / hifi_C_lef / hifi_damping_lef / hifi_rudder / hifi_ailerons / hifi_other_coeffs
+// (envs/models/F16/hifi_F16_AeroData.py:745-822) for arbitrary (alpha, beta, el) in degrees: the same normalisation and net
+// bodies nlplant runs (so what this returns IS what the step kernels use), out[43][ld_out] in the reference's evaluation order
+// (np_nets.h::NetId).  Row N_dCzq_lef (the net nlplant never reads, F16_dynamics.py:199) is not part of the device weights: 0.
+__global__ __launch_bounds__(BLOCK) void f16_aero_kernel(const float *__restrict__ alpha_deg, const float *__restrict__ beta_deg,
+                                                         const float *__restrict__ el, long long n, float *__restrict__ out,
+                                                         long long ld_out, int tables, AeroWeights wt) {
+    __shared__ float lds[NUM_LDS_SLOTS * BLOCK];
+    float *coef = lds + threadIdx.x;
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;  // wave-uniform control flow: the weights stay in SGPRs
+    const float a = alpha_deg[ic], b = beta_deg[ic], e = el[ic];
+    float xn[NUM_NORM_GROUPS];
+    normalise_inputs(wt, a, b, e, xn);
+    const float chk = ((a - a) + (b - b)) + (e - e);  // numerics spec: non-finite inputs poison every coefficient
+    const bool ok = (chk == chk);
+    eval_nets<BLOCK, AB_ALL, true>(wt, xn, coef, tables != 0);
+    if (!valid) return;
+    const float qnan = __builtin_nanf("");
+#pragma unroll
+    for (int net = 0; net < NUM_NETS; net++) {
+        const int slot = slot_of(net);
+        out[net * ld_out + i] = slot < 0 ? 0.0f : (ok ? coef[slot * BLOCK] : qnan);
+    }
+}
+
 // PlanningEnv.low_level_obs (planning_env.py:60-142): ControlTask-style observation for caller-supplied targets, no noise
 __global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                                  const float *__restrict__ tp, long long ld, float *__restrict__ obs,
@@ -1249,6 +1276,20 @@ int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, i
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipLaunchKernelGGL(f16_derived_kernel, grid, block, 0, (hipStream_t)stream, s, u, (long long)ld, out, (long long)ld_out,
                        (long long)n, ctx->cfg.airspeed, ctx->cfg.aero_1d_tables, ctx->wt);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_f16_aero_coefficients(np_f16_ctx *ctx, int64_t n, const float *alpha_deg, const float *beta_deg, const float *el, float *out,
+                             int64_t ld_out, void *stream) {
+    if (!ctx || !alpha_deg || !beta_deg || !el || !out) return fail("null argument");
+    if (n <= 0) return 0;
+    if (ld_out < n) return fail("leading dimension < n");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipLaunchKernelGGL(f16_aero_kernel, grid, block, 0, (hipStream_t)stream, alpha_deg, beta_deg, el, (long long)n, out,
+                       (long long)ld_out, ctx->cfg.aero_1d_tables, ctx->wt);
     NP_HIP(hipGetLastError());
     return 0;
 }

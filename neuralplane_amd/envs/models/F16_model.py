@@ -8,6 +8,7 @@ state version.  The FDM step itself is not here: it is fused into BaseEnv.step's
 """
 import torch
 
+from .F16.hifi_F16_AeroData import hifi_F16
 from .model_base import BaseModel
 
 
@@ -27,6 +28,7 @@ class F16Model(BaseModel):
         self.init_state = config.init_state
         self.recent_s = None
         self.recent_u = None
+        self.hifi_F16 = hifi_F16(batch)   # the surrogate object F16Dynamics holds (F16_dynamics.py:13)
 
     # state / control as the reference lays them out ([n,k]); views, not copies
     @property

@@ -179,6 +179,40 @@ def gen_aero(env):
     np.savez_compressed(os.path.join(OUT, 'aero_kat.npz'), alpha_deg=a, beta_deg=b, el=e, coef=out, coef_pin=out_pin)
 
 
+# ------------------------------------------------------------------------------------------------
+# The reference's own validation data for the aero surrogates: envs/models/F16/model/coefs.csv is the 630-point grid
+# (rows 0-2: alpha, beta, el in degrees) with the table-interpolated coefficient of every net (rows 3-45, the row map of
+# model/test_model.py:71-335), which the authors' script compares their MLPs against (r2 / mean absolute error).  The
+# leading-edge-flap and aileron tables only span the first 400 grid points (alpha <= 45 deg, test_model.py:163-301).
+# ------------------------------------------------------------------------------------------------
+# column of aero_eval()'s 43-vector -> row of coefs.csv
+MODEL_GRID_ROWS = (list(range(3, 9)) + list(range(9, 18)) + list(range(18, 24)) + list(range(24, 33)) + list(range(33, 36))
+                   + [36, 39, 37, 40, 38, 41] + list(range(42, 46)))
+MODEL_GRID_400 = set(range(15, 30)) | set(range(33, 39))   # C_lef, damping_lef, ailerons: first 400 points
+
+
+def gen_model_grid(env):
+    import pandas as pd
+    d = np.array(pd.read_csv('/root/reference/envs/models/F16/model/coefs.csv', header=None))
+    assert d.shape == (47, 630) and len(MODEL_GRID_ROWS) == 43
+    a, b, e = (d[k].astype(np.float32) for k in range(3))   # test_model.py feeds float64 tensors, MLP.forward casts to float32
+    hifi = env.model.dynamics.hifi_F16
+    out = aero_eval(hifi, a, b, e)
+    with pin_mode(mlp_class(env)):
+        out_pin = aero_eval(hifi, a, b, e)
+    table = d[MODEL_GRID_ROWS].T.copy()                     # [630, 43] float64, the reference's data file as it is
+    npts = np.array([400 if k in MODEL_GRID_400 else 630 for k in range(43)], np.int32)
+    r2 = np.zeros(43)
+    mae = np.zeros(43)
+    for k in range(43):
+        y, f = table[:npts[k], k], out[:npts[k], k].astype(np.float64)
+        r2[k] = 1.0 - np.sum((y - f) ** 2) / np.sum((y - y.mean()) ** 2)   # sklearn.metrics.r2_score
+        mae[k] = np.mean(np.abs(y - f))
+    np.savez_compressed(os.path.join(OUT, 'model_grid_kat.npz'), alpha_deg=a, beta_deg=b, el=e, table=table, npts=npts,
+                        coef=out, coef_pin=out_pin, ref_r2=r2, ref_mae=mae)
+    print('model grid: r2 of the reference MLPs against its tables: min %.4f median %.5f' % (r2.min(), np.median(r2)))
+
+
 def random_flight_states(rng, n):
     s = np.zeros((n, 12), np.float32)
     s[:, 0] = rng.uniform(-5e4, 5e4, n)
@@ -886,6 +920,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'actor':
         gen_actor()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'model_grid':
+        gen_model_grid(make_env('heading', 4))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'traj':
         gen_traj('heading', 256, 1000)     # BASELINE.json configs[0] / SURVEY.md App. D.3 #5: N = 256
         gen_traj('control', 64, 300)
@@ -894,6 +931,7 @@ def main():
         return
     env = make_env('heading', 4)
     gen_aero(env)
+    gen_model_grid(env)
     gen_nlplant(env)
     gen_getters(env)
     for task in ('heading', 'control', 'tracking'):
