@@ -9,10 +9,10 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int K>
-__global__ void stream(const float *base, int region_bytes, int trips, long long *out, float *sink) {
-    const float *p0 = base + (size_t)blockIdx.x * (region_bytes / 4);
+__global__ void stream(const float *base, int region_bytes, int trips, long long *out, float *sink, int misalign_floats) {
+    const float *p0 = base + (size_t)blockIdx.x * (region_bytes / 4) + misalign_floats;
     const float *p = p0;
-    const float *end = p0 + region_bytes / 4;
+    const float *end = p0 + region_bytes / 4 - 16;
     float acc = 0.f;
     long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < trips; i++) {
@@ -49,10 +49,10 @@ __global__ void stream(const float *base, int region_bytes, int trips, long long
 }
 
 template <int K>
-int run(const float *d, long long *out, float *sink, int region, int blocks) {
+int run(const float *d, long long *out, float *sink, int region, int blocks, int mis = 0) {
     const int trips = 2048;
     for (int rep = 0; rep < 2; rep++) {
-        hipLaunchKernelGGL(stream<K>, dim3(blocks), dim3(64), 0, 0, d, region, trips, out, sink);
+        hipLaunchKernelGGL(stream<K>, dim3(blocks), dim3(64), 0, 0, d, region, trips, out, sink, mis);
         CHECK(hipDeviceSynchronize());
     }
     std::vector<long long> h(blocks);
@@ -73,6 +73,12 @@ int main() {
         for (int blocks : {1, 256, 2048}) {
             printf("region %d KB per wave (%s), %d waves:\n", region / 1024, region <= 8192 ? "warm in the scalar cache" : "cold, L2 / HBM", blocks);
             if (run<1>(d, out, sink, region, blocks) || run<2>(d, out, sink, region, blocks) || run<3>(d, out, sink, region, blocks) || run<6>(d, out, sink, region, blocks)) return 1;
+        }
+    // the same with every load starting 48 bytes into a 64-byte line (a record stream behind a 112-byte header)
+    for (int region : {4096, 262144})
+        for (int blocks : {1, 2048}) {
+            printf("MISALIGNED by 48 bytes: region %d KB per wave, %d waves:\n", region / 1024, blocks);
+            if (run<1>(d, out, sink, region, blocks, 12) || run<3>(d, out, sink, region, blocks, 12) || run<6>(d, out, sink, region, blocks, 12)) return 1;
         }
     CHECK(hipDeviceSynchronize());
     return 0;
