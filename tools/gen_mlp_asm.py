@@ -42,6 +42,7 @@ V_H = [70, 90, 110]   # hidden activations of layer 1/2/3 (20, 20, 10 registers)
 V_X = 120        # v120,v122,v124: the (normalised) inputs, even registers
 V_Y = 126        # v[126:127] the two partial sums of the output layer; v126 = net output
 V_ADDR = 121     # LDS byte address of the output slot (the odd register between the input pairs: never read as an input)
+HALF_LOADS = os.environ.get('NPF16_GEN_HALF_LOADS') == '1'   # TIMING EXPERIMENT ONLY (wrong results): every other group's loads are not issued — what halving the scalar weight traffic would gain
 GEN_DUP = os.environ.get('NPF16_GEN_DUP') == '1'   # TIMING EXPERIMENT ONLY: every VALU instruction of a net body is issued twice (second copy on
                                                     # registers + 58), i.e. two accumulator sets per weight load — what 'two aircraft per lane' would cost
 V_CLOBBER = list(range(68 if os.environ.get('NPF16_GEN_EXTRA_MOVS') == '1' else 70, 186 if GEN_DUP else 128))
@@ -95,6 +96,8 @@ class Body:
             self.cur_group += 1
             c = CPG * self.cur_group
             self.ins.append('s_waitcnt lgkmcnt(0)')
+            if HALF_LOADS and self.cur_group % 2 == 1:
+                continue
             for cc in range(c + CPG, c + 2 * CPG):  # next group (runs into the next record when cc >= nch)
                 if self.use_next and cc >= self.nch:
                     base, off = S_NEXT, (cc - self.nch) * 64
