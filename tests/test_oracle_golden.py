@@ -198,6 +198,48 @@ def test_step_pin_mode_is_bit_exact(task, fixture, solver, pre, golden_dir):
         assert g[k + 'done_pin'].sum() > 10 and g[k + 'bad_pin'].sum() > 10  # the fixture really exercises the masks
 
 
+def test_rk4_step_is_the_published_three_eighths_rule(golden_dir):
+    """`solver: rk4` is torchdiffeq's fixed-grid "rk4" = Kutta's 3/8 rule (torchdiffeq 0.2.3, rk_common.py::rk4_alt_step_func; the
+    package is absent here, so the goldens come from a restatement and parity with the real package stays unpinned).  This test
+    is independent of that restatement: it composes the step from the PUBLISHED formula (Hairer, Norsett, Wanner I, II.1: k2 at
+    y + h k1/3, k3 at y + h (k2 - k1/3), k4 at y + h (k1 - k2 + k3), y + h (k1 + 3 k2 + 3 k3 + k4) / 8) out of the oracle's own
+    nlplant in numpy and requires the oracle's rk4 step to land on it; classic RK4 and Euler must NOT (they differ in O(h^5) / O(h^2))."""
+    g = np.load(f'{golden_dir}/step_kat_heading_rk4.npz')
+    keep = ~(g['in_done'] | g['in_bad'] | g['in_timeout']).astype(bool)        # rows the step does not re-initialise first
+    st, *_ = _run_step('heading', 'rk4', g, '', 0)
+    o = Oracle('heading')
+    h = np.float32(0.02)
+    s0 = g['in_s'][keep].astype(np.float32)
+    u = st['u'][keep].astype(np.float32)                                       # controls after clamp + lag: constant during the step
+
+    def f(y):
+        xd = o.nlplant(np.hstack([y, u]).astype(np.float32))
+        return xd.astype(np.float32)
+
+    third = np.float32(1.0 / 3.0)
+    k1 = f(s0)
+    k2 = f(s0 + h * k1 * third)
+    k3 = f(s0 + h * (k2 - k1 * third))
+    k4 = f(s0 + h * (k1 - k2 + k3))
+    y38 = s0 + (k1 + np.float32(3) * (k2 + k3) + k4) * h * np.float32(0.125)
+    got = st['s'][keep]
+    assert keep.sum() > 100
+    assert relerr(got, y38, STATE_FLOORS) < 2e-7                                # measured: 0 (every bit equal on this host)
+    # sensitivity of the check: the neighbours are measurably somewhere else
+    half = np.float32(0.5)
+    c2 = f(s0 + h * half * k1)
+    c3 = f(s0 + h * half * c2)
+    c4 = f(s0 + h * c3)
+    y_classic = s0 + h * (k1 + np.float32(2) * (c2 + c3) + c4) / np.float32(6)
+    y_euler = s0 + h * k1
+    e38 = np.abs(got - y38).max(axis=1)
+    assert np.median(np.abs(got - y_euler).max(axis=1)) > 1e3 * np.median(e38 + 1e-12)
+    assert relerr(got, y_euler, STATE_FLOORS) > 1e-5
+    # classic RK4 agrees to O(h^5): closer than Euler, yet the 3/8 composition is the closest of the three on most rows
+    closer = np.abs(got - y38).sum(axis=1) <= np.abs(got - y_classic).sum(axis=1)
+    assert closer.mean() > 0.9
+
+
 @pytest.mark.parametrize('task,fixture,solver', STEP_FIXTURES)
 @pytest.mark.parametrize('pre', ['', 'first_'])
 def test_step_plain_mode_within_tolerance_masks_exact(task, fixture, solver, pre, golden_dir):
