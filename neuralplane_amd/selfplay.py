@@ -49,7 +49,6 @@ class OpponentExchange:
         self.act_off = sum(self.act_sizes[:self.src_rank])
         self.use_streams = self.device.type == 'cuda'
         self.side = torch.cuda.Stream(device=self.device) if self.use_streams else None
-        self._done = torch.cuda.Event() if self.use_streams else None
         self._pending = None     # (opponent actions of my envs, event) produced by the exchange started last
         self._served_ids = torch.arange(self.served0, self.served0 + self.served_n, device=self.device)
 
