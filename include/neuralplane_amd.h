@@ -34,7 +34,7 @@ extern "C" {
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
 #define NP_NUM_TARGETS 3   /* task targets (heading: alt,heading,vt | control: pitch,heading,vt | tracking: n,e,alt) */
 #define NP_NUM_OBS 22      /* envs/tasks/heading_task.py:71-152                                                   */
-#define NP_NUM_DERIVED 20  /* rows written by np_f16_derived()                                                    */
+#define NP_NUM_DERIVED 23  /* rows written by np_f16_derived()                                                    */
 #define NP_NUM_NETS 43     /* rows written by np_f16_aero_coefficients(): the aero surrogates, hifi_F16_AeroData.py    */
 #define NP_NUM_TERM_COUNTERS 7 /* per-condition termination counters (np_f16_io.term_counters)                      */
 #define NP_NUM_CACHED 14   /* values per aircraft in the cross-step coefficient cache (np_f16_io.coef_cache)      */
@@ -136,12 +136,13 @@ int np_f16_reset(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream);
  * reward (task_base.py:60-73), fused into ONE kernel launch. */
 int np_f16_step(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream);
 
-/* Derived quantities behind F16Model's getters (F16_model.py:47-49, 132-181), SoA out[20][ld_out]:
+/* Derived quantities behind F16Model's getters (F16_model.py:47-49, 132-198), SoA out[23][ld_out]:
  *   rows 0..11  get_extended_state()[:, :12]  (xdot)
  *   rows 12..14 get_acceleration()            (ax, ay, az)
  *   rows 15..17 get_accels()                  (nx_cg, ny_cg, nz_cg)
  *   row  18     get_EAS2TAS()
- *   row  19     get_EAS()                                                                  */
+ *   row  19     get_EAS()
+ *   rows 20..22 get_atmos()                   (mach, qbar, ps; F16_model.py:183-198)      */
 int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, int64_t ld, float *out,
                    int64_t ld_out, void *stream);
 

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 ASSET_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'f16_aero_mlp.bin')
-NUM_DERIVED = 20
+NUM_DERIVED = 23
 NUM_NETS = 43
 NUM_CACHED = 14
 
@@ -193,6 +193,22 @@ class F16Batch:
         self._version += 1
         return obs
 
+    def observe(self, noise=None):
+        """BaseEnv.obs() (env_base.py:58-59 -> task.get_obs): the observation of the CURRENT state, nothing else changes (no row
+        is re-initialised, flags and counters stay).  One np_f16_reset launch with an all-clear flag input; the noise is a fresh
+        draw (the call counter advances, as the reference's obs() advances torch's generator)."""
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        scratch = torch.zeros((2, 3, self.n), dtype=torch.uint8, device=self.device)   # [0]: all-clear input flags, [1]: discarded output
+        keep = self.flags
+        self.flags = scratch[0]
+        try:
+            io = self._io(scratch[1], None, obs, None, None, self._inject(noise, 22))
+            _lib.check(self.lib.np_f16_reset(self._ctx, self.n, C.byref(io), self._stream()))
+        finally:
+            self.flags = keep
+        self.call_idx += 1
+        return obs
+
     def step(self, action, rand_u=None, noise=None, inner=False):
         """BaseEnv.step(action): ONE kernel launch.  Returns obs, reward, flags[3,n] (uint8).
         inner=True: one low-level iteration of PlanningEnv.step (np_f16_io.inner_step)."""
@@ -238,7 +254,7 @@ class F16Batch:
         return out
 
     def derived(self):
-        """[20,n] derived quantities at the current (s,u) (np_f16_derived), cached per state version."""
+        """[23,n] derived quantities at the current (s,u) (np_f16_derived), cached per state version."""
         key = (self._version, self.s.data_ptr(), self.u.data_ptr(), self.s._version, self.u._version)
         if self._derived is None or self._derived_key != key:
             out = torch.empty((NUM_DERIVED, self.n), dtype=torch.float32, device=self.device)
@@ -428,6 +444,20 @@ class F16CombatBatch:
         self.flags = new_flags
         self.call_idx += 1
         self._version += 1
+        return obs
+
+    def observe(self):
+        """SingleCombatEnv.obs() (singlecombat_env.py:64-138): the pairwise observation of the CURRENT state; no env is
+        re-initialised, flags, blood, counters and controller state stay (one np_f16_combat_reset launch with all-clear flags)."""
+        obs = torch.empty((self.n, NUM_OBS_COMBAT), dtype=torch.float32, device=self.device)
+        scratch = torch.zeros((2, 3, self.n), dtype=torch.uint8, device=self.device)
+        keep = self.flags
+        self.flags = scratch[0]
+        try:
+            io = self._io(scratch[1], None, obs, None, None)
+            _lib.check(self.lib.np_f16_combat_reset(self._ctx, self.num_envs, C.byref(io), self._stream()))
+        finally:
+            self.flags = keep
         return obs
 
     def step(self, action, rand_u=None):

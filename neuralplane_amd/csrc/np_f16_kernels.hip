@@ -492,7 +492,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
     }
 }
 
-// F16Model getters that need the dynamics (F16_model.py:47-49, 132-181): out[20][ld_out]
+// F16Model getters that need the dynamics or the atmosphere (F16_model.py:47-49, 132-198): out[23][ld_out]
 __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                             long long ld, float *__restrict__ out, long long ld_out,
                                                             long long n, float airspeed, int tables, AeroWeights wt) {
@@ -520,6 +520,15 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     const float nz = minv_grav * a3[2] + tr.ct * tr.cphi;
     const float e2t = eas2tas_of(s[2]);
     const float eas = (s[6] + airspeed * 1.0f) / e2t;
+    // F16Model.get_atmos (F16_model.py:183-198 == F16Dynamics.atmos, F16_dynamics.py:22-35): mach, qbar, ps
+    const float tfac = 1.0f - 0.703e-5f * s[2];
+    float temp = 519.0f * tfac;
+    temp = (s[2] >= 35000.0f ? 1.0f : 0.0f) * 390.0f + (s[2] < 35000.0f ? 1.0f : 0.0f) * temp;
+    const float rho = 2.377e-3f * np_pow(tfac, 4.14f);
+    const float mach = s[6] / sqrtf((float)(1.4 * 1716.3) * temp);
+    const float qbar = (0.5f * rho) * (s[6] * s[6]);
+    float ps = (1715.0f * rho) * temp;
+    ps = (ps == 0.0f ? 1.0f : 0.0f) * 1715.0f + (ps != 0.0f ? 1.0f : 0.0f) * ps;
     if (!valid) return;
 #pragma unroll
     for (int k = 0; k < 12; k++) out[k * ld_out + i] = xd[k];
@@ -530,6 +539,9 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     out[17 * ld_out + i] = nz;
     out[18 * ld_out + i] = e2t;
     out[19 * ld_out + i] = eas;
+    out[20 * ld_out + i] = mach;
+    out[21 * ld_out + i] = qbar;
+    out[22 * ld_out + i] = ps;
 }
 
 // hifi_F16.hifi_C / hifi_damping / hifi_C_lef / hifi_damping_lef / hifi_rudder / hifi_ailerons / hifi_other_coeffs

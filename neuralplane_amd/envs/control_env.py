@@ -24,3 +24,5 @@ class ControlEnv(BaseEnv):
         batch = self._make_batch(config, random_seed)
         self.model = F16Model(self.config, self.n, self.device, random_seed, batch)
         self.task = _TASKS[config](self.config, self.n, self.device, random_seed, batch)
+        if random_seed is not None:      # env_base.py:43-44: construction with a seed seeds the process-wide generators too
+            self.model.seed(random_seed)

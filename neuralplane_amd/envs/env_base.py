@@ -81,7 +81,22 @@ class BaseEnv(Env):
         return self.n
 
     def seed(self, random_seed):
+        """env_base.py:36-40 seeds the process-wide generators (torch, numpy, random); the env's own draws are counter-based and
+        keyed by the same seed."""
+        self.model.seed(random_seed)
         self._batch.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
+
+    # -- the three pieces BaseEnv.step is made of in the reference (env_base.py:58-72) --------------------------------------------
+    def obs(self):
+        """Observation of the current state (task.get_obs): one kernel launch, nothing else changes."""
+        return self._batch.observe()
+
+    def reward(self):
+        raise RuntimeError('BaseEnv.reward is fused into step() (one HIP kernel): use the reward step() returns')
+
+    def done(self, info=None):
+        raise RuntimeError('BaseEnv.done is fused into step() (one HIP kernel): use the masks step() returns '
+                           '(also kept as env.is_done / env.bad_done / env.exceed_time_limit)')
 
     def termination_counts(self, reset=False):
         """Per-condition termination statistics accumulated on the device (the reference prints them every step)."""

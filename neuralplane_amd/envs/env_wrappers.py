@@ -1,5 +1,7 @@
 """GPUVecEnv — numpy <-> torch adapter with the reference's contract (envs/env_wrappers.py:84-123):
 `reset() -> np[E,A,obs]`, `step(np[E,A,act]) -> (np[E,A,obs], np[E,A,1] x4, info)`."""
+from abc import ABC, abstractmethod
+
 import numpy as np
 import torch
 
@@ -8,10 +10,46 @@ def _t2n(x):
     return x.detach().cpu().numpy()
 
 
-class GPUVecEnv:
+class VecEnv(ABC):
+    """The reference's abstract vectorised-env protocol (envs/env_wrappers.py:9-82): reset / step_async / step_wait / close,
+    with step() = step_async + step_wait."""
+    closed = False
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_async(self, actions):
+        pass
+
+    @abstractmethod
+    def step_wait(self):
+        pass
+
+    def close_extras(self):
+        pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.close_extras()
+        self.closed = True
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+
+class GPUVecEnv(VecEnv):
     def __init__(self, env_fns):
         assert len(env_fns) == 1, 'GPUVecEnv wraps exactly one batched env'
-        self.env = env_fns[0]()
+        self.env = self.gpu_vec_env = env_fns[0]()      # `gpu_vec_env`: the attribute name of the reference (env_wrappers.py:88)
         self.num_envs = self.env.num_envs
         self.agents = self.num_agents = self.env.num_agents
         self.n = self.env.n

@@ -130,3 +130,8 @@ class F16Model(BaseModel):
 
     def get_EAS2TAS(self):
         return self._b.derived()[18]
+
+    def get_atmos(self):
+        """(mach, qbar, ps) — F16_model.py:183-198."""
+        d = self._b.derived()
+        return d[20], d[21], d[22]

@@ -40,6 +40,11 @@ class _ActorArgs:  # planning_env.py:18-29
         self.use_prior = False
 
 
+class Args(_ActorArgs):  # the reference's name for the same object (planning_env.py:18: built for the CPU by default)
+    def __init__(self, device=torch.device('cpu')):
+        super().__init__(device)
+
+
 class PlanningEnv(BaseEnv):
     def __init__(self, num_envs=1, config='tracking', model='F16', random_seed=None, device='cuda:0', controller=None,
                  controller_checkpoint=None, row0=0, aero_1d_tables=None):

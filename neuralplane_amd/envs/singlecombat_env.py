@@ -83,6 +83,19 @@ class SingleCombatEnv(Env):
     def seed(self, random_seed):
         self._batch.seed = int(random_seed) & 0xFFFFFFFFFFFFFFFF
 
+    # -- pieces of the reference's step (singlecombat_env.py:60-181) -------------------------------------------------------------
+    def obs(self):
+        """Pairwise observation obs[n,15] of the current state: one kernel launch, nothing else changes."""
+        return self._batch.observe()
+
+    def reward(self):
+        raise RuntimeError('SingleCombatEnv.reward is fused into step() (one HIP kernel): use the reward step() returns')
+
+    def update_recent_s(self, s):
+        """singlecombat_env.py:60-62 keeps the last two states for code that is commented out there (:141-142); kept as host
+        bookkeeping only."""
+        self.recent_s = [s, getattr(self, 'recent_s', [None, None])[0]]
+
     def termination_counts(self, reset=False):
         return self._batch.termination_counts(reset=reset)
 

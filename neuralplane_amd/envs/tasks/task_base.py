@@ -27,6 +27,31 @@ class BaseTask:
     def noise_scale(self):
         return self._b.noise_scale
 
+    # -- the reference's task protocol (task_base.py:33-96) ------------------------------------------------------------------------
+    def load_observation_space(self):
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.num_observation,))
+
+    def load_action_space(self):
+        self.action_space = Box(low=-np.inf, high=np.inf, shape=(self.num_actions,))
+
+    def seed(self, random_seed):
+        """task_base.py:45-49: the process-wide generators, as BaseModel.seed."""
+        from ..models.model_base import BaseModel
+        BaseModel.seed(self, random_seed)
+
+    def get_obs(self, env):
+        """Observation of the env's current state (one kernel launch)."""
+        return env.obs()
+
+    def reset(self, env):
+        raise RuntimeError('task.reset is fused into BaseEnv.reset()/step() (one HIP kernel)')
+
+    def get_reward(self, env):
+        raise RuntimeError('task.get_reward is fused into BaseEnv.step() (one HIP kernel)')
+
+    def get_termination(self, env, info=None):
+        raise RuntimeError('task.get_termination is fused into BaseEnv.step() (one HIP kernel)')
+
     def _target(self, k):
         return self._b.tgt[k]
 

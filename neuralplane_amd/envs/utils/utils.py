@@ -2,14 +2,19 @@
 
 Mirrors the interface of the reference's envs/utils/utils.py: `parse_config` (:12-27) returns an
 attribute bag whose keys are read with getattr(config, key, default); `wrap_PI` / `wrap_2PI`
-(:144-154) are provided for callers that use them on tensors (PID, renders).  The hot path does
-not call these: the kernels carry their own bit-exact wrap (csrc/np_math.h).
+(:144-154) are provided for callers that use them on tensors (PID, renders), as are the geodesy and pairwise
+geometry helpers (geometry.py).  The hot path does not call these: the kernels carry their own bit-exact
+versions (csrc/np_math.h, csrc/np_f16_combat.h).
 """
 import os
 
 import torch
 import yaml
 
+# WGS-84 conversions and the pairwise combat geometry / shaping functions of utils.py:35-250 (host-side helpers; the fused kernels
+# evaluate the same geometry themselves)
+from .geometry import (distance_fn, ecef_to_enu, ecef_to_geodetic, enu_to_ecef, enu_to_geodetic, geodetic_to_ecef,  # noqa: F401
+                       geodetic_to_enu, get2d_AO_TA_R, get_AO_TA_R, orientation_fn, orientation_reward, range_reward)
 
 CONFIG_DIR = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir, 'configs'))
 

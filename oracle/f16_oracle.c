@@ -716,6 +716,27 @@ void f16o_get_eas2tas(int64_t n, const float *s, float *out) {
     for (int64_t i = 0; i < n; i++) out[i] = eas2tas_row(s[12 * i + 2]);
 }
 
+/* F16Model.get_atmos — envs/models/F16_model.py:183-198 (the same arithmetic as F16Dynamics.atmos, F16_dynamics.py:22-35):
+ * (mach, qbar, ps) from altitude and airspeed.  `(alt >= 35000.0) * 390 + (alt < 35000.0) * temp` selects; `1.4 * 1716.3` is a
+ * Python double product rounded to fp32 when it meets the tensor; pow(vt, 2) is vt * vt in ATen. */
+void f16o_get_atmos(int64_t n, const float *s, float *out3) {
+    const float c_gas = (float)(1.4 * 1716.3);
+    for (int64_t i = 0; i < n; i++) {
+        float alt = s[12 * i + 2], vt = s[12 * i + 6];
+        float tfac = 1.0f - 0.703e-5f * alt;
+        float temp = 519.0f * tfac;
+        temp = (float)(alt >= 35000.0f) * 390.0f + (float)(alt < 35000.0f) * temp;
+        float rho = 2.377e-3f * f16o_pow(tfac, 4.14f);
+        float mach = vt / sqrtf(c_gas * temp);
+        float qbar = (0.5f * rho) * (vt * vt);
+        float ps = (1715.0f * rho) * temp;
+        ps = (float)(ps == 0.0f) * 1715.0f + (float)(ps != 0.0f) * ps;
+        out3[3 * i + 0] = mach;
+        out3[3 * i + 1] = qbar;
+        out3[3 * i + 2] = ps;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* env: reset / update / obs / termination / reward                                            */
 /* ------------------------------------------------------------------------------------------ */

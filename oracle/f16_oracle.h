@@ -71,6 +71,7 @@ void f16o_nlplant(const f16o_model *m, int64_t n, const float *x17, float *xdot1
 void f16o_get_acceleration(const f16o_model *m, int64_t n, const float *s, const float *u, float *a3);
 void f16o_get_accels(const f16o_model *m, int64_t n, const float *s, const float *u, float *n3);
 void f16o_get_eas2tas(int64_t n, const float *s, float *out);
+void f16o_get_atmos(int64_t n, const float *s, float *out3); /* (mach, qbar, ps) per row */
 
 /* Elementary functions of the numerics spec, exposed for unit tests. */
 void f16o_sincos(float x, float *s, float *c);

@@ -202,6 +202,14 @@ class Oracle:
         self.lib.f16o_get_eas2tas(C.c_int64(s.shape[0]), _p(s), _p(out))
         return out
 
+    def get_atmos(self, s):
+        """F16Model.get_atmos (F16_model.py:183-198) -> [n, 3] (mach, qbar, ps)."""
+        self._set_mode()
+        s = _f32(s)
+        out = np.empty((s.shape[0], 3), dtype=np.float32)
+        self.lib.f16o_get_atmos(C.c_int64(s.shape[0]), _p(s), _p(out))
+        return out
+
     # ---- env level -----------------------------------------------------------------------
     @staticmethod
     def new_state(n):

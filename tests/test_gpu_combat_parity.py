@@ -352,3 +352,24 @@ def test_two_rank_hip_selfplay_loop_equals_single_process_run(lag):
     want = _hip_selfplay_loop(e_total, 0, e_total, None, steps, lag)
     for g_, w_ in zip(got, want):
         assert np.array_equal(g_, w_)
+
+
+def test_combat_obs_is_the_observation_of_the_current_state_and_changes_nothing():
+    """SingleCombatEnv.obs() (singlecombat_env.py:64-138): no noise in this env, so it must repeat the observation the last step
+    returned, and leave state, blood, controller state, counters and flags alone."""
+    from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+    env = SingleCombatEnv(num_envs=96, config='selfplay', random_seed=4, device='cuda:0')
+    env.reset()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for _ in range(30):
+        out = env.step(torch.rand((env.n, 4), device='cuda', generator=g) * 2 - 1)
+    b = env._batch
+    before = {k: getattr(b, k).clone() for k in ('s', 'u', 'pid', 'blood', 'step_count', 'flags')}
+    obs = env.obs()
+    assert torch.equal(obs, out[0])
+    for k, v in before.items():
+        assert torch.equal(getattr(b, k), v), k
+    with pytest.raises(RuntimeError, match='fused'):
+        env.reward()
+    env.update_recent_s(env.s)
+    assert env.recent_s[0] is not None

@@ -123,10 +123,48 @@ def test_derived_getters_bit_exact_vs_oracle(golden_dir):
     assert _same(d[12:15].T, o.get_acceleration(g['s'], g['u']))
     assert _same(d[15:18].T, o.get_accels(g['s'], g['u']))
     assert _same(d[18], o.get_eas2tas(g['s']))
+    assert _same(d[20:23].T, o.get_atmos(g['s']))                  # F16Model.get_atmos: (mach, qbar, ps)
+    assert np.abs(d[20:23].T - g['atmos']).max() / 2000 < 1e-6
     # vs the reference itself
     err = np.abs(d[12:15].T - g['accel']) / np.maximum(np.abs(g['accel']), 1.0)
     assert err.max() < 1e-4
     assert np.abs(d[18] - g['eas2tas']).max() < 1e-6 and np.abs(d[19] - g['eas']).max() / 1000 < 1e-6
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_env_obs_is_the_observation_of_the_current_state_and_changes_nothing(task):
+    """BaseEnv.obs() (env_base.py:58-59): what task.get_obs returns for the state as it is — here one launch of the reset kernel
+    with all-clear flags.  Equal to the oracle's observation of that state (its noise draw keyed by the same call counter), and
+    state, targets, counters and the flags left by the last step are untouched, flagged rows included."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    n, seed = 200, 9
+    env = ControlEnv(num_envs=n, config=task, model='F16', random_seed=seed, device='cuda:0')
+    env.reset()
+    rng = np.random.RandomState(2)
+    for _ in range(40):
+        a = torch.from_numpy(rng.uniform(-1.5, 1.5, (n, 4)).astype(np.float32)).cuda()
+        last = env.step(a)
+    b = env._batch
+    b.s[7, :5] = 1.2                                                  # push a few rows over a limit: flagged by the next step
+    last = env.step(a)
+    before = {k: getattr(b, k).clone() for k in ('s', 'u', 'tgt', 'step_count', 'flags')}
+    assert before['flags'].any()
+    call_idx = b.call_idx
+    obs = env.obs()
+    for k, v in before.items():
+        assert torch.equal(getattr(b, k), v), k
+    assert b.call_idx == call_idx + 1
+    st = dict(s=before['s'].t().cpu().numpy().copy(), u=before['u'].t().cpu().numpy().copy(),
+              tgt=before['tgt'].t().cpu().numpy().copy(), step_count=before['step_count'].cpu().numpy().copy(),
+              done=np.zeros(n, np.uint8), bad=np.zeros(n, np.uint8), timeout=np.zeros(n, np.uint8))
+    o_obs = Oracle(task).reset(st, seed=seed, call_idx=call_idx, row0=0)
+    assert _same(obs.cpu().numpy(), o_obs)
+    if env.task.noise_scale == 0:                                     # tracking.yaml: the step's own observation, again
+        assert torch.equal(obs, last[0])
+    assert env.task.get_obs(env).shape == obs.shape
+    for fn in (env.reward, env.done, lambda: env.task.get_reward(env), lambda: env.task.reset(env)):
+        with pytest.raises(RuntimeError, match='fused'):
+            fn()
 
 
 def test_cross_step_cache_is_invalidated_by_external_state_edits():

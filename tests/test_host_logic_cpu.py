@@ -195,3 +195,76 @@ def test_bench_self_launch_and_prelude_count(monkeypatch):
     assert tm.prelude(0.0, i0=0, est_step_s=0.004)[0] == 0
     st = bench.stats([0.3, 0.1, 0.2])
     assert st['kernel_median_ms'] == 0.2 and st['kernel_min_ms'] == 0.1 and st['launches_timed'] == 3
+
+
+# ---------------------------------------------------------------------------------------------------
+# the env-side API surface of the reference, name by name (tests/golden/ref_api_surface.json <- tools/gen_api_surface.py)
+# ---------------------------------------------------------------------------------------------------
+def test_mirror_defines_every_name_of_the_reference_env_surface(golden_dir):
+    import ast
+    import json
+    import os
+    ref = json.load(open(f'{golden_dir}/ref_api_surface.json'))
+    root = os.path.join(os.path.dirname(golden_dir), '..', 'neuralplane_amd')
+    missing = []
+    for rel, surf in ref.items():
+        tree = ast.parse(open(os.path.join(root, rel)).read())
+        classes = {n.name: n for n in tree.body if isinstance(n, ast.ClassDef)}
+        names = {n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
+        for node in tree.body:                                       # names re-exported from a sibling module count
+            if isinstance(node, ast.ImportFrom):
+                names |= {a.asname or a.name for a in node.names}
+        for cls, methods in surf['classes'].items():
+            if cls not in classes:
+                missing.append(f'{rel}: class {cls}')
+                continue
+            have = {m.name for m in classes[cls].body if isinstance(m, ast.FunctionDef)}
+            have |= {t.id for m in classes[cls].body if isinstance(m, ast.Assign) for t in m.targets if isinstance(t, ast.Name)}
+            missing += [f'{rel}: {cls}.{m}' for m in methods if m not in have]
+        missing += [f'{rel}: {f}()' for f in surf['functions'] if f not in names]
+    assert not missing, missing
+
+
+def test_geodesy_helpers_against_the_reference(golden_dir):
+    from neuralplane_amd.envs.utils import utils as U
+    g = np.load(f'{golden_dir}/geodesy_kat.npz')
+    rows = range(len(g['lat']))
+    ecef = np.array([U.geodetic_to_ecef(g['lat'][i], g['lon'][i], g['h'][i]) for i in rows])
+    assert np.abs(ecef - g['ecef']).max() < 1e-6
+    enu = np.array([U.ecef_to_enu(*g['ecef'][i], g['lat0'][i], g['lon0'][i], g['h0'][i]) for i in rows])
+    assert np.abs(enu - g['enu']).max() < 1e-6
+    enu2 = np.array([U.geodetic_to_enu(g['lat'][i], g['lon'][i], g['h'][i], g['lat0'][i], g['lon0'][i], g['h0'][i]) for i in rows])
+    assert np.abs(enu2 - g['enu2']).max() < 1e-6
+    back = np.array([U.enu_to_ecef(*g['enu_in'][i], g['lat0'][i], g['lon0'][i], g['h0'][i]) for i in rows])
+    assert np.abs(back - g['ecef_from_enu']).max() < 1e-6
+    for got, key in ((np.array([U.ecef_to_geodetic(*g['ecef'][i]) for i in rows]), 'geo_from_ecef'),
+                     (np.array([U.enu_to_geodetic(*g['enu_in'][i], g['lat0'][i], g['lon0'][i], g['h0'][i]) for i in rows]), 'geo_from_enu')):
+        assert np.abs(got[:, :2] - g[key][:, :2]).max() < 1e-11 and np.abs(got[:, 2] - g[key][:, 2]).max() < 1e-6
+    # the round trip closes, also on the polar axis
+    assert np.allclose(U.ecef_to_geodetic(*U.geodetic_to_ecef(47.0, -122.0, 1234.5)), (47.0, -122.0, 1234.5), atol=1e-9)
+    assert abs(U.ecef_to_geodetic(0.0, 0.0, 6.4e6)[0] - 90.0) < 1e-12
+
+
+def test_pairwise_helpers_against_the_reference(golden_dir):
+    """get_AO_TA_R ... distance_fn on tensors (utils.py:156-250): the golden vectors the combat oracle is pinned with."""
+    from neuralplane_amd.envs.utils import utils as U
+    p = np.load(f'{golden_dir}/pairwise_kat.npz')
+    T = [torch.from_numpy(p[k]) for k in ('ego_pos', 'enm_pos', 'ego_vel', 'enm_vel')]
+    AO, TA, R = U.get_AO_TA_R(*T)
+    AO2, TA2, R2, side = U.get2d_AO_TA_R(*T, return_side=True)
+    assert len(U.get_AO_TA_R(*T, return_side=True)) == 4 and len(U.get2d_AO_TA_R(*T)) == 3
+    Rkm = R * 0.3048 / 1000
+    got = dict(AO=AO, TA=TA, R=R, AO2=AO2, TA2=TA2, R2=R2, side=side, orient=U.orientation_reward(AO, TA), range=U.range_reward(3, Rkm),
+               ofn=U.orientation_fn(AO), dfn=U.distance_fn(Rkm))
+    for k, v in got.items():
+        ref = p[k]
+        err = np.abs(v.numpy() - ref) / np.maximum(np.abs(ref), 1.0)
+        assert np.nanmax(err) < 1e-6, k
+        assert np.array_equal(np.isnan(v.numpy()), np.isnan(ref)), k
+    for fn, args in ((U.orientation_reward, (AO, TA)), (U.range_reward, (3, Rkm))):
+        with pytest.raises(NotImplementedError):
+            fn(*args, version='v9')
+    for v in ('v0', 'v1'):
+        assert torch.isfinite(U.orientation_reward(AO[4:], TA[4:], version=v)).all()
+    for v in ('v0', 'v1', 'v2'):
+        assert torch.isfinite(U.range_reward(3, Rkm, version=v)).all()

@@ -156,10 +156,12 @@ def test_model_getters(golden_dir):
     assert same(o.get_acceleration(g['s'], g['u']), g['accel_pin'])
     assert same(o.get_accels(g['s'], g['u']), g['accels_pin'])
     assert same(o.get_eas2tas(g['s']), g['eas2tas_pin'])
+    assert same(o.get_atmos(g['s']), g['atmos_pin'])
     o = Oracle('heading')
     assert relerr(o.get_acceleration(g['s'], g['u']), g['accel'], 1.0) < 1e-4
     assert relerr(o.get_accels(g['s'], g['u']), g['accels'], 0.1) < 1e-4
     assert relerr(o.get_eas2tas(g['s']), g['eas2tas'], 1.0) < 1e-6
+    assert relerr(o.get_atmos(g['s']), g['atmos'], np.array([0.01, 1.0, 1.0], np.float32)) < 1e-6   # (mach, qbar, ps), F16_model.py:183-198
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -268,6 +268,7 @@ def gen_getters(env_unused):
             out['eas2tas' + sfx] = m.get_EAS2TAS().numpy()
             out['eas' + sfx] = m.get_EAS().numpy()
             out['xdot' + sfx] = m.get_extended_state().numpy()[:, :12]
+            out['atmos' + sfx] = torch.stack(m.get_atmos(), 1).numpy()      # (mach, qbar, ps), F16_model.py:183-198
     np.savez_compressed(os.path.join(OUT, 'getters_kat.npz'), s=s, u=u, **out)
 
 
@@ -638,6 +639,25 @@ def gen_pairwise():
                         **{k: v.numpy() for k, v in out.items()})
 
 
+def gen_geodesy():
+    """Known-answer vectors of the WGS-84 helpers (envs/utils/utils.py:35-142), scalar float64."""
+    from utils.utils import geodetic_to_ecef, ecef_to_enu, enu_to_ecef, ecef_to_geodetic, geodetic_to_enu, enu_to_geodetic
+    rng = np.random.RandomState(77)
+    n = 256
+    lat, lon, h = rng.uniform(-89, 89, n), rng.uniform(-180, 180, n), rng.uniform(-500, 30000, n)
+    lat0, lon0, h0 = rng.uniform(-80, 80, n), rng.uniform(-180, 180, n), rng.uniform(0, 3000, n)
+    enu_in = rng.uniform(-2e5, 2e5, (n, 3))
+    lat0[:4], lon0[:4], h0[:4] = [0, 60, 60, -33.9], [0, 120, 120, 151.2], [0, 0, 0, 12.0]     # incl. the recorder's origin
+    out = dict(lat=lat, lon=lon, h=h, lat0=lat0, lon0=lon0, h0=h0, enu_in=enu_in)
+    out['ecef'] = np.array([geodetic_to_ecef(a, b, c) for a, b, c in zip(lat, lon, h)])
+    out['enu'] = np.array([ecef_to_enu(*e, a, b, c) for e, a, b, c in zip(out['ecef'], lat0, lon0, h0)])
+    out['enu2'] = np.array([geodetic_to_enu(a, b, c, d, e, f) for a, b, c, d, e, f in zip(lat, lon, h, lat0, lon0, h0)])
+    out['ecef_from_enu'] = np.array([enu_to_ecef(*v, a, b, c) for v, a, b, c in zip(enu_in, lat0, lon0, h0)])
+    out['geo_from_ecef'] = np.array([ecef_to_geodetic(*e) for e in out['ecef']])
+    out['geo_from_enu'] = np.array([enu_to_geodetic(*v, a, b, c) for v, a, b, c in zip(enu_in, lat0, lon0, h0)])
+    np.savez_compressed(os.path.join(OUT, 'geodesy_kat.npz'), **out)
+
+
 PID_STATE = ('roll_dem', 'pitch_dem', 'roll_err', 'roll_int', 'roll_last', 'pitch_err', 'pitch_int', 'pitch_last',
              'yaw_err', 'yaw_int', 'yaw_last')
 
@@ -838,6 +858,7 @@ def gen_actor(n=96, steps=4):
 
 
 def gen_combat_all():
+    gen_geodesy()
     gen_pairwise()
     gen_combat(pin=True)
     gen_combat(pin=False)
@@ -919,6 +940,12 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'actor':
         gen_actor()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'geodesy':
+        gen_geodesy()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'getters':
+        gen_getters(None)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'model_grid':
         gen_model_grid(make_env('heading', 4))
