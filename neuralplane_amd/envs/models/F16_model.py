@@ -8,7 +8,7 @@ state version.  The FDM step itself is not here: it is fused into BaseEnv.step's
 """
 import torch
 
-from .F16.hifi_F16_AeroData import hifi_F16
+from .F16.F16_dynamics import F16Dynamics
 from .model_base import BaseModel
 
 
@@ -28,7 +28,8 @@ class F16Model(BaseModel):
         self.init_state = config.init_state
         self.recent_s = None
         self.recent_u = None
-        self.hifi_F16 = hifi_F16(batch)   # the surrogate object F16Dynamics holds (F16_dynamics.py:13)
+        self.dynamics = F16Dynamics(batch)          # F16_model.py:20; `dynamics.hifi_F16` is the surrogate object (F16_dynamics.py:13)
+        self.hifi_F16 = self.dynamics.hifi_F16
 
     # state / control as the reference lays them out ([n,k]); views, not copies
     @property

@@ -1,0 +1,3 @@
+"""ControlTask under the reference's module path (envs/tasks/control_task.py); the class itself lives in task_base.py — target re-draw,
+observation, reward and termination of this task are fused into the HIP step / reset kernels."""
+from .task_base import ControlTask  # noqa: F401

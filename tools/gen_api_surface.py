@@ -11,7 +11,8 @@ import os
 
 REF = '/root/reference'
 FILES = ['envs/env_base.py', 'envs/control_env.py', 'envs/planning_env.py', 'envs/singlecombat_env.py', 'envs/env_wrappers.py',
-         'envs/models/model_base.py', 'envs/models/F16_model.py', 'envs/tasks/task_base.py', 'envs/utils/utils.py']
+         'envs/models/model_base.py', 'envs/models/F16_model.py', 'envs/models/F16/F16_dynamics.py', 'envs/tasks/task_base.py',
+         'envs/tasks/heading_task.py', 'envs/tasks/control_task.py', 'envs/tasks/tracking_task.py', 'envs/utils/utils.py']
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'ref_api_surface.json')
 
 
