@@ -107,6 +107,10 @@ typedef struct np_f16_io {
      * (`print(torch.sum(bad_done), ...)`, envs/termination_conditions/<condition>.py) at the price of a host sync each.  Order:
      * overload, low_altitude, high_speed, low_speed, extreme_state, unreach_* (bad), target reached (done). */
     uint32_t *term_counters;
+    /* Optional DEVICE bytes [n] written by np_f16_step: the same conditions per aircraft (bit k = counter k above) at the state
+     * reached by this step — which of the termination-condition classes (envs/termination_conditions/*.py, called from
+     * task_base.py:75-96) fired for which row.  NULL = not wanted. */
+    uint8_t *term_reasons;
 } np_f16_io;
 
 typedef struct np_f16_ctx np_f16_ctx;

@@ -101,6 +101,8 @@ class F16Batch:
         self.call_base = torch.zeros(1, dtype=torch.int64, device=d)
         # per-condition termination counters (np_f16_io.term_counters), accumulated on the device, read lazily
         self.term_counters = torch.zeros(7, dtype=torch.int32, device=d)
+        # per-aircraft condition bits of the last step (np_f16_io.term_reasons); allocated by track_termination_reasons()
+        self.term_reasons = None
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -134,6 +136,7 @@ class F16Batch:
         io.seed, io.call_idx, io.row0 = self.seed, int(call_offset), self.row0
         io.call_idx_base = self.call_base.data_ptr()
         io.term_counters = self.term_counters.data_ptr()
+        io.term_reasons = self.term_reasons.data_ptr() if self.term_reasons is not None else None
         fn = self.lib.np_f16_reset if action is None else self.lib.np_f16_step
         _lib.check(fn(self._ctx, self.n, C.byref(io), self._stream()))
 
@@ -150,6 +153,7 @@ class F16Batch:
             io.coef_cache = self.coef_cache.data_ptr()
             io.call_idx_base = None
             io.term_counters = self.term_counters.data_ptr()
+        io.term_reasons = self.term_reasons.data_ptr() if self.term_reasons is not None else None
         n = self.n
         if not self.flags.is_contiguous():
             self.flags = self.flags.contiguous()
@@ -299,6 +303,16 @@ class F16Batch:
         return [float(buf[i]) for i in range(cnt.value)]
 
     TERM_NAMES = ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'unreach', 'reached')
+
+    def track_termination_reasons(self, enable=True):
+        """Have every following step also write, per aircraft, WHICH conditions fired (uint8[n], bit k = TERM_NAMES[k]) — the
+        per-row version of the counters below; one more byte stored per aircraft and step.  Returns the tensor (zeros until the
+        next step)."""
+        if enable and self.term_reasons is None:
+            self.term_reasons = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        elif not enable:
+            self.term_reasons = None
+        return self.term_reasons
 
     def termination_counts(self, reset=False):
         """{condition: aircraft that tripped it since the last reset of the counters} — one small D2H copy, on demand (the

@@ -102,6 +102,13 @@ class BaseEnv(Env):
         """Per-condition termination statistics accumulated on the device (the reference prints them every step)."""
         return self._batch.termination_counts(reset=reset)
 
+    def termination_reasons(self):
+        """uint8[n]: which termination conditions fired for which aircraft at the state reached by the LAST step (bit k =
+        F16Batch.TERM_NAMES[k]: overload, low_altitude, high_speed, low_speed, extreme_state, unreach, reached).  The first call
+        switches the tracking on: the kernel then stores one more byte per aircraft and step; it reports from the next step on."""
+        r = self._batch.term_reasons
+        return r if r is not None else self._batch.track_termination_reasons(True)
+
     def state_dict(self):
         """Env-state checkpoint (tensors on the env device); see F16Batch.state_dict."""
         return self._batch.state_dict()

@@ -1,0 +1,16 @@
+"""UnreachPosture — control task: target pitch / heading / vt, same gates (unreach_posture.py); evaluated inside the step kernel, read back per aircraft."""
+import torch
+
+from .termination_condition_base import BITS, BaseTerminationCondition
+
+
+class UnreachPosture(BaseTerminationCondition):
+    def __init__(self, config, device=None):
+        super().__init__(config)
+        self.device = device
+
+    def get_termination(self, task, env, info={}):  # noqa: B006
+        reasons = env.termination_reasons()
+        bad_done = (reasons >> BITS['unreach']) & 1 != 0
+        done = (reasons >> BITS['reached']) & 1 != 0
+        return bad_done, done, torch.zeros_like(done), info

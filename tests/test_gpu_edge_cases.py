@@ -158,13 +158,20 @@ def test_termination_counters_match_per_condition_sums(task, variant):
     st = Oracle.new_state(n)
     rng = np.random.RandomState(1)
     expect = np.zeros(7, np.int64)
+    seen = np.zeros(n, np.uint8)
     for t in range(70):
         a = rng.uniform(-1.0, 1.0, (n, 4)).astype(np.float32)
         a[:, 1] = 1.0 if (t // 20) % 2 == 0 else -1.0
+        if t == 10:
+            reasons = b.track_termination_reasons(True)      # np_f16_io.term_reasons: the same conditions per aircraft, from here on
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
         o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=t)
         r = o.termination_reasons(st)
         expect += np.array([int(((r >> k) & 1).sum()) for k in range(7)])
+        if t >= 10:
+            assert np.array_equal(reasons.cpu().numpy(), r), f'per-aircraft condition bits differ from the oracle at step {t}'
+            seen |= r
+    assert sum(1 for k in range(7) if ((seen >> k) & 1).any()) >= 3
     _check(b, obs, rew, flags, st, o_obs, o_rew, 'final step')
     got = b.termination_counts()
     assert list(got.values()) == expect.tolist(), (got, expect)
@@ -266,3 +273,39 @@ def test_constant_division_sequence_equals_ieee_division_on_this_device_for_all_
         json.dump(rows, open(os.path.join(out, 'divc_selfcheck.json'), 'w'), indent=1)
     except OSError:
         pass
+
+
+def test_termination_condition_objects_read_the_step_kernels_verdict():
+    """envs/termination_conditions/*.py as objects: same constructors and get_termination(task, env, info) -> (bad_done, done,
+    exceed_time_limit, info) as the reference; each returns its bit of what the fused step found, and OR-ing them the way
+    task_base.py:75-96 does reproduces the three masks env.step returned."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.termination_conditions.extreme_state import ExtremeState
+    from neuralplane_amd.envs.termination_conditions.high_speed import HighSpeed
+    from neuralplane_amd.envs.termination_conditions.low_altitude import LowAltitude
+    from neuralplane_amd.envs.termination_conditions.low_speed import LowSpeed
+    from neuralplane_amd.envs.termination_conditions.overload import Overload
+    from neuralplane_amd.envs.termination_conditions.timeout import Timeout
+    from neuralplane_amd.envs.termination_conditions.unreach_heading import UnreachHeading
+    n = 600
+    env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=3, device='cuda:0')
+    conds = [Overload(env.config), LowAltitude(env.config), HighSpeed(env.config), LowSpeed(env.config), ExtremeState(env.config),
+             UnreachHeading(env.config, env.device), Timeout(env.config)]
+    env.termination_reasons()                                   # switches the per-aircraft bits on
+    env.reset()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    fired = 0
+    for t in range(330):
+        a = torch.rand((n, 4), device='cuda', generator=g) * 2 - 1
+        a[:, 1] = 1.0
+        obs, rew, done, bad, tmo, info = env.step(a)
+        bd = torch.zeros_like(bad)
+        dn = torch.zeros_like(done)
+        tl = torch.zeros_like(tmo)
+        for c in conds:
+            b_, d_, t_, info_ = c.get_termination(env.task, env, {})
+            assert b_.dtype == torch.bool and b_.shape == (n,) and info_ == {}
+            bd, dn, tl = bd | b_, dn | d_, tl | t_
+        assert torch.equal(bd, bad) and torch.equal(dn, done) and torch.equal(tl, tmo), t
+        fired += int(bad.sum()) + int(done.sum())
+    assert fired > 50

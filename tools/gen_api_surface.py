@@ -12,14 +12,19 @@ import os
 REF = '/root/reference'
 FILES = ['envs/env_base.py', 'envs/control_env.py', 'envs/planning_env.py', 'envs/singlecombat_env.py', 'envs/env_wrappers.py',
          'envs/models/model_base.py', 'envs/models/F16_model.py', 'envs/models/F16/F16_dynamics.py', 'envs/tasks/task_base.py',
-         'envs/tasks/heading_task.py', 'envs/tasks/control_task.py', 'envs/tasks/tracking_task.py', 'envs/utils/utils.py']
+         'envs/tasks/heading_task.py', 'envs/tasks/control_task.py', 'envs/tasks/tracking_task.py', 'envs/utils/utils.py',
+         'envs/termination_conditions/termination_condition_base.py'] + [
+    f'envs/termination_conditions/{m}.py' for m in ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'unreach_heading',
+                                                   'unreach_posture', 'unreach_target', 'timeout')]
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'ref_api_surface.json')
 
 
 def surface(path):
     tree = ast.parse(open(path).read())
-    classes = {n.name: sorted(m.name for m in n.body if isinstance(m, ast.FunctionDef)) for n in tree.body if isinstance(n, ast.ClassDef)}
-    functions = sorted(n.name for n in tree.body if isinstance(n, ast.FunctionDef))
+    public = lambda name: not name.startswith('_') or name.startswith('__')      # noqa: E731  (private helpers are not surface)
+    classes = {n.name: sorted(m.name for m in n.body if isinstance(m, ast.FunctionDef) and public(m.name))
+               for n in tree.body if isinstance(n, ast.ClassDef)}
+    functions = sorted(n.name for n in tree.body if isinstance(n, ast.FunctionDef) and public(n.name))
     return {'classes': classes, 'functions': functions}
 
 
