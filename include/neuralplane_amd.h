@@ -111,6 +111,10 @@ typedef struct np_f16_io {
      * reached by this step — which of the termination-condition classes (envs/termination_conditions/*.py, called from
      * task_base.py:75-96) fired for which row.  NULL = not wanted. */
     uint8_t *term_reasons;
+    /* Optional DEVICE floats [n] written by np_f16_step: the value of the task's own reward function (HeadingReward /
+     * PostureReward / PositionReward, envs/reward_functions/*.py) before EventDrivenReward's -200 * bad_done + 200 * done is added
+     * (task_base.py:60-73): `reward` = this + that, in fp32.  NULL = not wanted. */
+    float *reward_task;
 } np_f16_io;
 
 typedef struct np_f16_ctx np_f16_ctx;

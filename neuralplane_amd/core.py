@@ -103,6 +103,7 @@ class F16Batch:
         self.term_counters = torch.zeros(7, dtype=torch.int32, device=d)
         # per-aircraft condition bits of the last step (np_f16_io.term_reasons); allocated by track_termination_reasons()
         self.term_reasons = None
+        self.reward_task = None     # the task reward term of the last step (np_f16_io.reward_task); allocated by track_reward_terms()
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -137,6 +138,7 @@ class F16Batch:
         io.call_idx_base = self.call_base.data_ptr()
         io.term_counters = self.term_counters.data_ptr()
         io.term_reasons = self.term_reasons.data_ptr() if self.term_reasons is not None else None
+        io.reward_task = self.reward_task.data_ptr() if self.reward_task is not None else None
         fn = self.lib.np_f16_reset if action is None else self.lib.np_f16_step
         _lib.check(fn(self._ctx, self.n, C.byref(io), self._stream()))
 
@@ -154,6 +156,7 @@ class F16Batch:
             io.call_idx_base = None
             io.term_counters = self.term_counters.data_ptr()
         io.term_reasons = self.term_reasons.data_ptr() if self.term_reasons is not None else None
+        io.reward_task = self.reward_task.data_ptr() if self.reward_task is not None else None
         n = self.n
         if not self.flags.is_contiguous():
             self.flags = self.flags.contiguous()
@@ -313,6 +316,15 @@ class F16Batch:
         elif not enable:
             self.term_reasons = None
         return self.term_reasons
+
+    def track_reward_terms(self, enable=True):
+        """Have every following step also write the task's own reward term per aircraft (float32[n]; `reward` = it + the event
+        term -200 * bad_done + 200 * done).  Returns the tensor (zeros until the next step)."""
+        if enable and self.reward_task is None:
+            self.reward_task = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        elif not enable:
+            self.reward_task = None
+        return self.reward_task
 
     def termination_counts(self, reset=False):
         """{condition: aircraft that tripped it since the last reset of the counters} — one small D2H copy, on demand (the

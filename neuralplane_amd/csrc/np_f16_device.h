@@ -865,7 +865,7 @@ __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, 
 template <int TASK, class CFG>  // CFG: DevCfg, or DevCfg in the constant address space (scalar loads)
 __device__ __forceinline__ void done_and_reward(const CFG &cfg, const float (&s)[12], const float (&tgt)[3],
                                                 const float (&acc3)[3], long long step_count, bool done_prev, bool bad_prev,
-                                                bool &done, bool &bad, float &reward, unsigned &reasons) {
+                                                bool &done, bool &bad, float &reward, unsigned &reasons, float &reward_task) {
     // `reasons`: which condition fired at THIS state (NP_TERM_* bits) — what the reference prints per condition
     const float PI_F = 3.14159265358979323846f;
     const float acc = sqrtf((acc3[0] * acc3[0] + acc3[1] * acc3[1]) + acc3[2] * acc3[2]);
@@ -918,6 +918,7 @@ __device__ __forceinline__ void done_and_reward(const CFG &cfg, const float (&s)
     b |= bad_prev;                                               // env_base.py:72-74: flags accumulate until the next reset()
     const bool d = r_reach | done_prev;
     rew = 0.0f + rew;                                            // task_base.py:70-72
+    reward_task = rew;                                           // the task's own reward function, before the event term
     rew = rew + (float)(-200 * (int)b + 200 * (int)d);           // event_driven_reward.py:28
     done = d;
     bad = b;

@@ -83,6 +83,7 @@ struct KArgs {
     const uint64_t *call_idx_base;  // optional device word added to call_idx (launches replayed from a HIP graph)
     unsigned *term_counters;        // optional [NP_NUM_TERM_COUNTERS] per-condition counters (one atomic per wave and condition)
     unsigned char *term_reasons;    // optional [n]: the same conditions per aircraft, bit k = counter k
+    float *reward_task;             // optional [n]: the task's reward function alone (reward = this + the event term)
     long long row0, n;
     DevCfg cfg;
     // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once
@@ -368,7 +369,9 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
             // inner iterations: the env flags keep accumulating (env_base.py:72-74) and the event reward sees the sum
             const bool done_prev = INNER && at_off(ap->fin0, r32) != 0, bad_prev = INNER && at_off(ap->fin1, r32) != 0;
             unsigned reasons = 0;
-            done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons);
+            float reward_task = 0.0f;
+            done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons, reward_task);
+            if (ap->reward_task && valid && part == STATE_WAVE) ap->reward_task[i] = reward_task;  // wave-uniform pointer test
             if (ap->term_reasons && valid && part == STATE_WAVE) ap->term_reasons[i] = (unsigned char)reasons;  // wave-uniform pointer test
             if (ap->term_counters) {
                 // the reference prints torch.sum(mask) per termination condition and step (a host sync each); here: one wave
@@ -993,6 +996,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.call_idx_base = io->call_idx_base;
     a.term_counters = io->term_counters;
     a.term_reasons = STEP ? io->term_reasons : nullptr;
+    a.reward_task = STEP ? io->reward_task : nullptr;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
     a.wt = ctx->wt;

@@ -109,6 +109,17 @@ class BaseEnv(Env):
         r = self._batch.term_reasons
         return r if r is not None else self._batch.track_termination_reasons(True)
 
+    def reward_terms(self):
+        """(task term, event term) of the LAST step's reward, float32[n] each: the task's reward function (HeadingReward /
+        PostureReward / PositionReward) and EventDrivenReward's -200 * bad_done + 200 * done; their fp32 sum is the reward step()
+        returned.  The first call switches the tracking on (one more float stored per aircraft and step, from the next step on)."""
+        r = self._batch.reward_task
+        if r is None:
+            r = self._batch.track_reward_terms(True)
+        f = self._batch.flags
+        event = -200.0 * f[1].to(torch.float32) + 200.0 * f[0].to(torch.float32)
+        return r, event
+
     def state_dict(self):
         """Env-state checkpoint (tensors on the env device); see F16Batch.state_dict."""
         return self._batch.state_dict()

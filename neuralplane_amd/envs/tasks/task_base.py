@@ -63,8 +63,29 @@ def _target_property(k):
     return property(lambda self: self._target(k), lambda self, v: self._set_target(k, v))
 
 
+def _members(task, reward_cls, unreach_cls):
+    """`reward_functions` / `termination_conditions` as the reference's tasks list them (heading_task.py:34-48 and siblings; Timeout
+    is commented out there too).  The objects report what the fused step computed (reward_functions/, termination_conditions/)."""
+    from ..reward_functions.event_driven_reward import EventDrivenReward
+    from ..termination_conditions.extreme_state import ExtremeState
+    from ..termination_conditions.high_speed import HighSpeed
+    from ..termination_conditions.low_altitude import LowAltitude
+    from ..termination_conditions.low_speed import LowSpeed
+    from ..termination_conditions.overload import Overload
+    c = task.config
+    task.reward_functions = [reward_cls(c), EventDrivenReward(c)]
+    task.termination_conditions = [Overload(c), LowAltitude(c), HighSpeed(c), LowSpeed(c), ExtremeState(c), unreach_cls(c, task.device)]
+
+
 class HeadingTask(BaseTask):
     """targets: altitude [ft], heading [rad], vt [ft/s]  (heading_task.py:26-28)"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from ..reward_functions.heading_reward import HeadingReward
+        from ..termination_conditions.unreach_heading import UnreachHeading
+        _members(self, HeadingReward, UnreachHeading)
+
     target_altitude = _target_property(0)
     target_heading = _target_property(1)
     target_vt = _target_property(2)
@@ -72,6 +93,13 @@ class HeadingTask(BaseTask):
 
 class ControlTask(BaseTask):
     """targets: pitch [rad], heading [rad], vt [ft/s]  (control_task.py:27-29)"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from ..reward_functions.posture_reward import PostureReward
+        from ..termination_conditions.unreach_posture import UnreachPosture
+        _members(self, PostureReward, UnreachPosture)
+
     target_pitch = _target_property(0)
     target_heading = _target_property(1)
     target_vt = _target_property(2)
@@ -79,6 +107,13 @@ class ControlTask(BaseTask):
 
 class TrackingTask(BaseTask):
     """targets: npos, epos, altitude [ft]  (tracking_task.py:27-29)"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from ..reward_functions.position_reward import PositionReward
+        from ..termination_conditions.unreach_target import UnreachTarget
+        _members(self, PositionReward, UnreachTarget)
+
     target_npos = _target_property(0)
     target_epos = _target_property(1)
     target_altitude = _target_property(2)

@@ -307,5 +307,22 @@ def test_termination_condition_objects_read_the_step_kernels_verdict():
             assert b_.dtype == torch.bool and b_.shape == (n,) and info_ == {}
             bd, dn, tl = bd | b_, dn | d_, tl | t_
         assert torch.equal(bd, bad) and torch.equal(dn, done) and torch.equal(tl, tmo), t
+        # the same through the lists the task carries (heading_task.py:34-48), and the reward as the sum of its reward functions
+        bd2 = torch.zeros_like(bad)
+        for c in env.task.termination_conditions:
+            bd2 |= c.get_termination(env.task, env, {})[0]
+        assert torch.equal(bd2, bad)
+        if t > 0:      # the term tracking was switched on by the first call below, it reports from the following step on
+            terms = [f.get_reward(env.task, env) for f in env.task.reward_functions]
+            assert len(terms) == 2 and torch.equal((0.0 + terms[0]) + terms[1], rew)
+            s_ = env.model.s
+            da = (s_[:, 2] - env.task.target_altitude) * 0.3048 / 1000
+            dh = torch.remainder(s_[:, 5] - env.task.target_heading + torch.pi, 2 * torch.pi) - torch.pi
+            dv = (s_[:, 6] - env.task.target_vt) * 0.3048 / 340
+            want = -(da ** 2) - (dh / torch.pi) ** 2 - dv ** 2
+            live = ~(bad | done)
+            assert torch.allclose(terms[0][live], want[live], rtol=1e-4, atol=1e-6)
+        else:
+            env.reward_terms()
         fired += int(bad.sum()) + int(done.sum())
     assert fired > 50

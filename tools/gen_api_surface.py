@@ -15,7 +15,8 @@ FILES = ['envs/env_base.py', 'envs/control_env.py', 'envs/planning_env.py', 'env
          'envs/tasks/heading_task.py', 'envs/tasks/control_task.py', 'envs/tasks/tracking_task.py', 'envs/utils/utils.py',
          'envs/termination_conditions/termination_condition_base.py'] + [
     f'envs/termination_conditions/{m}.py' for m in ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'unreach_heading',
-                                                   'unreach_posture', 'unreach_target', 'timeout')]
+                                                   'unreach_posture', 'unreach_target', 'timeout')] + [
+    f'envs/reward_functions/{m}.py' for m in ('reward_function_base', 'heading_reward', 'posture_reward', 'position_reward', 'event_driven_reward')]
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'ref_api_surface.json')
 
 
