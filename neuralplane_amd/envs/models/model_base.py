@@ -10,6 +10,15 @@ import numpy as np
 import torch
 
 
+def _getter(doc):
+    """An abstract no-argument getter with this docstring."""
+    @abstractmethod
+    def getter(self):
+        raise NotImplementedError
+    getter.__doc__ = doc
+    return getter
+
+
 class BaseModel(ABC):
     def __init__(self, config, n, device, random_seed):
         self.config = config
@@ -46,98 +55,23 @@ class BaseModel(ABC):
     def get_control(self):
         raise NotImplementedError
 
-    # the remaining getters of model_base.py:62-250 — every aircraft model answers all of them
-    @abstractmethod
-    def get_position(self):
-        """(npos, epos, altitude) [ft]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_ground_speed(self):
-        """(npos_dot, epos_dot) [ft/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_climb_rate(self):
-        """altitude rate [ft/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_posture(self):
-        """(roll, pitch, yaw) [rad]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_euler_angular_velocity(self):
-        """(roll_dot, pitch_dot, yaw_dot) [rad/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_vt(self):
-        """airspeed vt [ft/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_TAS(self):
-        """true airspeed [ft/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_EAS(self):
-        """equivalent airspeed [ft/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_AOA(self):
-        """angle of attack [rad]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_AOS(self):
-        """sideslip angle [rad]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_angular_velocity(self):
-        """(P, Q, R) [rad/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_thrust(self):
-        """thrust [lbf]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_control_surface(self):
-        """(el, ail, rud, lef) [deg]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_velocity(self):
-        """body-axis (U, V, W) [ft/s]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_acceleration(self):
-        """body-axis (ax, ay, az) [ft/s^2]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_accels(self):
-        """load factors (nx, ny, nz) [g]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_G(self):
-        """total load factor [g]"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_EAS2TAS(self):
-        """EAS -> TAS ratio"""
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_atmos(self):
-        """(mach, qbar, ps)"""
-        raise NotImplementedError
+    # the remaining getters of model_base.py:62-250 — every aircraft model answers all of them (declared abstract: what / unit)
+    get_position               = _getter('(npos, epos, altitude) [ft]')
+    get_ground_speed           = _getter('(npos_dot, epos_dot) [ft/s]')
+    get_climb_rate             = _getter('altitude rate [ft/s]')
+    get_posture                = _getter('(roll, pitch, yaw) [rad]')
+    get_euler_angular_velocity = _getter('(roll_dot, pitch_dot, yaw_dot) [rad/s]')
+    get_vt                     = _getter('airspeed vt [ft/s]')
+    get_TAS                    = _getter('true airspeed [ft/s]')
+    get_EAS                    = _getter('equivalent airspeed [ft/s]')
+    get_AOA                    = _getter('angle of attack [rad]')
+    get_AOS                    = _getter('sideslip angle [rad]')
+    get_angular_velocity       = _getter('(P, Q, R) [rad/s]')
+    get_thrust                 = _getter('thrust [lbf]')
+    get_control_surface        = _getter('(el, ail, rud, lef) [deg]')
+    get_velocity               = _getter('body-axis (U, V, W) [ft/s]')
+    get_acceleration           = _getter('body-axis (ax, ay, az) [ft/s^2]')
+    get_accels                 = _getter('load factors (nx, ny, nz) [g]')
+    get_G                      = _getter('total load factor [g]')
+    get_EAS2TAS                = _getter('EAS -> TAS ratio')
+    get_atmos                  = _getter('(mach, qbar, ps)')
