@@ -322,7 +322,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), NPF16_COMBAT_MINWAVES) v
             u[2] = -ail;
             u[3] = -rud;
             // ---- one integrator step (F16_model.py:64-67) ----
-            const AeroWeights wt1 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
+            const AeroWeights wt1 = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
             const bool tables1 = ap->cfg.aero_1d_tables != 0;
             if (SOLVER == 0) {
                 float k1[12];
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), NPF16_COMBAT_MINWAVES) v
             np_sincos(s[5], spsi, cpsi);
             float xd[12], acc3[3];
             {
-                const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
+                const AeroWeights wt2 = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
                 nlplant<false, AB_FORCE, B, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, part);
             }
             NP_REREAD_ARGS(ap);

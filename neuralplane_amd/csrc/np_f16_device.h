@@ -23,6 +23,7 @@ typedef const float __attribute__((address_space(4))) *cf32_ptr;
 #define NPF16_CONST(p) ((cf32_ptr)(unsigned long long)(p))
 struct AeroWeights {
     const float *kblob;       // [KBLOB_FLOATS]
+    const float *kblob_dual;  // [KBLOB_DUAL_FLOATS] the same nets in the record layout of the two-set bodies (np_nets.h)
     const float *pwl;         // [NUM_PWL_TABLES * PWL_TABLE_FLOATS] or null
     const float *pwl_unnorm;  // [NUM_PWL_TABLES * 2] or null
 };
@@ -348,7 +349,8 @@ __device__ __forceinline__ void eval_plan_wave(const AeroWeights &wt, const floa
 
 // ---- pair variant (WPT == 2): the two waves of a 128-aircraft workgroup split the nets of an evaluation between them, and each
 // evaluates its half for BOTH waves' aircraft (dual class bodies, np_mlp_asm_dual.inc: set A = the lane's own aircraft, set
-// B = the same lane of the other wave).  Every scalar weight load then feeds two accumulator sets: half the scalar-cache traffic
+// B = the same lane of the other wave; since round 2 in the neuron-major layout — one neuron of both sets per packed register,
+// biases fused into the first FMA, records from wt.kblob_dual, np_nets.h::dual_record_len).  Every scalar weight load then feeds two accumulator sets: half the scalar-cache traffic
 // per aircraft, twice the arithmetic behind every wait.  The normalised inputs of the partner come through LDS columns
 // NUM_LIVE_NETS.. of the same matrix.  Plans balanced by FLOPs as above.
 constexpr int PAIR_MAX = 7;
@@ -393,7 +395,7 @@ __device__ __forceinline__ void eval_class_dual(const AeroWeights &wt, const flo
     const unsigned addr_a = (unsigned)(unsigned long long)(out_a + (class_slot(CL) + FIRST) * LD);
     const unsigned addr_b = (unsigned)(unsigned long long)(out_b + (class_slot(CL) + FIRST) * LD);
     constexpr int g0 = c.grp[0], g1 = c.grp[c.n_in > 1 ? 1 : 0], g2 = c.grp[c.n_in > 2 ? 2 : 0];
-    mlp_class_asm_dual<c.n_in, c.h1, c.h2, c.h3, N, (int)(LD * sizeof(float))>(wt.kblob + class_base(CL) + FIRST * class_stride(CL), addr_a, addr_b, xa[g0],
+    mlp_class_asm_dual<c.n_in, c.h1, c.h2, c.h3, N, (int)(LD * sizeof(float))>(wt.kblob_dual + dual_class_base(CL) + FIRST * dual_class_stride(CL), addr_a, addr_b, xa[g0],
                                                                               c.n_in > 1 ? xa[g1] : 0.0f, c.n_in > 2 ? xa[g2] : 0.0f, xb[g0],
                                                                               c.n_in > 1 ? xb[g1] : 0.0f, c.n_in > 2 ? xb[g2] : 0.0f);
 }
@@ -428,17 +430,19 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
 #pragma unroll
         for (int g = 0; g < NUM_NORM_GROUPS; g++) out[(NUM_LIVE_NETS + g) * LD] = xn[g];
         __syncthreads();  // inputs are visible; both waves have finished reading the coefficients of the previous evaluation
+#if NPF16_PHASE_ASM  // one asm statement per wave and phase: the weight stream runs across the class boundaries of the wave's plan;
+                     // the statements read the normalised inputs of both sets from these LDS columns themselves (no VGPR operands)
+        const unsigned base_a = (unsigned)(unsigned long long)out, base_b = (unsigned)(unsigned long long)out_b;
+        constexpr int STEP_BYTES = (int)(LD * sizeof(float));
+        static_assert((NUM_LIVE_NETS + NUM_NORM_GROUPS) * STEP_BYTES < 65536, "ds_read offsets of the input columns");
+#define NPF16_WAVE(W)                                                                                                                  \
+    if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_dual_ALL_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_ALL_##W##_START, base_a, base_b);          \
+    else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_dual_REST_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_REST_##W##_START, base_a, base_b);  \
+    else mlp_phase_asm_dual_FORCE2_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_FORCE2_##W##_START, base_a, base_b)
+#else
         float xb[NUM_NORM_GROUPS];
 #pragma unroll
         for (int g = 0; g < NUM_NORM_GROUPS; g++) xb[g] = out_b[(NUM_LIVE_NETS + g) * LD];
-#if NPF16_PHASE_ASM  // one asm statement per wave and phase: the weight stream runs across the class boundaries of the wave's plan
-        const unsigned base_a = (unsigned)(unsigned long long)out, base_b = (unsigned)(unsigned long long)out_b;
-        constexpr int STEP_BYTES = (int)(LD * sizeof(float));
-#define NPF16_WAVE(W)                                                                                                                  \
-    if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_dual_ALL_##W<STEP_BYTES>(wt.kblob + MLP_PAIR_ALL_##W##_START, base_a, base_b, xn, xb);          \
-    else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_dual_REST_##W<STEP_BYTES>(wt.kblob + MLP_PAIR_REST_##W##_START, base_a, base_b, xn, xb);  \
-    else mlp_phase_asm_dual_FORCE2_##W<STEP_BYTES>(wt.kblob + MLP_PAIR_FORCE2_##W##_START, base_a, base_b, xn, xb)
-#else
 #define NPF16_WAVE(W)                                                                                    \
     if constexpr (FULL && PART == AB_ALL) eval_pair_wave<PAIR_ALL, W, LD>(wt, xn, xb, out, out_b);           \
     else if constexpr (FULL && PART == AB_REST) eval_pair_wave<PAIR_REST, W, LD>(wt, xn, xb, out, out_b);    \

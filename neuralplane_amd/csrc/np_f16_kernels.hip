@@ -349,7 +349,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
         for (int k = 0; k < 12; k++) xd[k] = s[k];
 #else
         {
-            const AeroWeights wt2 = {ap->wt.kblob, ap->wt.pwl, ap->wt.pwl_unnorm};
+            const AeroWeights wt2 = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
             if constexpr (SHARED) {
                 NP_LT(3);
                 nlplant<false, AB_FORCE, TILE, WPT, true, 1>(wt2, s, u, sc1, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
@@ -709,7 +709,8 @@ struct BlobRec {  // NPF16MLP v1 record (tools/export_weights.py)
 static_assert(sizeof(BlobRec) == 128, "blob record is 128 bytes");
 
 // asset blob (torch layout W[out][in]) -> kernel-order blob (np_nets.h)
-int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vector<float> &pwl, std::vector<float> &pwl_unnorm) {
+int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vector<float> &kbd, std::vector<float> &pwl,
+               std::vector<float> &pwl_unnorm) {
     const unsigned char *p = (const unsigned char *)blob;
     if (!p || nbytes < 16 || std::memcmp(p, "NPF16MLP", 8) != 0) return fail("weights blob: bad magic");
     uint32_t ver, nn;
@@ -794,6 +795,37 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vec
     }
     for (int g = 0; g < NUM_NORM_GROUPS; g++)
         if (!grp_set[g]) return fail("weights blob: a normalisation group is unused");
+    // the same records in the layout of the two-set bodies (np_nets.h::dual_record_len): pure re-arrangement of `kb`
+    kbd.assign(KBLOB_DUAL_FLOATS, 0.0f);
+    for (int cl = 0; cl < NUM_CLASSES; cl++) {
+        const NetClass c = CLASSES[cl];
+        const int hid[3] = {c.h1, c.h2, c.h3};
+        const int n_hidden = c.h3 > 0 ? 3 : 2;
+        for (int m = 0; m < c.count; m++) {
+            const float *src = kb.data() + class_base(cl) + (size_t)m * class_stride(cl);
+            float *dst = kbd.data() + dual_class_base(cl) + (size_t)m * dual_class_stride(cl);
+            int in = c.n_in;
+            for (int l = 0; l < n_hidden; l++) {
+                const int out = hid[l], row = pad2(out);
+                for (int j = 0; j < out; j++) {
+                    dst[2 * j] = src[row + j];  // W[j][0]
+                    dst[2 * j + 1] = src[j];    // bias[j]
+                }
+                for (int k = 1; k < in; k++)
+                    for (int j = 0; j < out; j++) dst[2 * out + (k - 1) * out + j] = src[row * (k + 1) + j];
+                src += (size_t)row * (in + 1);
+                dst += pad2(out * (in + 1));
+                in = out;
+            }
+            dst[0] = src[2];  // W[0][0]
+            dst[1] = src[0];  // bias
+            for (int k = 1; k < in; k++) dst[1 + k] = src[2 + k];
+            src += 2 + pad2(in);
+            dst += pad2(in + 1);
+            dst[0] = src[0];  // out_std
+            dst[1] = src[1];  // out_mean
+        }
+    }
     // PWL section (blob v2): "PWL1", n_tables, seg_cap, then {net_index, n_segments, t[64], a[64], x0[64], c[64]}
     pwl.clear();
     pwl_unnorm.clear();
@@ -1167,8 +1199,8 @@ int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / 
 const char *np_last_error(void) { return g_err.c_str(); }
 
 static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables, int device, np_f16_ctx **out) {
-    std::vector<float> kb, pwl, pwl_unnorm;
-    if (pack_kblob(weights_blob, nbytes, kb, pwl, pwl_unnorm)) return 1;
+    std::vector<float> kb, kbd, pwl, pwl_unnorm;
+    if (pack_kblob(weights_blob, nbytes, kb, kbd, pwl, pwl_unnorm)) return 1;
     if (tables && pwl.empty()) return fail("cfg.aero_1d_tables needs a version-2 weights blob (PWL section)");
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
@@ -1179,17 +1211,20 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     NP_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("device arch ") + prop.gcnArchName + " is not gfx950 (MI355X)");
-    // one device allocation per context: KBLOB | PWL tables | PWL (std, mean) — a context is one aircraft type
+    // one device allocation per context: KBLOB | PWL tables | PWL (std, mean) | KBLOB in the two-set layout — a context is one aircraft type
     const size_t n_kb = KBLOB_FLOATS, n_pwl = (size_t)NUM_PWL_TABLES * PWL_TABLE_FLOATS, n_un = (size_t)NUM_PWL_TABLES * 2;
+    const size_t off_dual = (n_kb + n_pwl + n_un + 63) / 64 * 64;  // 256-byte aligned
     float *d_w = nullptr, *d_rc = nullptr;
-    NP_HIP(hipMalloc(&d_w, sizeof(float) * (n_kb + n_pwl + n_un)));
+    NP_HIP(hipMalloc(&d_w, sizeof(float) * (off_dual + KBLOB_DUAL_FLOATS)));
     hipError_t e0 = hipMemcpy(d_w, kb.data(), sizeof(float) * n_kb, hipMemcpyHostToDevice);
+    if (e0 == hipSuccess) e0 = hipMemcpy(d_w + off_dual, kbd.data(), sizeof(float) * KBLOB_DUAL_FLOATS, hipMemcpyHostToDevice);
     if (e0 == hipSuccess && !pwl.empty()) {
         e0 = hipMemcpy(d_w + n_kb, pwl.data(), sizeof(float) * n_pwl, hipMemcpyHostToDevice);
         if (e0 == hipSuccess) e0 = hipMemcpy(d_w + n_kb + n_pwl, pwl_unnorm.data(), sizeof(float) * n_un, hipMemcpyHostToDevice);
     }
     AeroWeights wt;
     wt.kblob = d_w;
+    wt.kblob_dual = d_w + off_dual;
     wt.pwl = pwl.empty() ? nullptr : d_w + n_kb;
     wt.pwl_unnorm = pwl.empty() ? nullptr : d_w + n_kb + n_pwl;
     hipError_t e1 = e0 == hipSuccess ? hipMalloc(&d_rc, sizeof(float) * NUM_CACHED) : e0;

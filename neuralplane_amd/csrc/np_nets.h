@@ -160,6 +160,32 @@ constexpr int class_slot(int cl) {  // output slot of the first net of class cl
 }
 // + padding: the weight stream prefetches one group (32 floats) past the last record it evaluates
 constexpr int KBLOB_FLOATS = class_base(NUM_CLASSES) + 2 * ASM_GROUP;
+
+// ---- second record layout, for the bodies with TWO accumulator sets (pair variant, np_mlp_asm_dual.inc) -------------------------
+// There a packed register holds ONE neuron of BOTH sets (lo = set A, hi = set B), every v_pk_fma_f32 broadcasts ONE weight
+// (either half of an SGPR pair, op_sel) to both halves, and the first FMA of a chain takes its bias from the OTHER half of the
+// same SGPR pair — `v_pk_fma acc, s[w:b], x, s[w:b] op_sel:[0,0,1] op_sel_hi:[0,1,1]` is legal where two different SGPR pairs in
+// one VOP3P are not — so no accumulator is ever initialised by a move.  Record of one net (floats, "neuron-major"):
+//   per hidden layer (in -> out):  (W[j][0], bias[j]) for j < out, then for k = 1 .. in-1 the row W[.][k] of `out` weights; padded
+//                                  to an even length (the next layer's pairs stay even-aligned)
+//   output layer (in -> 1):        (W[0][0], bias), W[0][1 .. in), padded to even   [two interleaved partial chains as before:
+//                                  lo = bias + even inputs, hi = 0 + odd inputs, y = lo + hi]
+//   out_std, out_mean, zero padding to whole weight-stream groups.
+// Same values (same 2^-ACT_SHIFT scaling) as the first layout, no header; np_pack_kblob derives it from the first.
+constexpr int dual_record_len(int n_in, int h1, int h2, int h3) {
+    int n = pad2(h1 * (n_in + 1)) + pad2(h2 * (h1 + 1));
+    if (h3 > 0) n += pad2(h3 * (h2 + 1)) + pad2(h3 + 1);
+    else n += pad2(h2 + 1);
+    n += 2;  // out_std, out_mean
+    return (n + ASM_GROUP - 1) / ASM_GROUP * ASM_GROUP;
+}
+constexpr int dual_class_stride(int cl) { return dual_record_len(CLASSES[cl].n_in, CLASSES[cl].h1, CLASSES[cl].h2, CLASSES[cl].h3); }
+constexpr int dual_class_base(int cl) {
+    int off = 0;
+    for (int k = 0; k < cl; k++) off += CLASSES[k].count * dual_class_stride(k);
+    return off;
+}
+constexpr int KBLOB_DUAL_FLOATS = dual_class_base(NUM_CLASSES) + 2 * ASM_GROUP;
 static_assert(class_slot(NUM_CLASSES) == NUM_LIVE_NETS, "every live net belongs to exactly one class");
 static_assert(class_slot(NUM_AB_CLASSES) == NUM_AB_NETS, "alpha/beta-only nets occupy slots 0..35");
 constexpr int num_force_ab() {

@@ -139,14 +139,37 @@ def test_generated_asm_is_up_to_date(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith('NPF16_GEN_')}
     env['NPF16_GEN_OUTDIR'] = str(tmp_path)
     subprocess.run([sys.executable, os.path.join(root, 'tools', 'gen_mlp_asm.py')], check=True, env=env, stdout=subprocess.DEVNULL)
-    for name in ('np_mlp_asm.inc', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc'):
+    for name in ('np_mlp_asm.inc', 'np_mlp_asm_dual.inc', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc'):
         with open(tmp_path / name, 'rb') as f, open(os.path.join(root, 'neuralplane_amd', 'csrc', name), 'rb') as g:
             assert f.read() == g.read(), f'{name} is stale: run python tools/gen_mlp_asm.py'
 
 
+def test_two_set_phase_statements_by_emulation():
+    """The generated pair-variant statements (np_mlp_asm_dual.inc: ~20 000 lines of inline asm) executed as TEXT by
+    tools/emulate_dual_asm.py — scalar control flow, weight stream, packed FMAs with op_sel / clamp, LDS traffic — on a synthetic
+    blob in the KBLOB_DUAL layout: every net of every phase, both accumulator sets, equals the spec's evaluation; with the scalar
+    loads landing at their s_waitcnt and at once (no instruction reads a buffer with a load in flight); every load inside the blob."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('emulate_dual_asm', os.path.join(root, 'tools', 'emulate_dual_asm.py'))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    assert emu.check(land_at_wait=True) == []
+    assert emu.check(land_at_wait=False, seed=3) == []
+    # the emulator does notice a broken stream: scale the first record of the blob and its coefficient goes wrong
+    blob, nets, xa, xb = emu.build_blob(0)
+    lines, start = emu.statement(open(emu.INC).read(), 'FORCE2', 0)
+    good, loads = emu.run_statement(lines, start, blob, xa, xb, True)
+    blob2 = blob.copy()
+    blob2[start:start + 288] *= 1.5
+    bad, _ = emu.run_statement(lines, start, blob2, xa, xb, True)
+    assert any(good[k] != bad[k] for k in good) and min(loads) >= 0
+
+
 def test_pair_plans_are_balanced_and_complete():
     """tools/gen_mlp_asm.py::PAIR_PLANS (mirrored by np_f16_device.h::PAIR_*, tied by static_asserts in the generated file): the
-    two waves of a pair get the same number of VALU instructions within 3 %, and together they cover every net of the phase
+    two waves of a pair get the same number of VALU instructions within 3 % (4 % in the un-cached phase), and together they cover every net of the phase
     exactly once."""
     import importlib.util
     import os
@@ -154,11 +177,11 @@ def test_pair_plans_are_balanced_and_complete():
     src = open(os.path.join(root, 'tools', 'gen_mlp_asm.py')).read().replace("if __name__ == '__main__':", 'if False:')
     g = {'__file__': os.path.join(root, 'tools', 'gen_mlp_asm.py')}
     exec(compile(src, 'gen_mlp_asm', 'exec'), g)
-    cost = {shape: sum(1 for i in g['Body'](shape, 0).build() if i.startswith('v_')) for shape in g['SHAPES']}
+    cost = {shape: sum(1 for i in g['BodyNM'](shape, 0).build() if i.startswith('v_')) for shape in g['SHAPES']}   # the two-set bodies
     classes = {c[0]: c for c in g['CLASSES']}
     for kind, waves in g['PAIR_PLANS'].items():
         loads = [sum(cost[classes[c][1]] * n for c, _, n in w) for w in waves]
-        assert abs(loads[0] - loads[1]) <= 0.03 * max(loads), (kind, loads)
+        assert abs(loads[0] - loads[1]) <= (0.04 if kind == 'ALL' else 0.03) * max(loads), (kind, loads)   # ALL: the un-cached evaluation, first step only
         want = {(classes_name, k) for ci, first, n in g['phase_items'](kind) for classes_name in [g['CLASSES'][ci][0]] for k in range(first, first + n)}
         got = [(c, k) for w in waves for c, first, n in w for k in range(first, first + n)]
         assert len(got) == len(set(got)) and set(got) == want, kind

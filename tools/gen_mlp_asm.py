@@ -77,6 +77,7 @@ class Body:
         self.cur_group = -1
         # for the dual bodies (second_set): instructions that set B does not repeat (bias moves) and instructions whose set-B
         # version is special and goes FIRST (the first FMA of a chain takes the bias from set A's freshly initialised register)
+        self.advanced = False
         self.skip_dup = set()
         self.b_first = {}
 
@@ -99,7 +100,15 @@ class Body:
             if HALF_LOADS and self.cur_group % 2 == 1:
                 continue
             for cc in range(c + CPG, c + 2 * CPG):  # next group (runs into the next record when cc >= nch)
-                if self.use_next and cc >= self.nch:
+                if self.use_next == 'advance' and cc >= self.nch:
+                    # two-set phases: the record pointer itself moves on (by the byte distance the caller left in vcc_hi) as soon as
+                    # the last group of this record has been requested — no second pointer pair, s2 / s3 stay free for the compiler
+                    if not self.advanced:
+                        self.ins.append(f's_add_u32 s{S_BASE}, s{S_BASE}, vcc_hi')
+                        self.ins.append(f's_addc_u32 s{S_BASE + 1}, s{S_BASE + 1}, 0')
+                        self.advanced = True
+                    base, off = S_BASE, (cc - self.nch) * 64
+                elif self.use_next and cc >= self.nch:
                     base, off = S_NEXT, (cc - self.nch) * 64
                 else:
                     base, off = S_BASE, cc * 64
@@ -244,12 +253,110 @@ def second_set(ins_list, body=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# Two accumulator sets, "neuron-major" (the bodies of np_mlp_asm_dual.inc since round 2): a packed register holds ONE neuron
+# of BOTH sets (lo = set A, hi = set B), every v_pk_fma_f32 broadcasts ONE weight — either half of an SGPR pair, chosen by
+# op_sel — to both halves, and the FIRST FMA of every chain reads its bias from the other half of the same SGPR pair:
+#     v_pk_fma_f32 acc, s[w:b], x, s[w:b] op_sel:[0,0,1] op_sel_hi:[0,1,1]      acc.lo = fma(w, xA, b), acc.hi = fma(w, xB, b)
+# (one SGPR pair used twice is one constant-bus read; two different pairs in one VOP3P do not assemble).  So no accumulator is
+# initialised by a move (16 v_pk_mov per net before), the un-normalisation is packed too, odd layer widths waste nothing, and the
+# chains are still acc = fma(W[j][0], x[0], bias[j]); acc = fma(W[j][k], x[k], acc), k ascending: same bits.
+# Record layout: np_nets.h::dual_record_len (KBLOB_DUAL, derived from the first layout by np_pack_kblob).
+# ------------------------------------------------------------------------------------------------
+NM_H = [70, 110, 150]   # activation pairs of layer 1 / 2 / 3 (20, 20, 10 pairs): v70-109, v110-149, v150-169
+NM_X = 170              # v[170:171], v[172:173], v[174:175]: the (set A, set B) input pairs
+NM_YLO = 176            # v[176:177]: low chain of the output layer, then the net output (A, B)
+NM_YHI = 178            # v[178:179]: high chain
+NM_ADDR_A, NM_ADDR_B = 180, 181
+NM_CLOBBER = list(range(70, 182))
+
+
+def record_len_nm(IN, H1, H2, H3):
+    n = pad2(H1 * (IN + 1)) + pad2(H2 * (H1 + 1))
+    n += (pad2(H3 * (H2 + 1)) + pad2(H3 + 1)) if H3 else pad2(H2 + 1)
+    n += 2
+    return (n + GROUP - 1) // GROUP * GROUP
+
+
+class BodyNM(Body):
+    """One net for both accumulator sets in the neuron-major layout.  Reuses Body's weight-stream bookkeeping (touch / sreg)."""
+
+    def __init__(self, shape, parity, use_next=False):
+        super().__init__(shape, parity, use_next)
+        self.len = record_len_nm(*shape)
+        self.nch = self.len // 16
+
+    def sw(self, pos):
+        """(aligned SGPR pair holding record position `pos`, which half)"""
+        self.touch(pos)
+        r = self.sreg(pos)
+        return f's[{r & ~1}:{(r & ~1) + 1}]', r & 1
+
+    @staticmethod
+    def pr(r):
+        return f'v[{r}:{r + 1}]'
+
+    def dense(self, n_in, n_out, in_base, out_base):
+        p0 = self.pos
+        assert p0 % 2 == 0
+        for k in range(n_in):
+            relu = ' clamp' if k == n_in - 1 else ''
+            x = self.pr(in_base + 2 * k)
+            for j in range(n_out):
+                acc = self.pr(out_base + 2 * j)
+                if k == 0:      # (W[j][0], bias[j]) in one SGPR pair: acc = fma(w, x, bias) for both sets
+                    sp, half = self.sw(p0 + 2 * j)
+                    assert half == 0
+                    self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {x}, {sp} op_sel:[0,0,1] op_sel_hi:[0,1,1]{relu}')
+                else:
+                    sp, half = self.sw(p0 + 2 * n_out + (k - 1) * n_out + j)
+                    self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {x}, {acc} op_sel:[{half},0,0] op_sel_hi:[{half},1,1]{relu}')
+        self.pos = p0 + pad2(n_out * (n_in + 1))
+
+    def final(self, n_in, in_base):
+        """two interleaved partial chains (numerics spec): lo = bias + even inputs, hi = 0 + odd inputs, y = lo + hi"""
+        p0 = self.pos
+        assert p0 % 2 == 0 and n_in >= 2
+        lo, hi = self.pr(NM_YLO), self.pr(NM_YHI)
+        sp, half = self.sw(p0)
+        self.ins.append(f'v_pk_fma_f32 {lo}, {sp}, {self.pr(in_base)}, {sp} op_sel:[0,0,1] op_sel_hi:[0,1,1]')
+        for k in range(1, n_in):
+            sp, half = self.sw(p0 + 1 + k)
+            x = self.pr(in_base + 2 * k)
+            if k == 1:
+                self.ins.append(f'v_pk_fma_f32 {hi}, {sp}, {x}, 0 op_sel:[{half},0,0] op_sel_hi:[{half},1,0]')
+            else:
+                acc = lo if k % 2 == 0 else hi
+                self.ins.append(f'v_pk_fma_f32 {acc}, {sp}, {x}, {acc} op_sel:[{half},0,0] op_sel_hi:[{half},1,1]')
+        self.ins.append(f'v_pk_add_f32 {lo}, {lo}, {hi}')
+        self.pos = p0 + pad2(n_in + 1)
+        # unnormalize: X * std + mean, two roundings (hifi_F16_AeroData.py:36-37), both sets at once
+        sp, half = self.sw(self.pos)
+        self.ins.append(f'v_pk_mul_f32 {lo}, {sp}, {lo} op_sel:[{half},0] op_sel_hi:[{half},1]')
+        sp, half = self.sw(self.pos + 1)
+        self.ins.append(f'v_pk_add_f32 {lo}, {sp}, {lo} op_sel:[{half},0] op_sel_hi:[{half},1]')
+        self.pos += 2
+
+    def build(self):
+        self.dense(self.IN, self.H1, NM_X, NM_H[0])
+        self.dense(self.H1, self.H2, NM_H[0], NM_H[1])
+        if self.H3:
+            self.dense(self.H2, self.H3, NM_H[1], NM_H[2])
+            self.final(self.H3, NM_H[2])
+        else:
+            self.final(self.H2, NM_H[1])
+        assert self.pos <= self.len, (self.pos, self.len)
+        self.touch(self.len - 1)
+        assert self.cur_group == self.len // GROUP - 1
+        return self.ins
+
+
 def gen_function_dual(shape):
     """The class body for TWO aircraft per lane ("pair" kernel variant): one weight stream, two accumulator sets.  Set A = the
     lane's own aircraft, set B = the aircraft of the same lane in the other wave of the workgroup (inputs and output column
     come from / go to LDS); every s_load_dwordx16 now feeds 16 instead of 8 v_pk_fma_f32."""
     IN, H1, H2, H3 = shape
-    ln = record_len(*shape)
+    ln = record_len_nm(*shape)
     ngroups = ln // GROUP
     two_parities = ngroups % 2 == 1
     name = f'mlp_class_asm_dual_{IN}_{H1}_{H2}_{H3}'
@@ -265,24 +372,21 @@ def gen_function_dual(shape):
 
     emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
     emit(f's_mov_b32 {S_CNT}, %[cnt]')
-    for sfx, off in (('a', 0), ('b', SET_B)):
-        emit(f'v_mov_b32 v{V_X + off}, %[x0{sfx}]')
-        if IN > 1:
-            emit(f'v_mov_b32 v{V_X + 2 + off}, %[x1{sfx}]')
-        if IN > 2:
-            emit(f'v_mov_b32 v{V_X + 4 + off}, %[x2{sfx}]')
-        emit(f'v_mov_b32 v{V_ADDR + off}, %[addr{sfx}]')
+    for sfx, off in (('a', 0), ('b', 1)):
+        for k in range(IN):
+            emit(f'v_mov_b32 v{NM_X + 2 * k + off}, %[x{k}{sfx}]')
+    emit(f'v_mov_b32 v{NM_ADDR_A}, %[addra]')
+    emit(f'v_mov_b32 v{NM_ADDR_B}, %[addrb]')
     for c in range(CPG):
         emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
     emit('.LNP_LOOP_%=:')
     for parity in ([0, 1] if two_parities else [0]):
-        body = Body(shape, parity)
-        for ins in second_set(body.build(), body):
+        for ins in BodyNM(shape, parity).build():
             emit(ins)
-        emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
-        emit(f'ds_write_b32 v{V_ADDR + SET_B}, v{V_Y + SET_B}')
-        emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
-        emit(f'v_add_u32 v{V_ADDR + SET_B}, %[step], v{V_ADDR + SET_B}')
+        emit(f'ds_write_b32 v{NM_ADDR_A}, v{NM_YLO}')
+        emit(f'ds_write_b32 v{NM_ADDR_B}, v{NM_YLO + 1}')
+        emit(f'v_add_u32 v{NM_ADDR_A}, %[step], v{NM_ADDR_A}')
+        emit(f'v_add_u32 v{NM_ADDR_B}, %[step], v{NM_ADDR_B}')
         emit(f's_add_u32 s{S_BASE}, s{S_BASE}, 0x{ln * 4:x}')
         emit(f's_addc_u32 s{S_BASE + 1}, s{S_BASE + 1}, 0')
         emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
@@ -296,7 +400,7 @@ def gen_function_dual(shape):
     A('        :')
     A('        : [w] "s"(w), [cnt] "n"(COUNT), [addra] "v"(lds_addr_a), [addrb] "v"(lds_addr_b), [step] "n"(LDS_STEP), [x0a] "v"(x0a), [x1a] "v"(x1a),')
     A('          [x2a] "v"(x2a), [x0b] "v"(x0b), [x1b] "v"(x1b), [x2b] "v"(x2b)')
-    regs = list(range(70, 128 + SET_B))
+    regs = NM_CLOBBER
     clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in S_CLOBBER] + ['"vcc"', '"scc"', '"memory"'])
     A(f'        : {clob});')
     A('}')
@@ -326,52 +430,53 @@ def gen_phase_dual(kind, wave):
     A = lines.append
     A(f'// pair phase {kind}, wave {wave}: ' + ', '.join(f'{CLASSES[ci][0]}[{first}:{first + n}]' for ci, first, n in items))
     A('template <int LDS_STEP>')
-    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base_a, unsigned lds_base_b, const float (&xa)[{len(G)}],')
-    A(f'                                       const float (&xb)[{len(G)}]) {{')
+    A(f'__device__ __forceinline__ void {name}(const float *w, unsigned lds_base_a, unsigned lds_base_b) {{')
     A('    asm volatile(')
 
     def emit(s):
         A(f'        "{s}\\n\\t"')
 
     used_x = sorted({G[g] for ci, _, _ in items for g in CLASSES[ci][2]})
+    # the record pointer is the only scalar operand: with s4-s101 and vcc clobbered it (and whatever the compiler keeps in scalar
+    # registers across the statement) has s0-s3 to live in — which is why this statement has no second pointer pair
     emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], %[w]')
     for c in range(CPG):
         emit(f's_load_dwordx16 s[{S_W0 + 16 * c}:{S_W0 + 16 * c + 15}], s[{S_BASE}:{S_BASE + 1}], 0x{c * 64:x}')
     parity = 0
     for idx, (ci, first, n) in enumerate(items):
         cname, shape, grps, _, _ = CLASSES[ci]
-        ln = record_len(*shape)
+        ln = record_len_nm(*shape)
         ngroups = ln // GROUP
-        start = class_base(ci) + first * ln
+        start = class_base_nm(ci) + first * ln
         has_next = idx + 1 < len(items)
         if has_next:
             nci, nfirst, _ = items[idx + 1]
-            nstart = class_base(nci) + nfirst * record_len(*CLASSES[nci][1])
+            nstart = class_base_nm(nci) + nfirst * record_len_nm(*CLASSES[nci][1])
             delta = nstart - (start + (n - 1) * ln)
             assert delta > 0, (kind, cname, delta)
         emit(f's_mov_b32 {S_CNT}, {n}')
         for k, g in enumerate(grps):
-            emit(f'v_mov_b32 v{V_X + 2 * k}, %[xa{G[g]}]')
-            emit(f'v_mov_b32 v{V_X + 2 * k + SET_B}, %[xb{G[g]}]')
-        emit(f'v_add_u32 v{V_ADDR}, %[step]*{class_slot(ci) + first}, %[addra]')
-        emit(f'v_add_u32 v{V_ADDR + SET_B}, %[step]*{class_slot(ci) + first}, %[addrb]')
+            # the normalised inputs of both sets come straight from their LDS columns (NUM_LIVE + group): no VGPR operands, the
+            # first `s_waitcnt lgkmcnt(0)` of the class's first record (records start on group boundaries) covers the reads
+            emit(f'ds_read_b32 v{NM_X + 2 * k}, %[addra] offset:%[step]*{NUM_LIVE + G[g]}')
+            emit(f'ds_read_b32 v{NM_X + 2 * k + 1}, %[addrb] offset:%[step]*{NUM_LIVE + G[g]}')
+        emit(f'v_add_u32 v{NM_ADDR_A}, %[step]*{class_slot(ci) + first}, %[addra]')
+        emit(f'v_add_u32 v{NM_ADDR_B}, %[step]*{class_slot(ci) + first}, %[addrb]')
         emit(f'.LNP_L{idx}_%=:')
         pars = [parity, 1 - parity] if (ngroups % 2 == 1 and n > 1) else [parity]
         for pi, par in enumerate(pars):
-            emit(f's_mov_b32 s{S_NEXT}, 0x{ln * 4:x}')
+            emit(f's_mov_b32 vcc_hi, 0x{ln * 4:x}')          # bytes to the record that follows in the sequence
             if has_next:
                 emit(f's_cmp_eq_u32 {S_CNT}, 1')
-                emit(f's_cmov_b32 s{S_NEXT}, 0x{delta * 4:x}')
-            emit(f's_add_u32 s{S_NEXT}, s{S_BASE}, s{S_NEXT}')
-            emit(f's_addc_u32 s{S_NEXT + 1}, s{S_BASE + 1}, 0')
-            body = Body(shape, par, use_next=True)
-            for ins in second_set(body.build(), body):
+                emit(f's_cmov_b32 vcc_hi, 0x{delta * 4:x}')
+            body = BodyNM(shape, par, use_next='advance')
+            for ins in body.build():
                 emit(ins)
-            emit(f'ds_write_b32 v{V_ADDR}, v{V_Y}')
-            emit(f'ds_write_b32 v{V_ADDR + SET_B}, v{V_Y + SET_B}')
-            emit(f'v_add_u32 v{V_ADDR}, %[step], v{V_ADDR}')
-            emit(f'v_add_u32 v{V_ADDR + SET_B}, %[step], v{V_ADDR + SET_B}')
-            emit(f's_mov_b64 s[{S_BASE}:{S_BASE + 1}], s[{S_NEXT}:{S_NEXT + 1}]')
+            assert body.advanced
+            emit(f'ds_write_b32 v{NM_ADDR_A}, v{NM_YLO}')
+            emit(f'ds_write_b32 v{NM_ADDR_B}, v{NM_YLO + 1}')
+            emit(f'v_add_u32 v{NM_ADDR_A}, %[step], v{NM_ADDR_A}')
+            emit(f'v_add_u32 v{NM_ADDR_B}, %[step], v{NM_ADDR_B}')
             emit(f's_sub_u32 {S_CNT}, {S_CNT}, 1')
             emit(f's_cmp_lg_u32 {S_CNT}, 0')
             if len(pars) == 2 and pi == 0:
@@ -383,14 +488,13 @@ def gen_phase_dual(kind, wave):
     emit('s_waitcnt lgkmcnt(0)')
     A('        :')
     ops = '[w] "s"(w), [addra] "v"(lds_base_a), [addrb] "v"(lds_base_b), [step] "n"(LDS_STEP)'
-    ops += ', ' + ', '.join(f'[xa{k}] "v"(xa[{k}])' for k in used_x) + ', ' + ', '.join(f'[xb{k}] "v"(xb[{k}])' for k in used_x)
     A(f'        : {ops}')
-    regs = list(range(70, 128 + SET_B))
-    clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in S_CLOBBER + [S_NEXT, S_NEXT + 1]] + ['"vcc"', '"scc"', '"memory"'])
+    regs = NM_CLOBBER
+    clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in S_CLOBBER] + ['"vcc"', '"scc"', '"memory"'])
     A(f'        : {clob});')
     A('}')
-    first_off = class_base(items[0][0]) + items[0][1] * record_len(*CLASSES[items[0][0]][1])
-    A(f'constexpr int MLP_PAIR_{kind}_{wave}_START = {first_off};  // KBLOB offset of the first record')
+    first_off = class_base_nm(items[0][0]) + items[0][1] * record_len_nm(*CLASSES[items[0][0]][1])
+    A(f'constexpr int MLP_PAIR_{kind}_{wave}_START = {first_off};  // KBLOB_DUAL offset of the first record')
     A('')
     return lines
 
@@ -412,6 +516,10 @@ def gen_dual_file():
     for shape in SHAPES:
         lines, _ = gen_function_dual(shape)
         out += lines
+    out.append('// record lengths of the two-set layout the generator assumed (checked against np_nets.h::dual_record_len)')
+    for IN, H1, H2, H3 in SHAPES:
+        out.append(f'static_assert(dual_record_len({IN}, {H1}, {H2}, {H3}) == {record_len_nm(IN, H1, H2, H3)}, "KBLOB_DUAL record layout");')
+    out.append('')
     out.append('template <int IN, int H1, int H2, int H3, int COUNT, int LDS_STEP>')
     out.append('__device__ __forceinline__ void mlp_class_asm_dual(const float *w, unsigned addr_a, unsigned addr_b, float x0a, float x1a, float x2a, float x0b,')
     out.append('                                                   float x1b, float x2b) {')
@@ -515,6 +623,10 @@ NUM_AB = 9
 
 def class_base(ci):
     return KBLOB_HEADER + sum(c[3] * record_len(*c[1]) for c in CLASSES[:ci])
+
+
+def class_base_nm(ci):
+    return sum(c[3] * record_len_nm(*c[1]) for c in CLASSES[:ci])
 
 
 def class_slot(ci):
