@@ -843,23 +843,37 @@ __device__ __forceinline__ void noise_block_indices(const uint32_t (&w)[4], uint
     k1[2] = ((w[0] & 0x7FFu) << 10) | ((w[1] >> 1) & 0x3FFu);
     k2[2] = ((w[2] & 0x7FFu) << 10) | ((w[3] >> 1) & 0x3FFu);
 }
+// two pairs at once (np_math.h: the packed forms of the same sequences): o[2 pa], o[2 pa + 1], o[2 pb], o[2 pb + 1]
+__device__ __forceinline__ void add_noise_pairs2(uint32_t k1a, uint32_t k2a, int pa, uint32_t k1b, uint32_t k2b, int pb, float scale,
+                                                 float (&o)[22]) {
+    np_f32x2 kf = {(float)k1a, (float)k1b};
+    const np_f32x2 u = np_fma2(kf, 4.76837158203125e-07f, 2.384185791015625e-07f);
+    const np_f32x2 rs = sqrt_spec2(neg2ln_spec2(u)) * (np_f32x2)(scale);
+    const uint32_t k2[2] = {k2a, k2b};
+    np_f32x2 cs, sn;
+    unit_vector_spec2(k2, cs, sn);
+    np_f32x2 oc = {o[2 * pa], o[2 * pb]}, os = {o[2 * pa + 1], o[2 * pb + 1]};
+    oc = np_fma2(rs, cs, oc);
+    os = np_fma2(rs, sn, os);
+    o[2 * pa] = oc[0];
+    o[2 * pb] = oc[1];
+    o[2 * pa + 1] = os[0];
+    o[2 * pb + 1] = os[1];
+}
 __device__ __forceinline__ void add_rng_noise(uint64_t seed, uint64_t call_idx, int64_t row, float scale, float (&o)[22]) {
+    uint32_t k1[4][3], k2[4][3];
 #pragma unroll
     for (uint32_t b = 0; b < 4; b++) {
-        uint32_t blk[4], k1[3], k2[3];
+        uint32_t blk[4];
         rng_block(seed, call_idx, row, 2 + b, blk);
-        noise_block_indices(blk, k1, k2);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int pair = j < 2 ? 2 * (int)b + j : 8 + (int)b;
-            if (pair < 11) {
-                float rs, cs, sn;
-                noise_pair(k1[j], k2[j], scale, rs, cs, sn);
-                o[2 * pair] = fmaf(rs, cs, o[2 * pair]);
-                o[2 * pair + 1] = fmaf(rs, sn, o[2 * pair + 1]);
-            }
-        }
+        noise_block_indices(blk, k1[b], k2[b]);
+        add_noise_pairs2(k1[b][0], k2[b][0], 2 * (int)b, k1[b][1], k2[b][1], 2 * (int)b + 1, scale, o);   // pairs 2b, 2b + 1
     }
+    add_noise_pairs2(k1[0][2], k2[0][2], 8, k1[1][2], k2[1][2], 9, scale, o);                               // pairs 8, 9
+    float rs, cs, sn;                                                                                       // pair 10 (the 4th block's low bits are unused)
+    noise_pair(k1[2][2], k2[2][2], scale, rs, cs, sn);
+    o[20] = fmaf(rs, cs, o[20]);
+    o[21] = fmaf(rs, sn, o[21]);
 }
 
 // ---------------------------------------------------------------------------------------------

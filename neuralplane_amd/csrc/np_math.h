@@ -340,4 +340,68 @@ __device__ __forceinline__ void unit_vector_spec(uint32_t k2, float &cs, float &
     sn = __uint_as_float((__float_as_uint(b) & 0x7FFFFFFFu) | ((k2 << 11) & 0x80000000u));
 }
 
+// ---- the same three sequences for TWO Box-Muller pairs at once (element k of every vector = pair k): every float operation is a
+// packed instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 perform the IEEE operation per half, so each element gets exactly
+// the bits of the scalar sequence above); the integer parts stay scalar per element.
+typedef float np_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ np_f32x2 np_fma2(np_f32x2 a, np_f32x2 b, np_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ np_f32x2 np_fma2(np_f32x2 a, float b, float c) { return __builtin_elementwise_fma(a, (np_f32x2)(b), (np_f32x2)(c)); }
+__device__ __forceinline__ np_f32x2 np_fma2(np_f32x2 a, np_f32x2 b, float c) { return __builtin_elementwise_fma(a, b, (np_f32x2)(c)); }
+
+__device__ __forceinline__ np_f32x2 neg2ln_spec2(np_f32x2 u) {
+    np_f32x2 m, ef;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t ix = __float_as_uint(u[k]) + 0x004AFB0Du;
+        ef[k] = (float)((int)(ix >> 23) - 127);
+        m[k] = __uint_as_float((ix & 0x007FFFFFu) + 0x3F3504F3u);
+    }
+    const np_f32x2 f = m - (np_f32x2)(1.0f);
+    np_f32x2 p = np_fma2(f, 0.2026811391115188f, -0.3246837854385376f);
+    p = np_fma2(f, p, 0.34494027495384216f);
+    p = np_fma2(f, p, -0.3979713022708893f);
+    p = np_fma2(f, p, 0.49940142035484314f);
+    p = np_fma2(f, p, -0.6667022705078125f);
+    p = np_fma2(f, p, 1.0000072717666626f);
+    p = np_fma2(f, p, -1.9999998807907104f);
+    return np_fma2(ef, (np_f32x2)(-1.3862943649291992f), f * p);
+}
+
+__device__ __forceinline__ np_f32x2 sqrt_spec2(np_f32x2 w) {
+    np_f32x2 y;
+#pragma unroll
+    for (int k = 0; k < 2; k++) y[k] = __uint_as_float(0x5F1FFFF9u - (__float_as_uint(w[k]) >> 1));
+    np_f32x2 t = w * y;
+    t = np_fma2(-t, y, 2.38924456f);
+    y = y * ((np_f32x2)(0.703952253f) * t);
+    const np_f32x2 h = (np_f32x2)(0.5f) * w;
+    t = h * y;
+    t = np_fma2(-t, y, 1.5f);
+    y = y * t;
+    return w * y;
+}
+
+__device__ __forceinline__ void unit_vector_spec2(const uint32_t (&k2)[2], np_f32x2 &cs, np_f32x2 &sn) {
+    np_f32x2 kf;
+#pragma unroll
+    for (int k = 0; k < 2; k++) kf[k] = (float)(k2[k] & 0x3FFFFu);
+    const np_f32x2 th = np_fma2(kf, 2.9960562e-06f, 1.4980281e-06f);
+    const np_f32x2 z = th * th;
+    np_f32x2 p = np_fma2(z, -0.00019587951828725636f, 0.008332748897373676f);
+    p = np_fma2(z, p, -0.166666641831398f);
+    p = z * p;
+    const np_f32x2 s = np_fma2(th, p, th);
+    np_f32x2 q = np_fma2(z, 2.4463830413878895e-05f, -0.001388759003020823f);
+    q = np_fma2(z, q, 0.04166664928197861f);
+    q = np_fma2(z, q, -0.5f);
+    const np_f32x2 c = np_fma2(z, q, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const bool swap = (k2[k] & 0x40000u) != 0;
+        const float a = swap ? s[k] : c[k], b = swap ? c[k] : s[k];
+        cs[k] = __uint_as_float((__float_as_uint(a) & 0x7FFFFFFFu) | ((k2[k] << 12) & 0x80000000u));
+        sn[k] = __uint_as_float((__float_as_uint(b) & 0x7FFFFFFFu) | ((k2[k] << 11) & 0x80000000u));
+    }
+}
+
 }  // namespace npf16
