@@ -124,8 +124,10 @@ def self_launch(args):
 class Timer:
     """cold window / prelude / timed region around a `step(i)` callable; `batch` gives the HIP-event kernel times."""
 
-    def __init__(self, step, batch, dev, dist, backend):
-        self.step, self.batch, self.dev, self.dist, self.backend = step, batch, dev, dist, backend
+    def __init__(self, step, batch, dev, dist, backend, per_launch=False):
+        """per_launch: keep per-dispatch events on the timed launches too — for steps that hold more than the one kernel
+        (policies, the opponent exchange), where an event pair around the region would time all of it."""
+        self.step, self.batch, self.dev, self.dist, self.backend, self.per_launch = step, batch, dev, dist, backend, per_launch
 
     def barrier(self):
         import torch
@@ -135,22 +137,58 @@ class Timer:
             torch.cuda.synchronize(self.dev)
 
     def window(self, warmup, steps, i0=0):
-        """W untimed steps, then K timed ones between two barriers.  -> (elapsed_s max over ranks, kernel samples ms, next index)"""
+        """W untimed steps, then K timed ones between two barriers.
+        -> (elapsed_s max over ranks, Samples, next index)
+
+        Kernel time is measured twice, both with HIP events on the launch stream (= torch's current stream):
+          * per launch (start / stop events attached to each dispatch, np_f16_set_timing) on the W warm-up launches and the
+            launches of the prelude before them — median / min / max, the quantity rocprofv3 reports per kernel;
+          * in the timed region: a per-dispatch pair on launch 1 and ONE event pair spanning launches 2..K;
+            (d_1 + span) / K = average launch duration there, the gaps between back-to-back launches (~1.3 us) included.
+            Launches 2..K carry no per-dispatch events: each
+            pair costs ~4.5 us of dispatch time (tools/microbench/launch_gap.py: 0.3074 vs 0.3029 ms per step at N = 1e6), which
+            would be the benchmark measuring its own instrumentation."""
+        import torch
         from neuralplane_amd import sharding
         i = i0
+        self.batch.set_timing(True)
         for _ in range(warmup):
             self.step(i)
             i += 1
-        self.batch.set_timing(True)
+        torch.cuda.synchronize(self.dev)
+        samples = Samples(getattr(self, 'recent', []) + list(self.batch.get_timing_samples()))
+        self.recent = []
+        if not self.per_launch:
+            self.batch.set_timing(False)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(i)
-            i += 1
+        if self.per_launch:
+            for _ in range(steps):
+                self.step(i)
+                i += 1
+        else:
+            # launch 1 of K carries its own event pair (the GPU idles for the host's first-call latency before it, which is
+            # not kernel time); ONE pair spans launches 2..K.  average launch duration = (d_1 + span_2..K) / K
+            self.batch.set_timing(True)
+            if steps > 0:
+                self.step(i)
+                i += 1
+            self.batch.set_timing(False)
+            ev0.record()
+            for _ in range(max(0, steps - 1)):
+                self.step(i)
+                i += 1
+            ev1.record()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        samples = self.batch.get_timing_samples()
-        self.batch.set_timing(False)
+        if self.per_launch:
+            samples = Samples(self.batch.get_timing_samples())
+            self.batch.set_timing(False)
+        else:
+            first = list(self.batch.get_timing_samples())
+            samples.region_avg_ms = (sum(first) + ev0.elapsed_time(ev1)) / max(1, steps)
+            samples.region_launches = steps
         elapsed = sharding.max_over_ranks(elapsed, self.dist, self.dev if self.backend == 'nccl' else 'cpu')
         return elapsed, samples, i
 
@@ -164,6 +202,8 @@ class Timer:
             return 0, 0.0, i
         n = max_steps if not est_step_s else max(8, min(max_steps, int(seconds / est_step_s + 0.999)))
         for k in range(n):
+            if est_step_s and k == n - 64 and self.batch is not None:
+                self.batch.set_timing(True)      # per-dispatch events on the last 64 launches: the median / min / max beside the average
             self.step(i)
             i += 1
             if k % 8 == 7:
@@ -171,15 +211,31 @@ class Timer:
             if not est_step_s and time.perf_counter() - t0 >= seconds:   # single-process callers without an estimate: time-based
                 break
         torch.cuda.synchronize(self.dev)
-        return i - i0, time.perf_counter() - t0, i
+        el = time.perf_counter() - t0
+        if est_step_s and n >= 64 and self.batch is not None:
+            self.recent = list(self.batch.get_timing_samples())
+            self.batch.set_timing(False)
+        return i - i0, el, i
+
+
+class Samples(list):
+    """per-launch kernel durations (ms) of the launches just before a timed region + the region's own average launch duration"""
+    region_avg_ms = None
+    region_launches = 0
 
 
 def stats(samples):
-    if not samples:
+    """kernel_avg_ms = the timed region's (t_last_end - t_first_start) / K from ONE HIP event pair on the launch stream;
+    median / min / max = per-dispatch HIP events on the launches right before the region (warm-up, end of the prelude)."""
+    region = getattr(samples, 'region_avg_ms', None)
+    if not samples and not region:
         return {'kernel_avg_ms': 0.0, 'kernel_median_ms': 0.0, 'kernel_min_ms': 0.0, 'kernel_max_ms': 0.0, 'launches_timed': 0}
-    s = sorted(samples)
-    return {'kernel_avg_ms': sum(s) / len(s), 'kernel_median_ms': s[len(s) // 2], 'kernel_min_ms': s[0], 'kernel_max_ms': s[-1],
-            'launches_timed': len(s)}
+    s = sorted(samples) or [region]
+    return {'kernel_avg_ms': region if region else sum(s) / len(s), 'kernel_median_ms': s[len(s) // 2], 'kernel_min_ms': s[0],
+            'kernel_max_ms': s[-1], 'launches_timed': getattr(samples, 'region_launches', 0) or len(s),
+            'launches_sampled_individually': len(samples),
+            'kernel_avg_source': '(per-dispatch HIP event pair on timed launch 1 + one HIP event pair spanning timed launches 2..K on the launch stream) / K, inter-launch gaps included'
+                                 if region else 'per-dispatch HIP events'}
 
 
 def shader_mhz(batch, step, n, dev):
@@ -276,7 +332,7 @@ def run_env(args, rank, local_rank, world, dev, dist):
                      'kernel': 'f16_env_kernel<task,solver,STEP>', **st, 'effective_shader_mhz': mhz,
                      'note': 'fp32 VECTOR (VALU) roof: 157.3 TFLOP/s is both the fp32 vector peak and the f32-input MFMA peak on '
                              'gfx950; the kernel issues no MFMA.  achieved = algorithmic FLOP x N / average launch duration (HIP '
-                             'events on the launch stream around each of the K timed launches); executed = the FLOP the kernel '
+                             'events on the launch stream: one pair around the K timed launches; per-dispatch pairs on the launches before them for the median); executed = the FLOP the kernel '
                              'really performs (cross-step coefficient reuse)'},
         'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                          'frac': ach_gbs / PEAK_HBM_GBS, 'note': '278 algorithmic B per aircraft-step; not the binding roof'},
@@ -333,7 +389,7 @@ def run_env(args, rank, local_rank, world, dev, dist):
         envs.step(a_s[i % 4])
     torch.cuda.synchronize(dev)
     el6 = time.perf_counter() - t1
-    tm6 = Timer(lambda i: envs.step(a_s[i % 4]), envs._batch, dev, None, 'nccl')
+    tm6 = Timer(lambda i: envs.step(a_s[i % 4]), envs._batch, dev, None, 'nccl', per_launch=True)   # launch-bound: per-dispatch events
     _, s6, _ = tm6.window(20, 500)
     modes['latency_n256'] = {'value': 1e6 * el6 / k6, 'unit': 'us per env.step (wall, back-to-back launches, no timing events)', 'steps': k6,
                              'kernel_avg_us': 1e3 * stats(s6)['kernel_avg_ms'], 'kernel_median_us': 1e3 * stats(s6)['kernel_median_ms'],
@@ -356,7 +412,7 @@ def combat_mode(dev, E, steps, warmup, prelude_s):
     cenv.reset()
     g2 = torch.Generator(device='cpu').manual_seed(5)
     cpool = [(torch.rand((2 * E, 4), generator=g2) * 2 - 1).to(dev) for _ in range(4)]
-    tm = Timer(lambda i: cenv.step(cpool[i % 4]), cenv._batch, dev, None, 'nccl')
+    tm = Timer(lambda i: cenv.step(cpool[i % 4]), cenv._batch, dev, None, 'nccl', per_launch=True)
     _, _, i = tm.prelude(prelude_s)
     el, samples, _ = tm.window(warmup, steps, i)
     st = stats(samples)
@@ -426,7 +482,7 @@ def run_combat(args, rank, local_rank, world, dev, dist):
         a = ex.actions(state['obs'], ego_policy)
         state['obs'] = cenv.step(a)[0]
 
-    tm = Timer(step, cenv._batch, dev, dist, args.backend)
+    tm = Timer(step, cenv._batch, dev, dist, args.backend, per_launch=True)
     cold_el, cold_samples, i = tm.window(args.warmup, args.steps)
     p_steps, p_sec, i = tm.prelude(args.prelude_ms * 1e-3, i, est_step_s=cold_el / max(1, args.steps))   # same count on every rank: steps hold collectives
     elapsed, samples, i = tm.window(args.warmup, args.steps, i)

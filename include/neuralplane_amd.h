@@ -276,7 +276,8 @@ int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 /* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context, measured with
  * HIP events on the launch stream: a start / stop pair attached to each kernel's own dispatch (hipExtLaunchKernelGGL — the
  * timestamps of the kernel's packet, no extra barrier packets between back-to-back launches; 0 disables, enable with
- * np_f16_set_timing(ctx, 1)).  Synchronises on the recorded events.  A caller that enables timing and never polls is bounded:
+ * np_f16_set_timing(ctx, 1), which starts a new series; disabling keeps the series recorded so far readable).  Synchronises on
+ * the recorded events.  A caller that enables timing and never polls is bounded:
  * after 8192 unresolved launches the next launch resolves them itself (it waits for them), and the per-launch sample list
  * below stops growing at 2^20 entries (the running average continues). */
 int np_f16_set_timing(np_f16_ctx *ctx, int enable);

@@ -1437,6 +1437,7 @@ int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
 int np_f16_set_timing(np_f16_ctx *ctx, int enable) {
     if (!ctx) return fail("null ctx");
     ctx->timing = enable != 0;
+    if (!enable) return 0;  // stop attaching events; what was recorded so far stays readable (a new series starts on enable)
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
     ctx->samples.clear();
