@@ -31,11 +31,20 @@ namespace npf16 {
 #ifndef NPF16_BLOCK
 #define NPF16_BLOCK 128
 #endif
+// pair variant, de-phasing of the first generation: (blockIdx % groups) x stagger cycles; groups odd (co-resident workgroups differ
+// by powers of two in index).  Two builds of the step kernel: PW = 2 waves per SIMD (188 VGPRs, nothing in scratch) and PW = 3
+// (168 VGPRs, ~20 cold dwords per lane in scratch, stored once and reloaded once per step); launch_env picks per grid size.
 #ifndef NPF16_PAIR_STAGGER
-#define NPF16_PAIR_STAGGER 14000  // 10 000 / 14 000 / 20 000 / 26 000 cycles: N = 1e6 0.38 ms all; 3e6 1.02 / 1.02 / 1.05 / -; 1e7 3.21 / 3.19 / 3.49 / 3.51 ms
+#define NPF16_PAIR_STAGGER 14000  // PW = 2
 #endif
 #ifndef NPF16_PAIR_GROUPS
-#define NPF16_PAIR_GROUPS 3
+#define NPF16_PAIR_GROUPS 3       // PW = 2
+#endif
+#ifndef NPF16_PAIR3_STAGGER
+#define NPF16_PAIR3_STAGGER 9000  // PW = 3 (profiles/r02b_ab_sessions.md s25)
+#endif
+#ifndef NPF16_PAIR3_GROUPS
+#define NPF16_PAIR3_GROUPS 7      // PW = 3
 #endif
 #ifndef NPF16_MINWAVES
 #define NPF16_MINWAVES 3  // waves per SIMD the register allocator must leave room for
@@ -111,8 +120,8 @@ struct KArgs {
 //                                  lone wave's time; wave 0 stores.
 // INNER     : one low-level iteration of PlanningEnv.step (np_f16_io.inner_step): no auto-reset, flagged rows keep their state, flags
 //             accumulate.  A template parameter so that the plain env.step carries none of its selects (~30 VALU instructions).
-template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1, bool INNER = false>
-__global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
+template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1, bool INNER = false, int PW = 2>
+__global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
     // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
     // terminations / reward / state stores
@@ -163,14 +172,16 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? 2 : NPF16_
     // worse: 0.45 ms); later workgroups inherit the phase of the workgroup whose slot they take.  Only done
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
-    constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * 2 / (BLOCK / 64) : FIRST_GENERATION;  // pair variant: two waves per SIMD
+    constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * PW / (BLOCK / 64) : FIRST_GENERATION;
     if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GEN && blockIdx.x < FIRST_GEN) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
         const long long unit = gridDim.x >= 8 * FIRST_GENERATION ? NPF16_STAGGER_CYCLES_LONG : NPF16_STAGGER_CYCLES;
-        // pair variant: two waves per SIMD -> two phase groups (NPF16_PAIR_STAGGER cycles apart)
-        const long long wait = WPT == 2 ? (long long)(blockIdx.x % NPF16_PAIR_GROUPS) * NPF16_PAIR_STAGGER : (long long)(blockIdx.x % 3) * unit;
+        // pair variant: NPF16_PAIR_GROUPS phase groups, NPF16_PAIR_STAGGER cycles apart
+        const long long wait = WPT != 2 ? (long long)(blockIdx.x % 3) * unit
+                               : PW == 3 ? (long long)(blockIdx.x % NPF16_PAIR3_GROUPS) * NPF16_PAIR3_STAGGER
+                                         : (long long)(blockIdx.x % NPF16_PAIR_GROUPS) * NPF16_PAIR_STAGGER;
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
@@ -997,8 +1008,8 @@ bool use_pair_kernel(const np_f16_ctx *ctx, int64_t n) {
 // and the duration is the kernel's execution time, as rocprofv3 reports it)
 #define NP_DISPATCH(ARGS, ...)                                                                                       \
     do {                                                                                                             \
-        if (timed) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, ev.first, ev.second, 0, ARGS);            \
-        else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, ARGS);                                             \
+        if (timed) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, lds_pad, st, ev.first, ev.second, 0, ARGS);      \
+        else hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds_pad, st, ARGS);                                       \
     } while (0)
 
 template <bool STEP>
@@ -1047,6 +1058,15 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)),
         block(latency8 ? LAT_TILE * 8 : latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
+    // Pair variant at three waves per SIMD (six workgroups per CU) or at two (four per CU)?  Measured per grid size (heading,
+    // one session, profiles/r02b_ab_sessions.md s25): long grids gain 5-9 % from the third wave; grids of up to three generations
+    // are quantised — 1 025-1 536 workgroups fit ONE generation of six per CU (-11..-15 %), but <= 1 024 fill the chip evenly at
+    // four per CU (a kernel that MAY hold three waves per SIMD is placed unevenly there: +13..+20 %) and 1 537-3 071 are better
+    // off in rounds of 1 024 (+16..+26 % otherwise).  Euler step kernel outside PlanningEnv's inner loop only.
+    static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
+    const bool pair3 = pair && ctx->solver == 0 && !a.inner &&
+                       (pw_env ? pw_env == 3 : ((grid.x > 1024 && grid.x <= 1536) || grid.x >= 3072));
+    const unsigned lds_pad = 0;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
     const bool timed = STEP && ctx->timing;
@@ -1056,7 +1076,10 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
 #define NP_LAUNCH_I(T, S, I)                                                                                          \
     do {                                                                                                              \
-        if (pair) {                                                                                                   \
+        if (pair3 && S == 0 && !I) {                                                                                  \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, BLOCK, 2, false, 3>); \
+            else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, BLOCK, 2, false, 3>);       \
+        } else if (pair) {                                                                                            \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, I>);       \
             else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, I>);             \
         } else if (latency8 && S == 0) {                                                                              \
@@ -1175,6 +1198,7 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
         block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     const bool timed = STEP && ctx->timing;
+    const unsigned lds_pad = 0;  // the combat kernels run at two waves per SIMD
     EventLease lease(ctx);
     if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;  // a caller that never polls
     if (timed) NP_HIP(lease.take());

@@ -263,12 +263,12 @@ def second_set(ins_list, body=None):
 # chains are still acc = fma(W[j][0], x[0], bias[j]); acc = fma(W[j][k], x[k], acc), k ascending: same bits.
 # Record layout: np_nets.h::dual_record_len (KBLOB_DUAL, derived from the first layout by np_pack_kblob).
 # ------------------------------------------------------------------------------------------------
-NM_H = [70, 110, 150]   # activation pairs of layer 1 / 2 / 3 (20, 20, 10 pairs): v70-109, v110-149, v150-169
-NM_X = 170              # v[170:171], v[172:173], v[174:175]: the (set A, set B) input pairs
-NM_YLO = 176            # v[176:177]: low chain of the output layer, then the net output (A, B)
-NM_YHI = 178            # v[178:179]: high chain
-NM_ADDR_A, NM_ADDR_B = 180, 181
-NM_CLOBBER = list(range(70, 182))
+NM_H = [70, 110, 70]    # activation pairs of layer 1 / 2 / 3 (20, 20, 10 pairs): v70-109, v110-149, and layer 3 over the (dead) layer 1: v70-89
+NM_YLO = 90             # v[90:91]: low chain of the output layer, then the net output (A, B) — layer 1's registers are dead by then
+NM_YHI = 92             # v[92:93]: high chain
+NM_X = 150              # v[150:151], v[152:153], v[154:155]: the (set A, set B) input pairs (live over all records of a class)
+NM_ADDR_A, NM_ADDR_B = 156, 157
+NM_CLOBBER = list(range(70, 158))
 
 
 def record_len_nm(IN, H1, H2, H3):
