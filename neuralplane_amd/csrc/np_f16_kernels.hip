@@ -1062,9 +1062,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     // one session, profiles/r02b_ab_sessions.md s25): long grids gain 5-9 % from the third wave; grids of up to three generations
     // are quantised — 1 025-1 536 workgroups fit ONE generation of six per CU (-11..-15 %), but <= 1 024 fill the chip evenly at
     // four per CU (a kernel that MAY hold three waves per SIMD is placed unevenly there: +13..+20 %) and 1 537-3 071 are better
-    // off in rounds of 1 024 (+16..+26 % otherwise).  Euler step kernel outside PlanningEnv's inner loop only.
+    // off in rounds of 1 024 (+16..+26 % otherwise).  Step kernels outside PlanningEnv's inner loop only.
     static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
-    const bool pair3 = pair && ctx->solver == 0 && !a.inner &&
+    const bool pair3 = pair && !a.inner &&
                        (pw_env ? pw_env == 3 : ((grid.x > 1024 && grid.x <= 1536) || grid.x >= 3072));
     const unsigned lds_pad = 0;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
@@ -1076,9 +1076,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
 #define NP_LAUNCH_I(T, S, I)                                                                                          \
     do {                                                                                                              \
-        if (pair3 && S == 0 && !I) {                                                                                  \
-            if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, BLOCK, 2, false, 3>); \
-            else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, BLOCK, 2, false, 3>);       \
+        if (pair3 && !I) {                                                                                            \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, false, 3>); \
+            else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, false, 3>);       \
         } else if (pair) {                                                                                            \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, I>);       \
             else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, I>);             \
