@@ -78,6 +78,30 @@ def test_sharded_batches_reproduce_the_unsharded_batch():
         assert torch.equal(torch.cat([p[1][k] for p in parts]), o_full[k])
 
 
+@pytest.mark.parametrize('solver', ['euler', 'rk4'])
+def test_pair_kernel_builds_agree_across_the_grid_size_rule(solver):
+    """The pair variant exists in two builds (two / three waves per SIMD, the second with cold registers parked in scratch);
+    launch_env picks one per grid size (<= 1024, 1025-1536, 1537-3071, >= 3072 workgroups of 128 aircraft).  On either side of
+    every threshold the default must equal the single-set throughput variant bit for bit."""
+    steps, seed = 4, 11
+    for wgs in (1024, 1025, 1536, 1537, 3071, 3072):
+        n = wgs * 128 - 37                    # ragged last workgroup
+        acts = _actions(steps, n, wgs)
+        res = []
+        for variant in ('auto', 'throughput'):
+            from neuralplane_amd.envs.control_env import ControlEnv
+            e = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=seed, device='cuda:0', solver=solver)
+            e._batch.set_kernel_variant(variant)
+            e.reset()
+            for a in acts:
+                out = e.step(a)
+            res.append((e.model.s.clone(), [x.clone() for x in out[:5]]))
+            del e
+        assert torch.equal(res[0][0], res[1][0]), wgs
+        for k in range(5):
+            assert torch.equal(res[0][1][k], res[1][1][k]), (wgs, k)
+
+
 def test_same_seed_same_trajectory_and_flagged_rows_are_reinitialised():
     n, steps = N, 30
     acts = _actions(steps, n, 11)
