@@ -97,8 +97,7 @@ class Body:
             self.cur_group += 1
             c = CPG * self.cur_group
             self.ins.append('s_waitcnt lgkmcnt(0)')
-            if HALF_LOADS and self.cur_group % 2 == 1:
-                continue
+            skip = HALF_LOADS and self.cur_group % 2 == 1
             for cc in range(c + CPG, c + 2 * CPG):  # next group (runs into the next record when cc >= nch)
                 if self.use_next == 'advance' and cc >= self.nch:
                     # two-set phases: the record pointer itself moves on (by the byte distance the caller left in vcc_hi) as soon as
@@ -112,8 +111,9 @@ class Body:
                     base, off = S_NEXT, (cc - self.nch) * 64
                 else:
                     base, off = S_BASE, cc * 64
-                self.ins.append(f's_load_dwordx16 s[{self.buf_of_chunk(cc)}:{self.buf_of_chunk(cc) + 15}], '
-                                f's[{base}:{base + 1}], 0x{off:x}')
+                if not skip:
+                    self.ins.append(f's_load_dwordx16 s[{self.buf_of_chunk(cc)}:{self.buf_of_chunk(cc) + 15}], '
+                                    f's[{base}:{base + 1}], 0x{off:x}')
 
     def spair(self, pos):
         assert pos % 2 == 0
