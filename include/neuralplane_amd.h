@@ -268,8 +268,10 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
  * Euler solver), "latency8" (eight waves per tile — two per SIMD, so one wave's scalar-load latency is the other's FMA time;
  * chosen automatically for n <= 16384, where every tile still has a CU of its own), "pair" (the two waves of a 128-aircraft
  * workgroup split the nets and evaluate them for each other's aircraft: half the scalar weight traffic per aircraft; the default
- * above that size with the MLP numerics) and "throughput" (two independent waves per workgroup; the 1-D table mode).  This call
- * pins the choice for a context (tests, tuning); np_f16_combat_step has latency, pair and throughput. */
+ * above that size with the MLP numerics; built twice, for two and for three waves per SIMD — the second with ~20 cold registers per
+ * lane in scratch — and picked per grid size, environment NPF16_PAIR_WAVES=2|3 pins one) and "throughput" (two independent waves per
+ * workgroup; the 1-D table mode).  This call pins the choice for a context (tests, tuning); np_f16_combat_step has latency, pair and
+ * throughput. */
 enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
