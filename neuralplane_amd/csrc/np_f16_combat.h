@@ -224,8 +224,10 @@ static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as th
 // of every evaluation and evaluate their half for both waves' aircraft (dual asm bodies, half the scalar weight traffic);
 // (64, 4) latency variant: four waves hold the same 64 aircraft (32 engagements), split the net evaluations and repeat the
 // rest.  The engagement's pair exchange stays inside each wave in every variant.
-template <int SOLVER, bool STEP, int TILE = COMBAT_BLOCK, int WPT = 1>
-__global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), NPF16_COMBAT_MINWAVES) void f16_combat_kernel(const CombatArgs a) {
+// PW: waves per SIMD the pair variant is built for (3: 168 VGPRs with ~46 dwords per lane in scratch — only worth it where six
+// workgroups per CU hold a whole grid in ONE generation, see launch_combat)
+template <int SOLVER, bool STEP, int TILE = COMBAT_BLOCK, int WPT = 1, int PW = NPF16_COMBAT_MINWAVES>
+__global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kernel(const CombatArgs a) {
     constexpr int B = TILE;
     constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0);  // pair variant: nine more columns carry the inputs to the partner wave
     __shared__ float lds[COLS * TILE];  // > TILE * COMBAT_OBS

@@ -1198,14 +1198,19 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
         block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     const bool timed = STEP && ctx->timing;
-    const unsigned lds_pad = 0;  // the combat kernels run at two waves per SIMD
+    const unsigned lds_pad = 0;
     EventLease lease(ctx);
     if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;  // a caller that never polls
     if (timed) NP_HIP(lease.take());
     const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
     // pair variant (Euler, MLP numerics): the default above the latency variant's range; NP_KERNEL_THROUGHPUT pins the single-set kernel
     const bool pair = STEP && !latency && ctx->solver == 0 && !ctx->ccfg.aero_1d_tables && ctx->variant != NP_KERNEL_THROUGHPUT;
+    // 1 025-1 536 workgroups (65 537-98 304 engagements): one generation at six workgroups per CU instead of two rounds of four —
+    // 0.300 vs 0.356 ms at 98 304 engagements; longer grids gain nothing from the third wave here (46 parked dwords per lane)
+    static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
+    const bool pair3 = pair && (pw_env ? pw_env == 3 : (grid.x > 1024 && grid.x <= 1536));
     if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
+    else if (pair3) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2, 3>);
     else if (pair) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>);
     else if (STEP && ctx->solver == 1) NP_DISPATCH(a, f16_combat_kernel<1, STEP>);
     else NP_DISPATCH(a, f16_combat_kernel<0, STEP>);
