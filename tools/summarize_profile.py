@@ -73,7 +73,7 @@ def main(tag):
                 w.writerow([row[0], row[1], f'{row[2]:.6g}', f'{row[3]:.4g}'])
     if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
         n = json.load(open(os.path.join(dst, f'{tag}_bench.json')))['config']['aircraft_per_gpu'] if os.path.exists(os.path.join(dst, f'{tag}_bench.json')) else 1000000
-        json.dump({'round': int(tag[1:3]) if tag[1:3].isdigit() else None, 'kernel': 'f16_env_kernel<0, 0, true, true, 128, 2>', 'n': n, 'task': 'heading', 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
+        json.dump({'round': int(tag[1:3]) if tag[1:3].isdigit() else None, 'kernel': 'f16_env_kernel<0, 0, true, true, 128, 2, false, 3> (pair variant, three waves per SIMD; before r02i: <..., 128, 2>)', 'n': n, 'task': 'heading', 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
                    'WRITE_SIZE_KB': traffic['WRITE_SIZE'],
                    'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), mean over the '
                            'cached-kernel launches. MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at '
