@@ -65,9 +65,12 @@ constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22
 constexpr int LDS_FLOATS = (NUM_LDS_SLOTS * BLOCK > BLOCK * OBS_LD) ? NUM_LDS_SLOTS * BLOCK : BLOCK * OBS_LD;
 
 // row-indexed access as (uniform base) + (32-bit BYTE offset): selects the SGPR-base + VGPR-offset addressing mode
+// (every such array is device memory handed over through np_f16_io: the reference is typed as GLOBAL address space, so that pointers
+// re-read from the kernel-argument segment — plain generic pointers to the compiler — do not turn into flat_store + a 64-bit VALU add)
 template <class T>
-__device__ __forceinline__ T &at_off(T *base, unsigned byte_off) {
-    return *reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+__device__ __forceinline__ __attribute__((address_space(1))) T &at_off(T *base, unsigned byte_off) {
+    typedef __attribute__((address_space(1))) T GT;
+    return *reinterpret_cast<GT *>(reinterpret_cast<uintptr_t>(base) + byte_off);
 }
 
 struct KArgs;
