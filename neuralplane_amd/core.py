@@ -335,8 +335,8 @@ class F16Batch:
         return dict(zip(self.TERM_NAMES, c))
 
     def set_kernel_variant(self, variant):
-        """'auto' (default: 'latency8' while n <= 16384, 'latency' while n <= 65536, then 'pair'), 'latency8', 'latency',
-        'throughput', 'pair' — bit-identical results."""
+        """'auto' (default: 'latency8' while n <= 16384, 'latency' while n <= 49152, 'latency2' while n <= 98304, then 'pair'),
+        'latency8', 'latency', 'latency2', 'throughput', 'pair' — bit-identical results."""
         _lib.check(self.lib.np_f16_set_kernel_variant(self._ctx, _lib.KERNEL_VARIANTS[variant]))
 
 

@@ -260,6 +260,11 @@ __device__ __forceinline__ void eval_el(const AeroWeights &wt, const float (&xn)
 struct SplitItem {
     int cl, first, cnt;
 };
+// WPT codes of the latency family (several waves share ONE tile of 64 aircraft): 4 and 8 waves, and WPT_LAT2 = two waves per tile
+// (mid-size batches, 32 K - 98 K aircraft: twice the waves of the pair variant for the same aircraft, so every SIMD holds two or
+// three waves where the pair variant leaves it one; the two waves split the nets by the pair plans below, single-set bodies)
+constexpr int WPT_LAT2 = 16;
+constexpr int lat_waves(int wpt) { return wpt == WPT_LAT2 ? 2 : (wpt >= 4 ? wpt : 1); }
 constexpr int SPLIT_WAVES = 8, SPLIT_MAX = 4;  // rows 4..7 stay empty in the four-wave plans
 struct SplitPlan {
     SplitItem it[SPLIT_WAVES][SPLIT_MAX];
@@ -415,6 +420,21 @@ __device__ __forceinline__ void eval_pair_wave(const AeroWeights &wt, const floa
 #undef NPF16_ITEM
 }
 
+// the same plans with ONE accumulator set (WPT_LAT2: the two waves hold the same 64 aircraft)
+template <const PairPlan &P, int W, int LD>
+__device__ __forceinline__ void eval_pairplan_single(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
+#define NPF16_ITEM(K) \
+    if constexpr (P.it[W][K].cnt > 0) eval_class<P.it[W][K].cl, P.it[W][K].cnt, LD, P.it[W][K].first>(wt, xn, out, tables)
+    NPF16_ITEM(0);
+    NPF16_ITEM(1);
+    NPF16_ITEM(2);
+    NPF16_ITEM(3);
+    NPF16_ITEM(4);
+    NPF16_ITEM(5);
+    NPF16_ITEM(6);
+#undef NPF16_ITEM
+}
+
 // All nets of one nlplant evaluation.  With the asm bodies and the default numerics the whole sequence of classes is ONE
 // asm statement (tools/gen_mlp_asm.py, "phase functions"): the weight stream keeps running across class boundaries.
 // WPT = 4: the latency variant above; `part` is the wave's index within its workgroup (wave-uniform).
@@ -452,6 +472,18 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
         else { NPF16_WAVE(1); }
 #undef NPF16_WAVE
         __syncthreads();  // all coefficient columns of both waves are complete
+        return;
+    } else if constexpr (WPT == WPT_LAT2) {  // two waves per 64-aircraft tile: the pair plans, evaluated with the single-set class bodies
+        static_assert(has_phase, "no split plan for this evaluation");
+        __syncthreads();  // both waves have finished reading the coefficients of the previous evaluation
+#define NPF16_WAVE(W)                                                                                        \
+    if constexpr (FULL && PART == AB_ALL) eval_pairplan_single<PAIR_ALL, W, LD>(wt, xn, out, tables);        \
+    else if constexpr (FULL && PART == AB_REST) eval_pairplan_single<PAIR_REST, W, LD>(wt, xn, out, tables); \
+    else eval_pairplan_single<PAIR_FORCE2, W, LD>(wt, xn, out, tables)
+        if (part == 0) { NPF16_WAVE(0); }
+        else { NPF16_WAVE(1); }
+#undef NPF16_WAVE
+        __syncthreads();  // all coefficient columns are complete
         return;
     } else if constexpr (WPT == 4 || WPT == 8) {
         static_assert(has_phase, "no split plan for this evaluation");
@@ -541,7 +573,7 @@ constexpr int NUM_SHARED_SCALARS = 12;
 template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0>
 __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], StateScalars &sc,
                                         float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
-    static_assert(!SHARE || WPT == 4 || WPT == 8, "shared state scalars belong to the latency variants");
+    static_assert(!SHARE || WPT == 4 || WPT == 8 || WPT == WPT_LAT2, "shared state scalars belong to the latency variants");
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
     const float xc = (float)(0.35 - 0.30);
@@ -562,7 +594,32 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
 
     if constexpr (SHARE) {  // this wave's share of the state's serial chains -> LDS (published by the barrier inside eval_nets)
         float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
-        if (part == 0 || (WPT == 8 && part == 4)) {  // four waves: wave 0 takes alpha and psi; eight: wave 4 takes psi
+        if constexpr (WPT == WPT_LAT2) {  // two waves: wave 0 alpha, theta (+ tan), psi; wave 1 beta, phi, tfac^4.14
+            float a_, b_, c_ = 0.0f;
+            if (part == 0) {
+                np_sincos(s[7], a_, b_);
+                shr[0 * LD] = a_;
+                shr[1 * LD] = b_;
+                if (FULL) np_sincostan(s[4], a_, b_, c_);
+                else np_sincos(s[4], a_, b_);
+                shr[4 * LD] = a_;
+                shr[5 * LD] = b_;
+                shr[8 * LD] = c_;
+                if (FULL) {
+                    np_sincos(s[5], a_, b_);
+                    shr[9 * LD] = a_;
+                    shr[10 * LD] = b_;
+                }
+            } else {
+                np_sincos(s[8], a_, b_);
+                shr[2 * LD] = a_;
+                shr[3 * LD] = b_;
+                np_sincos(s[3], a_, b_);
+                shr[6 * LD] = a_;
+                shr[7 * LD] = b_;
+                shr[11 * LD] = np_pow(tfac, 4.14f);
+            }
+        } else if (part == 0 || (WPT == 8 && part == 4)) {  // four waves: wave 0 takes alpha and psi; eight: wave 4 takes psi
             float a_, b_;
             if (part == 0) {
                 np_sincos(s[7], a_, b_);

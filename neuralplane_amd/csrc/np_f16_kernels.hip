@@ -52,6 +52,9 @@ namespace npf16 {
 #ifndef NPF16_STAGGER_CYCLES
 #define NPF16_STAGGER_CYCLES 20000  // ~10 us at 2 GHz per phase step; 0 disables the de-phasing
 #endif
+#ifndef NPF16_STAGGER_MIN_GENS
+#define NPF16_STAGGER_MIN_GENS 2  // de-phase only grids of at least this many generations (experiments: 0 = every grid)
+#endif
 #ifndef NPF16_STAGGER_CYCLES_LONG
 #define NPF16_STAGGER_CYCLES_LONG 30000  // grids of 8 generations and more (N >= 1.6e6 on 256 CUs), see the kernel
 #endif
@@ -124,7 +127,7 @@ struct KArgs {
 // INNER     : one low-level iteration of PlanningEnv.step (np_f16_io.inner_step): no auto-reset, flagged rows keep their state, flags
 //             accumulate.  A template parameter so that the plain env.step carries none of its selects (~30 VALU instructions).
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1, bool INNER = false, int PW = 2>
-__global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
+__global__ __launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
     // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
     // terminations / reward / state stores
@@ -152,7 +155,6 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
     KArgsC ap = (KArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter: offset 0 of the segment
     const bool tables = a.cfg.aero_1d_tables != 0;
     const uint64_t call_idx = a.call_idx + (a.call_idx_base ? *a.call_idx_base : 0ull);
-    unsigned long long tr_c0 = 0, tr_r0 = 0, tr_c1 = 0;
 #ifdef NPF16_LAT_TRACE  // experiment builds only (tools/microbench/lat_trace.py): 100 MHz stamps at the phase boundaries of every wave
     unsigned long long lt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define NP_LT(k) lt[k] = wall_clock64()
@@ -160,9 +162,12 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
 #define NP_LT(k)
 #endif
     NP_LT(0);
-    if (a.trace) {  // wave-uniform, null outside profiling runs
-        tr_c0 = __builtin_readcyclecounter();
-        tr_r0 = wall_clock64();
+    // profiling hook: the stamps go to the workgroup's record as they are taken (nothing stays live across the kernel; a.trace is
+    // wave-uniform and null outside profiling runs)
+    if (a.trace && threadIdx.x == 0) {
+        unsigned long long *rec = a.trace + (unsigned long long)blockIdx.x * NP_TRACE_WORDS;
+        rec[0] = __builtin_readcyclecounter();
+        rec[3] = wall_clock64();
     }
 
     // ---- de-phasing -----------------------------------------------------------------------------------
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
     constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * PW / (BLOCK / 64) : FIRST_GENERATION;
-    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= 2 * FIRST_GEN && blockIdx.x < FIRST_GEN) {
+    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= NPF16_STAGGER_MIN_GENS * FIRST_GEN && blockIdx.x < FIRST_GEN) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
-    if (a.trace) tr_c1 = __builtin_readcyclecounter();
+    if (a.trace && threadIdx.x == 0) a.trace[(unsigned long long)blockIdx.x * NP_TRACE_WORDS + 1] = __builtin_readcyclecounter();
 
     // row-indexed arrays are addressed as (uniform 64-bit base in SGPRs) + (32-bit per-lane offset): ld < 2^30 is checked on the
     // host, so the byte offset of a row fits 32 bits and no per-access 64-bit VALU address arithmetic is left
@@ -311,6 +316,8 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
     }
 
     // ---- observation at the new state (task.get_obs) ----
+    // Every variant but the latency family builds it AFTER the Overload evaluation (below): its 22 values would otherwise stay live
+    // across that asm phase — 20 of them were what the three-waves-per-SIMD build of the pair variant parked in scratch (round 2).
     Trig tr;
     float o[22];
     StateScalars sc1;  // SHARED: filled by the Overload evaluation below
@@ -318,21 +325,14 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
     if constexpr (!SHARED) {
         float tt_unused;
         trig_of(s, tr, tt_unused);
-        observe<TASK>(ap->cfg, s, u, tgt, tr, o);
-        if (ap->noise) {  // obs + randn_like(obs) * noise_scale
-#pragma unroll
-            for (int k = 0; k < 22; k++) o[k] = o[k] + ap->noise[ic * 22 + k] * ap->cfg.noise_scale;
-        } else if (gen_noise) {
-#if !(defined(NPF16_EXP) && (NPF16_EXP & 1))  // timing experiment only: no observation noise
-            const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
-            add_rng_noise(ap->seed, call_idx2, ap->row0 + ic, ap->cfg.noise_scale, o);
-#endif
-        }
     } else if (gen_noise) {
         // this wave's Philox block of the row -> its two or three Box-Muller pairs -> LDS (published by the barrier that opens the
         // Overload evaluation; wave 0 adds them to the observation afterwards: same values, same fma as add_rng_noise)
         const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
-        const int nb = WPT == 8 ? part - 4 : part;  // eight waves: 0..3 are computing the state's trigonometry meanwhile
+#pragma unroll
+        for (int q = 0; q < (WPT == WPT_LAT2 ? 2 : 1); q++) {  // two waves per tile: blocks {0, 3} and {1, 2} (5 and 6 pairs)
+        // eight waves: 0..3 are computing the state's trigonometry meanwhile
+        const int nb = WPT == 8 ? part - 4 : WPT == WPT_LAT2 ? (q == 0 ? part : 3 - part) : part;
         if (nb >= 0) {
         uint32_t blk[4], k1[3], k2[3];
         rng_block(ap->seed, call_idx2, ap->row0 + ic, 2u + (uint32_t)nb, blk);
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
                 nz[(3 * pair + 1) * TILE] = cs;
                 nz[(3 * pair + 2) * TILE] = sn;
             }
+        }
         }
         }
     }
@@ -427,8 +428,10 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
         for (int k = 0; k < 12; k++) at_off(ap->s + k * ap->ld, w4) = s[k];
 #pragma unroll
         for (int k = 0; k < 4; k++) at_off(ap->u + k * ap->ld, w4) = u[k];
+        if (flagged && !INNER) {  // the targets change only when the row is re-initialised (task.reset)
 #pragma unroll
-        for (int k = 0; k < 3; k++) at_off(ap->tgt + k * ap->ld, w4) = tgt[k];
+            for (int k = 0; k < 3; k++) at_off(ap->tgt + k * ap->ld, w4) = tgt[k];
+        }
         at_off(ap->step_count, iw * 8u) = sc;
         at_off(ap->fout0, iw) = done ? 1 : 0;
         at_off(ap->fout1, iw) = bad ? 1 : 0;
@@ -441,13 +444,27 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
         }
     }
 
+    if constexpr (!SHARED) {
+        NP_REREAD_ARGS(ap);
+        observe<TASK>(ap->cfg, s, u, tgt, tr, o);
+        if (ap->noise) {  // obs + randn_like(obs) * noise_scale
+#pragma unroll
+            for (int k = 0; k < 22; k++) o[k] = o[k] + ap->noise[ic * 22 + k] * ap->cfg.noise_scale;
+        } else if (gen_noise) {
+#if !(defined(NPF16_EXP) && (NPF16_EXP & 1))  // timing experiment only: no observation noise
+            const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
+            add_rng_noise(ap->seed, call_idx2, ap->row0 + ic, ap->cfg.noise_scale, o);
+#endif
+        }
+    }
+
     NP_LT(5);
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
     if (ap->obs) {
         __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
         const long long rows = (ap->n - i0) < TILE ? (ap->n - i0) : TILE;
         float *dst = ap->obs + i0 * 22;
-        constexpr int THREADS = TILE * (WPT >= 4 ? WPT : 1);
+        constexpr int THREADS = TILE * lat_waves(WPT);
         if (rows == TILE && ((uintptr_t)dst & 15) == 0) {  // workgroup-uniform: a full tile and a 16-byte aligned destination
             // unpadded rows (pitch 22 floats): 11 ds_write_b64 per lane, then the tile leaves as 16-byte vectors — 6 (2)
             // ds_read_b128 + global_store_dwordx4 per thread instead of 22 dword pairs; the LDS bank conflicts of the unpadded
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
 #ifdef NPF16_LAT_TRACE
     NP_LT(6);
     if (ap->trace && (threadIdx.x & 63) == 0) {  // 8 words per wave (the caller sizes the buffer)
-        constexpr int NW = TILE * (WPT >= 4 ? WPT : 1) / 64;
+        constexpr int NW = TILE * lat_waves(WPT) / 64;
         unsigned long long *rec = ap->trace + ((unsigned long long)blockIdx.x * NW + threadIdx.x / 64) * 8;
         for (int k = 0; k < 7; k++) rec[k] = lt[k];
     }
@@ -502,10 +519,7 @@ __global__ __launch_bounds__(TILE * (WPT >= 4 ? WPT : 1), (WPT == 2 ? PW : NPF16
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        rec[0] = tr_c0;
-        rec[1] = tr_c1;
         rec[2] = __builtin_readcyclecounter();
-        rec[3] = tr_r0;
         rec[4] = wall_clock64();
         rec[5] = ((unsigned long long)xcc << 32) | hw;
     }
@@ -979,7 +993,17 @@ struct EventLease {
 constexpr int LAT_TILE = 64;
 constexpr int64_t LAT8_MAX_N = 16384;  // eight waves per tile while every tile still gets a CU of its own (256 tiles)
 constexpr int64_t COMBAT_LAT_MAX_N = 40000;  // aircraft; against the pair variant (round 2): 16 384 engagements 0.116 vs 0.127 ms, 20 000 a tie (0.197), 24 576 0.213 vs 0.198
-constexpr int64_t LAT_MAX_N = 65536;  // measured crossover (tools/microbench/small_n.py): 65536: 53.6 vs 58.9 us, 98304: 73.5 vs 59.2 us
+// latency family up to LAT_MAX_N, the pair variant above.  Round 3 (profiles/r03_n_sweep.json): four waves per tile fill one generation
+// of 768 tiles at three waves per SIMD up to LAT4_MAX_N (49 152: 30.6 us; 65 536 needs a second round: 45.6 us); two waves per
+// tile (latency2) keep 1 024 - 1 536 tiles in ONE generation of two to three waves per SIMD up to 98 304 aircraft
+#ifndef NPF16_LAT4_MAX_N
+#define NPF16_LAT4_MAX_N 49152
+#endif
+#ifndef NPF16_LAT_MAX_N
+#define NPF16_LAT_MAX_N 98304
+#endif
+constexpr int64_t LAT4_MAX_N = NPF16_LAT4_MAX_N;
+constexpr int64_t LAT_MAX_N = NPF16_LAT_MAX_N;
 bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
     static const int forced = [] {  // process-wide override for experiments: NPF16_KERNEL=latency|throughput
         const char *e = std::getenv("NPF16_KERNEL");
@@ -987,7 +1011,7 @@ bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
         return std::strcmp(e, "latency") == 0 ? (int)NP_KERNEL_LATENCY : std::strcmp(e, "throughput") == 0 ? (int)NP_KERNEL_THROUGHPUT : (int)NP_KERNEL_AUTO;
     }();
     const int v = ctx->variant != NP_KERNEL_AUTO ? ctx->variant : forced;
-    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY || v == NP_KERNEL_LATENCY8;
+    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY || v == NP_KERNEL_LATENCY8 || v == NP_KERNEL_LATENCY2;
     return n <= LAT_MAX_N;
 }
 // pair variant (two waves split the nets and evaluate them for each other's aircraft): Euler, MLP numerics (no 1-D tables)
@@ -1058,8 +1082,11 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     // eight waves per tile: small batches of the MLP numerics (the table mode's classes are too short to split further)
     const bool latency8 = latency && !ctx->cfg.aero_1d_tables &&
                           (ctx->variant == NP_KERNEL_LATENCY8 || (ctx->variant == NP_KERNEL_AUTO && n <= LAT8_MAX_N));
+    // two waves per tile: above the four-wave variant's single generation (both numerics; Euler)
+    const bool latency2 = latency && !latency8 &&
+                          (ctx->variant == NP_KERNEL_LATENCY2 || (ctx->variant == NP_KERNEL_AUTO && n > LAT4_MAX_N));
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)),
-        block(latency8 ? LAT_TILE * 8 : latency ? LAT_TILE * 4 : BLOCK);
+        block(latency8 ? LAT_TILE * 8 : latency2 ? LAT_TILE * 2 : latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
     // Pair variant at three waves per SIMD (six workgroups per CU) or at two (four per CU)?  Measured per grid size (heading,
     // one session, profiles/r02b_ab_sessions.md s25): long grids gain 5-9 % from the third wave; grids of up to three generations
@@ -1088,6 +1115,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         } else if (latency8 && S == 0) {                                                                              \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 8, I>);    \
             else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, 8, I>);          \
+        } else if (latency2 && S == 0) {                                                                              \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, WPT_LAT2, I>);    \
+            else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, WPT_LAT2, I>);          \
         } else if (latency && S == 0) {                                                                               \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4, I>);    \
             else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4, I>);          \
@@ -1460,7 +1490,7 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
     if (!ctx) return fail("null ctx");
     if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR &&
-        variant != NP_KERNEL_LATENCY8)
+        variant != NP_KERNEL_LATENCY8 && variant != NP_KERNEL_LATENCY2)
         return fail("unknown kernel variant");
     ctx->variant = variant;
     return 0;
