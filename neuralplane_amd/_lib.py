@@ -82,8 +82,15 @@ _lib = None
 
 
 def so_path():
-    # NPF16_LIB: A/B timing of experimental builds inside one gpurun session (tools/microbench/ab_libs.py); never set in production
-    return os.environ.get('NPF16_LIB') or _build.SO
+    # NPF16_LIB: A/B timing of experimental builds inside one gpurun session (tools/microbench/ab_libs.py); never set in production.
+    # An experimental build may carry other numerics under the same ABI number, so the override is announced on every load.
+    override = os.environ.get('NPF16_LIB')
+    if override:
+        import warnings
+        warnings.warn(f'NPF16_LIB is set: loading the HIP extension from {override} instead of the built library {_build.SO} '
+                      '(measurement builds only: results may differ from the shipped numerics)', RuntimeWarning, stacklevel=3)
+        return override
+    return _build.SO
 
 
 def load():

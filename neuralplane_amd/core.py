@@ -15,6 +15,11 @@ from . import _lib
 
 ASSET_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'f16_aero_mlp.bin')
 NUM_DERIVED = 23
+# Identifier of the numerics spec the kernels implement: bumped whenever a change alters the bits of a run (round 2:
+# observation-noise generator v2, packed output layers, Markstein constant divisions = 2).  Checkpoints carry it together with the
+# library's ABI version; load_state_dict warns when a checkpoint was written under another spec — it still loads, but the continued
+# trajectories will not reproduce the recorded ones bit for bit.
+NUMERICS_SPEC = 2
 NUM_NETS = 43
 NUM_CACHED = 14
 
@@ -51,6 +56,15 @@ def cfg_from_config(config, task, solver=None, aero_1d_tables=None):
         aero_1d_tables = g('aero_1d_tables', int(os.environ.get('NPF16_AERO_1D_TABLES', '0')))
     c.aero_1d_tables = 1 if aero_1d_tables else 0
     return c
+
+
+def _check_numerics_spec(sd):
+    spec = sd.get('numerics_spec')
+    if spec != NUMERICS_SPEC:
+        import warnings
+        warnings.warn(f"checkpoint written under numerics spec {spec if spec is not None else '<unrecorded>'} (ABI {sd.get('abi_version', '?')}), "
+                      f'this library implements spec {NUMERICS_SPEC} (ABI {_lib.ABI_VERSION}): the state loads, but the continued '
+                      'trajectories will differ in the last bits from a run recorded under the old spec', RuntimeWarning, stacklevel=3)
 
 
 class F16Batch:
@@ -104,6 +118,9 @@ class F16Batch:
         # per-aircraft condition bits of the last step (np_f16_io.term_reasons); allocated by track_termination_reasons()
         self.term_reasons = None
         self.reward_task = None     # the task reward term of the last step (np_f16_io.reward_task); allocated by track_reward_terms()
+        # bumped whenever one of the optional output pointers above changes: a HIP graph that baked the old pointers must be
+        # re-captured before its next replay (PlanningEnv._step_graph checks it)
+        self._io_epoch = 0
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -276,11 +293,12 @@ class F16Batch:
         left by the last step and the RNG counter (the RNG is counter-based: no generator state)."""
         return {'s': self.s.clone(), 'u': self.u.clone(), 'tgt': self.tgt.clone(), 'step_count': self.step_count.clone(),
                 'flags': self.flags.clone(), 'call_idx': int(self.call_idx), 'seed': int(self.seed), 'row0': int(self.row0),
-                'task': self.task, 'n': self.n}
+                'task': self.task, 'n': self.n, 'numerics_spec': NUMERICS_SPEC, 'abi_version': _lib.ABI_VERSION}
 
     def load_state_dict(self, sd):
         if sd['n'] != self.n or sd['task'] != self.task:
             raise ValueError(f"checkpoint is for n={sd['n']}, task={sd['task']}; this batch is n={self.n}, task={self.task}")
+        _check_numerics_spec(sd)
         for k in ('s', 'u', 'tgt', 'step_count'):
             getattr(self, k).copy_(sd[k].to(self.device))
         self.flags = sd['flags'].to(self.device).clone()
@@ -313,8 +331,10 @@ class F16Batch:
         next step)."""
         if enable and self.term_reasons is None:
             self.term_reasons = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
-        elif not enable:
+            self._io_epoch += 1
+        elif not enable and self.term_reasons is not None:
             self.term_reasons = None
+            self._io_epoch += 1
         return self.term_reasons
 
     def track_reward_terms(self, enable=True):
@@ -322,8 +342,10 @@ class F16Batch:
         term -200 * bad_done + 200 * done).  Returns the tensor (zeros until the next step)."""
         if enable and self.reward_task is None:
             self.reward_task = torch.zeros(self.n, dtype=torch.float32, device=self.device)
-        elif not enable:
+            self._io_epoch += 1
+        elif not enable and self.reward_task is not None:
             self.reward_task = None
+            self._io_epoch += 1
         return self.reward_task
 
     def termination_counts(self, reset=False):
@@ -508,11 +530,13 @@ class F16CombatBatch:
     def state_dict(self):
         return {'s': self.s.clone(), 'u': self.u.clone(), 'pid': self.pid.clone(), 'blood': self.blood.clone(),
                 'step_count': self.step_count.clone(), 'flags': self.flags.clone(), 'pid_first': bool(self.pid_first),
-                'call_idx': int(self.call_idx), 'seed': int(self.seed), 'env0': int(self.env0), 'num_envs': self.num_envs}
+                'call_idx': int(self.call_idx), 'seed': int(self.seed), 'env0': int(self.env0), 'num_envs': self.num_envs,
+                'numerics_spec': NUMERICS_SPEC, 'abi_version': _lib.ABI_VERSION}
 
     def load_state_dict(self, sd):
         if sd['num_envs'] != self.num_envs:
             raise ValueError(f"checkpoint is for num_envs={sd['num_envs']}; this batch has {self.num_envs}")
+        _check_numerics_spec(sd)
         for k in ('s', 'u', 'pid', 'blood', 'step_count'):
             getattr(self, k).copy_(sd[k].to(self.device))
         self.flags = sd['flags'].to(self.device).clone()

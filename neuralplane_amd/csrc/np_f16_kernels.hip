@@ -127,7 +127,13 @@ struct KArgs {
 // INNER     : one low-level iteration of PlanningEnv.step (np_f16_io.inner_step): no auto-reset, flagged rows keep their state, flags
 //             accumulate.  A template parameter so that the plain env.step carries none of its selects (~30 VALU instructions).
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1, bool INNER = false, int PW = 2>
-__global__ __launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWAVES)) void f16_env_kernel(const KArgs a) {
+__global__
+#ifdef NPF16_OLD_BOUNDS
+__launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWAVES))
+#else
+__launch_bounds__(TILE * lat_waves(WPT)) __attribute__((amdgpu_waves_per_eu((WPT == 2 ? PW : NPF16_MINWAVES), (WPT == 2 && PW == 2 ? 2 : 8))))
+#endif
+void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
     // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
     // terminations / reward / state stores
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWA
             for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * TILE] = a.reset_coef[k];
         }
     }
+    if (!STEP && a.term_reasons && valid && part == 0) a.term_reasons[i] = 0;  // reset(): every flag cleared, no condition evaluated
     if (!STEP && a.cache && flagged && valid && !INNER && part == 0) {  // reset(): keep the cache consistent for re-initialised rows
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * CACHE_TILE] = a.reset_coef[k];
@@ -325,6 +332,22 @@ __global__ __launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWA
     if constexpr (!SHARED) {
         float tt_unused;
         trig_of(s, tr, tt_unused);
+        if (STEP) {
+            // The Overload phase below is an asm statement that owns v70-v157.  Left alone, the compiler SINKS whatever the code before
+            // that statement does not need past it — the moment equations of the integrator evaluation (the new P, Q, R are first read
+            // by the force build-up after the statement: ~30 raw coefficients stayed live instead of 3 states) and the tails of the
+            // fp64 sine / cosine sequences (their 64-bit intermediates stayed live instead of 8 floats): 93 registers live across the
+            // statement, 20 of them in scratch in the three-waves-per-SIMD build.  Pin the new state and its trigonometry here.
+#ifndef NPF16_PIN_MASK
+#define NPF16_PIN_MASK 3
+#endif
+            if ((NPF16_PIN_MASK & 1) && (WPT == 2 || (NPF16_PIN_MASK & 4))) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) asm volatile("" : "+v"(s[k]));
+            }
+            if ((NPF16_PIN_MASK & 2) && (WPT == 2 || (NPF16_PIN_MASK & 4)))
+                asm volatile("" : "+v"(tr.sa), "+v"(tr.ca), "+v"(tr.sb), "+v"(tr.cb), "+v"(tr.st), "+v"(tr.ct), "+v"(tr.sphi), "+v"(tr.cphi));
+        }
     } else if (gen_noise) {
         // this wave's Philox block of the row -> its two or three Box-Muller pairs -> LDS (published by the barrier that opens the
         // Overload evaluation; wave 0 adds them to the observation afterwards: same values, same fma as add_rng_noise)
@@ -387,7 +410,12 @@ __global__ __launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWA
             float reward_task = 0.0f;
             done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons, reward_task);
             if (ap->reward_task && valid && part == STATE_WAVE) ap->reward_task[i] = reward_task;  // wave-uniform pointer test
-            if (ap->term_reasons && valid && part == STATE_WAVE) ap->term_reasons[i] = (unsigned char)reasons;  // wave-uniform pointer test
+            if (ap->term_reasons && valid && part == STATE_WAVE) {  // wave-uniform pointer test
+                // inner iterations of PlanningEnv.step: the bits accumulate like the flags they explain (the reset launch that opens
+                // the macro-step cleared them), so a row that tripped a condition at inner step 3 still shows it after step 50
+                if (INNER) reasons |= ap->term_reasons[i];
+                ap->term_reasons[i] = (unsigned char)reasons;
+            }
             if (ap->term_counters) {
                 // the reference prints torch.sum(mask) per termination condition and step (a host sync each); here: one wave
                 // ballot per condition, population count, ONE atomic per wave for a condition that fired at all
@@ -990,6 +1018,16 @@ struct EventLease {
     }
 };
 
+// a launch whose stream is being captured into a HIP graph (PlanningEnv.enable_graph, a caller's torch.cuda.graph)
+bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return status != hipStreamCaptureStatusNone;
+}
+
 constexpr int LAT_TILE = 64;
 constexpr int64_t LAT8_MAX_N = 16384;  // eight waves per tile while every tile still gets a CU of its own (256 tiles)
 constexpr int64_t COMBAT_LAT_MAX_N = 40000;  // aircraft; against the pair variant (round 2): 16 384 engagements 0.116 vs 0.127 ms, 20 000 a tie (0.197), 24 576 0.213 vs 0.198
@@ -1065,7 +1103,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
     a.call_idx_base = io->call_idx_base;
     a.term_counters = io->term_counters;
-    a.term_reasons = STEP ? io->term_reasons : nullptr;
+    a.term_reasons = io->term_reasons;
     a.reward_task = STEP ? io->reward_task : nullptr;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
@@ -1099,7 +1137,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     const unsigned lds_pad = 0;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
-    const bool timed = STEP && ctx->timing;
+    const bool timed = STEP && ctx->timing && !stream_is_capturing(st);  // event-attached dispatches cannot be captured into a graph
     EventLease lease(ctx);
     if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;  // a caller that never polls
     if (timed) NP_HIP(lease.take());
@@ -1230,7 +1268,7 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)),
         block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-    const bool timed = STEP && ctx->timing;
+    const bool timed = STEP && ctx->timing && !stream_is_capturing(st);
     const unsigned lds_pad = 0;
     EventLease lease(ctx);
     if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;  // a caller that never polls
@@ -1502,9 +1540,20 @@ int np_f16_set_timing(np_f16_ctx *ctx, int enable) {
     if (!enable) return 0;  // stop attaching events; what was recorded so far stays readable (a new series starts on enable)
     ctx->t_sum_ms = 0.0;
     ctx->t_count = 0;
-    ctx->samples.clear();
-    for (auto &e : ctx->events) ctx->pool.push_back(e);
+    // pairs still pending belong to launches that may not have finished: wait for them before they go back to the pool (a
+    // recycled pair would otherwise be re-recorded while its old recording is in flight)
+    {
+        DeviceGuard guard;
+        NP_HIP(guard.enter(ctx->device));
+        for (auto &e : ctx->events) {
+            (void)hipEventSynchronize(e.second);
+            ctx->pool.push_back(e);
+        }
+    }
     ctx->events.clear();
+    ctx->t_sum_ms = 0.0;
+    ctx->t_count = 0;
+    ctx->samples.clear();
     return 0;
 }
 

@@ -105,7 +105,9 @@ class BaseEnv(Env):
     def termination_reasons(self):
         """uint8[n]: which termination conditions fired for which aircraft at the state reached by the LAST step (bit k =
         F16Batch.TERM_NAMES[k]: overload, low_altitude, high_speed, low_speed, extreme_state, unreach, reached).  The first call
-        switches the tracking on: the kernel then stores one more byte per aircraft and step; it reports from the next step on."""
+        switches the tracking on: the kernel then stores one more byte per aircraft and step; it reports from the next step on.
+        PlanningEnv: the bits accumulate over the 50 inner iterations of one step (as its done / bad_done flags do), so a row that
+        tripped Overload at inner iteration 3 still shows the bit after the step; reset() clears them."""
         r = self._batch.term_reasons
         return r if r is not None else self._batch.track_termination_reasons(True)
 

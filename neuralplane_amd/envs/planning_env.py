@@ -179,11 +179,19 @@ class PlanningEnv(BaseEnv):
         with torch.cuda.graph(graph), torch.no_grad():
             self._macro_body(g)
         # capture does not execute: the device counter and the flags are still those of the current state
+        # the optional per-aircraft outputs are baked into the graph's launches: keep them alive as long as the graph is, and remember
+        # which set of pointers it was captured with (F16Batch._io_epoch)
+        g['term_reasons'], g['reward_task'] = b.term_reasons, b.reward_task
         self._graph, self._gbuf = graph, g
         self._graph_call_idx = b.call_idx
+        self._graph_io_epoch = b._io_epoch
 
     def _step_graph(self, action):
         b = self._batch
+        if getattr(self, '_graph', None) is not None and self._graph_io_epoch != b._io_epoch:
+            # track_termination_reasons / track_reward_terms changed an output pointer since the capture: the old graph would keep
+            # writing to (or never write) the old buffers
+            self._graph = None
         if getattr(self, '_graph', None) is None:
             self._capture()
         g = self._gbuf

@@ -412,6 +412,48 @@ def test_planning_env_hip_graph_replay_equals_eager():
         fresh.load_state_dict(envs[0]._batch.state_dict())      # a bare batch checkpoint lacks the controller state
 
 
+def test_planning_env_graph_follows_the_optional_output_pointers():
+    """termination_reasons() / reward_terms() switched on AFTER enable_graph() has captured: the captured launches baked NULL
+    pointers, so the graph is re-captured before its next replay and the per-aircraft outputs equal the eager env's; switched off
+    again, the graph no longer writes the freed buffers.  The reason bits accumulate over the 50 inner iterations: every row the
+    step flags bad_done shows at least one of the bad conditions."""
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    n = 300
+    torch.manual_seed(0)
+    ctrl = _TinyActor().cuda().eval()
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=9, device='cuda:0', controller=ctrl) for _ in range(2)]
+    envs[1].enable_graph()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    acts = [(torch.rand((n, 3), generator=g) * 2.4 - 1.2).cuda() for _ in range(5)]
+    for e in envs:
+        e.step(acts[0])                                      # the graph is captured here, without the optional outputs
+    first_graph = envs[1]._graph
+    reasons = [e.termination_reasons() for e in envs]        # tracking on: a new pointer
+    terms = [e.reward_terms()[0] for e in envs]
+    n_bad = 0
+    for a in acts[1:4]:
+        outs = [e.step(a) for e in envs]
+        for x, y in zip(outs[0][:5], outs[1][:5]):
+            assert torch.equal(x, y)
+        r0, r1 = envs[0].termination_reasons(), envs[1].termination_reasons()
+        assert torch.equal(r0, r1), 'graph replay did not write the per-aircraft condition bits'
+        assert torch.equal(envs[0].reward_terms()[0], envs[1].reward_terms()[0])
+        bad = outs[0][3]
+        n_bad += int(bad.sum())
+        assert bool(((r0[bad] & 0x3F) != 0).all()), 'a row flagged bad_done shows no bad condition: the bits did not accumulate over the inner steps'
+        assert bool((r0[~bad & ~outs[0][2]] & 0x3F).eq(0).all())
+    assert envs[1]._graph is not first_graph, 'the graph was not re-captured after the output pointers changed'
+    assert n_bad > 0
+    second_graph = envs[1]._graph
+    envs[1]._batch.track_termination_reasons(False)          # pointer dropped: the next replay must come from a fresh capture
+    envs[0]._batch.track_termination_reasons(False)
+    outs = [e.step(acts[4]) for e in envs]
+    for x, y in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(x, y)
+    assert envs[1]._graph is not second_graph
+    del reasons, terms
+
+
 def test_hip_parity_report_vs_reference_recordings():
     """The headline parity claim, directly, and the artefact SURVEY.md §8(d) asks for: the HIP env against what the REFERENCE
     recorded (tests/golden/traj_*.npz, plain ATen arithmetic; the authors' CUDA episode) — tools/parity_report.py with the HIP
