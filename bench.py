@@ -352,7 +352,15 @@ def run_env(args, rank, local_rank, world, dev, dist):
         k2 = min(args.steps, 100)
         el2, s2 = side_mode(lambda: ControlEnv(num_envs=n, config=args.task, model='F16', random_seed=0, device=str(dev), row0=row0,
                                                aero_1d_tables=1), lambda: pool, dev, k2, 5, ps)
+        ms2 = stats(s2)['kernel_avg_ms']
+        # executed per aircraft-step in this mode: the multi-input nets of the cached integrator evaluation (14 nets, 9 350 FLOP) and of the
+        # Overload re-evaluation (9 nets, 5 910), 22 + 14 table lookups (one fma each behind a 6-step search) and ~900 of non-MLP arithmetic
+        exec_tab = 9350 + 5910 + 2 * 36 + 900
         modes['aero_1d_tables'] = {'value': n * k2 / el2, 'unit': 'aircraft-steps/s', 'steps': k2, **stats(s2),
+                                   'executed_flop_per_aircraft_step': exec_tab,
+                                   'executed_tflops': n * exec_tab / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
+                                   'executed_frac_of_fp32_peak': n * exec_tab / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if ms2 > 0 else 0.0,
+                                   'kernel': 'pair variant (round 3): the 20 multi-input nets on the two-set bodies, the 22 single-input nets as per-lane table lookups',
                                    'note': 'not the headline: changes the rounding of 22 of the 42 aero coefficients by ~1e-5 rel '
                                            '(tests: masks identical to the reference, HIP == oracle bit-exact)'}
     if args.solver != 'rk4':
@@ -459,6 +467,32 @@ def planning_mode(dev, g):
                     'the same step with the controller as eager torch modules: 22 ms (tools/microbench/planning_bench.py)'}
 
 
+def _wall(step, batch, dev, warmup, k):
+    """seconds per step, back-to-back launches, no per-dispatch timing events (each pair stretches a dispatch by ~4.5 us)"""
+    import torch
+    batch.set_timing(False)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(k):
+        step(i)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / k
+
+
+def _kernel_ms(step, batch, dev, k):
+    """average duration of the context's kernel over k steps (events attached to each dispatch)"""
+    import torch
+    batch.set_timing(True)
+    for i in range(k):
+        step(i)
+    torch.cuda.synchronize(dev)
+    smp = batch.get_timing_samples()
+    batch.set_timing(False)
+    return sum(smp) / max(1, len(smp))
+
+
 def run_combat(args, rank, local_rank, world, dev, dist):
     """BASELINE.json configs[4]: SingleCombat 1v1 self-play, `--engagements` in total sharded BY ENV over the ranks (strong
     scaling), with the opponent-observation exchange of the self-play runner inside the stepped loop
@@ -476,17 +510,52 @@ def run_combat(args, rank, local_rank, world, dev, dist):
     ego_policy = lambda o: torch.tanh(o @ W_ego)                # noqa: E731
     opp_policy = lambda o, ids: torch.tanh(o @ W_opp)           # noqa: E731
     ex = OpponentExchange(e_loc, env0, e_total, dist, dev, opponent_policy=opp_policy, lag=args.opponent_lag)
-    state = {'obs': cenv.reset()}
+    # the split layout (np_f16_combat_io.action_opp / obs_opp): ego / opponent halves are separate contiguous arrays the kernel reads
+    # and writes itself, so the exchange and the policies work on the kernel's buffers — no split / stack / contiguous copies
+    state = {'obs': cenv.reset_split()} if not args.interleaved else {'obs': cenv.reset()}
 
     def step(i):
-        a = ex.actions(state['obs'], ego_policy)
-        state['obs'] = cenv.step(a)[0]
+        if args.interleaved:   # round-2 loop, kept for A/B: interleaved [2E, .] rows, torch split / contiguous / stack around the launch
+            a = ex.actions(state['obs'], ego_policy)
+            state['obs'] = cenv.step(a)[0]
+        else:
+            ea, oa = ex.actions_split(state['obs'][0], state['obs'][1], ego_policy)
+            state['obs'] = cenv.step_split(ea, oa)[:2]
 
     tm = Timer(step, cenv._batch, dev, dist, args.backend, per_launch=True)
     cold_el, cold_samples, i = tm.window(args.warmup, args.steps)
     p_steps, p_sec, i = tm.prelude(args.prelude_ms * 1e-3, i, est_step_s=cold_el / max(1, args.steps))   # same count on every rank: steps hold collectives
     elapsed, samples, i = tm.window(args.warmup, args.steps, i)
     fin = bool(torch.isfinite(cenv.s).all().item())
+    plain_ms = 1e3 * _wall(step, cenv._batch, dev, 10, max(50, args.steps)) if world == 1 else None   # the loop without timing events
+    # What the 1 -> 8 GPU curve of this config should look like, from numbers measured in THIS run (single-GPU runs only): the
+    # per-GPU share of an 8-rank job stepped through the same loop on this GPU (no collective in it), plus an estimate for the two
+    # all-gathers of a step.  Strong scaling: the work per GPU shrinks 8x, the per-step floor (kernel latency at a small grid,
+    # policy launches, exchange) does not.
+    expected = None
+    if world == 1 and not args.headline_only:
+        share = max(64, e_total // 8)
+        senv = SingleCombatEnv(num_envs=share, config='selfplay', random_seed=0, device=str(dev), env0=0)
+        sex = OpponentExchange(share, 0, share, None, dev, opponent_policy=opp_policy, lag=args.opponent_lag)
+        sst = {'obs': senv.reset_split()}
+
+        def sstep(i):
+            ea, oa = sex.actions_split(sst['obs'][0], sst['obs'][1], ego_policy)
+            sst['obs'] = senv.step_split(ea, oa)[:2]
+        s_step_ms = 1e3 * _wall(sstep, senv._batch, dev, 30, 300)          # no timing events in this window
+        s_kernel_ms = _kernel_ms(sstep, senv._batch, dev, 100)
+        ag_lo, ag_hi = 0.04, 0.06   # ms per all-gather on xGMI at this payload (0.75 MB / 0.2 MB per rank): launch + ring latency bound, DESIGN.md §7 — an estimate, no multi-GPU box was available
+        t1 = plain_ms
+        lag0 = (s_step_ms + 2 * ag_lo, s_step_ms + 2 * ag_hi)       # both collectives exposed behind the ego policy's two small kernels
+        lag1 = (max(s_step_ms, 2 * ag_lo), max(s_step_ms, 2 * ag_hi))  # the exchange overlaps the env kernel of the previous step
+        expected = {'per_gpu_share_engagements': share, 'kernel_ms_at_share': s_kernel_ms, 'loop_ms_at_share_one_gpu': s_step_ms,
+                    'loop_overhead_ms_at_share': s_step_ms - s_kernel_ms, 'allgather_ms_each_estimate': [ag_lo, ag_hi],
+                    'ms_per_step_one_gpu_full_size': t1,
+                    'predicted_ms_per_step_8_gpus_lag0': list(lag0), 'predicted_speedup_8_gpus_lag0': [t1 / lag0[1], t1 / lag0[0]],
+                    'predicted_ms_per_step_8_gpus_lag1': list(lag1), 'predicted_speedup_8_gpus_lag1': [t1 / lag1[1], t1 / lag1[0]],
+                    'note': 'strong scaling of a latency-bound step: the kernel at the per-GPU share is a one-generation grid (no 8x from 8x '
+                            'fewer rows), so >= 6x is not expected for this config; Heading / Tracking (weak scaling, no collective) are'}
+        del senv, sex
     if rank != 0:
         return None
     st = stats(samples)
@@ -504,6 +573,9 @@ def run_combat(args, rank, local_rank, world, dev, dist):
         'world_size': world, 'backend': args.backend if world > 1 else None, 'rccl_ranks': world if (world > 1 and args.backend == 'nccl') else 0,
         'exchange': {'collectives_per_step': 2 if world > 1 else 0, 'obs_bytes_gathered_per_step': e_total * 15 * 4, 'action_bytes_gathered_per_step': e_total * 4 * 4,
                      'opponent_lag': args.opponent_lag},
+        'expected_scaling': expected,
+        'layout': 'interleaved rows + torch split / stack (round-2 loop)' if args.interleaved else 'split ego / opponent arrays (np_f16_combat_io.action_opp / obs_opp): no copies around the launch',
+        'ms_per_step_without_timing_events': plain_ms, 'loop_overhead_ms': (plain_ms - st['kernel_avg_ms']) if plain_ms is not None else None,
         'prelude': {'steps': p_steps, 'seconds': p_sec, 'timed': False},
         'cold_start': {'value': e_total * args.steps / cold_el, 'ms_per_step': 1e3 * cold_el / args.steps, **stats(cold_samples)},
         'roofline': {'bound': 'valu', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS,
@@ -522,6 +594,7 @@ def main():
     ap.add_argument('--task', default='heading', choices=['heading', 'control', 'tracking', 'combat'])
     ap.add_argument('--solver', default=None, choices=['euler', 'rk4'], help='default: the scenario YAML (euler)')
     ap.add_argument('--actions', default='random', choices=['random', 'constant'])
+    ap.add_argument('--interleaved', action='store_true', help='--task combat: the interleaved [2E, .] action / observation rows with torch-side split / stack (round-2 loop)')
     ap.add_argument('--engagements', type=int, default=100_000, help='--task combat: engagements in TOTAL (sharded by env over the ranks)')
     ap.add_argument('--opponent-lag', type=int, default=0, choices=[0, 1],
                     help='--task combat: 0 = the opponent acts on the current observation (the reference runner); 1 = on the previous one, '

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 10
+#define NP_ABI_VERSION 11
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -233,6 +233,15 @@ typedef struct np_f16_combat_io {
     /* optional DEVICE counters [NP_NUM_COMBAT_TERM_COUNTERS] (see np_f16_io.term_counters), one evaluation per inner FDM step:
      * overload, low_altitude, high_speed, low_speed, extreme_state, crash, timeout, shutdown (bad), shutdown (done) */
     uint32_t *term_counters;
+    /* Split ("self-play") layout, both optional: the two halves of the self-play runner's data (runner/selfplay_F16sim_runner.py:62-67
+     * `obs[:, :A//2]` / `obs[:, A//2:]`, :96-100 `actions = concatenate((ego, opponent), axis=1)`) as SEPARATE contiguous per-env
+     * arrays, so that the opponent exchange (an all-gather over the ranks) reads and writes the kernel's own buffers — no split /
+     * stack / contiguous copies around the launch.
+     *   action_opp != NULL: `action` holds the EGO rows only, [num_envs][act_stride], `action_opp` the opponent rows, same stride
+     *   obs_opp    != NULL: `obs` receives the EGO rows only, [num_envs][15], `obs_opp` the opponent rows [num_envs][15]
+     * NULL (the default): the interleaved [n][...] layout above (rows 2k / 2k+1 = ego / opponent of env k). */
+    const float *action_opp;
+    float *obs_opp;
 } np_f16_combat_io;
 
 /* Same context type as np_f16_ctx_create; the weights blob is shared. */

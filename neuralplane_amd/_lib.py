@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class NpF16Cfg(C.Structure):
@@ -70,7 +70,8 @@ class NpF16CombatIo(C.Structure):
                 ('done_out', C.c_void_p), ('bad_out', C.c_void_p), ('timeout_out', C.c_void_p),
                 ('action', C.c_void_p), ('act_stride', C.c_int64), ('obs', C.c_void_p), ('reward', C.c_void_p),
                 ('rand_u', C.c_void_p), ('pid_first', C.c_int32), ('reserved_io_', C.c_int32),
-                ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64), ('term_counters', C.c_void_p)]
+                ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64), ('term_counters', C.c_void_p),
+                ('action_opp', C.c_void_p), ('obs_opp', C.c_void_p)]
 
 
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',

@@ -458,8 +458,10 @@ class F16CombatBatch:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _io(self, new_flags, action, obs, reward, rand_u):
+    def _io(self, new_flags, action, obs, reward, rand_u, action_opp=None, obs_opp=None):
         io = _lib.NpF16CombatIo()
+        io.action_opp = action_opp.data_ptr() if action_opp is not None else None
+        io.obs_opp = obs_opp.data_ptr() if obs_opp is not None else None
         io.s, io.u, io.pid, io.blood, io.ld = self.s.data_ptr(), self.u.data_ptr(), self.pid.data_ptr(), self.blood.data_ptr(), self.n
         io.step_count = self.step_count.data_ptr()
         f, g = self.flags, new_flags
@@ -526,6 +528,45 @@ class F16CombatBatch:
         self.call_idx += 1
         self._version += 1
         return obs, reward, new_flags
+
+    # -- split (self-play) layout: ego / opponent halves as separate contiguous per-env arrays (np_f16_combat_io.action_opp /
+    # obs_opp) — what the self-play runner slices out of the interleaved arrays (runner/selfplay_F16sim_runner.py:62-67, 96-100),
+    # produced and consumed by the kernel directly so that the opponent exchange needs no split / stack / contiguous copies
+    def _check_half(self, a, name):
+        if a.device != self.device or a.dtype != torch.float32:
+            a = a.to(device=self.device, dtype=torch.float32)
+        if a.dim() != 2 or a.shape[0] != self.num_envs or a.shape[1] < 4:
+            raise ValueError(f'{name} must be [num_envs={self.num_envs}, >=4], got {tuple(a.shape)}')
+        return a if a.stride(1) == 1 else a.contiguous()
+
+    def reset_split(self, rand_u=None, out=None):
+        """reset() with the observation as (ego[E,15], opponent[E,15]); `out` = two caller-owned buffers to write into."""
+        oe, oo = out if out is not None else (torch.empty((self.num_envs, NUM_OBS_COMBAT), dtype=torch.float32, device=self.device) for _ in range(2))
+        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        io = self._io(new_flags, None, oe, None, self._inject(rand_u), obs_opp=oo)
+        _lib.check(self.lib.np_f16_combat_reset(self._ctx, self.num_envs, C.byref(io), self._stream()))
+        self.flags = new_flags
+        self.call_idx += 1
+        self._version += 1
+        return oe, oo
+
+    def step_split(self, ego_action, opp_action, rand_u=None, out=None):
+        """step() on the two action halves ego_action[E,>=4], opp_action[E,>=4] (equal row strides) -> obs_ego[E,15],
+        obs_opp[E,15], reward[n], flags[3,n]: ONE kernel launch, no copies on either side."""
+        ego_action, opp_action = self._check_half(ego_action, 'ego_action'), self._check_half(opp_action, 'opp_action')
+        if ego_action.stride(0) != opp_action.stride(0):
+            opp_action = opp_action.contiguous()
+            ego_action = ego_action.contiguous()
+        oe, oo = out if out is not None else (torch.empty((self.num_envs, NUM_OBS_COMBAT), dtype=torch.float32, device=self.device) for _ in range(2))
+        reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        io = self._io(new_flags, ego_action, oe, reward, self._inject(rand_u), action_opp=opp_action, obs_opp=oo)
+        _lib.check(self.lib.np_f16_combat_step(self._ctx, self.num_envs, C.byref(io), self._stream()))
+        self.flags = new_flags
+        self.pid_first = False
+        self.call_idx += 1
+        self._version += 1
+        return oe, oo, reward, new_flags
 
     def state_dict(self):
         return {'s': self.s.clone(), 'u': self.u.clone(), 'pid': self.pid.clone(), 'blood': self.blood.clone(),

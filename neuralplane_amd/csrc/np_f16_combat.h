@@ -59,6 +59,9 @@ struct CombatArgs {
     unsigned *term_counters;  // optional [NP_NUM_COMBAT_TERM_COUNTERS]
     AeroWeights wt;
     CombatDevCfg cfg;
+    // split (self-play) layout, np_f16_combat_io: per-env ego / opponent halves in separate contiguous arrays
+    const float *action_opp;  // non-null: `action` = ego rows [E][act_stride], this = opponent rows
+    float *obs_opp;           // non-null: `obs` = ego rows [E][15], this = opponent rows
 };
 
 enum { PID_ROLL_DEM = 0, PID_PITCH_DEM, PID_R_ERR, PID_R_INT, PID_R_LAST, PID_P_ERR, PID_P_INT, PID_P_LAST, PID_Y_ERR,
@@ -296,8 +299,12 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kern
 #pragma unroll
         for (int k = 0; k < NUM_PID; k++) pid[k] = a.pid[k * a.ld + ic];
         float act[3];
+        {
+            // interleaved rows [n][stride], or the split layout: ego / opponent rows of env ic / 2 from their own arrays
+            const float *arow = a.action_opp ? ((ic & 1) ? a.action_opp : a.action) + (ic >> 1) * a.act_stride : a.action + ic * a.act_stride;
 #pragma unroll
-        for (int k = 0; k < 3; k++) act[k] = clampf(a.action[ic * a.act_stride + k], -1.0f, 1.0f);
+            for (int k = 0; k < 3; k++) act[k] = clampf(arow[k], -1.0f, 1.0f);
+        }
         // shutdown.py:31-38 reads the blood of the previous env.step for all inner steps
         const float blood_o = partner(blood);
         const bool m1 = (is_ego ? blood : blood_o) <= 0.0f, m2 = (is_ego ? blood_o : blood) <= 0.0f;
@@ -374,6 +381,15 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kern
             // ---- terminations at the new state ----
             trig_of(s, tr, tt);
             np_sincos(s[5], spsi, cpsi);
+            if constexpr (WPT == 2) {
+                // as in f16_env_kernel: without these the compiler sinks the moment equations of the integrator evaluation and the
+                // tails of the fp64 sine / cosine sequences past the Overload statement (which owns v70-v157) and keeps their
+                // operands live across it
+#pragma unroll
+                for (int k = 0; k < 12; k++) asm volatile("" : "+v"(s[k]));
+                asm volatile("" : "+v"(tr.sa), "+v"(tr.ca), "+v"(tr.sb), "+v"(tr.cb), "+v"(tr.st), "+v"(tr.ct), "+v"(tr.sphi), "+v"(tr.cphi));
+                asm volatile("" : "+v"(tt), "+v"(spsi), "+v"(cpsi));
+            }
             float xd[12], acc3[3];
             {
                 const AeroWeights wt2 = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
@@ -488,19 +504,37 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kern
     // ---- [n][15] observation rows: transpose through LDS, store coalesced ----
     if (ap->obs) {
         __syncthreads();
+        const bool split = ap->obs_opp != nullptr;  // workgroup-uniform
+        // split layout: the tile holds its TILE / 2 ego rows first, then its TILE / 2 opponent rows — two contiguous blocks
+        const int trow = split ? (t >> 1) + (t & 1) * (TILE / 2) : t;
         if (storer) {
 #pragma unroll
-            for (int k = 0; k < COMBAT_OBS; k++) lds[t * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
+            for (int k = 0; k < COMBAT_OBS; k++) lds[trow * COMBAT_OBS + k] = o[k];  // pitch 15 is odd: conflict-free
         }
         __syncthreads();
         const long long rows = (ap->n - i0) < B ? (ap->n - i0) : B;
-        const int total = (int)rows * COMBAT_OBS;
-        float *dst = ap->obs + i0 * COMBAT_OBS;
         constexpr int THREADS = TILE * (WPT == 4 ? 4 : 1);
+        if (!split) {
+            const int total = (int)rows * COMBAT_OBS;
+            float *dst = ap->obs + i0 * COMBAT_OBS;
 #pragma unroll
-        for (int itr = 0; itr < (COMBAT_OBS * TILE + THREADS - 1) / THREADS; itr++) {
-            const int L = itr * THREADS + (int)threadIdx.x;
-            if (L < total) dst[L] = lds[L];
+            for (int itr = 0; itr < (COMBAT_OBS * TILE + THREADS - 1) / THREADS; itr++) {
+                const int L = itr * THREADS + (int)threadIdx.x;
+                if (L < total) dst[L] = lds[L];
+            }
+        } else {
+            constexpr int HALF = COMBAT_OBS * (TILE / 2);
+            const int half_total = (int)(rows / 2) * COMBAT_OBS;  // n is even: a tile holds whole engagements
+            float *dst_e = ap->obs + (i0 / 2) * COMBAT_OBS, *dst_o = ap->obs_opp + (i0 / 2) * COMBAT_OBS;
+#pragma unroll
+            for (int itr = 0; itr < (COMBAT_OBS * TILE + THREADS - 1) / THREADS; itr++) {
+                const int L = itr * THREADS + (int)threadIdx.x;
+                if (L < HALF) {
+                    if (L < half_total) dst_e[L] = lds[L];
+                } else if (L < 2 * HALF) {
+                    if (L - HALF < half_total) dst_o[L - HALF] = lds[L];
+                }
+            }
         }
     }
 }

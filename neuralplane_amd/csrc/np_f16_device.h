@@ -368,7 +368,15 @@ constexpr PairPlan PAIR_ALL = {{{{CL_DAMP, 0, 12}, {CL_DLEF, 0, 7}, {CL_E_LEF, 0
                                 {{CL_D_RUD, 0, 2}, {CL_D_LEF, 0, 2}, {CL_E_RUD, 0, 4}, {CL_F, 0, 3}, {CL_YA20, 0, 1}, {CL_C, 0, 5}, {CL_ETA, 0, 1}}}};
 constexpr PairPlan PAIR_FORCE2 = {{{{CL_DAMP, 0, 4}, {CL_DLEF, 0, 2}, {CL_E_LEF, 0, 2}, {CL_E_RUD, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
                                    {{CL_D_RUD, 0, 1}, {CL_D_LEF, 0, 1}, {CL_F, 0, 1}, {CL_YPLEF, 0, 1}, {CL_YA20, 0, 1}, {CL_C, 0, 2}, NO_ITEM}}};
-constexpr bool pair_plan_covers(const PairPlan &p, int part, int n_c, int n_eta) {
+// aero_1d_tables mode: the single-input nets are table lookups (eval_class_pwl, each wave for its own aircraft); only the multi-input
+// nets go through the two-set bodies
+constexpr PairPlan PAIR_T_REST = {{{{CL_D_RUD, 1, 1}, {CL_D_LEF, 1, 1}, {CL_E_LEF, 2, 2}, {CL_F, 1, 1}, {CL_C, 0, 2}, NO_ITEM, NO_ITEM},
+                                   {{CL_E_RUD, 1, 3}, {CL_F, 2, 1}, {CL_C, 2, 3}, NO_ITEM, NO_ITEM, NO_ITEM, NO_ITEM}}};
+constexpr PairPlan PAIR_T_ALL = {{{{CL_D_LEF, 0, 1}, {CL_E_LEF, 0, 4}, {CL_E_RUD, 0, 4}, {CL_YA20, 0, 1}, {CL_C, 0, 2}, NO_ITEM, NO_ITEM},
+                                  {{CL_D_RUD, 0, 2}, {CL_D_LEF, 1, 1}, {CL_F, 0, 3}, {CL_C, 2, 3}, NO_ITEM, NO_ITEM, NO_ITEM}}};
+constexpr PairPlan PAIR_T_FORCE2 = {{{{CL_D_LEF, 0, 1}, {CL_E_RUD, 0, 1}, {CL_F, 0, 1}, {CL_C, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                     {{CL_D_RUD, 0, 1}, {CL_E_LEF, 0, 2}, {CL_YA20, 0, 1}, {CL_C, 1, 1}, NO_ITEM, NO_ITEM, NO_ITEM}}};
+constexpr bool pair_plan_covers(const PairPlan &p, int part, int n_c, int n_eta, bool multi_input_only = false) {
     for (int cl = 0; cl < NUM_CLASSES; cl++) {
         int lo = 0, hi = 0;
         if (cl < NUM_AB_CLASSES) {
@@ -377,6 +385,7 @@ constexpr bool pair_plan_covers(const PairPlan &p, int part, int n_c, int n_eta)
         } else {
             hi = cl == CL_C ? n_c : n_eta;
         }
+        if (multi_input_only && CLASSES[cl].n_in == 1) hi = lo = 0;
         for (int net = 0; net < CLASSES[cl].count; net++) {
             int hits = 0;
             for (int w = 0; w < 2; w++)
@@ -389,6 +398,12 @@ constexpr bool pair_plan_covers(const PairPlan &p, int part, int n_c, int n_eta)
 }
 static_assert(pair_plan_covers(PAIR_REST, AB_REST, 5, 1) && pair_plan_covers(PAIR_ALL, AB_ALL, 5, 1) && pair_plan_covers(PAIR_FORCE2, AB_FORCE, 2, 0),
               "pair plans must cover each net of their phase exactly once");
+static_assert(pair_plan_covers(PAIR_T_REST, AB_REST, 5, 1, true) && pair_plan_covers(PAIR_T_ALL, AB_ALL, 5, 1, true) &&
+                  pair_plan_covers(PAIR_T_FORCE2, AB_FORCE, 2, 0, true),
+              "table-mode pair plans must cover each multi-input net of their phase exactly once");
+static_assert(NPF16_PAIR_PLAN_CHECK_T_REST_0 && NPF16_PAIR_PLAN_CHECK_T_REST_1 && NPF16_PAIR_PLAN_CHECK_T_ALL_0 && NPF16_PAIR_PLAN_CHECK_T_ALL_1 &&
+                  NPF16_PAIR_PLAN_CHECK_T_FORCE2_0 && NPF16_PAIR_PLAN_CHECK_T_FORCE2_1,
+              "the table-mode dual phase statements were generated from other plans (tools/gen_mlp_asm.py::PAIR_PLANS)");
 static_assert(NPF16_PAIR_PLAN_CHECK_REST_0 && NPF16_PAIR_PLAN_CHECK_REST_1 && NPF16_PAIR_PLAN_CHECK_ALL_0 && NPF16_PAIR_PLAN_CHECK_ALL_1 &&
                   NPF16_PAIR_PLAN_CHECK_FORCE2_0 && NPF16_PAIR_PLAN_CHECK_FORCE2_1,
               "the dual phase statements were generated from other plans (tools/gen_mlp_asm.py::PAIR_PLANS)");
@@ -444,7 +459,7 @@ __device__ __forceinline__ void eval_pairplan_single(const AeroWeights &wt, cons
 template <int LD, int PART, bool FULL, int WPT = 1>
 __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables, int part = 0) {
     constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
-    if constexpr (WPT == 2) {  // pair variant: `part` = this wave's index in its 128-aircraft workgroup; never used with `tables`
+    if constexpr (WPT == 2) {  // pair variant: `part` = this wave's index in its 128-aircraft workgroup
         static_assert(has_phase, "no pair plan for this evaluation");
         float *out_b = out + 64 - 128 * part;  // the same lane's column in the other wave's half of the matrix
 #pragma unroll
@@ -459,6 +474,25 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
     if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_dual_ALL_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_ALL_##W##_START, base_a, base_b);          \
     else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_dual_REST_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_REST_##W##_START, base_a, base_b);  \
     else mlp_phase_asm_dual_FORCE2_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_FORCE2_##W##_START, base_a, base_b)
+#define NPF16_WAVE_T(W)                                                                                                                    \
+    if constexpr (FULL && PART == AB_ALL) mlp_phase_asm_dual_T_ALL_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_T_ALL_##W##_START, base_a, base_b);          \
+    else if constexpr (FULL && PART == AB_REST) mlp_phase_asm_dual_T_REST_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_T_REST_##W##_START, base_a, base_b);  \
+    else mlp_phase_asm_dual_T_FORCE2_##W<STEP_BYTES>(wt.kblob_dual + MLP_PAIR_T_FORCE2_##W##_START, base_a, base_b)
+        if (tables) {  // wave-uniform.  aero_1d_tables: the single-input nets of this phase are table lookups — every wave for its OWN
+                       // aircraft, straight into its own columns — and the pair splits only the multi-input nets
+            constexpr int f_damp = PART == AB_REST ? CLASSES[CL_DAMP].n_force : 0, n_damp = (PART == AB_FORCE ? CLASSES[CL_DAMP].n_force : CLASSES[CL_DAMP].count) - f_damp;
+            constexpr int f_dlef = PART == AB_REST ? CLASSES[CL_DLEF].n_force : 0, n_dlef = (PART == AB_FORCE ? CLASSES[CL_DLEF].n_force : CLASSES[CL_DLEF].count) - f_dlef;
+            constexpr int f_yp = PART == AB_REST ? CLASSES[CL_YPLEF].n_force : 0, n_yp = (PART == AB_FORCE ? CLASSES[CL_YPLEF].n_force : CLASSES[CL_YPLEF].count) - f_yp;
+            if constexpr (n_damp > 0) eval_class_pwl<CL_DAMP, n_damp, LD, f_damp>(wt, xn[CLASSES[CL_DAMP].grp[0]], out);
+            if constexpr (n_dlef > 0) eval_class_pwl<CL_DLEF, n_dlef, LD, f_dlef>(wt, xn[CLASSES[CL_DLEF].grp[0]], out);
+            if constexpr (n_yp > 0) eval_class_pwl<CL_YPLEF, n_yp, LD, f_yp>(wt, xn[CLASSES[CL_YPLEF].grp[0]], out);
+            if constexpr (FULL) eval_class_pwl<CL_ETA, 1, LD, 0>(wt, xn[CLASSES[CL_ETA].grp[0]], out);
+            if (part == 0) { NPF16_WAVE_T(0); }
+            else { NPF16_WAVE_T(1); }
+            __syncthreads();
+            return;
+        }
+#undef NPF16_WAVE_T
 #else
         float xb[NUM_NORM_GROUPS];
 #pragma unroll

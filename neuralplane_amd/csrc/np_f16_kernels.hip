@@ -41,10 +41,10 @@ namespace npf16 {
 #define NPF16_PAIR_GROUPS 3       // PW = 2
 #endif
 #ifndef NPF16_PAIR3_STAGGER
-#define NPF16_PAIR3_STAGGER 9000  // PW = 3 (profiles/r02b_ab_sessions.md s25)
+#define NPF16_PAIR3_STAGGER 7000  // PW = 3 (round 2: 7 x 9 000, profiles/r02b_ab_sessions.md s25; re-tuned on the round-3 kernel, profiles/r03b_ab_dephasing.log: 9 x 7 000 -1.1 % at N = 1e6, -0.7 % at 1e7)
 #endif
 #ifndef NPF16_PAIR3_GROUPS
-#define NPF16_PAIR3_GROUPS 7      // PW = 3
+#define NPF16_PAIR3_GROUPS 9      // PW = 3
 #endif
 #ifndef NPF16_MINWAVES
 #define NPF16_MINWAVES 3  // waves per SIMD the register allocator must leave room for
@@ -290,8 +290,13 @@ void f16_env_kernel(const KArgs a) {
 #pragma nounroll
             for (int stage = 0; stage < 4; stage++) {
                 float kk[12];
-                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(a.wt, y, u, coef, tables, kk, pw);  // y == s: cached coefficients apply
-                else xdot_full<AB_ALL, TILE, WPT>(a.wt, y, u, coef, tables, kk, pw);
+                // weights pointer and numerics switch re-read per stage: nothing scalar but `ap` stays live across the asm phases (they
+                // own s4-s101; the statement's record pointer and `ap` fill s0-s3)
+                NP_REREAD_ARGS(ap);
+                const AeroWeights wts = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
+                const bool tbs = ap->cfg.aero_1d_tables != 0;
+                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(wts, y, u, coef, tbs, kk, pw);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, TILE, WPT>(wts, y, u, coef, tbs, kk, pw);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -1115,7 +1120,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         a.trace = ctx->trace;
     }
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
-    const bool pair = STEP && !ctx->cfg.aero_1d_tables && use_pair_kernel(ctx, n);
+    const bool pair = STEP && use_pair_kernel(ctx, n);  // both numerics (round 3: the table mode's multi-input nets on the two-set bodies)
     const bool latency = !pair && STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
     // eight waves per tile: small batches of the MLP numerics (the table mode's classes are too short to split further)
     const bool latency8 = latency && !ctx->cfg.aero_1d_tables &&
@@ -1262,6 +1267,9 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     a.pid_first = io->pid_first; a.seed = io->seed; a.call_idx = io->call_idx; a.row0 = io->row0; a.n = n; a.cfg = ctx->ccfg;
     a.term_counters = io->term_counters;
     a.wt = ctx->wt;
+    a.action_opp = STEP ? io->action_opp : nullptr;
+    a.obs_opp = io->obs_opp;
+    if (io->obs_opp && !io->obs) return fail("obs_opp needs obs (the ego half)");
     // small batches: the latency variant (one generation of 4-wave workgroups at 2 waves per SIMD = 512 x 64 aircraft)
     const bool latency = STEP && ctx->solver == 0 &&
                          (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= COMBAT_LAT_MAX_N));
@@ -1276,10 +1284,11 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
     // pair variant (Euler, MLP numerics): the default above the latency variant's range; NP_KERNEL_THROUGHPUT pins the single-set kernel
     const bool pair = STEP && !latency && ctx->solver == 0 && !ctx->ccfg.aero_1d_tables && ctx->variant != NP_KERNEL_THROUGHPUT;
-    // 1 025-1 536 workgroups (65 537-98 304 engagements): one generation at six workgroups per CU instead of two rounds of four —
-    // 0.300 vs 0.356 ms at 98 304 engagements; longer grids gain nothing from the third wave here (46 parked dwords per lane)
+    // three waves per SIMD (168 VGPRs, 4 dwords per lane in scratch since the state is pinned before the Overload phase — round 2: 46)
+    // from 1 025 workgroups on: 70 000 engagements 0.275 vs 0.290 ms, 100 000 0.355 vs 0.379, 500 000 1.294 vs 1.412; a tie below
+    // (profiles/r03b_combat_pair_waves.log)
     static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
-    const bool pair3 = pair && (pw_env ? pw_env == 3 : (grid.x > 1024 && grid.x <= 1536));
+    const bool pair3 = pair && (pw_env ? pw_env == 3 : grid.x > 1024);
     if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
     else if (pair3) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2, 3>);
     else if (pair) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>);

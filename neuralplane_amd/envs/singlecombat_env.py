@@ -121,6 +121,20 @@ class SingleCombatEnv(Env):
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
 
+    # -- the self-play runner's halves without the slicing (runner/selfplay_F16sim_runner.py:62-67, 96-100) ------------------------
+    def reset_split(self, rand_u=None, out=None):
+        """reset() returning (obs_ego[E,15], obs_opponent[E,15]) — `obs[:, :A//2]`, `obs[:, A//2:]` of the runner — as two
+        contiguous arrays written by the kernel itself."""
+        self._batch.flags = torch.ones_like(self._batch.flags)
+        return self._batch.reset_split(rand_u=rand_u, out=out)
+
+    def step_split(self, ego_action, opp_action, rand_u=None, out=None):
+        """step() on (ego_action[E,4], opponent_action[E,4]) -> (obs_ego, obs_opponent, reward[n], done, bad_done,
+        exceed_time_limit, info): the concatenate / split around env.step of the runner happens inside the kernel."""
+        oe, oo, reward, flags = self._batch.step_split(ego_action, opp_action, rand_u=rand_u, out=out)
+        f = flags.view(torch.bool)
+        return oe, oo, reward, f[0], f[1], f[2], self.info()
+
     def render(self, count, filepath='./F16SimRecording.txt.acmi', env_index=0):
         """Append one TacView frame of engagement `env_index` (singlecombat_env.py:276-321): id 100 Red = ego, 101 Blue = enemy."""
         from .utils.acmi import AcmiRecorder

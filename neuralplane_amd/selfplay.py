@@ -62,15 +62,20 @@ class OpponentExchange:
         return allact[self.act_off:self.act_off + self.e_loc]
 
     def start(self, obs):
-        """Begin the exchange for the observation obs[2 * E_loc, 15] on the side stream (returns at once)."""
+        """Begin the exchange for the interleaved observation obs[2 * E_loc, 15] on the side stream (returns at once)."""
         _, opp_obs = sharding.split_ego_opponent(obs, self.e_loc)
+        self.start_opp(opp_obs, keep=obs)
+
+    def start_opp(self, opp_obs, keep=None):
+        """Begin the exchange for the opponent half opp_obs[E_loc, 15] (a contiguous buffer — SingleCombatEnv.step_split's — is
+        read by the all-gather as it is: no copy)."""
         if not self.use_streams:
             self._pending = (self._exchange(opp_obs), None)
             return
-        self.side.wait_stream(torch.cuda.current_stream(self.device))      # obs was produced on the main stream
+        self.side.wait_stream(torch.cuda.current_stream(self.device))      # the observation was produced on the main stream
         with torch.cuda.stream(self.side):
             out = self._exchange(opp_obs)
-            obs.record_stream(self.side)
+            (keep if keep is not None else opp_obs).record_stream(self.side)
             ev = torch.cuda.Event()
             ev.record(self.side)
         self._pending = (out, ev)
@@ -101,3 +106,18 @@ class OpponentExchange:
             ego_act = ego_policy(ego_obs)
             self.start(obs)
         return sharding.merge_actions(ego_act, opp_act)
+
+    def actions_split(self, obs_ego, obs_opp, ego_policy):
+        """The same step on the split layout (SingleCombatEnv.reset_split / step_split): obs_ego[E_loc, 15], obs_opp[E_loc, 15] ->
+        (ego actions[E_loc, 4], opponent actions[E_loc, 4]) for env.step_split.  Nothing is copied on this rank: the all-gather
+        reads the kernel's opponent-observation buffer, the env kernel reads its opponent actions out of the gathered action
+        buffer (a contiguous slice of it)."""
+        if self.lag == 0:
+            self.start_opp(obs_opp)
+            ego_act = ego_policy(obs_ego)
+            opp_act = self.finish()
+        else:
+            opp_act = self.finish() if self._pending is not None else torch.zeros((self.e_loc, 4), dtype=obs_ego.dtype, device=obs_ego.device)
+            ego_act = ego_policy(obs_ego)
+            self.start_opp(obs_opp)
+        return ego_act, opp_act

@@ -104,7 +104,7 @@ def test_combat_macro_step_close_to_plain_reference(golden_dir):
     for k in range(K):
         obs, rew, done, bad, tmo = o.combat_step(st, d['actions'][k], rand_u=d['rand_u'][k], pid_first=(k == 0))
         err = float(np.max(np.abs(st['s'] - d[f's_{k}']) / np.maximum(np.abs(d[f's_{k}']), STATE_FLOORS)))
-        assert err < 5e-3, (k, err)
+        assert err < 3e-3, (k, err)   # P, Q, R behind the rate PID: measured max 1.8e-3, p99 1.1e-4 — and shipped-vs-pin-mode is 1.8e-3 too (profiles/r03_parity.json)
         assert np.max(np.abs(st['s'][:, :9] - d[f's_{k}'][:, :9]) / np.maximum(np.abs(d[f's_{k}'][:, :9]), STATE_FLOORS[:9])) < 1e-4
         assert np.array_equal(np.stack([done, bad, tmo]), d[f'flags_{k}']), k
         assert np.allclose(obs, d[f'obs_{k}'], rtol=0, atol=1e-4), k

@@ -96,7 +96,7 @@ def test_combat_fixture_vs_reference_teacher_forced(golden_dir):
         obs, rew, flags = b.step(torch.from_numpy(d['actions'][k]).cuda(), rand_u=d['rand_u'][k])
         s = b.s.cpu().numpy().T
         ref = d[f's_{k}']
-        assert np.max(np.abs(s - ref) / np.maximum(np.abs(ref), STATE_FLOORS)) < 5e-3, k
+        assert np.max(np.abs(s - ref) / np.maximum(np.abs(ref), STATE_FLOORS)) < 3e-3, k   # P, Q, R: measured 1.8e-3 (the rate PID amplifies fp32 noise; profiles/r03_parity.json)
         assert np.max(np.abs(s[:, :9] - ref[:, :9]) / np.maximum(np.abs(ref[:, :9]), STATE_FLOORS[:9])) < 1e-4, k
         assert np.array_equal(flags.cpu().numpy(), d[f'flags_{k}']), k
         assert np.allclose(obs.cpu().numpy(), d[f'obs_{k}'], rtol=0, atol=1e-4), k
@@ -254,6 +254,36 @@ def test_combat_hostile_inputs(variant):
         obs, rew, flags = b.step(torch.from_numpy(a).cuda())
         o_obs, o_rew, _, _, _ = o.combat_step(st, a, pid_first=False, seed=seed, call_idx=t + 1)
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'hostile step {t}')
+
+
+@pytest.mark.parametrize('variant,num_envs', [('latency', 97), ('pair', 97), ('pair', 640), ('throughput', 33)])
+def test_split_layout_equals_interleaved_layout(variant, num_envs):
+    """np_f16_combat_io.action_opp / obs_opp: the ego / opponent halves as separate contiguous per-env arrays give exactly the
+    interleaved launch's results — observations, rewards, masks, every state array — through resets, a ragged last workgroup and
+    caller-owned output buffers; the action halves may be row-strided views (a slice of a gathered buffer)."""
+    seed = 9
+    a, b = _batch(num_envs, seed=seed, variant=variant), _batch(num_envs, seed=seed, variant=variant)
+    rng = np.random.RandomState(4)
+    obs = a.reset()
+    oe, oo = b.reset_split()
+    assert torch.equal(obs.view(num_envs, 2, 15)[:, 0], oe) and torch.equal(obs.view(num_envs, 2, 15)[:, 1], oo)
+    out = (torch.empty((num_envs, 15), device='cuda'), torch.empty((num_envs, 15), device='cuda'))
+    gathered = torch.zeros((num_envs + 5, 6), device='cuda')     # the opponent actions as a slice of a larger, wider buffer
+    for t in range(12):
+        act = torch.from_numpy(rng.uniform(-1.3, 1.3, (2 * num_envs, 4)).astype(np.float32)).cuda()
+        act[:, 0] = act[:, 0].abs()
+        obs, rew, flags = a.step(act)
+        pairs = act.view(num_envs, 2, 4)
+        gathered[3:3 + num_envs, :4] = pairs[:, 1]
+        ego = torch.zeros((num_envs, 6), device='cuda')
+        ego[:, :4] = pairs[:, 0]
+        oe, oo, rew2, flags2 = b.step_split(ego, gathered[3:3 + num_envs], out=out if t % 2 else None)
+        v = obs.view(num_envs, 2, 15)
+        assert torch.equal(v[:, 0], oe) and torch.equal(v[:, 1], oo), f'step {t}: observations'
+        assert torch.equal(rew, rew2) and torch.equal(flags, flags2), f'step {t}: reward / masks'
+        for k in ('s', 'u', 'pid', 'blood', 'step_count'):
+            assert torch.equal(getattr(a, k), getattr(b, k)), f'step {t}: {k}'
+    assert a.call_idx == b.call_idx
 
 
 def test_opponent_exchange_runs_over_rccl():

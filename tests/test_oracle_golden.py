@@ -343,7 +343,7 @@ def planning_targets(st, hi_action):
 def test_planning_env_replay_vs_reference(golden_dir):
     """The reference's PlanningEnv.step driven by a seeded random-init low-level actor (its checkpoint is not in
     the snapshot); the recorded low-level actions are replayed through the oracle's reset / low_level_obs /
-    inner-step restatement.  Plain-mode tolerance (the reference ran ATen arithmetic); masks must agree."""
+    inner-step restatement.  Plain-mode tolerance (the reference ran ATen arithmetic): BASELINE's 1e-4; masks must agree."""
     g = np.load(f'{golden_dir}/planning_kat.npz')
     hi = g['hi_actions']
     n = hi.shape[1]
@@ -355,16 +355,19 @@ def test_planning_env_replay_vs_reference(golden_dir):
         tgt3 = planning_targets(st, hi[k])
         for i in range(50):
             ll = o.lowlevel_obs(st, tgt3)
-            assert relerr(ll, g[f'll_obs_{k}'][i], 0.1) < 2e-4, (k, i)
+            assert relerr(ll, g[f'll_obs_{k}'][i], 0.1) < 1e-4, (k, i)      # measured 7.6e-5 (profiles/r03_parity.json, planning_env)
             obs, rew, d, b, t = o.step_inner(st, g[f'll_act_{k}'][i])
         fl = g[f'flags_{k}']
         assert np.array_equal(d, fl[0]) and np.array_equal(b, fl[1]) and np.array_equal(t, fl[2]), f'outer {k}: masks'
         assert np.array_equal(st['step_count'], g[f'step_count_{k}'])
         live = ~(fl[1].astype(bool))      # terminated rows were frozen mid-way: compare them too, same tolerance
-        assert relerr(st['s'], g[f's_{k}'], STATE_FLOORS) < 5e-4
-        assert relerr(st['s'][live], g[f's_{k}'][live], STATE_FLOORS) < 2e-4
+        # bounds = BASELINE's 1e-4 (states: half of it).  Measured after 150 inner steps: states 1.0e-5 (rows still flying and rows
+        # frozen mid-step alike), observation 5.8e-5, reward 3e-9 — the same size as the oracle's own pin mode against the reference
+        # and as shipped-vs-pin, i.e. fp32 evaluation-order noise of the reference's arithmetic (tools/parity_report.py)
+        assert relerr(st['s'], g[f's_{k}'], STATE_FLOORS) < 5e-5
+        assert relerr(st['s'][live], g[f's_{k}'][live], STATE_FLOORS) < 5e-5
         assert relerr(st['u'], g[f'u_{k}'], 1.0) < 1e-6 and relerr(st['tgt'], g[f'tgt_{k}'], 1.0) < 1e-6
-        assert relerr(obs, g[f'obs_{k}'], 0.1) < 5e-4 and relerr(rew, g[f'reward_{k}'], 1.0) < 5e-4
+        assert relerr(obs, g[f'obs_{k}'], 0.1) < 1e-4 and relerr(rew, g[f'reward_{k}'], 1.0) < 1e-6
         total_bad += int(fl[1].sum())
     assert 0 < total_bad < 3 * n, 'fixture should mix terminated (frozen) and surviving rows'
 

@@ -153,7 +153,8 @@ def test_two_rank_combat_shards_with_opponent_exchange_equal_single_process_run(
 # The self-play loop bench.py --task combat steps (neuralplane_amd/selfplay.py::OpponentExchange): opponent
 # observations all-gathered to the rank hosting the opponent policy, opponent actions all-gathered back
 # ---------------------------------------------------------------------------------------------------
-def _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag):
+def _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag, split=False):
+    from neuralplane_amd import sharding
     from neuralplane_amd.selfplay import OpponentExchange
     W_ego = torch.linspace(-1, 1, 15 * 4).reshape(15, 4)
     W_opp = torch.linspace(1, -1, 15 * 4).reshape(15, 4)
@@ -164,13 +165,19 @@ def _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag):
     ex = OpponentExchange(e_loc, env0, e_total, d, 'cpu', opponent_policy=opp_policy, lag=lag)
     obs = torch.from_numpy(o.combat_reset(st, seed=21, call_idx=0, env0=env0))
     for t in range(steps):
-        a = ex.actions(obs, lambda x: torch.tanh(x @ W_ego))
+        if split and d is not None:
+            # the split layout of SingleCombatEnv.step_split (the two halves as separate contiguous arrays, nothing copied by the
+            # exchange); the oracle engine takes interleaved rows, so the halves are cut and joined here, outside the exchange
+            oe, oo = (h.contiguous() for h in sharding.split_ego_opponent(obs, e_loc))
+            a = sharding.merge_actions(*ex.actions_split(oe, oo, lambda x: torch.tanh(x @ W_ego)))
+        else:
+            a = ex.actions(obs, lambda x: torch.tanh(x @ W_ego))
         o_np, rew, dn, bd, tm = o.combat_step(st, a.numpy(), pid_first=(t == 0), seed=21, call_idx=t + 1, env0=env0)
         obs = torch.from_numpy(o_np)
     return o_np, rew
 
 
-def _selfplay_worker(rank, world, port, e_total, steps, lag, q):
+def _selfplay_worker(rank, world, port, e_total, steps, lag, q, split=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port), OMP_NUM_THREADS='1')
@@ -180,7 +187,7 @@ def _selfplay_worker(rank, world, port, e_total, steps, lag, q):
     env0, e_loc = sharding.shard_rows(e_total, world, rank)
     o = CombatOracle()
     st = o.new_state(e_loc)
-    o_np, rew = _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag)
+    o_np, rew = _selfplay_loop(o, st, e_loc, env0, e_total, d, steps, lag, split)
     parts = [None] * world
     d.all_gather_object(parts, (env0, st['s'], o_np, rew, st['blood']))
     if rank == 0:
@@ -189,13 +196,14 @@ def _selfplay_worker(rank, world, port, e_total, steps, lag, q):
     d.destroy_process_group()
 
 
-@pytest.mark.parametrize('e_total,lag', [(21, 0), (20, 0), (20, 1), (21, 1)], ids=['ragged_lag0', 'equal_lag0', 'equal_lag1', 'ragged_lag1'])
-def test_two_rank_selfplay_exchange_equals_single_process_run(e_total, lag):
+@pytest.mark.parametrize('e_total,lag,split', [(21, 0, False), (20, 0, False), (20, 1, False), (21, 1, False), (20, 0, True), (21, 1, True)],
+                         ids=['ragged_lag0', 'equal_lag0', 'equal_lag1', 'ragged_lag1', 'equal_lag0_split', 'ragged_lag1_split'])
+def test_two_rank_selfplay_exchange_equals_single_process_run(e_total, lag, split):
     steps, world = 6, 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_selfplay_worker, args=(r, world, port, e_total, steps, lag, q)) for r in range(world)]
+    procs = [ctx.Process(target=_selfplay_worker, args=(r, world, port, e_total, steps, lag, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     parts = q.get(timeout=240)

@@ -419,6 +419,14 @@ PAIR_PLANS = {
             [('CL_D_RUD', 0, 2), ('CL_D_LEF', 0, 2), ('CL_E_RUD', 0, 4), ('CL_F', 0, 3), ('CL_YA20', 0, 1), ('CL_C', 0, 5), ('CL_ETA', 0, 1)]),
     'FORCE2': ([('CL_DAMP', 0, 4), ('CL_DLEF', 0, 2), ('CL_E_LEF', 0, 2), ('CL_E_RUD', 0, 1)],
                [('CL_D_RUD', 0, 1), ('CL_D_LEF', 0, 1), ('CL_F', 0, 1), ('CL_YPLEF', 0, 1), ('CL_YA20', 0, 1), ('CL_C', 0, 2)]),
+    # aero_1d_tables mode: the 22 single-input nets are table lookups (each wave for its own aircraft, np_f16_device.h::eval_class_pwl);
+    # only the multi-input nets go through the two-set bodies.  Balanced by VALU instructions of the two-set bodies (253 / 298 / 653 / 353 / 273 per net).
+    'T_REST': ([('CL_D_RUD', 1, 1), ('CL_D_LEF', 1, 1), ('CL_E_LEF', 2, 2), ('CL_F', 1, 1), ('CL_C', 0, 2)],
+               [('CL_E_RUD', 1, 3), ('CL_F', 2, 1), ('CL_C', 2, 3)]),
+    'T_ALL': ([('CL_D_LEF', 0, 1), ('CL_E_LEF', 0, 4), ('CL_E_RUD', 0, 4), ('CL_YA20', 0, 1), ('CL_C', 0, 2)],
+              [('CL_D_RUD', 0, 2), ('CL_D_LEF', 1, 1), ('CL_F', 0, 3), ('CL_C', 2, 3)]),
+    'T_FORCE2': ([('CL_D_LEF', 0, 1), ('CL_E_RUD', 0, 1), ('CL_F', 0, 1), ('CL_C', 0, 1)],
+                 [('CL_D_RUD', 0, 1), ('CL_E_LEF', 0, 2), ('CL_YA20', 0, 1), ('CL_C', 1, 1)]),
 }
 
 
@@ -634,6 +642,8 @@ def class_slot(ci):
 
 
 def phase_items(kind):
+    if kind.startswith('T_'):   # aero_1d_tables mode: the multi-input nets of the phase only (the others are table lookups)
+        return [(ci, first, n) for ci, first, n in phase_items(kind[2:]) if CLASSES[ci][1][0] > 1 and n > 0]
     ab = range(NUM_AB)
     if kind == 'ALL':
         items = [(ci, 0, CLASSES[ci][3]) for ci in ab] + [(9, 0, 5), (10, 0, 1)]

@@ -1,11 +1,11 @@
 """SingleCombat macro-step throughput / latency.  usage: combat_bench.py [E ...] (engagements)"""
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, '.')
 from neuralplane_amd.core import F16CombatBatch
 from neuralplane_amd.envs.utils.utils import parse_config
 sizes = [int(x) for x in sys.argv[1:]] or [100_000, 500_000]
 for E in sizes:
-    for variant in (('latency', 'throughput', 'pair') if E <= 65536 else ('throughput', 'pair')):
+    for variant in (os.environ['COMBAT_VARIANTS'].split(',') if os.environ.get('COMBAT_VARIANTS') else (('latency', 'throughput', 'pair') if E <= 65536 else ('throughput', 'pair'))):
         b = F16CombatBatch(E, parse_config('selfplay'), 'cuda:0', seed=1)
         b.set_kernel_variant(variant)
         b.reset()
