@@ -117,6 +117,13 @@ typedef struct np_f16_io {
      * PostureReward / PositionReward, envs/reward_functions/*.py) before EventDrivenReward's -200 * bad_done + 200 * done is added
      * (task_base.py:60-73): `reward` = this + that, in fp32.  NULL = not wanted. */
     float *reward_task;
+    /* PlanningEnv's inner loop (inner_step set), both optional: ll_tgt [3][ld] = the low-level controller's targets (pitch, heading,
+     * vt: planning_env.py:150-152), ll_obs [n][22] receives PlanningEnv.low_level_obs (planning_env.py:60-142) of the state this
+     * launch REACHES — the controller's input for the next inner iteration, written by the step kernel itself (same values as
+     * np_f16_lowlevel_obs on the new state), so the 50 iterations of a macro-step need that kernel once instead of 50 times.  With
+     * ll_obs set, `obs` may be NULL (the task observation of an intermediate inner iteration is never read: planning_env.py:153-176). */
+    const float *ll_tgt;
+    float *ll_obs;
 } np_f16_io;
 
 typedef struct np_f16_ctx np_f16_ctx;

@@ -42,7 +42,7 @@ class NpF16Io(C.Structure):
                 ('rand_u', C.c_void_p), ('noise', C.c_void_p),
                 ('coef_cache', C.c_void_p), ('cache_valid', C.c_int32), ('inner_step', C.c_int32),
                 ('seed', C.c_uint64), ('call_idx', C.c_uint64), ('row0', C.c_int64), ('call_idx_base', C.c_void_p), ('term_counters', C.c_void_p),
-                ('term_reasons', C.c_void_p), ('reward_task', C.c_void_p)]
+                ('term_reasons', C.c_void_p), ('reward_task', C.c_void_p), ('ll_tgt', C.c_void_p), ('ll_obs', C.c_void_p)]
 
 
 class NpPidGains(C.Structure):

@@ -136,7 +136,8 @@ class F16Batch:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- graph-safe raw launches: caller-owned static buffers, no Python-side state is touched -------------
-    def launch_static(self, flags_in, flags_out, call_offset, action=None, obs=None, reward=None, inner=False, cache_valid=False):
+    def launch_static(self, flags_in, flags_out, call_offset, action=None, obs=None, reward=None, inner=False, cache_valid=False,
+                      ll_tgt=None, ll_obs=None):
         """One np_f16_reset (action is None) or np_f16_step launch on fixed buffers, RNG counter = *call_base + call_offset.
         Safe to capture in a HIP graph (torch.cuda.graph): every argument is baked, the counter base lives on the device."""
         io = _lib.NpF16Io()
@@ -156,6 +157,8 @@ class F16Batch:
         io.term_counters = self.term_counters.data_ptr()
         io.term_reasons = self.term_reasons.data_ptr() if self.term_reasons is not None else None
         io.reward_task = self.reward_task.data_ptr() if self.reward_task is not None else None
+        io.ll_tgt = ll_tgt.data_ptr() if ll_tgt is not None else None      # inner step: the step kernel also writes the NEXT low-level observation
+        io.ll_obs = ll_obs.data_ptr() if ll_obs is not None else None
         fn = self.lib.np_f16_reset if action is None else self.lib.np_f16_step
         _lib.check(fn(self._ctx, self.n, C.byref(io), self._stream()))
 
@@ -163,7 +166,7 @@ class F16Batch:
         _lib.check(self.lib.np_f16_lowlevel_obs(self._ctx, self.n, self.s.data_ptr(), self.u.data_ptr(), tgt3.data_ptr(), self.n,
                                                 obs.data_ptr(), self._stream()))
 
-    def _io(self, new_flags, action, obs, reward, rand_u, noise, inner=False):
+    def _io(self, new_flags, action, obs, reward, rand_u, noise, inner=False, ll_tgt=None, ll_obs=None):
         io = self._io_cached
         if io is None:  # the fields that never change are filled once (the struct is re-used: ~10 us less host time per step)
             io = self._io_cached = _lib.NpF16Io()
@@ -193,6 +196,8 @@ class F16Batch:
             self._s_version = self.s._version
         io.cache_valid = 1 if (self._cache_valid and not self._no_cache) else 0
         io.inner_step = 1 if inner else 0
+        io.ll_tgt = ll_tgt.data_ptr() if ll_tgt is not None else None
+        io.ll_obs = ll_obs.data_ptr() if ll_obs is not None else None
         io.seed, io.call_idx, io.row0 = self.seed, self.call_idx, self.row0
         return io
 
@@ -233,20 +238,26 @@ class F16Batch:
         self.call_idx += 1
         return obs
 
-    def step(self, action, rand_u=None, noise=None, inner=False):
+    def step(self, action, rand_u=None, noise=None, inner=False, ll_tgt=None, ll_obs=None, want_obs=True):
         """BaseEnv.step(action): ONE kernel launch.  Returns obs, reward, flags[3,n] (uint8).
-        inner=True: one low-level iteration of PlanningEnv.step (np_f16_io.inner_step)."""
+        inner=True: one low-level iteration of PlanningEnv.step (np_f16_io.inner_step); with ll_tgt[3,n] and ll_obs[n,22] the
+        launch also writes the low-level controller's NEXT observation into ll_obs (np_f16_io.ll_obs), and want_obs=False then skips
+        the task observation (returned as None)."""
         if action.device != self.device or action.dtype != torch.float32:
             action = action.to(device=self.device, dtype=torch.float32)
         if action.dim() != 2 or action.shape[0] != self.n or action.shape[1] < 4:
             raise ValueError(f'action must be [n={self.n}, >=4], got {tuple(action.shape)}')
         if action.stride(1) != 1:
             action = action.contiguous()
-        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        if (ll_obs is None) != (ll_tgt is None) or (ll_obs is not None and not inner):
+            raise ValueError('ll_tgt and ll_obs come together, with inner=True')
+        if not want_obs and ll_obs is None:
+            raise ValueError('want_obs=False needs ll_obs (an inner step that writes the low-level observation instead)')
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device) if want_obs else None
         reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
         new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
         rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
-        io = self._io(new_flags, action, obs, reward, rand_u, noise, inner=inner)
+        io = self._io(new_flags, action, obs, reward, rand_u, noise, inner=inner, ll_tgt=ll_tgt, ll_obs=ll_obs)
         _lib.check(self.lib.np_f16_step(self._ctx, self.n, C.byref(io), self._stream()))
         self._cache_valid = True  # every row's coefficients were just rewritten for its new state
         self.flags = new_flags

@@ -693,7 +693,11 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     const bool ok = (chk == chk);
     const float qnan = __builtin_nanf("");
     eval_nets<LD, PART, FULL, WPT>(wt, xn, coef, tables, part);
-#define NPF16_NET(id) (ok ? coef[slot_of(id) * LD] : qnan)
+    // "non-finite inputs poison every coefficient": every coefficient enters xdot through one of the six totals below, and a NaN
+    // coefficient makes its total NaN — so the rule is applied to the six totals (six selects) instead of to each of the 42 / 16
+    // coefficient reads; same values, same NaN-ness of every output (the payload of a NaN is not part of the spec)
+#define NPF16_NET(id) (coef[slot_of(id) * LD])
+#define NPF16_POISON(v) (ok ? (v) : qnan)
 
     if constexpr (SHARE) {
         const float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
@@ -735,16 +739,16 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     // --- X / Z force ---------------------------------------------------------------------
     const float dCx_lef = NPF16_NET(N_dCx_lef);
     const float dXdQ = c2v * (NPF16_NET(N_Cxq) + NPF16_NET(N_dCxq_lef));
-    const float Cx_tot = (NPF16_NET(N_Cx) + dCx_lef) + dXdQ * Q;
+    const float Cx_tot = NPF16_POISON((NPF16_NET(N_Cx) + dCx_lef) + dXdQ * Q);
     const float dCz_lef = NPF16_NET(N_dCz_lef);
     const float dZdQ = c2v * (NPF16_NET(N_Czq) + dCz_lef);  // reference uses delta_Cz_lef here (:199)
-    const float Cz_tot = (NPF16_NET(N_Cz) + dCz_lef) + dZdQ * Q;
+    const float Cz_tot = NPF16_POISON((NPF16_NET(N_Cz) + dCz_lef) + dZdQ * Q);
     // --- Y force ---------------------------------------------------------------------------
     const float dYdail = NPF16_NET(N_dCy_a20) + NPF16_NET(N_dCy_a20_lef);
     const float dYdR = b2v * (NPF16_NET(N_Cyr) + NPF16_NET(N_dCyr_lef));
     const float dYdP = b2v * (NPF16_NET(N_Cyp) + NPF16_NET(N_dCyp_lef));
     const float Cy_tot =
-        ((((NPF16_NET(N_Cy) + NPF16_NET(N_dCy_lef)) + dYdail * dail) + NPF16_NET(N_dCy_r30) * drud) + dYdR * R) + dYdP * P;
+        NPF16_POISON(((((NPF16_NET(N_Cy) + NPF16_NET(N_dCy_lef)) + dYdail * dail) + NPF16_NET(N_dCy_r30) * drud) + dYdR * R) + dYdP * P);
 
     const float Udot = (((R * V - Q * W) - g * st) + NP_DIVC((qbar * S) * Cx_tot, mass)) + NP_DIVC(T, mass);
     const float Vdot = ((P * W - R * U) + (g * ct) * sphi) + NP_DIVC((qbar * S) * Cy_tot, mass);
@@ -757,20 +761,20 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         // --- pitching moment ----------------------------------------------------------------
         const float dMdQ = c2v * (NPF16_NET(N_Cmq) + NPF16_NET(N_dCmq_lef));
         const float Cm_tot =
-            ((((NPF16_NET(N_Cm) * NPF16_NET(N_eta_el) + Cz_tot * xc) + NPF16_NET(N_dCm_lef)) + dMdQ * Q) + NPF16_NET(N_dCm)) +
-            0.0f;
+            NPF16_POISON(((((NPF16_NET(N_Cm) * NPF16_NET(N_eta_el) + Cz_tot * xc) + NPF16_NET(N_dCm_lef)) + dMdQ * Q) + NPF16_NET(N_dCm)) +
+                         0.0f);
         // --- yawing moment ------------------------------------------------------------------
         const float dNdail = NPF16_NET(N_dCn_a20) + NPF16_NET(N_dCn_a20_lef);
         const float dNdR = b2v * (NPF16_NET(N_Cnr) + NPF16_NET(N_dCnr_lef));
         const float dNdP = b2v * (NPF16_NET(N_Cnp) + NPF16_NET(N_dCnp_lef));
-        const float Cn_tot = ((((((NPF16_NET(N_Cn) + NPF16_NET(N_dCn_lef)) - (Cy_tot * xc) * cbar_over_B) + dNdail * dail) +
-                                NPF16_NET(N_dCn_r30) * drud) + dNdR * R) + dNdP * P) + NPF16_NET(N_dCnbeta) * beta;
+        const float Cn_tot = NPF16_POISON(((((((NPF16_NET(N_Cn) + NPF16_NET(N_dCn_lef)) - (Cy_tot * xc) * cbar_over_B) + dNdail * dail) +
+                                             NPF16_NET(N_dCn_r30) * drud) + dNdR * R) + dNdP * P) + NPF16_NET(N_dCnbeta) * beta);
         // --- rolling moment -----------------------------------------------------------------
         const float dLdail = NPF16_NET(N_dCl_a20) + NPF16_NET(N_dCl_a20_lef);
         const float dLdR = b2v * (NPF16_NET(N_Clr) + NPF16_NET(N_dClr_lef));
         const float dLdP = b2v * (NPF16_NET(N_Clp) + NPF16_NET(N_dClp_lef));
-        const float Cl_tot = (((((NPF16_NET(N_Cl) + NPF16_NET(N_dCl_lef)) + dLdail * dail) + NPF16_NET(N_dCl_r30) * drud) +
-                               dLdR * R) + dLdP * P) + NPF16_NET(N_dClbeta) * beta;
+        const float Cl_tot = NPF16_POISON((((((NPF16_NET(N_Cl) + NPF16_NET(N_dCl_lef)) + dLdail * dail) + NPF16_NET(N_dCl_r30) * drud) +
+                                            dLdR * R) + dLdP * P) + NPF16_NET(N_dClbeta) * beta);
 
         const float L_tot = ((Cl_tot * qbar) * S) * B;
         const float M_tot = ((Cm_tot * qbar) * S) * cbar;
@@ -780,6 +784,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         xd[11] = NP_DIVC((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom);
     }
 #undef NPF16_NET
+#undef NPF16_POISON
 }
 
 // the state's trigonometry computed by the caller (every variant but the latency one)

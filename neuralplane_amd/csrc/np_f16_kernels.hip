@@ -99,6 +99,8 @@ struct KArgs {
     unsigned *term_counters;        // optional [NP_NUM_TERM_COUNTERS] per-condition counters (one atomic per wave and condition)
     unsigned char *term_reasons;    // optional [n]: the same conditions per aircraft, bit k = counter k
     float *reward_task;             // optional [n]: the task's reward function alone (reward = this + the event term)
+    const float *ll_tgt;            // INNER, optional [3][ld]: the low-level controller's targets
+    float *ll_obs;                  // INNER, optional [n][22]: PlanningEnv.low_level_obs of the state this launch reaches
     long long row0, n;
     DevCfg cfg;
     // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once
@@ -479,6 +481,7 @@ void f16_env_kernel(const KArgs a) {
 
     if constexpr (!SHARED) {
         NP_REREAD_ARGS(ap);
+        if (!INNER || ap->obs) {  // an intermediate inner iteration of PlanningEnv.step may not want the task observation at all
         observe<TASK>(ap->cfg, s, u, tgt, tr, o);
         if (ap->noise) {  // obs + randn_like(obs) * noise_scale
 #pragma unroll
@@ -489,14 +492,15 @@ void f16_env_kernel(const KArgs a) {
             add_rng_noise(ap->seed, call_idx2, ap->row0 + ic, ap->cfg.noise_scale, o);
 #endif
         }
+        }
     }
 
     NP_LT(5);
     // ---- [n][22] observation rows: transpose through LDS, store coalesced ----
-    if (ap->obs) {
-        __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
+    auto store_rows22 = [&](float *out_base, const float (&o)[22]) {
+        __syncthreads();  // every lane is done with its coefficient column (or the previous tile) before the tile overwrites it
         const long long rows = (ap->n - i0) < TILE ? (ap->n - i0) : TILE;
-        float *dst = ap->obs + i0 * 22;
+        float *dst = out_base + i0 * 22;
         constexpr int THREADS = TILE * lat_waves(WPT);
         if (rows == TILE && ((uintptr_t)dst & 15) == 0) {  // workgroup-uniform: a full tile and a 16-byte aligned destination
             // unpadded rows (pitch 22 floats): 11 ds_write_b64 per lane, then the tile leaves as 16-byte vectors — 6 (2)
@@ -535,6 +539,23 @@ void f16_env_kernel(const KArgs a) {
                     dst[L] = obs_tile[(unsigned)L + r];
                 }
             }
+        }
+    };
+    if (ap->obs) store_rows22(ap->obs, o);
+    if constexpr (INNER) {
+        // PlanningEnv.low_level_obs (planning_env.py:60-142) of the state just reached, for the controller's next call: the
+        // ControlTask-style observation against the caller's targets, no noise — the arithmetic of f16_lowlevel_obs_kernel on
+        // the trigonometry this step already has
+        if (ap->ll_obs) {  // wave-uniform
+            float o2[22];
+            if (part == 0) {
+                float t3[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) t3[k] = at_off(ap->ll_tgt + k * ap->ld, o4);
+                if constexpr (SHARED) observe<1, true>(ap->cfg, s, u, t3, tr, o2, sc1.powv);
+                else observe<1>(ap->cfg, s, u, t3, tr, o2);
+            }
+            store_rows22(ap->ll_obs, o2);
         }
     }
 #ifdef NPF16_LAT_TRACE
@@ -1093,8 +1114,8 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     if (io->ld < n) return fail("ld < n");
     if (io->ld >= (1ll << 30)) return fail("ld must be below 2^30 rows (32-bit byte offsets inside a row-indexed array)");
     if (!STEP && io->inner_step) return fail("inner_step applies to np_f16_step only");
-    if (STEP && (!io->action || !io->obs || !io->reward || io->act_stride < 4))
-        return fail("step needs action (>=4 columns), obs and reward buffers");
+    if (STEP && (!io->action || !io->reward || io->act_stride < 4 || (!io->obs && !(io->inner_step && io->ll_obs))))
+        return fail("step needs action (>=4 columns), obs and reward buffers (obs may be NULL only for an inner step that writes ll_obs)");
     if (io->done_out == io->done_in || io->bad_out == io->bad_in || io->timeout_out == io->timeout_in)
         return fail("flag outputs may not alias flag inputs");
     DeviceGuard guard;
@@ -1110,6 +1131,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.term_counters = io->term_counters;
     a.term_reasons = io->term_reasons;
     a.reward_task = STEP ? io->reward_task : nullptr;
+    a.ll_tgt = (STEP && io->inner_step) ? io->ll_tgt : nullptr;
+    a.ll_obs = (STEP && io->inner_step) ? io->ll_obs : nullptr;
+    if (a.ll_obs && !a.ll_tgt) return fail("ll_obs needs ll_tgt");
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
     a.wt = ctx->wt;

@@ -1,8 +1,11 @@
 """PlanningEnv — hierarchical tracking env with the reference's surface (envs/planning_env.py:32-177).
 
 One high-level action (Δpitch, Δheading, Δvt) per `step`; inside, 50 low-level iterations of
-{low-level observation -> frozen recurrent controller -> fused FDM step}.  Each iteration is two
-kernel launches (np_f16_lowlevel_obs, np_f16_step with inner_step=1) plus the controller's forward;
+{low-level observation -> frozen recurrent controller -> fused FDM step}.  Each iteration is ONE
+kernel launch of this library (np_f16_step with inner_step=1, which also writes the low-level
+observation of the state it reaches: np_f16_io.ll_obs; np_f16_lowlevel_obs runs once per macro-step,
+for the first iteration) plus the controller's forward — 102 launches per step with the fused
+controller (round 2: 151);
 the env keeps the reference's quirks: rows that terminated earlier in the same outer step keep their
 state while their controls keep moving, `step_count` advances for every row, flags accumulate.
 
@@ -104,11 +107,17 @@ class PlanningEnv(BaseEnv):
         vt = self.model.get_vt()
         tgt3 = torch.stack((pitch + action[:, 0] * 0.3, yaw + action[:, 1] * 0.3, vt + action[:, 2] * 30))  # :150-152
         masks = torch.ones((self.n, 1), device=self.device)
-        for _ in range(INNER_STEPS):
-            ego_obs = b.lowlevel_obs(tgt3)
+        tgt3 = tgt3.contiguous()
+        ego_obs = b.lowlevel_obs(tgt3)        # the controller's first input; every later one is written by the inner step itself
+        for k in range(INNER_STEPS):
             with torch.no_grad():
                 ego_actions, _, self.ego_rnn_states = self.controller(ego_obs, self.ego_rnn_states, masks, deterministic=True)
-            obs, reward, flags = b.step(ego_actions, inner=True)
+            last = k == INNER_STEPS - 1
+            nxt = None if last else torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+            # one launch: the FDM step + the low-level observation of the state it reaches (np_f16_io.ll_obs); the task observation
+            # is only wanted from the last iteration (planning_env.py:153-176 overwrites it every iteration)
+            obs, reward, flags = b.step(ego_actions, inner=True, ll_tgt=None if last else tgt3, ll_obs=nxt, want_obs=last or render)
+            ego_obs = nxt
             if render:
                 self.render(count=count)
                 count += 1                                             # :171-173: one frame per inner iteration
@@ -134,8 +143,10 @@ class PlanningEnv(BaseEnv):
         fin, fout = g['fb'], g['fa']
         fused = isinstance(self.controller, FusedActor)   # writes into caller-owned buffers: no allocation, no state copy
         rnn_a, rnn_b = g['rnn'], g.get('rnn2')
+        tgt3 = tgt3.contiguous()
+        b.lowlevel_obs_into(tgt3, g['ll_obs'])       # the controller's first input; the inner steps write the following ones
         for k in range(INNER_STEPS):
-            b.lowlevel_obs_into(tgt3, g['ll_obs'])
+            last = k == INNER_STEPS - 1
             if fused:
                 ego_actions, _, _ = self.controller(g['ll_obs'], rnn_a, g['masks'], deterministic=True, out=(g['ll_act'], rnn_b))
                 rnn_a, rnn_b = rnn_b, rnn_a          # INNER_STEPS is even: the state ends up in g['rnn'] again
@@ -144,7 +155,8 @@ class PlanningEnv(BaseEnv):
                 g['rnn'].copy_(rnn)
                 ego_actions = ego_actions.to(torch.float32).contiguous()
             # the first inner step re-evaluates the cached coefficients: the caller may have edited `s` between steps
-            b.launch_static(fin, fout, 1 + k, action=ego_actions, obs=g['obs'], reward=g['reward'], inner=True, cache_valid=(k > 0))
+            b.launch_static(fin, fout, 1 + k, action=ego_actions, obs=g['obs'] if last else None, reward=g['reward'], inner=True, cache_valid=(k > 0),
+                            ll_tgt=None if last else tgt3, ll_obs=None if last else g['ll_obs'])
             fin, fout = fout, fin
         g['fa'].copy_(fin)                       # 1 + 50 flips end in the other buffer; the next replay starts from `fa`
         b.call_base.add_(1 + INNER_STEPS)

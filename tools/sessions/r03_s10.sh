@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 3, GPU session 10: Philox 3-input xor as v_bitop3, NaN poison on the six coefficient totals: A/B vs the previous head, PMC
+# instruction count, full GPU suite
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+out=gpurun_out/r03_s10; mkdir -p $out
+timeout 2400 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+timeout 900 python tools/microbench/ab_libs.py --rounds 3 --steps 100 f_prev g_head > $out/ab_1e6.log 2>&1; grep -v Warn $out/ab_1e6.log | tail -3
+timeout 250 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $out/pmc_valu -o p -- python bench.py --steps 3 --warmup 2 --prelude-ms 0 --headline-only > $out/pmc_valu.log 2>&1 < /dev/null
+python - <<'PY'
+import csv,glob
+cc=glob.glob('gpurun_out/r03_s10/pmc_valu/**/*counter_collection.csv',recursive=True)
+acc={}
+for r in csv.DictReader(open(cc[0])):
+    if 'f16_env_kernel' not in r['Kernel_Name'] or 'true, true' not in r['Kernel_Name']: continue
+    a=acc.setdefault(r['Counter_Name'],{}); a[r['Dispatch_Id']]=a.get(r['Dispatch_Id'],0)+float(r['Counter_Value']); g=int(r['Grid_Size'])
+for k,a in acc.items():
+    v=list(a.values()); print(k, sum(v)/len(v)/(g/64))
+PY
