@@ -94,7 +94,17 @@ def cpu_baseline(task, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 2000:
             break
+    eager = None
+    if task == 'heading':
+        # a from-scratch eager-PyTorch formulation of the same step on the same host cores (oracle/torch_eager.py — test /
+        # bench infrastructure, checked against the reference's fixtures; the reference's own files cannot travel to this box)
+        try:
+            from oracle.torch_eager import timed_rate
+            eager = timed_rate(n=100_000, budget_s=8.0, threads=cpus)
+        except Exception as e:   # the baseline is context, never a reason to lose the bench line
+            eager = {'error': repr(e)}
     return {'value': n * steps / el, 'unit': 'aircraft-steps/s', 'cores': int(o.threads), 'kind': 'port',
+            'torch_eager': eager,
             'sample': f'F-16 {task}, N={n} aircraft x {steps} steps, oracle/f16_oracle.c (OpenMP, fp32 scalar, '
                       f'same numerics spec), {el:.1f} s',
             # context only: the reference's own eager-PyTorch path cannot travel to this box (its source never leaves the build
@@ -407,7 +417,8 @@ def run_env(args, rank, local_rank, world, dev, dist):
                                      'envs, scripts/train_heading.sh)'}
     del envs, tm6
     modes['singlecombat_1v1'] = combat_mode(dev, 100_000, min(args.steps, 100), 5, ps)
-    modes['planning_tracking_n1e4'] = planning_mode(dev, g)
+    modes['planning_tracking_n1e4'] = planning_mode(dev, g, 10_000, 20)
+    modes['planning_tracking_n262144'] = planning_mode(dev, g, 262_144, 4)
     return out
 
 
@@ -440,31 +451,51 @@ def combat_mode(dev, E, steps, warmup, prelude_s):
     return out
 
 
-def planning_mode(dev, g):
-    """BASELINE.json configs[3] as the reference ships it (hierarchical Tracking): PlanningEnv.step = 50 x {low-level obs, frozen
-    PPOActor-architecture controller as ONE fused MFMA kernel, fused env step}, at the batch size of the reference's own training
-    script (n = 1e4); random-init controller weights of that architecture."""
+def planning_mode(dev, g, npl, k7):
+    """BASELINE.json configs[3] as the reference ships it (hierarchical Tracking): PlanningEnv.step = 50 x {frozen PPOActor-
+    architecture controller as ONE fused MFMA kernel, fused env step that also writes the controller's next observation}, at the
+    batch size of the reference's own training script (n = 1e4) and at a size that fills the GPU (262 144); random-init controller
+    weights of that architecture."""
     import numpy as np
     import torch
     from neuralplane_amd.actor import FusedActor, NUM_FLOATS
     from neuralplane_amd.envs.planning_env import PlanningEnv
-    npl = 10_000
     ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), str(dev))
     penv = PlanningEnv(num_envs=npl, config='tracking', model='F16', random_seed=0, device=str(dev), controller=ctrl)
     ap = torch.rand((npl, 3), generator=g, device=dev) * 2 - 1
-    for _ in range(5):
+    for _ in range(3):
         penv.step(ap)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    k7 = 20
     for _ in range(k7):
         penv.step(ap)
     torch.cuda.synchronize(dev)
     el7 = time.perf_counter() - t1
-    return {'value': 1e3 * el7 / k7, 'unit': 'ms per PlanningEnv.step (50 inner FDM steps + 50 controller calls)', 'steps': k7,
-            'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7,
-            'note': 'controller = np_actor_forward (K=1 fp32 MFMA chains, bit-exact to its oracle: tests/test_gpu_actor.py); '
-                    'the same step with the controller as eager torch modules: 22 ms (tools/microbench/planning_bench.py)'}
+    # the env kernel's share of a macro-step (HIP events attached to the 50 inner launches of one more step)
+    penv._batch.set_timing(True)
+    penv.step(ap)
+    torch.cuda.synchronize(dev)
+    env_ms = sum(penv._batch.get_timing_samples())
+    penv._batch.set_timing(False)
+    ms = 1e3 * el7 / k7
+    flop_actor, flop_env = 2 * 151_000.0, ALGO_FLOP     # PPOActor.forward: 151 K multiply-adds per aircraft and call; one FDM step
+    per_macro = 50 * (flop_actor + flop_env)
+    ach = npl * per_macro / (ms * 1e-3) / 1e12
+    out = {'value': ms, 'unit': 'ms per PlanningEnv.step (50 inner FDM steps + 50 controller calls)', 'steps': k7, 'aircraft': npl,
+           'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7, 'launches_per_macro_step': 1 + 1 + 50 * 2,
+           'env_kernels_ms_per_macro_step': env_ms, 'controller_and_gaps_ms_per_macro_step': ms - env_ms,
+           'roofline': {'bound': 'mfma+valu (fp32: the f32-input MFMA and the vector ALU share one 157.3 TFLOP/s pipe, tools/microbench/mfma_coissue.hip)',
+                        'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS,
+                        'algorithmic_flop_per_aircraft_macro_step': per_macro,
+                        'note': '50 x (302 KFLOP controller forward + 33.8 KFLOP FDM step) = 16.8 MFLOP per aircraft and PlanningEnv.step; wall clock '
+                                'of back-to-back macro-steps, i.e. launch gaps included'},
+           'note': 'controller = np_actor_forward (K=1 fp32 MFMA chains, bit-exact to its oracle: tests/test_gpu_actor.py); the inner step writes '
+                   'the next low-level observation itself (np_f16_io.ll_obs): 102 launches per macro-step (round 2: 151).  At n = 1e4 the step is bound by '
+                   'the controller\'s latency: 157 tiles of 64 aircraft on 256 CUs, one wave per SIMD, 1 180 dependent K = 1 MFMA steps of 64 cycles per '
+                   'call = 31.5 us of matrix pipe per call even at 100 % issue (measured ~60 us per call)'}
+    del penv, ctrl
+    torch.cuda.empty_cache()
+    return out
 
 
 def _wall(step, batch, dev, warmup, k):
@@ -528,6 +559,11 @@ def run_combat(args, rank, local_rank, world, dev, dist):
     elapsed, samples, i = tm.window(args.warmup, args.steps, i)
     fin = bool(torch.isfinite(cenv.s).all().item())
     plain_ms = 1e3 * _wall(step, cenv._batch, dev, 10, max(50, args.steps)) if world == 1 else None   # the loop without timing events
+    policy_ms = None
+    if world == 1 and not args.interleaved:   # the two stand-in policies alone (4 small torch kernels): what the loop spends outside this library
+        oe, oo = state['obs']
+        ids = torch.arange(e_loc, device=dev)
+        policy_ms = 1e3 * _wall(lambda i: (ego_policy(oe), opp_policy(oo, ids)), cenv._batch, dev, 10, 200)
     # What the 1 -> 8 GPU curve of this config should look like, from numbers measured in THIS run (single-GPU runs only): the
     # per-GPU share of an 8-rank job stepped through the same loop on this GPU (no collective in it), plus an estimate for the two
     # all-gathers of a step.  Strong scaling: the work per GPU shrinks 8x, the per-step floor (kernel latency at a small grid,
@@ -576,6 +612,8 @@ def run_combat(args, rank, local_rank, world, dev, dist):
         'expected_scaling': expected,
         'layout': 'interleaved rows + torch split / stack (round-2 loop)' if args.interleaved else 'split ego / opponent arrays (np_f16_combat_io.action_opp / obs_opp): no copies around the launch',
         'ms_per_step_without_timing_events': plain_ms, 'loop_overhead_ms': (plain_ms - st['kernel_avg_ms']) if plain_ms is not None else None,
+        'stand_in_policies_ms': policy_ms,
+        'exchange_and_glue_ms': (plain_ms - st['kernel_avg_ms'] - policy_ms) if (plain_ms is not None and policy_ms is not None) else None,
         'prelude': {'steps': p_steps, 'seconds': p_sec, 'timed': False},
         'cold_start': {'value': e_total * args.steps / cold_el, 'ms_per_step': 1e3 * cold_el / args.steps, **stats(cold_samples)},
         'roofline': {'bound': 'valu', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS,

@@ -478,3 +478,34 @@ def test_constant_division_sequence_changes_no_bit_of_a_run(task):
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py's second CPU baseline: the from-scratch eager-PyTorch formulation (oracle/torch_eager.py)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('pre', ['', 'first_'])
+def test_torch_eager_formulation_matches_the_reference_fixture_and_the_oracle(golden_dir, pre):
+    """The tensor-op formulation bench.py times as `cpu_baseline.torch_eager` is the same env.step: against the imported
+    reference's recorded step (plain ATen arithmetic, its reset draws and noise injected) states / observation within 1e-5
+    relative (per-state floors), reward within 1e-6, all masks equal; and within 1e-4 of the C oracle."""
+    import torch
+    from oracle.torch_eager import TorchEagerHeading
+    g = np.load(f'{golden_dir}/step_kat_heading.npz')
+    n = g['action'].shape[0]
+    e = TorchEagerHeading(n)
+    st = Oracle.new_state(n)
+    if pre == '':
+        for k in ('s', 'u', 'tgt', 'step_count', 'done', 'bad', 'timeout'):
+            st[k] = g['in_' + k].copy()
+        e.s, e.u, e.tgt = (torch.from_numpy(g['in_' + k].copy()) for k in ('s', 'u', 'tgt'))
+        e.step_count = torch.from_numpy(g['in_step_count'].copy())
+        e.is_done, e.bad_done, e.exceed = (torch.from_numpy(g['in_' + k].astype(bool)) for k in ('done', 'bad', 'timeout'))
+    ru, nz = g[pre + 'rand_u'] if pre else g['rand_u'], g[pre + 'noise'] if pre else g['noise']
+    with torch.no_grad():
+        obs, rew, d, b, t = e.step(torch.from_numpy(g['action']), rand_u=torch.from_numpy(ru), noise=torch.from_numpy(nz))
+    key = pre + 'out_'
+    assert relerr(e.s.numpy(), g[key + 's'], STATE_FLOORS) < 1e-5 and relerr(obs.numpy(), g[key + 'obs'], 0.1) < 1e-5
+    assert np.max(np.abs(rew.numpy() - g[key + 'reward'])) < 1e-4
+    assert np.array_equal(d.numpy(), g[key + 'done'].astype(bool)) and np.array_equal(b.numpy(), g[key + 'bad'].astype(bool))
+    o_obs, o_rew, _, _, _ = Oracle('heading').step(st, g['action'], rand_u=ru, noise=nz)
+    assert relerr(e.s.numpy(), st['s'], STATE_FLOORS) < 1e-4 and relerr(obs.numpy(), o_obs, 0.1) < 1e-4
