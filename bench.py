@@ -333,8 +333,9 @@ def run_env(args, rank, local_rank, world, dev, dist):
         'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach_tflops / PEAK_FP32_TFLOPS,
                      'traffic': traffic, 'traffic_source': traffic_src,
-                     'traffic_unit': 'HBM bytes per launch: rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE read from the committed '
-                                     'profile named in traffic_source (not measured by this run)',
+                     'traffic_unit': 'HBM bytes per launch: rocprofv3 PMC passes FETCH_SIZE x 2.0 + WRITE_SIZE x 1.0 (factors calibrated on this '
+                                     'access pattern, profiles/r03_counter_calibration.json) read from the committed profile named in '
+                                     'traffic_source (not measured by this run)',
                      'algorithmic_bytes_per_launch': n * ALGO_BYTES,
                      'algorithmic_flop_per_aircraft_step': flop,
                      'executed_flop_per_aircraft_step': EXEC_FLOP if exe_tflops is not None else None,

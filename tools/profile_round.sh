@@ -7,6 +7,11 @@ out=gpurun_out/$tag; mkdir -p $out
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err < /dev/null
 timeout 300 python bench.py --steps 200 --warmup 20 --headline-only > $out/bench.json 2> $out/bench.err < /dev/null
 timeout 120 python tools/wg_timeline.py --n 1000000 --out $out/wg_timeline_n1e6.json > /dev/null 2> $out/timeline.err < /dev/null
+timeout 400 python tools/microbench/mid_n.py --variants auto --out $out/n_sweep.json 3000 10000 30000 49152 65536 81920 98304 100000 131072 196608 262144 > $out/n_sweep.log 2>&1 < /dev/null
+timeout 300 python bench.py --task combat --engagements 12500 --steps 200 --warmup 20 > $out/bench_combat_e12500.json 2>> $out/bench.err < /dev/null
+timeout 300 python bench.py --task combat --engagements 100000 --steps 100 --warmup 10 > $out/bench_combat_e1e5.json 2>> $out/bench.err < /dev/null
+timeout 300 python bench.py --task tracking --steps 20 --warmup 5 --headline-only > $out/bench_tracking.json 2>> $out/bench.err < /dev/null
+timeout 300 python bench.py --task control --steps 20 --warmup 5 --headline-only > $out/bench_control.json 2>> $out/bench.err < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python bench.py --gpus 1 --steps 20 --warmup 5 --headline-only > $out/stats.log 2>&1 < /dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_combat -o p -- python tools/microbench/combat_bench.py 100000 > $out/stats_combat.log 2>&1 < /dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_actor -o p -- python tools/microbench/actor_bench.py 262144 > $out/stats_actor.log 2>&1 < /dev/null

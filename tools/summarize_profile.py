@@ -37,7 +37,7 @@ def main(tag):
                 w = csv.writer(f)
                 for r in rows:
                     w.writerow([c[:100] for c in r])
-    for extra in ('wg_timeline_n1e6.json', 'bench_driver_cmd.json', 'cold_start.json'):
+    for extra in ('wg_timeline_n1e6.json', 'bench_driver_cmd.json', 'cold_start.json', 'n_sweep.json', 'bench_combat_e12500.json', 'bench_combat_e1e5.json', 'bench_tracking.json', 'bench_control.json'):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, f'{tag}_{extra}'))
     # PMC passes: mean per launch / per wave for the dominant kernel
@@ -71,14 +71,23 @@ def main(tag):
             w.writerow(['counter', 'launches', 'mean_per_launch', 'mean_per_wave'])
             for row in sorted(summary):
                 w.writerow([row[0], row[1], f'{row[2]:.6g}', f'{row[3]:.4g}'])
+    # correction factors measured on this access pattern (tools/calibrate_counters.sh -> profiles/r03_counter_calibration.json); the
+    # guide's x2 / x1 when no calibration file exists
+    rf, wf, cal_src = 2.0, 1.0, 'MI355X_MICROARCH.md (FETCH_SIZE x2, WRITE_SIZE uncalibrated)'
+    cal = os.path.join(dst, 'r03_counter_calibration.json')
+    if os.path.exists(cal):
+        c = json.load(open(cal))['env_kernel_factors']
+        rf, wf, cal_src = float(c['read']), float(c['write']), 'profiles/r03_counter_calibration.json (known-byte-count kernels in the env kernel\'s access pattern)'
     if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
         n = json.load(open(os.path.join(dst, f'{tag}_bench.json')))['config']['aircraft_per_gpu'] if os.path.exists(os.path.join(dst, f'{tag}_bench.json')) else 1000000
-        json.dump({'round': int(tag[1:3]) if tag[1:3].isdigit() else None, 'kernel': 'f16_env_kernel<0, 0, true, true, 128, 2, false, 3> (pair variant, three waves per SIMD; before r02i: <..., 128, 2>)', 'n': n, 'task': 'heading', 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
+        json.dump({'round': int(tag[1:3]) if tag[1:3].isdigit() else None, 'kernel': 'f16_env_kernel<0, 0, true, true, 128, 2, false, 3> (pair variant, three waves per SIMD)', 'n': n, 'task': 'heading', 'FETCH_SIZE_KB': traffic['FETCH_SIZE'],
                    'WRITE_SIZE_KB': traffic['WRITE_SIZE'],
                    'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), mean over the '
                            'cached-kernel launches. MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at '
                            '64 B -> doubled; WRITE_SIZE taken as is (uncalibrated).',
-                   'traffic_bytes_per_launch': (2 * traffic['FETCH_SIZE'] + traffic['WRITE_SIZE']) * 1024.0},
+                   'read_factor': rf, 'write_factor': wf, 'factor_source': cal_src,
+                   'read_bytes_per_launch': rf * traffic['FETCH_SIZE'] * 1024.0, 'write_bytes_per_launch': wf * traffic['WRITE_SIZE'] * 1024.0,
+                   'traffic_bytes_per_launch': (rf * traffic['FETCH_SIZE'] + wf * traffic['WRITE_SIZE']) * 1024.0},
                   open(os.path.join(dst, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
     print('profiles/ updated for', tag, ':', sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 
