@@ -283,16 +283,17 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 
 /* np_f16_step has five bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
  * evaluations of a step, the serial fp64 chains of the state and the observation noise; chosen automatically for n <= 49152 —
- * one generation of 768 tiles at three waves per SIMD — Euler solver), "latency8" (eight waves per tile — two per SIMD, so one
+ * one generation of 768 tiles at three waves per SIMD; "latency4w" = the same kernel built for four waves per SIMD, 1 024 tiles in
+ * one generation, chosen for 49152 < n <= 65536 — Euler solver), "latency8" (eight waves per tile — two per SIMD, so one
  * wave's scalar-load latency is the other's FMA time; chosen automatically for n <= 16384, where every tile still has a CU of
- * its own), "latency2" (two waves per tile: two to three waves on every SIMD for 49152 < n <= 98304, where the pair variant
+ * its own), "latency2" (two waves per tile: two to three waves on every SIMD for 65536 < n <= 98304, where the pair variant
  * leaves a SIMD one or two), "pair" (the two waves of a 128-aircraft
  * workgroup split the nets and evaluate them for each other's aircraft: half the scalar weight traffic per aircraft; the default
  * above that size with the MLP numerics; built twice, for two and for three waves per SIMD — the second with ~20 cold registers per
  * lane in scratch — and picked per grid size, environment NPF16_PAIR_WAVES=2|3 pins one) and "throughput" (two independent waves per
  * workgroup; the 1-D table mode).  This call pins the choice for a context (tests, tuning); np_f16_combat_step has latency, pair and
  * throughput. */
-enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4, NP_KERNEL_LATENCY2 = 5 };
+enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4, NP_KERNEL_LATENCY2 = 5, NP_KERNEL_LATENCY4W = 6 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
 /* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context, measured with

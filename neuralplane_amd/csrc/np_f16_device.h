@@ -160,26 +160,34 @@ __device__ __forceinline__ float mlp_body(const float *kblob, int w, const float
 // Single-input nets as table lookups (spec option aero_1d_tables): per net a 6-step binary search over 63 sorted
 // breakpoints, then one fma on the segment's line.  The searches of all nets of the class are interleaved so
 // that their dependent gathers (per-lane addresses into __constant__ tables, served by the vector L1) overlap.
+// a float of a context-owned table at (wave-uniform base) + (per-lane 32-bit byte offset): selects the SGPR-base + VGPR-offset
+// addressing mode (one global_load_dword, no 64-bit address arithmetic per lane)
+__device__ __forceinline__ float ld_table(const float *base, unsigned byte_off) {
+    typedef const float __attribute__((address_space(1))) GT;
+    return *reinterpret_cast<GT *>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+
 template <int CL, int COUNT, int LD, int FIRST>
 __device__ __forceinline__ void eval_class_pwl(const AeroWeights &wt, float x, float *__restrict__ out) {
     constexpr NetClass c = CLASSES[CL];
-    const cf32_ptr pwl = NPF16_CONST(wt.pwl), pwl_unnorm = NPF16_CONST(wt.pwl_unnorm);
-    int idx[COUNT > 0 ? COUNT : 1];
+    const float *pwl = wt.pwl;
+    const cf32_ptr pwl_unnorm = NPF16_CONST(wt.pwl_unnorm);
+    unsigned idx4[COUNT > 0 ? COUNT : 1];  // segment index x 4 (a byte offset)
 #pragma unroll
-    for (int m = 0; m < COUNT; m++) idx[m] = 0;
+    for (int m = 0; m < COUNT; m++) idx4[m] = 0;
 #pragma unroll
     for (int h = PWL_SEG / 2; h >= 1; h >>= 1) {
 #pragma unroll
         for (int m = 0; m < COUNT; m++) {
-            const int tb = pwl_index(c.nets[FIRST + m]) * PWL_TABLE_FLOATS;
-            idx[m] += (x >= pwl[tb + idx[m] + h - 1]) ? h : 0;
+            const unsigned tb4 = (unsigned)(pwl_index(c.nets[FIRST + m]) * PWL_TABLE_FLOATS) * 4u;
+            idx4[m] += (x >= ld_table(pwl, tb4 + idx4[m] + 4u * (unsigned)(h - 1))) ? 4u * (unsigned)h : 0u;
         }
     }
 #pragma unroll
     for (int m = 0; m < COUNT; m++) {
         const int ti = pwl_index(c.nets[FIRST + m]);
-        const int tb = ti * PWL_TABLE_FLOATS;
-        const float yn = fmaf(pwl[tb + PWL_SEG + idx[m]], x - pwl[tb + 2 * PWL_SEG + idx[m]], pwl[tb + 3 * PWL_SEG + idx[m]]);
+        const unsigned tb4 = (unsigned)(ti * PWL_TABLE_FLOATS) * 4u;
+        const float yn = fmaf(ld_table(pwl, tb4 + 4u * PWL_SEG + idx4[m]), x - ld_table(pwl, tb4 + 8u * PWL_SEG + idx4[m]), ld_table(pwl, tb4 + 12u * PWL_SEG + idx4[m]));
         out[(class_slot(CL) + FIRST + m) * LD] = yn * pwl_unnorm[2 * ti] + pwl_unnorm[2 * ti + 1];
     }
 }
@@ -604,7 +612,7 @@ struct StateScalars {
     float tt, spsi, cpsi, powv;  // tan(theta), sin / cos(psi), (1 - 0.703e-5 alt)^4.14
 };
 constexpr int NUM_SHARED_SCALARS = 12;
-template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0>
+template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0, bool HAVE_POW = false>
 __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], StateScalars &sc,
                                         float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
     static_assert(!SHARE || WPT == 4 || WPT == 8 || WPT == WPT_LAT2, "shared state scalars belong to the latency variants");
@@ -634,7 +642,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
                 np_sincos(s[7], a_, b_);
                 shr[0 * LD] = a_;
                 shr[1 * LD] = b_;
-                if (FULL) np_sincostan(s[4], a_, b_, c_);
+                if (FULL || NUM_CACHED_TRIG > 0) np_sincostan(s[4], a_, b_, c_);   // tan(theta) of the new state travels in the cross-step cache
                 else np_sincos(s[4], a_, b_);
                 shr[4 * LD] = a_;
                 shr[5 * LD] = b_;
@@ -673,7 +681,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
             shr[11 * LD] = np_pow(tfac, 4.14f);
         } else if (part == 2) {
             float a_, b_, c_ = 0.0f;
-            if (FULL) np_sincostan(s[4], a_, b_, c_);
+            if (FULL || NUM_CACHED_TRIG > 0) np_sincostan(s[4], a_, b_, c_);   // tan(theta) of the new state travels in the cross-step cache
             else np_sincos(s[4], a_, b_);
             shr[4 * LD] = a_;
             shr[5 * LD] = b_;
@@ -707,7 +715,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         sc.spsi = FULL ? shr[9 * LD] : 0.0f;
         sc.cpsi = FULL ? shr[10 * LD] : 0.0f;
         sc.powv = shr[11 * LD];
-    } else {
+    } else if constexpr (!HAVE_POW) {  // HAVE_POW: the caller brought it (the cross-step cache: the previous step computed it for this state)
         sc.powv = np_pow(tfac, 4.14f);
     }
     const Trig &tr = sc.tr;

@@ -133,7 +133,7 @@ __global__
 #ifdef NPF16_OLD_BOUNDS
 __launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWAVES))
 #else
-__launch_bounds__(TILE * lat_waves(WPT)) __attribute__((amdgpu_waves_per_eu((WPT == 2 ? PW : NPF16_MINWAVES), (WPT == 2 && PW == 2 ? 2 : 8))))
+__launch_bounds__(TILE * lat_waves(WPT)) __attribute__((amdgpu_waves_per_eu((WPT == 2 ? PW : (WPT == 4 && PW == 4) ? 4 : NPF16_MINWAVES), (WPT == 2 && PW == 2 ? 2 : 8))))
 #endif
 void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
@@ -214,7 +214,41 @@ void f16_env_kernel(const KArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; k++) tgt[k] = at_off(a.tgt + k * a.ld, o4);
     long long sc = at_off(a.step_count, o8);
-    const bool flagged = (at_off(a.fin0, r32) | at_off(a.fin1, r32) | at_off(a.fin2, r32)) != 0;
+    const unsigned fl_in = at_off(a.fin0, r32) | at_off(a.fin1, r32) | at_off(a.fin2, r32);
+    if constexpr (SHARED) {
+        // Observation noise first (round 3): it depends on (seed, call index, row) only, so this wave's share — its Philox block(s) and
+        // their Box-Muller pairs, ~150-300 instructions — runs while the state loads above are in flight instead of between the two
+        // net phases; the values wait in their own LDS columns for the wave that finishes the observation (same values, same fma).
+        if (!a.noise && a.cfg.noise_scale != 0.0f) {
+        // this wave's Philox block of the row -> its two or three Box-Muller pairs -> LDS (published by the barrier that opens the
+        // Overload evaluation; wave 0 adds them to the observation afterwards: same values, same fma as add_rng_noise)
+        const uint64_t call_idx2 = a.call_idx + (a.call_idx_base ? *a.call_idx_base : 0ull);
+#pragma unroll
+        for (int q = 0; q < (WPT == WPT_LAT2 ? 2 : 1); q++) {  // two waves per tile: blocks {0, 3} and {1, 2} (5 and 6 pairs)
+        // eight waves: 0..3 are computing the state's trigonometry meanwhile
+        const int nb = WPT == 8 ? part - 4 : WPT == WPT_LAT2 ? (q == 0 ? part : 3 - part) : part;
+        if (nb >= 0) {
+        uint32_t blk[4], k1[3], k2[3];
+        rng_block(a.seed, call_idx2, a.row0 + ic, 2u + (uint32_t)nb, blk);
+        noise_block_indices(blk, k1, k2);
+        float *nz = coef + NOISE_COL0 * TILE;
+        const float scale = a.cfg.noise_scale;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j < 2 || nb < 3) {
+                const int pair = j < 2 ? 2 * nb + j : 8 + nb;  // wave-uniform
+                float rs, cs, sn;
+                noise_pair(k1[j], k2[j], scale, rs, cs, sn);
+                nz[(3 * pair) * TILE] = rs;
+                nz[(3 * pair + 1) * TILE] = cs;
+                nz[(3 * pair + 2) * TILE] = sn;
+            }
+        }
+        }
+        }
+        }
+    }
+    const bool flagged = fl_in != 0;
 
     const bool frozen = INNER && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
     const bool tmo_prev = INNER && at_off(a.fin2, r32) != 0;
@@ -235,9 +269,12 @@ void f16_env_kernel(const KArgs a) {
         reset_row<TASK>(a.cfg, ru, s, u, tgt, sc);
     }
 
-    // cache tile of this workgroup: 14 rows of BLOCK floats, contiguous
-    // cache layout (private to the library, the same for every kernel variant): [row / 64][14][row % 64]
-    float *cache_blk = a.cache ? a.cache + ((i >> 6) * NUM_CACHED) * CACHE_TILE + (i & (CACHE_TILE - 1)) : nullptr;
+    // cache tile of this workgroup: NUM_CACHE_ROWS rows of 64 floats, contiguous
+    // cache layout (private to the library, the same for every kernel variant): [row / 64][NUM_CACHE_ROWS][row % 64] — rows 0..13 the
+    // force-side alpha/beta-only coefficients at the row's CURRENT state, rows 14..23 that state's trigonometry (np_nets.h)
+    float *cache_blk = a.cache ? a.cache + ((i >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (i & (CACHE_TILE - 1)) : nullptr;
+    constexpr bool TRIG_CACHED = STEP && CACHED && NUM_CACHED_TRIG > 0 && !SHARED;   // the integrator evaluation takes the state's trigonometry from the cache
+    StateScalars sc_old;
     if (STEP && CACHED) {  // coefficient columns <- cache (a reset aircraft sits at alpha = beta = 0)
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) {
@@ -247,11 +284,30 @@ void f16_env_kernel(const KArgs a) {
 #pragma unroll
             for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * TILE] = a.reset_coef[k];
         }
+        if constexpr (TRIG_CACHED) {
+            float tv[NUM_CACHED_TRIG > 0 ? NUM_CACHED_TRIG : 1];
+#pragma unroll
+            for (int k = 0; k < NUM_CACHED_TRIG; k++) tv[k] = cache_blk[(NUM_CACHED + k) * CACHE_TILE];
+            if (flagged && !INNER) {  // a re-initialised aircraft: every angle is 0 (F16_model.py:33-45); its altitude was just drawn
+                tv[0] = tv[2] = tv[4] = tv[6] = tv[8] = 0.0f;
+                tv[1] = tv[3] = tv[5] = tv[7] = 1.0f;
+                tv[9] = np_pow(1.0f - 0.703e-5f * s[2], 4.14f);
+            }
+            sc_old.tr.sa = tv[0]; sc_old.tr.ca = tv[1]; sc_old.tr.sb = tv[2]; sc_old.tr.cb = tv[3];
+            sc_old.tr.st = tv[4]; sc_old.tr.ct = tv[5]; sc_old.tr.sphi = tv[6]; sc_old.tr.cphi = tv[7];
+            sc_old.tt = tv[8];
+            sc_old.powv = tv[9];
+        }
     }
     if (!STEP && a.term_reasons && valid && part == 0) a.term_reasons[i] = 0;  // reset(): every flag cleared, no condition evaluated
     if (!STEP && a.cache && flagged && valid && !INNER && part == 0) {  // reset(): keep the cache consistent for re-initialised rows
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) cache_blk[k * CACHE_TILE] = a.reset_coef[k];
+        if constexpr (NUM_CACHED_TRIG > 0) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) cache_blk[(NUM_CACHED + k) * CACHE_TILE] = (k & 1) && k < 8 ? 1.0f : 0.0f;   // sin 0, cos 0 x 4, tan 0
+            cache_blk[(NUM_CACHED + 9) * CACHE_TILE] = np_pow(1.0f - 0.703e-5f * s[2], 4.14f);
+        }
     }
 
     if (STEP) {
@@ -274,6 +330,10 @@ void f16_env_kernel(const KArgs a) {
             if constexpr (SHARED) {
                 StateScalars sc0;
                 nlplant<true, (CACHED ? AB_REST : AB_ALL), TILE, WPT, true, 0>(a.wt, s, u, sc0, coef, tables, k1, pw);
+                NP_LT(2);
+            } else if constexpr (TRIG_CACHED) {  // the state's trigonometry comes from the cache; only the heading's is evaluated here
+                np_sincos(s[5], sc_old.spsi, sc_old.cpsi);
+                nlplant<true, AB_REST, TILE, WPT, false, 0, true>(a.wt, s, u, sc_old, coef, tables, k1, pw);
                 NP_LT(2);
             } else {
                 xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
@@ -336,9 +396,9 @@ void f16_env_kernel(const KArgs a) {
     float o[22];
     StateScalars sc1;  // SHARED: filled by the Overload evaluation below
     const bool gen_noise = !ap->noise && ap->cfg.noise_scale != 0.0f;
+    float tt_new = 0.0f, pow_new = 0.0f;   // tan(theta) and the atmosphere power of the state this step reaches (cache rows)
     if constexpr (!SHARED) {
-        float tt_unused;
-        trig_of(s, tr, tt_unused);
+        trig_of(s, tr, tt_new);
         if (STEP) {
             // The Overload phase below is an asm statement that owns v70-v157.  Left alone, the compiler SINKS whatever the code before
             // that statement does not need past it — the moment equations of the integrator evaluation (the new P, Q, R are first read
@@ -354,33 +414,6 @@ void f16_env_kernel(const KArgs a) {
             }
             if ((NPF16_PIN_MASK & 2) && (WPT == 2 || (NPF16_PIN_MASK & 4)))
                 asm volatile("" : "+v"(tr.sa), "+v"(tr.ca), "+v"(tr.sb), "+v"(tr.cb), "+v"(tr.st), "+v"(tr.ct), "+v"(tr.sphi), "+v"(tr.cphi));
-        }
-    } else if (gen_noise) {
-        // this wave's Philox block of the row -> its two or three Box-Muller pairs -> LDS (published by the barrier that opens the
-        // Overload evaluation; wave 0 adds them to the observation afterwards: same values, same fma as add_rng_noise)
-        const uint64_t call_idx2 = ap->call_idx + (ap->call_idx_base ? *ap->call_idx_base : 0ull);
-#pragma unroll
-        for (int q = 0; q < (WPT == WPT_LAT2 ? 2 : 1); q++) {  // two waves per tile: blocks {0, 3} and {1, 2} (5 and 6 pairs)
-        // eight waves: 0..3 are computing the state's trigonometry meanwhile
-        const int nb = WPT == 8 ? part - 4 : WPT == WPT_LAT2 ? (q == 0 ? part : 3 - part) : part;
-        if (nb >= 0) {
-        uint32_t blk[4], k1[3], k2[3];
-        rng_block(ap->seed, call_idx2, ap->row0 + ic, 2u + (uint32_t)nb, blk);
-        noise_block_indices(blk, k1, k2);
-        float *nz = coef + NOISE_COL0 * TILE;
-        const float scale = ap->cfg.noise_scale;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            if (j < 2 || nb < 3) {
-                const int pair = j < 2 ? 2 * nb + j : 8 + nb;  // wave-uniform
-                float rs, cs, sn;
-                noise_pair(k1[j], k2[j], scale, rs, cs, sn);
-                nz[(3 * pair) * TILE] = rs;
-                nz[(3 * pair + 1) * TILE] = cs;
-                nz[(3 * pair + 2) * TILE] = sn;
-            }
-        }
-        }
         }
     }
 
@@ -400,9 +433,15 @@ void f16_env_kernel(const KArgs a) {
                 nlplant<false, AB_FORCE, TILE, WPT, true, 1>(wt2, s, u, sc1, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
                 NP_LT(4);
                 tr = sc1.tr;
+                tt_new = sc1.tt;
+                pow_new = sc1.powv;
             } else {
                 NP_LT(3);
-                nlplant<false, AB_FORCE, TILE, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                StateScalars scn;
+                scn.tr = tr;
+                scn.tt = scn.spsi = scn.cpsi = 0.0f;
+                nlplant<false, AB_FORCE, TILE, WPT, false, 0>(wt2, s, u, scn, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                pow_new = scn.powv;
                 NP_LT(4);
             }
         }
@@ -473,9 +512,14 @@ void f16_env_kernel(const KArgs a) {
         at_off(ap->fout2, iw) = tmo_prev ? 1 : 0;
         if (STEP) at_off(ap->reward, w4) = reward;
         if (STEP && ap->cache) {
-            float *cache_w = ap->cache + ((long long)(iw >> 6) * NUM_CACHED) * CACHE_TILE + (iw & (CACHE_TILE - 1));
+            float *cache_w = ap->cache + ((long long)(iw >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (iw & (CACHE_TILE - 1));
 #pragma unroll
             for (int k = 0; k < NUM_CACHED; k++) cache_w[k * CACHE_TILE] = coef[cached_slot(k) * TILE];
+            if constexpr (NUM_CACHED_TRIG > 0) {
+                const float tv[10] = {tr.sa, tr.ca, tr.sb, tr.cb, tr.st, tr.ct, tr.sphi, tr.cphi, tt_new, pow_new};
+#pragma unroll
+                for (int k = 0; k < NUM_CACHED_TRIG; k++) cache_w[(NUM_CACHED + k) * CACHE_TILE] = tv[k];
+            }
         }
     }
 
@@ -1066,6 +1110,12 @@ constexpr int64_t COMBAT_LAT_MAX_N = 40000;  // aircraft; against the pair varia
 #ifndef NPF16_LAT_MAX_N
 #define NPF16_LAT_MAX_N 98304
 #endif
+// between the two: the four-wave variant built for FOUR waves per SIMD (128 VGPRs: it needs 132, a handful of dwords in scratch) holds
+// 1 024 tiles in one generation: 65 536 aircraft in 34.6 us against 38.1 with two waves per tile (profiles/r03d_mid_n_lat4w.json)
+#ifndef NPF16_LAT4W_MAX_N
+#define NPF16_LAT4W_MAX_N 65536
+#endif
+constexpr int64_t LAT4W_MAX_N = NPF16_LAT4W_MAX_N;
 constexpr int64_t LAT4_MAX_N = NPF16_LAT4_MAX_N;
 constexpr int64_t LAT_MAX_N = NPF16_LAT_MAX_N;
 bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
@@ -1075,7 +1125,7 @@ bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
         return std::strcmp(e, "latency") == 0 ? (int)NP_KERNEL_LATENCY : std::strcmp(e, "throughput") == 0 ? (int)NP_KERNEL_THROUGHPUT : (int)NP_KERNEL_AUTO;
     }();
     const int v = ctx->variant != NP_KERNEL_AUTO ? ctx->variant : forced;
-    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY || v == NP_KERNEL_LATENCY8 || v == NP_KERNEL_LATENCY2;
+    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY || v == NP_KERNEL_LATENCY8 || v == NP_KERNEL_LATENCY2 || v == NP_KERNEL_LATENCY4W;
     return n <= LAT_MAX_N;
 }
 // pair variant (two waves split the nets and evaluate them for each other's aircraft): Euler, MLP numerics (no 1-D tables)
@@ -1151,7 +1201,10 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
                           (ctx->variant == NP_KERNEL_LATENCY8 || (ctx->variant == NP_KERNEL_AUTO && n <= LAT8_MAX_N));
     // two waves per tile: above the four-wave variant's single generation (both numerics; Euler)
     const bool latency2 = latency && !latency8 &&
-                          (ctx->variant == NP_KERNEL_LATENCY2 || (ctx->variant == NP_KERNEL_AUTO && n > LAT4_MAX_N));
+                          (ctx->variant == NP_KERNEL_LATENCY2 || (ctx->variant == NP_KERNEL_AUTO && n > LAT4W_MAX_N));
+    // four waves per tile at four waves per SIMD: one generation of 1 024 tiles (MLP numerics; the table mode's kernels are not built for it)
+    const bool latency4w = latency && !latency8 && !latency2 && !ctx->cfg.aero_1d_tables &&
+                           (ctx->variant == NP_KERNEL_LATENCY4W || (ctx->variant == NP_KERNEL_AUTO && n > LAT4_MAX_N));
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)),
         block(latency8 ? LAT_TILE * 8 : latency2 ? LAT_TILE * 2 : latency ? LAT_TILE * 4 : BLOCK);
     hipStream_t st = (hipStream_t)stream;
@@ -1185,6 +1238,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         } else if (latency2 && S == 0) {                                                                              \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, WPT_LAT2, I>);    \
             else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, WPT_LAT2, I>);          \
+        } else if (latency4w && S == 0 && !I) {                                                                       \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4, false, 4>);    \
+            else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4, false, 4>);          \
         } else if (latency && S == 0) {                                                                               \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, STEP, LAT_TILE, 4, I>);    \
             else NP_DISPATCH(a, f16_env_kernel<T, 0, STEP, false, LAT_TILE, 4, I>);          \
@@ -1328,7 +1384,7 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
 extern "C" {
 
 int np_abi_version(void) { return NP_ABI_VERSION; }
-int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHED; }
+int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHE_ROWS; }
 const char *np_last_error(void) { return g_err.c_str(); }
 
 static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables, int device, np_f16_ctx **out) {
@@ -1561,7 +1617,7 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
     if (!ctx) return fail("null ctx");
     if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR &&
-        variant != NP_KERNEL_LATENCY8 && variant != NP_KERNEL_LATENCY2)
+        variant != NP_KERNEL_LATENCY8 && variant != NP_KERNEL_LATENCY2 && variant != NP_KERNEL_LATENCY4W)
         return fail("unknown kernel variant");
     ctx->variant = variant;
     return 0;

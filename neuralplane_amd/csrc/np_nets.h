@@ -84,6 +84,17 @@ enum ClassId : int { CL_DAMP, CL_DLEF, CL_D_RUD, CL_D_LEF, CL_E_LEF, CL_E_RUD, C
 constexpr int NUM_AB_CLASSES = 9;  // CL_DAMP .. CL_YA20
 constexpr int NUM_AB_NETS = 36;    // output slots 0..35
 constexpr int NUM_CACHED = 14;     // force-side alpha/beta-only nets: the first n_force of every AB class
+// Experiment switch, OFF in every shipped build (round 3, profiles/r03d_trig_cache_ab.log): with NPF16_TRIG_CACHE=1 the cross-step
+// cache also carries the trigonometry of the state a step reaches — sin / cos of alpha, beta, theta, phi, tan(theta) and
+// (1 - 0.703e-5 alt)^4.14 — which the NEXT step's integrator evaluation otherwise recomputes from the unchanged state (four fp64
+// sine / cosine sequences and one pow).  It removes 269 of 8 747 VALU instructions per wave (-3.1 %) for 80 B more traffic per
+// aircraft-step — and is SLOWER: +0.6 % at N = 1e6, +1.2 % at 1e7, +9..+47 % on one-generation grids (98 304 - 262 144), where the ten
+// extra loads in front of the first instruction and the longer store burst are not hidden.  Bit-identical either way (351 GPU tests).
+#ifndef NPF16_TRIG_CACHE
+#define NPF16_TRIG_CACHE 0
+#endif
+constexpr int NUM_CACHED_TRIG = NPF16_TRIG_CACHE ? 10 : 0;   // sa, ca, sb, cb, st, ct, sphi, cphi, tan(theta), pow
+constexpr int NUM_CACHE_ROWS = NUM_CACHED + NUM_CACHED_TRIG;
 
 constexpr NetClass CLASSES[NUM_CLASSES] = {
     /* CL_DAMP  */ {1, 20, 10, 0, {G_A_DAMP, G_NONE, G_NONE}, 12, 4,

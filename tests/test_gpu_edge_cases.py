@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle.f16_oracle import Oracle  # noqa: E402  (the checker; test infrastructure)
 
-VARIANTS = ['latency', 'latency8', 'latency2', 'throughput', 'pair']
+VARIANTS = ['latency', 'latency4w', 'latency8', 'latency2', 'throughput', 'pair']
 
 
 def _same(a, b):

@@ -24,7 +24,7 @@ def _batch(task, n, solver=None, seed=0, row0=0, tables=False, variant='auto'):
     return b
 
 
-VARIANTS = ['latency', 'latency8', 'latency2', 'throughput', 'pair']   # 'pair' and 'latency8' fall back to the throughput kernel in the 1-D table mode
+VARIANTS = ['latency', 'latency4w', 'latency8', 'latency2', 'throughput', 'pair']   # 'pair' and 'latency8' fall back to the throughput kernel in the 1-D table mode
 
 
 def _load_state(b, st):
