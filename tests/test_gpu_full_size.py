@@ -56,6 +56,34 @@ def test_sampled_blocks_match_oracle_bit_for_bit_at_full_size(task):
     assert n_flag > 0, 'the sample never exercised a termination / auto-reset'
 
 
+@pytest.mark.parametrize('n', [20_000, 57_344, 81_921, 120_000, 262_144])
+def test_automatic_variant_at_the_mid_sizes_matches_oracle(n):
+    """The variant np_f16_step picks on its own at each of the batch-size ranges the reference trains in and above — latency
+    (four waves per tile), latency4w (the same at four waves per SIMD), latency2, the pair variant capped at two waves per SIMD and
+    at three — against the oracle on sampled blocks, 20 fused steps with auto-resets (hazard-rich actions), ragged last tile."""
+    steps, seed = 20, 11
+    env = _env('heading', n, seed)
+    acts = _actions(steps, n, 5)
+    env.reset()
+    outs = [env.step(a) for a in acts]
+    torch.cuda.synchronize()
+    o = Oracle('heading', threads=8)
+    n_flag = 0
+    for r0 in (0, n - 150, n // 3):
+        m = 150
+        st = Oracle.new_state(m)
+        o.reset(st, seed=seed, call_idx=0, row0=r0)
+        for t in range(steps):
+            o_obs, o_rew, o_done, o_bad, _ = o.step(st, acts[t][r0:r0 + m].cpu().numpy(), seed=seed, call_idx=t + 1, row0=r0)
+            obs, rew, done, bad, tmo, _ = outs[t]
+            assert np.array_equal(obs[r0:r0 + m].cpu().numpy(), o_obs), f'n={n}: obs, rows {r0}.., step {t}'
+            assert np.array_equal(rew[r0:r0 + m].cpu().numpy(), o_rew, equal_nan=True)
+            assert np.array_equal(bad[r0:r0 + m].cpu().numpy(), o_bad.astype(bool)) and np.array_equal(done[r0:r0 + m].cpu().numpy(), o_done.astype(bool))
+            n_flag += int(o_bad.sum() + o_done.sum())
+        assert np.array_equal(env.model.s[r0:r0 + m].cpu().numpy(), st['s'], equal_nan=True), f'n={n}: final state rows {r0}..'
+    assert n_flag > 0
+
+
 def test_sharded_batches_reproduce_the_unsharded_batch():
     """Two shards with row0 offsets == the full batch (what every rank of a multi-GPU run relies on)."""
     n, steps, seed = 300_001, 12, 5          # odd size: ragged last workgroup in both shards
