@@ -88,6 +88,93 @@ __device__ __forceinline__ void net_mfma(const float *rec, int l4, float x, floa
         for (int r = 0; r < 4; r++) h2[4 * g + r] = relu1(acc[g][r]);
 }
 
+// three nets at once: nine independent layer-2 chains (3 nets x 3 neuron groups) issued round-robin
+__device__ __forceinline__ void net_mfma3(const float *rec, int l4, float x, float (&h2)[3][12]) {
+    f32x4 h1[3][G1];
+#pragma unroll
+    for (int g = 0; g < G1; g++) {
+        f32x4 w[3], acc[3];
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            w[n] = *reinterpret_cast<const f32x4 *>(rec + n * REC + (g * 4 + l4) * L1_PITCH);
+            acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int n = 0; n < 3; n++) acc[n] = mfma4(w[n][0], 1.0f, acc[n]);
+#pragma unroll
+        for (int n = 0; n < 3; n++) acc[n] = mfma4(w[n][1], x, acc[n]);
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[n][r] = relu1(acc[n][r]);
+            h1[n][g] = acc[n];
+        }
+    }
+    f32x4 acc[3][G2], w[3][G2];
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int g = 0; g < G2; g++) {
+            acc[n][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            w[n][g] = *reinterpret_cast<const f32x4 *>(rec + n * REC + G1 * 4 * L1_PITCH + (g * 4 + l4) * L2_PITCH);
+        }
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int g = 0; g < G2; g++) acc[n][g] = mfma4(w[n][g][0], 1.0f, acc[n][g]);
+#pragma unroll
+    for (int v = 0; v < 6; v++) {
+        if (v > 0) {
+#pragma unroll
+            for (int n = 0; n < 3; n++)
+#pragma unroll
+                for (int g = 0; g < G2; g++) w[n][g] = *reinterpret_cast<const f32x4 *>(rec + n * REC + G1 * 4 * L1_PITCH + (g * 4 + l4) * L2_PITCH + 4 * v);
+        }
+#pragma unroll
+        for (int j = (v == 0 ? 1 : 0); j < 4; j++) {
+            const int k = 4 * v + j - 1;
+            if (k < H1) {
+#pragma unroll
+                for (int n = 0; n < 3; n++)
+#pragma unroll
+                    for (int g = 0; g < G2; g++) acc[n][g] = mfma4(w[n][g][j], h1[n][k / 4][k % 4], acc[n][g]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int g = 0; g < G2; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) h2[n][4 * g + r] = relu1(acc[n][g][r]);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bench3_kernel(const float *__restrict__ recs, const float *__restrict__ xin, float *__restrict__ out,
+                                                            long long *__restrict__ cycles, int reps) {
+    __shared__ __attribute__((aligned(16))) float lds[NETS * REC];
+    for (int i = threadIdx.x; i < NETS * REC; i += blockDim.x) lds[i] = recs[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l4 = lane & 3;
+    const float x = xin[(long long)blockIdx.x * blockDim.x + threadIdx.x];
+    float sum = 0.0f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int rep = 0; rep < reps; rep++) {
+#pragma unroll 1
+        for (int n = 0; n < NETS; n += 3) {
+            float h2[3][12];
+            net_mfma3(lds + n * REC, l4, x + (float)rep * 1e-3f, h2);
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int j = 0; j < H2; j++) sum += h2[q][j];
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bench_kernel(const float *__restrict__ recs, const float *__restrict__ xin, float *__restrict__ out,
                                                            long long *__restrict__ cycles, int reps) {
@@ -190,6 +277,20 @@ int main() {
         for (auto c : cyc) mean += (double)c;
         mean /= grid;
         printf("%d wave(s) per CU: %.0f cycles per 1-20-10 net (two hidden layers, 73 MFMAs + 30 clamps) per wave\n", waves, mean / (reps * NETS));
+    }
+    for (int cfg = 0; cfg < 2; cfg++) {
+        const int waves = cfg == 0 ? 1 : 4, grid = 256;
+        for (int it = 0; it < 3; it++) {
+            if (waves == 1) hipLaunchKernelGGL(bench3_kernel<1>, dim3(grid), dim3(64), 0, 0, d_recs, d_x, d_out, d_cyc, reps);
+            else hipLaunchKernelGGL(bench3_kernel<4>, dim3(grid), dim3(256), 0, 0, d_recs, d_x, d_out, d_cyc, reps);
+            CHECK(hipDeviceSynchronize());
+        }
+        std::vector<long long> cyc(grid);
+        CHECK(hipMemcpy(cyc.data(), d_cyc, grid * 8, hipMemcpyDeviceToHost));
+        double mean = 0;
+        for (auto c : cyc) mean += (double)c;
+        mean /= grid;
+        printf("three nets interleaved (nine chains), %d wave(s) per CU: %.0f cycles per net per wave\n", waves, mean / (reps * NETS));
     }
     return 0;
 }
