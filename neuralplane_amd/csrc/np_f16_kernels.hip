@@ -129,12 +129,10 @@ struct KArgs {
 // INNER     : one low-level iteration of PlanningEnv.step (np_f16_io.inner_step): no auto-reset, flagged rows keep their state, flags
 //             accumulate.  A template parameter so that the plain env.step carries none of its selects (~30 VALU instructions).
 template <int TASK, int SOLVER, bool STEP, bool CACHED, int TILE = BLOCK, int WPT = 1, bool INNER = false, int PW = 2>
-__global__
-#ifdef NPF16_OLD_BOUNDS
-__launch_bounds__(TILE * lat_waves(WPT), (WPT == 2 ? PW : NPF16_MINWAVES))
-#else
-__launch_bounds__(TILE * lat_waves(WPT)) __attribute__((amdgpu_waves_per_eu((WPT == 2 ? PW : (WPT == 4 && PW == 4) ? 4 : NPF16_MINWAVES), (WPT == 2 && PW == 2 ? 2 : 8))))
-#endif
+// waves per SIMD the register allocator builds for: pair variant PW (PW = 2 is also an occupancy CAP — 159 VGPRs would fit three — for the
+// grid sizes where six workgroups per CU are placed unevenly), latency4w four, everything else NPF16_MINWAVES
+__global__ __launch_bounds__(TILE * lat_waves(WPT))
+__attribute__((amdgpu_waves_per_eu((WPT == 2 ? PW : (WPT == 4 && PW == 4) ? 4 : NPF16_MINWAVES), (WPT == 2 && PW == 2 ? 2 : 8))))
 void f16_env_kernel(const KArgs a) {
     // latency variant with shared scalar work (Euler step): wave w computes a quarter of the tile's serial fp64 chains and of its
     // observation noise for ALL four waves (np_f16_device.h::nlplant<.., SHARE>), wave 0 finishes the observation, wave 1 the
