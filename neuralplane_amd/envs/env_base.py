@@ -114,7 +114,9 @@ class BaseEnv(Env):
     def reward_terms(self):
         """(task term, event term) of the LAST step's reward, float32[n] each: the task's reward function (HeadingReward /
         PostureReward / PositionReward) and EventDrivenReward's -200 * bad_done + 200 * done; their fp32 sum is the reward step()
-        returned.  The first call switches the tracking on (one more float stored per aircraft and step, from the next step on)."""
+        returned.  The first call switches the tracking on (one more float stored per aircraft and step, from the next step on).
+        PlanningEnv: both terms are those of the LAST of the 50 inner iterations — the one whose reward step() returns — with the
+        event term on the flags accumulated over all 50 (planning_env.py:153-176)."""
         r = self._batch.reward_task
         if r is None:
             r = self._batch.track_reward_terms(True)
