@@ -418,6 +418,7 @@ def run_env(args, rank, local_rank, world, dev, dist):
                                      'envs, scripts/train_heading.sh)'}
     del envs, tm6
     modes['singlecombat_1v1'] = combat_mode(dev, 100_000, min(args.steps, 100), 5, ps)
+    modes['planning_tracking_n8192'] = planning_mode(dev, g, 8_192, 20)
     modes['planning_tracking_n1e4'] = planning_mode(dev, g, 10_000, 20)
     modes['planning_tracking_n262144'] = planning_mode(dev, g, 262_144, 4)
     return out
@@ -491,9 +492,11 @@ def planning_mode(dev, g, npl, k7):
                         'note': '50 x (302 KFLOP controller forward + 33.8 KFLOP FDM step) = 16.8 MFLOP per aircraft and PlanningEnv.step; wall clock '
                                 'of back-to-back macro-steps, i.e. launch gaps included'},
            'note': 'controller = np_actor_forward (K=1 fp32 MFMA chains, bit-exact to its oracle: tests/test_gpu_actor.py); the inner step writes '
-                   'the next low-level observation itself (np_f16_io.ll_obs): 102 launches per macro-step (round 2: 151).  At n = 1e4 the step is bound by '
-                   'the controller\'s latency: 157 tiles of 64 aircraft on 256 CUs, one wave per SIMD, 1 180 dependent K = 1 MFMA steps of 64 cycles per '
-                   'call = 31.5 us of matrix pipe per call even at 100 % issue (measured ~60 us per call)'}
+                   'the next low-level observation itself (np_f16_io.ll_obs): 102 launches per macro-step (round 2: 151).  Up to 16 384 aircraft the '
+                   'controller runs on 32-row tiles (v_mfma_f32_16x16x1_4b_f32: 1 174 dependent K = 1 steps of 32 cycles = 15.7 us of matrix pipe '
+                   'per tile, ~32 us per call with the LayerNorm / gate epilogues); from 8 193 aircraft on some CUs carry two tiles (313 tiles on '
+                   '256 CUs at n = 1e4) and the call takes ~55 us: the f32 MFMA and the vector ALU share one pipe, so two tiles cost '
+                   '2 x (15.7 + ~6) us of it.  Above 16 384: 64-row tiles (v_mfma_f32_32x32x1_2b_f32), throughput-bound'}
     del penv, ctrl
     torch.cuda.empty_cache()
     return out

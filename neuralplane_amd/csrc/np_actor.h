@@ -21,8 +21,12 @@
 #include <cstdint>
 #include "np_actor_asm.inc"
 #include "np_actor_mfma_asm.inc"
+#include "np_actor_mfma16_asm.inc"
 #ifndef NPACT_MFMA
 #define NPACT_MFMA 1  // 1: matrix-core kernel (4 waves per tile); 0: the vector-FMA kernel with the scalar weight stream (8 waves per tile)
+#endif
+#ifndef NPACT_TILE32_MAX_N
+#define NPACT_TILE32_MAX_N 16384  // up to here the 32-row tile kernel (actor_forward_mfma32_kernel), above it the 64-row one
 #endif
 #ifndef NPACT_EXP
 #define NPACT_EXP 0  // timing-only experiment switches (tools/microbench/README.md); 0 in every shipped build
@@ -488,5 +492,261 @@ __global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma_kernel(const f
 }
 
 constexpr size_t ACTOR_LDS_BYTES = sizeof(float) * (2 * HID * TILE + 2 * WAVES * TILE);
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Small-batch variant (round 3): tiles of 32 rows.  At n <= 16 K the 64-row kernel occupies n / 64 of the 256 CUs with one wave
+// per SIMD, every wave a serial chain of 1 174 sixteen-pass MFMAs (31 us) with the LayerNorm / gate epilogues exposed in between
+// (59 us per call, 50 calls per PlanningEnv.step).  Here a wave computes 32 features x 32 rows per v_mfma_f32_16x16x1_4b_f32
+// (eight passes; again ONE IEEE fma per element and instruction, tools/microbench/mfma16_exact.hip), so a tile's chain is half as
+// long, twice as many CUs carry tiles, and where two tiles share a CU one's epilogues hide behind the other's MFMAs.
+//   A operand = weights  (lane l -> feature 32w + 16 (l / 32) + l % 16),
+//   B operand = inputs   (lane l -> row l % 32; one ds_read from the LDS matrix [feature][32 rows]),
+//   D (16 VGPRs): register r, lane l -> feature 32w + 16 (r / 8) + 4 (l / 16) + r % 4, row 16 ((r / 4) % 2) + l % 16.
+// Row-per-lane phases (LayerNorm, state load / store): thread t -> row t % 32, the block of 16 features t / 32 — the blocks the
+// numerics spec sums in, so every result is bit-identical to the 64-row kernels.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int T32 = 32, BLK = 16;
+
+#ifndef NPACT_TRACE
+#define NPACT_TRACE 0  // 1: workgroup 0 / wave 0 stamps the shader clock after every phase (tools/microbench/actor_phases.py); never shipped
+#endif
+#if NPACT_TRACE
+__device__ long long npact_trace[64];
+#define NPACT_STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) npact_trace[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NPACT_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ int m16_feat(int r, int g4) { return 16 * (r >> 3) + 4 * g4 + (r & 3); }
+__device__ __forceinline__ int m16_row(int r, int l16) { return 16 * ((r >> 2) & 1) + l16; }
+
+template <int LD_W>
+__device__ __forceinline__ void prefetch_w16(const float *__restrict__ wt, const float *__restrict__ bias, int fl, float (&pa)[33]) {
+#pragma unroll
+    for (int u = 0; u < 32; u++) pa[u] = wt[u * LD_W + fl];
+    pa[32] = bias[fl];
+}
+
+template <int LD_W, int LD_NEXT>
+__device__ __forceinline__ void dense_mfma16(const float *__restrict__ wt, const float *__restrict__ wnext, const float *__restrict__ bnext,
+                                             const float *__restrict__ xin, int fl, float (&pa)[33], f32x16 &acc) {
+    const unsigned xaddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)xin;
+    actor_dense_mfma16_asm<LD_W, LD_NEXT>(wt, wnext, bnext, 4u * (unsigned)fl, xaddr, pa, acc);
+}
+
+template <bool RELU>
+__device__ __forceinline__ void store_transposed16(const f32x16 &acc, float *__restrict__ out, int f0, int l16, int g4) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float x = acc[r];
+        if (RELU) x = x > 0.0f ? x : 0.0f;
+        out[(f0 + m16_feat(r, g4)) * T32 + m16_row(r, l16)] = x;
+    }
+}
+
+// in-place LayerNorm of the LDS matrix `buf` [feature][32 rows]: thread -> (row, block of 16 features).  gb = {gains, shifts} of this
+// thread's block (per-lane loads: the block differs between the two halves of a wave).  v returns the values before the normalisation
+// (the caller stores the new recurrent state from them).  Ends with a barrier.
+__device__ __forceinline__ void layernorm_rows16(float *__restrict__ buf, const float *__restrict__ g, const float *__restrict__ b, int blk,
+                                                 int row, float *__restrict__ part_s, float *__restrict__ part_q, float (&v)[BLK]) {
+    const int f0 = blk * BLK;
+    float gg[BLK], bb[BLK];
+    {
+        const float4 *gp = reinterpret_cast<const float4 *>(g + f0), *bp = reinterpret_cast<const float4 *>(b + f0);
+#pragma unroll
+        for (int j = 0; j < BLK / 4; j++) {
+            const float4 x = gp[j], y = bp[j];
+            gg[4 * j] = x.x, gg[4 * j + 1] = x.y, gg[4 * j + 2] = x.z, gg[4 * j + 3] = x.w;
+            bb[4 * j] = y.x, bb[4 * j + 1] = y.y, bb[4 * j + 2] = y.z, bb[4 * j + 3] = y.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; j++) v[j] = buf[(f0 + j) * T32 + row];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < BLK; j++) s = s + v[j];
+    part_s[blk * T32 + row] = s;
+    __syncthreads();
+    float total = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) total = total + part_s[w * T32 + row];
+    const float mean = total / (float)HID;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+        const float d = v[j] - mean;
+        q = fmaf(d, d, q);
+    }
+    part_q[blk * T32 + row] = q;
+    __syncthreads();
+    float qt = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) qt = qt + part_q[w * T32 + row];
+    const float rstd = 1.0f / sqrtf(qt / (float)HID + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < BLK; j++) buf[(f0 + j) * T32 + row] = fmaf((v[j] - mean) * rstd, gg[j], bb[j]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma32_kernel(const float *__restrict__ weights, long long n,
+                                                                           const float *__restrict__ obs, const float *__restrict__ h_in,
+                                                                           const float *__restrict__ mask, float *__restrict__ act,
+                                                                           float *__restrict__ h_out) {
+    __shared__ float lds[2 * HID * T32 + 2 * 8 * T32 + 4 * HID];
+    float *bufA = lds, *bufB = lds + HID * T32;
+    float *part_s = lds + 2 * HID * T32, *part_q = part_s + 8 * T32;
+    float *head_w = part_q + 8 * T32;                      // mu_net weights [k][4], staged at entry: the head reads them 128 times in a row
+    const cw_ptr W = (cw_ptr)(unsigned long long)weights;  // wave-uniform reads: scalar loads
+    const float *Wv = weights;                             // per-lane reads
+    const int lane = (int)(threadIdx.x % TILE), row = lane & 31, l16 = lane & 15, g4 = lane >> 4, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));
+    const int f0 = wave * MSLICE;        // MFMA role: features [f0, f0 + 32); this lane's A operand is feature f0 + fl
+    const int fl = 16 * hi + l16;
+    const int blk = 2 * wave + hi;       // row role: features [16 blk, 16 blk + 16) of row `row`
+    const long long i = (long long)blockIdx.x * T32 + row;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;
+    NPACT_STAMP(0);
+
+    // requested first, consumed after the observation LayerNorm: the first layer's A operands (22 weights + the bias) and the
+    // masked recurrent state (gru.py:26: this thread's 16 features of its row, 64 B)
+    float a1[OBS];
+#pragma unroll
+    for (int k = 0; k < OBS; k++) a1[k] = Wv[L1_W + k * HID + f0 + fl];
+    const float b1 = Wv[L1_B + f0 + fl];
+    const float mk = mask[ic];
+    float hm[BLK];
+    {
+        const float4 *hp = reinterpret_cast<const float4 *>(h_in + ic * HID + blk * BLK);
+#pragma unroll
+        for (int j = 0; j < BLK / 4; j++) {
+            const float4 q = hp[j];
+            hm[4 * j] = q.x * mk;
+            hm[4 * j + 1] = q.y * mk;
+            hm[4 * j + 2] = q.z * mk;
+            hm[4 * j + 3] = q.w * mk;
+        }
+    }
+
+    if (threadIdx.x < HID) reinterpret_cast<float4 *>(head_w)[threadIdx.x] = reinterpret_cast<const float4 *>(Wv + HD_W)[threadIdx.x];
+    // base.feature_norm (two blocks: 16 + 6) -> bufB rows 0..21; every thread computes its row's, block 0 stores it
+    {
+        float xr[OBS];
+#pragma unroll
+        for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s0 = s0 + xr[j];
+#pragma unroll
+        for (int j = 16; j < OBS; j++) s1 = s1 + xr[j];
+        const float mean = ((0.0f + s0) + s1) / (float)OBS;
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float d = xr[j] - mean;
+            q0 = fmaf(d, d, q0);
+        }
+#pragma unroll
+        for (int j = 16; j < OBS; j++) {
+            const float d = xr[j] - mean;
+            q1 = fmaf(d, d, q1);
+        }
+        const float rstd = 1.0f / sqrtf(((0.0f + q0) + q1) / (float)OBS + 1e-5f);
+        if (blk == 0) {
+#pragma unroll
+            for (int j = 0; j < OBS; j++) bufB[j * T32 + row] = fmaf((xr[j] - mean) * rstd, W[LN0_G + j], W[LN0_B + j]);
+        }
+    }
+    float pa[33];
+    prefetch_w16<HID>(Wv + L2_W + f0, Wv + L2_B + f0, fl, pa);
+    __syncthreads();
+    NPACT_STAMP(1);
+
+    f32x16 acc;
+    float lv[BLK];  // LayerNorm inputs of this thread (only rnn.norm's are used afterwards)
+    // base.mlp: Linear(22, 128) + ReLU + LayerNorm -> bufA
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(b1, 1.0f, acc, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < OBS; k++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a1[k], bufB[k * T32 + row], acc, 0, 0, 0);
+    store_transposed16<true>(acc, bufA, f0, l16, g4);
+    __syncthreads();
+    NPACT_STAMP(2);
+    layernorm_rows16(bufA, Wv + LN1_G, Wv + LN1_B, blk, row, part_s, part_q, lv);
+    NPACT_STAMP(3);
+    // Linear(128, 128) + ReLU + LayerNorm -> bufB
+    dense_mfma16<HID, 3 * HID>(Wv + L2_W + f0, Wv + GI_W + f0, Wv + GI_B + f0, bufA + row, fl, pa, acc);
+    NPACT_STAMP(4);
+    store_transposed16<true>(acc, bufB, f0, l16, g4);
+    __syncthreads();  // also: every wave is done reading bufA
+    layernorm_rows16(bufB, Wv + LN2_G, Wv + LN2_B, blk, row, part_s, part_q, lv);
+    NPACT_STAMP(5);
+
+    // rnn: GRU cell (gate order r, z, n as in torch) on x = bufB, h = bufA
+#pragma unroll
+    for (int j = 0; j < BLK; j++) bufA[(blk * BLK + j) * T32 + row] = hm[j];
+    __syncthreads();
+    {
+        f32x16 gi, gh, rr, z;
+        dense_mfma16<3 * HID, 3 * HID>(Wv + GI_W + f0, Wv + GH_W + f0, Wv + GH_B + f0, bufB + row, fl, pa, gi);
+        NPACT_STAMP(6);
+        dense_mfma16<3 * HID, 3 * HID>(Wv + GH_W + f0, Wv + GI_W + HID + f0, Wv + GI_B + HID + f0, bufA + row, fl, pa, gh);
+NPACT_STAMP(7);
+#pragma unroll
+        for (int e = 0; e < 16; e++) rr[e] = act_sigmoid(gi[e] + gh[e]);
+        NPACT_STAMP(8);
+        dense_mfma16<3 * HID, 3 * HID>(Wv + GI_W + HID + f0, Wv + GH_W + HID + f0, Wv + GH_B + HID + f0, bufB + row, fl, pa, gi);
+        dense_mfma16<3 * HID, 3 * HID>(Wv + GH_W + HID + f0, Wv + GI_W + 2 * HID + f0, Wv + GI_B + 2 * HID + f0, bufA + row, fl, pa, gh);
+NPACT_STAMP(9);
+#pragma unroll
+        for (int e = 0; e < 16; e++) z[e] = act_sigmoid(gi[e] + gh[e]);
+        NPACT_STAMP(10);
+        dense_mfma16<3 * HID, 3 * HID>(Wv + GI_W + 2 * HID + f0, Wv + GH_W + 2 * HID + f0, Wv + GH_B + 2 * HID + f0, bufB + row, fl, pa, gi);
+        dense_mfma16<3 * HID, HID>(Wv + GH_W + 2 * HID + f0, Wv + A1_W + f0, Wv + A1_B + f0, bufA + row, fl, pa, gh);
+NPACT_STAMP(11);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const float nn = act_tanh(gi[e] + rr[e] * gh[e]);
+            const float hp = bufA[(f0 + m16_feat(e, g4)) * T32 + m16_row(e, l16)];
+            acc[e] = (hp - nn) * z[e] + nn;
+        }
+    }
+    __syncthreads();  // every wave is done reading x (bufB) and h (bufA)
+    NPACT_STAMP(12);
+    store_transposed16<false>(acc, bufB, f0, l16, g4);
+    __syncthreads();
+    // rnn.norm in place; hn = the new recurrent state (this thread's 16 features), stored at the very end: a store issued here would
+    // be the oldest entry of the vector-memory queue that the next layer's operand waits (s_waitcnt vmcnt) have to drain
+    float hn[BLK];
+    layernorm_rows16(bufB, Wv + LN3_G, Wv + LN3_B, blk, row, part_s, part_q, hn);
+    NPACT_STAMP(13);
+    // act.mlp
+    dense_mfma16<HID, HID>(Wv + A1_W + f0, Wv + A2_W + f0, Wv + A2_B + f0, bufB + row, fl, pa, acc);
+    NPACT_STAMP(14);
+    store_transposed16<true>(acc, bufA, f0, l16, g4);
+    __syncthreads();
+    layernorm_rows16(bufA, Wv + LN4_G, Wv + LN4_B, blk, row, part_s, part_q, lv);
+    NPACT_STAMP(15);
+    dense_mfma16<HID, HID>(Wv + A2_W + f0, Wv + A2_W + f0, Wv + A2_B + f0, bufA + row, fl, pa, acc);  // nothing follows
+    NPACT_STAMP(16);
+    store_transposed16<true>(acc, bufB, f0, l16, g4);
+    __syncthreads();
+    layernorm_rows16(bufB, Wv + LN5_G, Wv + LN5_B, blk, row, part_s, part_q, lv);
+    NPACT_STAMP(17);
+    // mu_net: Linear(128, 4) + tanh — wave j computes action j of the 32 rows
+    {
+        float m = W[HD_B + wave];
+#pragma unroll
+        for (int k = 0; k < HID; k++) m = fmaf(head_w[k * 4 + wave], bufB[k * T32 + row], m);
+        if (valid && hi == 0) act[i * 4 + wave] = act_tanh(m);
+    }
+    if (valid) {
+        float4 *hq = reinterpret_cast<float4 *>(h_out + i * HID + blk * BLK);
+#pragma unroll
+        for (int j = 0; j < BLK / 4; j++) hq[j] = make_float4(hn[4 * j], hn[4 * j + 1], hn[4 * j + 2], hn[4 * j + 3]);
+    }
+    NPACT_STAMP(18);
+}
 
 }  // namespace npact

@@ -52,6 +52,9 @@ namespace npf16 {
 #ifndef NPF16_STAGGER_CYCLES
 #define NPF16_STAGGER_CYCLES 20000  // ~10 us at 2 GHz per phase step; 0 disables the de-phasing
 #endif
+#ifndef NPF16_ONEGEN_DELAY
+#define NPF16_ONEGEN_DELAY 16000  // cycles; 0 disables (see f16_env_kernel)
+#endif
 #ifndef NPF16_STAGGER_MIN_GENS
 #define NPF16_STAGGER_MIN_GENS 2  // de-phase only grids of at least this many generations (experiments: 0 = every grid)
 #endif
@@ -198,6 +201,13 @@ void f16_env_kernel(const KArgs a) {
                                          : (long long)(blockIdx.x % NPF16_PAIR_GROUPS) * NPF16_PAIR_STAGGER;
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    // a grid that fills the chip exactly once with the two-wave pair variant (897..1024 workgroups, four per CU: e.g. N = 131 072)
+    // runs its co-resident workgroups in lock-step (all load, all compute, all store); every second generation of 256 starts
+    // NPF16_ONEGEN_DELAY cycles late: 64.8 -> 60.0 us at N = 131 072, nothing below 897 workgroups (profiles/r03e_onegen_phase_ab.log)
+    if (WPT == 2 && PW == 2 && STEP && NPF16_ONEGEN_DELAY > 0 && gridDim.x > 896 && gridDim.x <= 1024 && (blockIdx.x & 256)) {
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < NPF16_ONEGEN_DELAY) __builtin_amdgcn_s_sleep(32);
     }
     if (a.trace && threadIdx.x == 0) a.trace[(unsigned long long)blockIdx.x * NP_TRACE_WORDS + 1] = __builtin_readcyclecounter();
 
@@ -1561,6 +1571,17 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     DeviceGuard guard;
     NP_HIP(guard.enter(device));
 #if NPACT_MFMA
+    // small batches: 32-row tiles (twice the workgroups, half the MFMA chain per tile); NP_ACTOR_TILE=32|64 overrides (benchmarks)
+    const char *tile_str = std::getenv("NP_ACTOR_TILE");  // read per call: the tests switch it
+    const int tile_env = tile_str ? atoi(tile_str) : 0;
+    if (tile_env == 32 || (tile_env != 64 && n <= NPACT_TILE32_MAX_N)) {
+        if ((uintptr_t)weights & 15) return fail("packed actor weights must be 16-byte aligned");
+        const dim3 grid32((unsigned)((n + npact::T32 - 1) / npact::T32)), block32(npact::MTHREADS);
+        hipLaunchKernelGGL(npact::actor_forward_mfma32_kernel, grid32, block32, 0, (hipStream_t)stream, weights, (long long)n, obs, h_in,
+                           masks, actions, h_out);
+        NP_HIP(hipGetLastError());
+        return 0;
+    }
     const auto kernel = npact::actor_forward_mfma_kernel;
     const dim3 grid((unsigned)((n + npact::TILE - 1) / npact::TILE)), block(npact::MTHREADS);
 #else
@@ -1577,6 +1598,12 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     NP_HIP(hipGetLastError());
     return 0;
 }
+
+#if NPACT_TRACE
+extern "C" int np_actor_trace_read(long long *out) {  // diagnostics builds only (tools/microbench/actor_phases.py)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(npact::npact_trace), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int use_proper_time_limits,
                        const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,

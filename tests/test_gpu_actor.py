@@ -17,9 +17,12 @@ def _same(a, b):
     return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
 
 
-@pytest.mark.parametrize('n', [1, 63, 64, 65, 1000])
-def test_fused_actor_bit_exact_vs_oracle(golden_dir, n):
+@pytest.mark.parametrize('tile', ['32', '64'])
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 63, 64, 65, 1000])
+def test_fused_actor_bit_exact_vs_oracle(golden_dir, n, tile, monkeypatch):
+    """Both tilings of the controller (32-row tiles for small batches, 64-row tiles above NPACT_TILE32_MAX_N; NP_ACTOR_TILE forces one)."""
     from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    monkeypatch.setenv('NP_ACTOR_TILE', tile)
     d = np.load(f'{golden_dir}/actor_kat.npz')
     w = pack_ppo_actor(_sd(d))
     fa, o = FusedActor(w, 'cuda:0'), ActorOracle(w)
@@ -37,6 +40,28 @@ def test_fused_actor_bit_exact_vs_oracle(golden_dir, n):
         assert a_t.shape == (n, 4) and h_t.shape == (n, 1, 128)
         assert _same(a_t.cpu().numpy(), a_o), f'actions differ at call {t}'
         assert _same(h_t.cpu().numpy()[:, 0], h_o), f'rnn state differs at call {t}'
+
+
+def test_fused_actor_tilings_agree_at_the_switch_over(golden_dir, monkeypatch):
+    """n on both sides of the automatic switch: the two kernels return the same bits."""
+    from neuralplane_amd.actor import FusedActor
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    fa = FusedActor(_sd(d), 'cuda:0')
+    rng = np.random.RandomState(5)
+    for n in (16384, 16385):
+        obs = torch.from_numpy((rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 30, (1, 22))).astype(np.float32)).cuda()
+        h = torch.from_numpy(rng.normal(0, 0.5, (n, 1, 128)).astype(np.float32)).cuda()
+        m = torch.from_numpy((rng.uniform(0, 1, (n, 1)) > 0.2).astype(np.float32)).cuda()
+        res = {}
+        for tile in ('', '32', '64'):
+            if tile:
+                monkeypatch.setenv('NP_ACTOR_TILE', tile)
+            else:
+                monkeypatch.delenv('NP_ACTOR_TILE', raising=False)
+            a, _, h2 = fa(obs, h, m)
+            res[tile] = (a.cpu().numpy(), h2.cpu().numpy())
+        for tile in ('32', '64'):
+            assert _same(res[''][0], res[tile][0]) and _same(res[''][1], res[tile][1]), (n, tile)
 
 
 def test_fused_actor_close_to_reference_recording(golden_dir):

@@ -971,6 +971,147 @@ def gen_actor_mfma_file():
     print('wrote', out)
 
 
+# ------------------------------------------------------------------------------------------------
+# The same layer for the 32-row tile of actor_forward_mfma32_kernel (small batches: twice as many workgroups, half the chain
+# time per tile): one wave, 32 features x 32 rows as a chain of v_mfma_f32_16x16x1_4b_f32 (four 16 x 16 blocks: A = features
+# f0 + 16 (l / 32) + l % 16, B = rows l % 32).  The bias enters as one more K = 1 step (A = bias, B = 1.0, C = 0), so the chain
+# starts without a separate accumulator fill; operands are fetched a group of 16 features ahead (16 x 40 cycles of dependent
+# MFMAs cover the L2 latency of the weights with margin).
+# ------------------------------------------------------------------------------------------------
+N_G = 16                  # features per operand group
+N_RING = 3                # A operand groups in flight: group g + 2 is requested behind the first MFMA of group g
+N_A = [112, 128, 144]     # v[112:127] / v[128:143] / v[144:159]
+N_B = [160, 176]          # v[160:175] / v[176:191]: B operands (LDS: one group ahead is enough)
+N_VOFF = 192              # per-lane byte offset of the weight column
+N_XADDR = 193             # LDS byte address of x[first feature of the group][row]; v194 = the same + 8 features
+N_ONE = 195
+N_SBASE = 4               # s[4:5]: running row base of this layer, s[6:7]: of the next layer's prefetch
+N_ROWS = 32               # rows per tile = floats per LDS matrix row
+N_PRE = 2 * N_G + 1       # values handed from layer to layer: the first two A groups and the bias
+
+
+def gen_actor_mfma16(lines, LD, LDN, K=128):
+    A = lines.append
+    stride, nstride = LD * 4, LDN * 4
+    NGRP = K // N_G
+    assert K % N_G == 0 and NGRP >= 3
+    A(f'// 32 features x 32 rows of a Linear({K}, .) layer whose packed rows are {LD} floats apart: w = &Wt[0][f0] (wave-uniform),')
+    A('// voff = 4 * (16 * (lane / 32) + lane % 16), xaddr = LDS byte address of x[0][lane % 32]; pa[0..31] = W[f][0..31] of this lane and')
+    A('// pa[32] = bias[f] (prefetched); acc is written (not read).  wnext / bnext = &Wt[0][f0] / &bias[f0] of the layer that runs next')
+    A(f'// (rows {LDN} floats apart): its first 32 A operands and its bias are fetched behind the MFMAs of the last two groups and returned in pa')
+    A('template <>')
+    A(f'__device__ __forceinline__ void actor_dense_mfma16_asm<{LD}, {LDN}>(const float *w, const float *wnext, const float *bnext, unsigned voff,')
+    A(f'                                                                    unsigned xaddr, float (&pa)[{N_PRE}], f32x16 &acc) {{')
+    A('    asm volatile(')
+
+    def emit(s):
+        A(f'        "{s}\\n\\t"')
+
+    state = {'off': 0, 'noff': 0}
+    queue = []        # tags of the vector loads in issue order (they return in that order): ('A', group) or ('N',)
+
+    def a_loads(g, out):    # A operands of group g (features 16 g ..) into ring slot g % N_RING; the running base absorbs what the immediate cannot reach
+        for u in range(N_G):
+            if state['off'] > 4095:
+                out.append(f's_add_u32 s{N_SBASE}, s{N_SBASE}, {state["off"]}')
+                out.append(f's_addc_u32 s{N_SBASE + 1}, s{N_SBASE + 1}, 0')
+                state['off'] = 0
+            out.append(f'global_load_dword v{N_A[g % N_RING] + u}, v{N_VOFF}, s[{N_SBASE}:{N_SBASE + 1}] offset:{state["off"]}')
+            queue.append(('A', g))
+            state['off'] += stride
+
+    def next_loads(lo, hi, out):   # the next layer's A operands lo..hi-1 into the pa registers
+        for u in range(lo, hi):
+            if state['noff'] > 4095:
+                out.append(f's_add_u32 s{N_SBASE + 2}, s{N_SBASE + 2}, {state["noff"]}')
+                out.append(f's_addc_u32 s{N_SBASE + 3}, s{N_SBASE + 3}, 0')
+                state['noff'] = 0
+            out.append(f'global_load_dword %[p{u}], v{N_VOFF}, s[{N_SBASE + 2}:{N_SBASE + 3}] offset:{state["noff"]}')
+            queue.append(('N',))
+            state['noff'] += nstride
+
+    def b_reads(g, out):    # B operands of group g into slot g % 2
+        base = N_B[g % 2]
+        for u in range(0, N_G, 2):
+            addr = N_XADDR + (1 if u >= 8 else 0)
+            uu = u % 8
+            out.append(f'ds_read2_b32 v[{base + u}:{base + u + 1}], v{addr} offset0:{uu * N_ROWS} offset1:{(uu + 1) * N_ROWS}')
+        out.append(f'v_add_u32 v{N_XADDR}, {N_G * N_ROWS * 4}, v{N_XADDR}')
+        out.append(f'v_add_u32 v{N_XADDR + 1}, {N_G * N_ROWS * 4}, v{N_XADDR + 1}')
+
+    # prologue: groups 0 and 1 of the A operands and the bias arrive in pa (fetched during the previous layer)
+    emit(f's_mov_b64 s[{N_SBASE}:{N_SBASE + 1}], %[w]')
+    emit(f's_mov_b64 s[{N_SBASE + 2}:{N_SBASE + 3}], %[wn]')
+    emit(f'v_mov_b32 v{N_VOFF}, %[voff]')
+    emit(f'v_mov_b32 v{N_XADDR}, %[xaddr]')
+    emit(f'v_add_u32 v{N_XADDR + 1}, {8 * N_ROWS * 4}, v{N_XADDR}')
+    pro = []
+    b_reads(0, pro)
+    state['off'] = 2 * N_G * stride
+    a_loads(2, pro)
+    for x in pro:
+        emit(x)
+    emit(f'v_mov_b32 v{N_ONE}, 1.0')
+    for u in range(N_G):
+        emit(f'v_mov_b32 v{N_A[0] + u}, %[p{u}]')
+    emit(f'v_mfma_f32_16x16x1_4b_f32 %[acc], %[p{2 * N_G}], v{N_ONE}, 0')      # acc = fma(bias, 1, 0)
+    for u in range(N_G):
+        emit(f'v_mov_b32 v{N_A[1] + u}, %[p{N_G + u}]')
+    emit('s_waitcnt lgkmcnt(0)')
+    # other instructions are spread behind the MFMAs, 3 to 5 per gap (the chain is dependent: 32 cycles between two of them)
+    for g in range(NGRP):
+        # on entry: the A and B operands of group g have landed.  Behind its MFMAs: the B operands of group g + 1 (LDS), the A
+        # operands of group g + 2 (into the slot group g - 1 has just left), and in groups NGRP - 3 / NGRP - 2 the next layer's first
+        # two groups + bias, so that the statement's final wait finds them landed
+        side = []
+        if g + 1 < NGRP:
+            b_reads(g + 1, side)
+        if g >= 1 and g + 2 < NGRP:
+            a_loads(g + 2, side)
+        if g == NGRP - 3:
+            next_loads(0, N_G, side)
+            side.append(f'global_load_dword %[p{2 * N_G}], v{N_VOFF}, %[bn]')
+            queue.append(('N',))
+        if g == NGRP - 2:
+            next_loads(N_G, 2 * N_G, side)
+        PER_GAP = max(3, -(-len(side) // (N_G - 1)))
+        assert PER_GAP <= 5, len(side)
+        for u in range(N_G):
+            emit(f'v_mfma_f32_16x16x1_4b_f32 %[acc], v{N_A[g % N_RING] + u}, v{N_B[g % 2] + u}, %[acc]')
+            for x in side[PER_GAP * u:PER_GAP * (u + 1)]:
+                emit(x)
+        if g + 1 < NGRP:
+            if g + 1 <= 1:
+                emit('s_waitcnt lgkmcnt(0)')      # group 1 came in registers
+            else:
+                # loads still allowed in flight when group g + 1 starts: everything issued after the last of its own A operands
+                last = max(i for i, t in enumerate(queue) if t == ('A', g + 1))
+                emit(f's_waitcnt vmcnt({len(queue) - 1 - last}) lgkmcnt(0)')
+    emit('s_waitcnt vmcnt(0)')
+    emit('s_nop 15')          # 8-pass XDL result -> the VALU / LDS instructions the compiler places after this statement
+    outs = ', '.join(f'[p{u}] "+v"(pa[{u}])' for u in range(N_PRE))
+    A(f'        : [acc] "=&v"(acc), {outs}')
+    A('        : [w] "s"(w), [wn] "s"(wnext), [bn] "s"(bnext), [voff] "v"(voff), [xaddr] "v"(xaddr)')
+    regs = list(range(N_A[0], N_ONE + 1))
+    clob = ', '.join([f'"v{r}"' for r in regs] + [f'"s{r}"' for r in range(N_SBASE, N_SBASE + 4)] + ['"scc"', '"memory"'])
+    A(f'        : {clob});')
+    A('}')
+
+
+def gen_actor_mfma16_file():
+    out = os.path.join(CSRC, 'np_actor_mfma16_asm.inc')
+    lines = ['// GENERATED by tools/gen_mlp_asm.py (gen_actor_mfma16) — do not edit.', '#pragma once',
+             'typedef float f32x16 __attribute__((ext_vector_type(16)));',
+             'template <int LD, int LD_NEXT>',
+             '__device__ __forceinline__ void actor_dense_mfma16_asm(const float *w, const float *wnext, const float *bnext, unsigned voff, unsigned xaddr, float (&pa)[33], f32x16 &acc);']
+    for LD in (128, 384):
+        for LDN in (128, 384):
+            gen_actor_mfma16(lines, LD, LDN)
+    with open(out, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('wrote', out)
+
+
 def main():
     out = ['// GENERATED by tools/gen_mlp_asm.py — do not edit.  See that file for the design notes.',
            '// One asm statement per net class: double-buffered scalar weight stream + v_pk_fma_f32 chains.',
@@ -1010,3 +1151,4 @@ if __name__ == '__main__':
     gen_dual_file()
     gen_actor_dense()
     gen_actor_mfma_file()
+    gen_actor_mfma16_file()
