@@ -265,7 +265,9 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
  * GRU 128, act MLP 128-128, tanh mean head) as ONE kernel launch.  `weights`: NP_ACTOR_NUM_FLOATS floats on the device, the
  * actor's state_dict in kernel order (neuralplane_amd/actor.py::pack_ppo_actor documents the layout).  obs [n][22],
  * h_in / h_out [n][128] (rnn_states with the layer dimension squeezed; may not alias; 16-byte aligned), masks [n],
- * actions [n][4]. */
+ * actions [n][4].  Two tilings with identical results: 32-row tiles up to 16 384 rows (latency: 32 us per call up to 8 192
+ * rows; needs `weights` 16-byte aligned), 64-row tiles above (throughput).  Environment variable NP_ACTOR_TILE=32|64, read at
+ * every call, forces one (benchmarks and the parity tests of both). */
 #define NP_ACTOR_NUM_FLOATS 153392
 int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
                      float *actions, float *h_out, int device, void *stream);
