@@ -190,7 +190,13 @@ void f16_env_kernel(const KArgs a) {
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
     constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * PW / (BLOCK / 64) : FIRST_GENERATION;
-    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && gridDim.x >= NPF16_STAGGER_MIN_GENS * FIRST_GEN && blockIdx.x < FIRST_GEN) {
+    // Round 3 (profiles/r03f_mid_large_n.log, one session): the three-wave pair build gains from the delay on EVERY grid it is used
+    // for, also a single or a partial generation that fills the chip (1 025 .. 3 071 workgroups: 163 840 aircraft 73.2 -> 70.6 us,
+    // 196 608 86.4 -> 82.6, 229 376 124.2 -> 88.9, 262 144 106.5 -> 102.4, 327 680 126.4 -> 118.9) — unlike the two-wave build
+    // on its half-filled chip (profiles/r03a_one_generation_dephasing.json: nothing).
+    constexpr bool ALWAYS = WPT == 2 && PW == 3;
+    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && (ALWAYS ? gridDim.x > 1024 : gridDim.x >= NPF16_STAGGER_MIN_GENS * FIRST_GEN) &&
+        blockIdx.x < FIRST_GEN) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
@@ -1219,11 +1225,13 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     // Pair variant at three waves per SIMD (six workgroups per CU) or at two (four per CU)?  Measured per grid size (heading,
     // one session, profiles/r02b_ab_sessions.md s25): long grids gain 5-9 % from the third wave; grids of up to three generations
     // are quantised — 1 025-1 536 workgroups fit ONE generation of six per CU (-11..-15 %), but <= 1 024 fill the chip evenly at
-    // four per CU (a kernel that MAY hold three waves per SIMD is placed unevenly there: +13..+20 %) and 1 537-3 071 are better
-    // off in rounds of 1 024 (+16..+26 % otherwise).  Step kernels outside PlanningEnv's inner loop only.
+    // four per CU (a kernel that MAY hold three waves per SIMD is placed unevenly there: +13..+20 %).  1 537-3 071 workgroups were
+    // better off in rounds of 1 024 only while the three-wave build ran them in lock-step: with the first-generation delay applied
+    // to every three-wave grid (round 3, see the kernel) it wins there too (229 376 aircraft 124.2 -> 88.9 us, 327 680 126.4 ->
+    // 118.9; profiles/r03f_mid_large_n.log).  Step kernels outside PlanningEnv's inner loop only.
     static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
     const bool pair3 = pair && !a.inner &&
-                       (pw_env ? pw_env == 3 : ((grid.x > 1024 && grid.x <= 1536) || grid.x >= 3072));
+                       (pw_env ? pw_env == 3 : grid.x > 1024);
     const unsigned lds_pad = 0;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
