@@ -108,13 +108,13 @@ typedef struct np_f16_io {
      * overload, low_altitude, high_speed, low_speed, extreme_state, unreach_* (bad), target reached (done). */
     uint32_t *term_counters;
     /* Optional DEVICE bytes [n] written by np_f16_step: the same conditions per aircraft (bit k = counter k above) at the state
-     * reached by this step — which of the termination-condition classes (envs/termination_conditions/*.py, called from
+     * reached by this step — which of the termination-condition classes (envs/termination_conditions/<condition>.py, called from
      * task_base.py:75-96) fired for which row.  NULL = not wanted.  np_f16_reset clears the bytes of every row (all flags are
      * cleared, no condition is evaluated); with inner_step set the bits accumulate (OR) over the launches of one PlanningEnv.step,
      * like the done / bad_done flags they explain. */
     uint8_t *term_reasons;
     /* Optional DEVICE floats [n] written by np_f16_step: the value of the task's own reward function (HeadingReward /
-     * PostureReward / PositionReward, envs/reward_functions/*.py) before EventDrivenReward's -200 * bad_done + 200 * done is added
+     * PostureReward / PositionReward, envs/reward_functions/<function>.py) before EventDrivenReward's -200 * bad_done + 200 * done is added
      * (task_base.py:60-73): `reward` = this + that, in fp32.  NULL = not wanted. */
     float *reward_task;
     /* PlanningEnv's inner loop (inner_step set), both optional: ll_tgt [3][ld] = the low-level controller's targets (pitch, heading,

@@ -299,7 +299,7 @@ void f16_env_kernel(const KArgs a) {
             for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * TILE] = a.reset_coef[k];
         }
         if constexpr (TRIG_CACHED) {
-            float tv[NUM_CACHED_TRIG > 0 ? NUM_CACHED_TRIG : 1];
+            float tv[10];  // NUM_CACHED_TRIG values when the switch is on
 #pragma unroll
             for (int k = 0; k < NUM_CACHED_TRIG; k++) tv[k] = cache_blk[(NUM_CACHED + k) * CACHE_TILE];
             if (flagged && !INNER) {  // a re-initialised aircraft: every angle is 0 (F16_model.py:33-45); its altitude was just drawn
