@@ -1228,10 +1228,10 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     // four per CU (a kernel that MAY hold three waves per SIMD is placed unevenly there: +13..+20 %).  1 537-3 071 workgroups were
     // better off in rounds of 1 024 only while the three-wave build ran them in lock-step: with the first-generation delay applied
     // to every three-wave grid (round 3, see the kernel) it wins there too (229 376 aircraft 124.2 -> 88.9 us, 327 680 126.4 ->
-    // 118.9; profiles/r03f_mid_large_n.log).  Step kernels outside PlanningEnv's inner loop only.
+    // 118.9; profiles/r03f_mid_large_n.log).  PlanningEnv's inner steps take the same rule since the end of round 3 (165 VGPRs, no
+    // scratch; the macro-step at n = 150 000: 29.2 -> 27.6 ms, 262 144: 45.8 -> 44.2 ms, profiles/r03f_planning_inner_pair3.log).
     static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
-    const bool pair3 = pair && !a.inner &&
-                       (pw_env ? pw_env == 3 : grid.x > 1024);
+    const bool pair3 = pair && (pw_env ? pw_env == 3 : grid.x > 1024);
     const unsigned lds_pad = 0;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
@@ -1242,9 +1242,9 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     const std::pair<hipEvent_t, hipEvent_t> &ev = lease.ev;
 #define NP_LAUNCH_I(T, S, I)                                                                                          \
     do {                                                                                                              \
-        if (pair3 && !I) {                                                                                            \
-            if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, false, 3>); \
-            else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, false, 3>);       \
+        if (pair3 && (!I || S == 0)) {  /* PlanningEnv's inner step: the three-wave build for Euler only (six kernels, not twelve) */ \
+            if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, (I && S == 0), 3>); \
+            else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, (I && S == 0), 3>);       \
         } else if (pair) {                                                                                            \
             if (cached) NP_DISPATCH(a, f16_env_kernel<T, S, STEP, STEP, BLOCK, 2, I>);       \
             else NP_DISPATCH(a, f16_env_kernel<T, S, STEP, false, BLOCK, 2, I>);             \

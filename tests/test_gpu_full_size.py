@@ -130,6 +130,31 @@ def test_pair_kernel_builds_agree_across_the_grid_size_rule(solver):
             assert torch.equal(res[0][1][k], res[1][1][k]), (wgs, k)
 
 
+def test_inner_step_pair_builds_agree_across_the_grid_size_rule():
+    """PlanningEnv's inner iteration (np_f16_io.inner_step + ll_obs) follows the same grid-size rule as the plain step: two waves per
+    SIMD up to 1 024 workgroups, the three-wave build above.  On either side of the threshold the default must equal the single-set
+    throughput variant bit for bit — states, task observation, reward, flags and the low-level observation the launch writes."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    steps, seed = 4, 5
+    for wgs in (1024, 1025, 1537):
+        n = wgs * 128 - 19
+        acts = _actions(steps, n, wgs + 1)
+        tgt3 = (torch.rand((3, n), generator=torch.Generator().manual_seed(wgs)) * 0.4 - 0.2).to('cuda').contiguous()
+        res = []
+        for variant in ('auto', 'throughput'):
+            e = ControlEnv(num_envs=n, config='tracking', model='F16', random_seed=seed, device='cuda:0')
+            b = e._batch
+            b.set_kernel_variant(variant)
+            b.reset()
+            ll = torch.empty((n, 22), dtype=torch.float32, device='cuda')
+            for a in acts:
+                obs, rew, flags = b.step(a, inner=True, ll_tgt=tgt3, ll_obs=ll, want_obs=True)
+            res.append((b.s.clone(), obs.clone(), rew.clone(), flags.clone(), ll.clone()))
+            del e, b
+        for k in range(5):
+            assert torch.equal(res[0][k], res[1][k]), (wgs, k)
+
+
 def test_same_seed_same_trajectory_and_flagged_rows_are_reinitialised():
     n, steps = N, 30
     acts = _actions(steps, n, 11)
