@@ -109,8 +109,9 @@ def test_sharded_batches_reproduce_the_unsharded_batch():
 @pytest.mark.parametrize('solver', ['euler', 'rk4'])
 def test_pair_kernel_builds_agree_across_the_grid_size_rule(solver):
     """The pair variant exists in two builds (two / three waves per SIMD, the second with cold registers parked in scratch);
-    launch_env picks one per grid size (<= 1024, 1025-1536, 1537-3071, >= 3072 workgroups of 128 aircraft).  On either side of
-    every threshold the default must equal the single-set throughput variant bit for bit."""
+    launch_env picks one per grid size (two waves up to 1 024 workgroups of 128 aircraft, three — de-phased — above; until the end of
+    round 3 the two-wave build also served 1 537-3 071 workgroups).  On either side of every old and new threshold the default must
+    equal the single-set throughput variant bit for bit."""
     steps, seed = 4, 11
     for wgs in (1024, 1025, 1536, 1537, 3071, 3072):
         n = wgs * 128 - 37                    # ragged last workgroup
