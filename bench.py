@@ -492,7 +492,9 @@ def planning_mode(dev, g, npl, k7):
                         'note': '50 x (302 KFLOP controller forward + 33.8 KFLOP FDM step) = 16.8 MFLOP per aircraft and PlanningEnv.step; wall clock '
                                 'of back-to-back macro-steps, i.e. launch gaps included'},
            'note': 'controller = np_actor_forward (K=1 fp32 MFMA chains, bit-exact to its oracle: tests/test_gpu_actor.py); the inner step writes '
-                   'the next low-level observation itself (np_f16_io.ll_obs): 102 launches per macro-step (round 2: 151).  Up to 16 384 aircraft the '
+                   'the next low-level observation itself (np_f16_io.ll_obs): 102 launches per macro-step (round 2: 151), the 100 of the inner loop enqueued '
+                   'by ONE library call (np_planning_inner_loop) — as two or three row groups on their own streams for 8 192 < n <= 81 920, so that '
+                   "one group's controller call overlaps another's FDM step and every call runs on the 32-row tiles.  Up to 16 384 aircraft per call the "
                    'controller runs on 32-row tiles (v_mfma_f32_16x16x1_4b_f32: 1 174 dependent K = 1 steps of 32 cycles = 15.7 us of matrix pipe '
                    'per tile, ~32 us per call with the LayerNorm / gate epilogues); from 8 193 aircraft on some CUs carry two tiles (313 tiles on '
                    '256 CUs at n = 1e4) and the call takes ~55 us: the f32 MFMA and the vector ALU share one pipe, so two tiles cost '

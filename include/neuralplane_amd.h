@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 11
+#define NP_ABI_VERSION 12
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -271,6 +271,33 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
 #define NP_ACTOR_NUM_FLOATS 153392
 int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
                      float *actions, float *h_out, int device, void *stream);
+
+/* The 50 low-level iterations of PlanningEnv.step (reference envs/planning_env.py:153-176: ego_actions = self.controller(low_level_obs,
+ * rnn_states, masks); self.model.update(ego_actions); terminations / reward; next low_level_obs) enqueued by ONE call: per iteration
+ * np_actor_forward on ll_obs[k & 1] / rnn[k & 1] -> ll_act, rnn[(k + 1) & 1], then np_f16_step with inner_step set, action = ll_act,
+ * flags[k & 1] -> flags[(k + 1) & 1], which also writes the controller's next observation into ll_obs[(k + 1) & 1].  `io` carries what all
+ * iterations share (s, u, tgt, ld, step_count, coef_cache, reward, term_*, reward_task, seed, row0, call_idx_base; call_idx = the first
+ * iteration's, cache_valid = whether the cache is valid for the first iteration); io->obs receives the task observation of the LAST
+ * iteration only (planning_env.py overwrites it every iteration) and the last iteration writes no low-level observation.  The results
+ * are those of the 2 x iterations separate calls, bit for bit.
+ * groups: the rows are processed as that many independent row groups (boundaries at multiples of 64 rows), group 0 on `stream`, the
+ * others on streams the context owns, forked behind and joined back into `stream` by events: one group's controller call overlaps
+ * another's FDM step and every group's controller call runs on the 32-row tiles.  0 = the library chooses by n (one group up to
+ * 8 192 rows and from ~80 000 on, two or three in between: PlanningEnv.step 3.51 -> 3.23 ms at n = 1e4, 6.43 -> 4.44 ms at 20 000,
+ * 10.7 -> 9.2 ms at 49 152; profiles/r03g_planning_groups.log).
+ * A stream that is being captured into a graph always gets one group. */
+typedef struct np_planning_loop {
+    int32_t iterations;        /* planning_env.py:153: 50 */
+    int32_t groups;            /* 0 = automatic */
+    const float *actor_weights;/* np_actor_forward's packed weights [NP_ACTOR_NUM_FLOATS] */
+    float *ll_obs[2];          /* [n][22] each; [0] holds the first iteration's input (np_f16_lowlevel_obs) */
+    float *rnn[2];             /* [n][128] each, 16-byte aligned; [0] holds the recurrent state on entry; the final state ends in rnn[iterations & 1] */
+    const float *masks;        /* [n] */
+    float *ll_act;             /* [n][4] scratch: the controller's actions of the current iteration */
+    uint8_t *flags[2];         /* [3][n] each (done, bad_done, exceed_time_limit); [0] = the flags on entry; the final flags end in flags[iterations & 1] */
+    const float *ll_tgt;       /* [3][ld] the controller's targets (np_f16_io.ll_tgt) */
+} np_planning_loop;
+int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *loop, void *stream);
 
 /* Returns of one rollout for the device-resident rollout storage — replaces ReplayBuffer.compute_returns
  * (reference algorithms/utils/buffer.py:139-173; a Python loop over time with numpy array operations there): one launch, a

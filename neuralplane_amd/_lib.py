@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class NpF16Cfg(C.Structure):
@@ -63,6 +63,12 @@ class NpF16CombatCfg(C.Structure):
                 ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32)]
 
 
+class NpPlanningLoop(C.Structure):
+    _fields_ = [('iterations', C.c_int32), ('groups', C.c_int32), ('actor_weights', C.c_void_p),
+                ('ll_obs', C.c_void_p * 2), ('rnn', C.c_void_p * 2), ('masks', C.c_void_p), ('ll_act', C.c_void_p),
+                ('flags', C.c_void_p * 2), ('ll_tgt', C.c_void_p)]
+
+
 class NpF16CombatIo(C.Structure):
     _fields_ = [('s', C.c_void_p), ('u', C.c_void_p), ('pid', C.c_void_p), ('blood', C.c_void_p), ('ld', C.c_int64),
                 ('step_count', C.c_void_p),
@@ -76,7 +82,7 @@ class NpF16CombatIo(C.Structure):
 
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
            'np_f16_step', 'np_f16_derived', 'np_f16_aero_coefficients', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace', 'np_selfcheck_divc',
-           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns')
+           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop')
 KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4, 'latency2': 5, 'latency4w': 6}
 
 _lib = None
@@ -121,6 +127,7 @@ def load():
     lib.np_f16_set_kernel_variant.argtypes = [C.c_void_p, C.c_int]
     lib.np_actor_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p]
+    lib.np_planning_inner_loop.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NpF16Io), C.POINTER(NpPlanningLoop), C.c_void_p]
     lib.np_rollout_returns.argtypes = [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.np_f16_combat_ctx_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(NpF16CombatCfg), C.c_int, C.POINTER(C.c_void_p)]

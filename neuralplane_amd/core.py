@@ -265,6 +265,30 @@ class F16Batch:
         self._version += 1
         return obs, reward, new_flags
 
+    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0):
+        """np_planning_inner_loop: the `iterations` low-level iterations of PlanningEnv.step (controller forward + inner FDM step each)
+        enqueued by one library call.  ll_obs = (first input [n,22], scratch [n,22]); rnn = (state on entry [n,128], scratch [n,128]);
+        flags_scratch [3,n] uint8.  Returns obs (task observation of the last iteration), reward, flags; the final recurrent state is in
+        rnn[iterations & 1]."""
+        n = self.n
+        obs = torch.empty((n, 22), dtype=torch.float32, device=self.device)
+        reward = torch.empty(n, dtype=torch.float32, device=self.device)
+        io = self._io(flags_scratch, ll_act, obs, reward, None, None, inner=True, ll_tgt=tgt3, ll_obs=ll_obs[1])
+        lp = _lib.NpPlanningLoop()
+        lp.iterations, lp.groups = int(iterations), int(groups)
+        lp.actor_weights = actor_weights.data_ptr()
+        lp.ll_obs[0], lp.ll_obs[1] = ll_obs[0].data_ptr(), ll_obs[1].data_ptr()
+        lp.rnn[0], lp.rnn[1] = rnn[0].data_ptr(), rnn[1].data_ptr()
+        lp.masks, lp.ll_act, lp.ll_tgt = masks.data_ptr(), ll_act.data_ptr(), tgt3.data_ptr()
+        lp.flags[0], lp.flags[1] = self.flags.data_ptr(), flags_scratch.data_ptr()   # _io made self.flags contiguous
+        _lib.check(self.lib.np_planning_inner_loop(self._ctx, n, C.byref(io), C.byref(lp), self._stream()))
+        self._cache_valid = True
+        if iterations & 1:
+            self.flags = flags_scratch
+        self.call_idx += int(iterations)
+        self._version += 1
+        return obs, reward, self.flags
+
     def lowlevel_obs(self, tgt3):
         """PlanningEnv.low_level_obs for targets tgt3[3,n] (pitch, heading, vt) -> obs[n,22]."""
         tgt3 = torch.as_tensor(tgt3, dtype=torch.float32, device=self.device).contiguous()

@@ -832,6 +832,9 @@ struct np_f16_ctx {
     std::vector<float> samples;  // per-launch durations in launch order since np_f16_set_timing(ctx, 1)
     unsigned long long *trace;   // np_f16_set_trace
     int64_t trace_cap;
+    // np_planning_inner_loop: streams of row groups 1.. and the fork / join events (created on first use)
+    std::vector<hipStream_t> group_streams;
+    std::vector<hipEvent_t> group_events;  // [0] fork, [1 + g] join of group g + 1
 };
 
 namespace {
@@ -1518,6 +1521,16 @@ void np_f16_ctx_destroy(np_f16_ctx *ctx) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (!ctx->group_streams.empty() || !ctx->group_events.empty()) {
+        DeviceGuard guard;
+        if (guard.enter(ctx->device) == hipSuccess) {
+            for (auto st : ctx->group_streams) {
+                (void)hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+            }
+            for (auto ev : ctx->group_events) (void)hipEventDestroy(ev);
+        }
+    }
     delete ctx;
 }
 
@@ -1612,6 +1625,76 @@ extern "C" int np_actor_trace_read(long long *out) {  // diagnostics builds only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(npact::npact_trace), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
 }
 #endif
+
+int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, void *stream) {
+    if (!ctx || !io || !lp) return fail("null ctx/io/loop");
+    if (ctx->combat) return fail("combat context");
+    if (n <= 0 || lp->iterations <= 0) return 0;
+    if (!lp->actor_weights || !lp->ll_obs[0] || !lp->ll_obs[1] || !lp->rnn[0] || !lp->rnn[1] || !lp->masks || !lp->ll_act || !lp->flags[0] ||
+        !lp->flags[1] || !lp->ll_tgt)
+        return fail("np_planning_loop: null buffer");
+    if (lp->groups < 0 || lp->groups > 8) return fail("np_planning_loop: groups must be 0 (automatic) .. 8");
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    // automatic choice, measured per size (profiles/r03g_planning_groups.log; ms per PlanningEnv.step, one group -> the choice):
+    // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 6.43 -> 4.44, 24 576 6.74 -> 4.88, 32 768 6.90 -> 6.29, 49 152 10.7 -> 9.17,
+    // 65 536 12.75 -> 12.17; one group is the best up to 8 192 (one 32-row controller tile per CU) and from ~80 000 on (throughput)
+    int groups = lp->groups ? lp->groups
+                 : n <= 8192 ? 1 : n <= 16384 ? 2 : n <= 28672 ? 3 : n <= 57344 ? 2 : n <= 81920 ? 3 : 1;
+    if (stream_is_capturing(st)) groups = 1;  // a captured graph runs its branches one after the other
+    const int64_t per = ((n + groups - 1) / groups + 63) / 64 * 64;  // rows per group: boundaries on cache / kernel tiles
+    if (per * (groups - 1) >= n) groups = (int)((n + per - 1) / per);
+    while ((int)ctx->group_streams.size() < groups - 1) {
+        hipStream_t s2;
+        NP_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        ctx->group_streams.push_back(s2);
+    }
+    while ((int)ctx->group_events.size() < groups) {
+        hipEvent_t ev;
+        NP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->group_events.push_back(ev);
+    }
+    if (groups > 1) {
+        NP_HIP(hipEventRecord(ctx->group_events[0], st));
+        for (int g = 1; g < groups; g++) NP_HIP(hipStreamWaitEvent(ctx->group_streams[g - 1], ctx->group_events[0], 0));
+    }
+    for (int k = 0; k < lp->iterations; k++) {
+        const bool last = k == lp->iterations - 1;
+        const int a = k & 1, b = a ^ 1;
+        for (int g = 0; g < groups; g++) {
+            const int64_t r0 = g * per, m = (r0 + per <= n ? per : n - r0);
+            hipStream_t sg = g == 0 ? st : ctx->group_streams[g - 1];
+            if (np_actor_forward(lp->actor_weights, NP_ACTOR_NUM_FLOATS, m, lp->ll_obs[a] + r0 * npact::OBS, lp->rnn[a] + r0 * npact::HID, lp->masks + r0,
+                                 lp->ll_act + r0 * 4, lp->rnn[b] + r0 * npact::HID, ctx->device, (void *)sg))
+                return 1;
+            np_f16_io q = *io;
+            q.s = io->s + r0; q.u = io->u + r0; q.tgt = io->tgt + r0;
+            q.step_count = io->step_count + r0;
+            q.done_in = lp->flags[a] + r0; q.bad_in = lp->flags[a] + n + r0; q.timeout_in = lp->flags[a] + 2 * n + r0;
+            q.done_out = lp->flags[b] + r0; q.bad_out = lp->flags[b] + n + r0; q.timeout_out = lp->flags[b] + 2 * n + r0;
+            q.action = lp->ll_act + r0 * 4; q.act_stride = 4;
+            q.obs = last && io->obs ? io->obs + r0 * npact::OBS : nullptr;
+            q.reward = io->reward ? io->reward + r0 : nullptr;
+            q.rand_u = nullptr; q.noise = nullptr;
+            q.coef_cache = io->coef_cache ? io->coef_cache + (r0 / CACHE_TILE) * (int64_t)NUM_CACHE_ROWS * CACHE_TILE : nullptr;
+            q.cache_valid = k == 0 ? io->cache_valid : (io->coef_cache ? 1 : 0);
+            q.inner_step = 1;
+            q.call_idx = io->call_idx + (uint64_t)k;
+            q.row0 = io->row0 + r0;
+            q.term_reasons = io->term_reasons ? io->term_reasons + r0 : nullptr;
+            q.reward_task = io->reward_task ? io->reward_task + r0 : nullptr;
+            q.ll_tgt = last ? nullptr : lp->ll_tgt + r0;
+            q.ll_obs = last ? nullptr : lp->ll_obs[b] + r0 * npact::OBS;
+            if (launch_env<true>(ctx, m, &q, (void *)sg)) return 1;
+        }
+    }
+    for (int g = 1; g < groups; g++) {
+        NP_HIP(hipEventRecord(ctx->group_events[g], ctx->group_streams[g - 1]));
+        NP_HIP(hipStreamWaitEvent(st, ctx->group_events[g], 0));
+    }
+    return 0;
+}
 
 int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int use_proper_time_limits,
                        const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,

@@ -5,7 +5,8 @@ One high-level action (Δpitch, Δheading, Δvt) per `step`; inside, 50 low-leve
 kernel launch of this library (np_f16_step with inner_step=1, which also writes the low-level
 observation of the state it reaches: np_f16_io.ll_obs; np_f16_lowlevel_obs runs once per macro-step,
 for the first iteration) plus the controller's forward — 102 launches per step with the fused
-controller (round 2: 151);
+controller (round 2: 151), the 100 of the loop enqueued by one library call (np_planning_inner_loop:
+`_step_fused`; two or three row groups on their own streams for 8 192 < n <= 81 920);
 the env keeps the reference's quirks: rows that terminated earlier in the same outer step keep their
 state while their controls keep moving, `step_count` advances for every row, flags accumulate.
 
@@ -97,7 +98,39 @@ class PlanningEnv(BaseEnv):
         """22-float observation of the low-level controller (planning_env.py:60-142)."""
         return self._batch.lowlevel_obs(torch.stack((target_pitch, target_heading, target_vt)))
 
+    def _step_fused(self, action):
+        """PlanningEnv.step with the fused controller: reset, the first low-level observation and ONE library call that enqueues the 50
+        iterations (np_planning_inner_loop; for 8 192 < n <= 16 384 as two row groups on two streams).  Same kernels on the same inputs
+        as the launch-by-launch path below: bit-identical (tests/test_gpu_actor.py)."""
+        b, n, d = self._batch, self.n, self.device
+        b.reset(want_obs=False)                                    # self.reset()           :145
+        action = torch.clamp(torch.as_tensor(action, dtype=torch.float32, device=d), -1, 1)
+        roll, pitch, yaw = self.model.get_posture()
+        vt = self.model.get_vt()
+        tgt3 = torch.stack((pitch + action[:, 0] * 0.3, yaw + action[:, 1] * 0.3, vt + action[:, 2] * 30)).contiguous()  # :150-152
+        p = getattr(self, '_loop_buf', None)
+        if p is None:
+            p = self._loop_buf = {'ll': [None, torch.empty((n, 22), dtype=torch.float32, device=d)],
+                                  'rnn': [torch.empty((n, 128), dtype=torch.float32, device=d), torch.empty((n, 128), dtype=torch.float32, device=d)],
+                                  'masks': torch.ones(n, dtype=torch.float32, device=d), 'act': torch.empty((n, 4), dtype=torch.float32, device=d),
+                                  'flags': torch.empty((3, n), dtype=torch.uint8, device=d)}
+        p['ll'][0] = b.lowlevel_obs(tgt3)
+        h = self.ego_rnn_states
+        if h.data_ptr() != p['rnn'][0].data_ptr():   # somebody replaced the recurrent state (load_state_dict, the caller): take it over
+            p['rnn'][0].copy_(torch.as_tensor(h, dtype=torch.float32, device=d).reshape(n, 128))
+        flags_scratch = p['flags'] if p['flags'].data_ptr() != b.flags.data_ptr() else torch.empty((3, n), dtype=torch.uint8, device=d)
+        obs, reward, flags = b.planning_inner_loop(self.controller.weights, p['ll'], p['rnn'], p['masks'], p['act'], tgt3, flags_scratch,
+                                                   INNER_STEPS, groups=self.loop_groups)
+        self.ego_rnn_states = p['rnn'][INNER_STEPS & 1].view(n, 1, 128)
+        f = flags.view(torch.bool)
+        return obs, reward, f[0], f[1], f[2], self.info()
+
+    loop_groups = 0          # np_planning_loop.groups (0 = the library chooses)
+    use_inner_loop = True    # False: the launch-by-launch path (tests compare the two)
+
     def step(self, action, render=False, count=0):
+        if self.use_inner_loop and isinstance(self.controller, FusedActor) and not render:
+            return self._step_fused(action)
         if self._graph_enabled and not render:
             return self._step_graph(action)
         b = self._batch

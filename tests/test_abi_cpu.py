@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.np_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.np_abi_version() == _lib.ABI_VERSION == 12
 
 
 def _flat_fields(struct, prefix=''):
@@ -50,7 +50,7 @@ def test_struct_layout_matches_ctypes(tmp_path):
     """Compile a tiny C program against the public header and compare sizeof/offsetof with ctypes."""
     from neuralplane_amd import _lib
     pairs = [('np_f16_cfg', _lib.NpF16Cfg), ('np_f16_io', _lib.NpF16Io), ('np_pid_gains', _lib.NpPidGains),
-             ('np_f16_combat_cfg', _lib.NpF16CombatCfg), ('np_f16_combat_io', _lib.NpF16CombatIo)]
+             ('np_f16_combat_cfg', _lib.NpF16CombatCfg), ('np_f16_combat_io', _lib.NpF16CombatIo), ('np_planning_loop', _lib.NpPlanningLoop)]
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     exp = []
     for cname, st in pairs:

@@ -90,15 +90,17 @@ def test_planning_env_with_fused_actor_eager_and_graph(golden_dir):
     w = pack_ppo_actor(_sd(d))
     n = 200
     envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=5, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
-            for _ in range(2)]
+            for _ in range(3)]
+    envs[0].use_inner_loop = envs[1].use_inner_loop = False   # [0] launch by launch, [1] the same as a HIP graph, [2] np_planning_inner_loop
     envs[1].enable_graph()
     g = torch.Generator(device='cpu').manual_seed(2)
     for k in range(3):
         a = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
         outs = [e.step(a) for e in envs]
-        for x, y in zip(outs[0][:5], outs[1][:5]):
-            assert torch.equal(x, y), f'macro-step {k}'
-        assert torch.equal(envs[0].model.s, envs[1].model.s) and torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
+        for other in (1, 2):
+            for x, y in zip(outs[0][:5], outs[other][:5]):
+                assert torch.equal(x, y), f'macro-step {k}, path {other}'
+            assert torch.equal(envs[0].model.s, envs[other].model.s) and torch.equal(envs[0].ego_rnn_states, envs[other].ego_rnn_states)
     # one more inner iteration by hand: oracle actor on the env's low-level observation
     env = envs[0]
     tgt3 = torch.stack((env.model.s[:, 4], env.model.s[:, 5], env.model.s[:, 6]))
@@ -106,6 +108,32 @@ def test_planning_env_with_fused_actor_eager_and_graph(golden_dir):
     act, _, _ = env.controller(ll, env.ego_rnn_states, torch.ones((n, 1), device='cuda'))
     a_o, _ = ActorOracle(w).forward(ll.cpu().numpy(), env.ego_rnn_states.cpu().numpy()[:, 0], np.ones(n, np.float32))
     assert _same(act.cpu().numpy(), a_o)
+
+
+@pytest.mark.parametrize('n,groups', [(10_037, 0), (9_001, 3), (700, 2), (64, 4)])
+def test_planning_inner_loop_row_groups_equal_the_launch_by_launch_path(golden_dir, n, groups):
+    """np_planning_inner_loop: the 50 iterations enqueued by one call, as one or several row groups on their own streams (two
+    automatically for 8 192 < n <= 16 384) — states, observation, reward, flags, recurrent state and termination statistics equal
+    the launch-by-launch path bit for bit; ragged last group, more groups than 64-row blocks."""
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    w = pack_ppo_actor(_sd(np.load(f'{golden_dir}/actor_kat.npz')))
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=11, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+            for _ in range(2)]
+    envs[0].use_inner_loop = False
+    envs[1].loop_groups = groups
+    for e in envs:
+        e.termination_reasons()           # switches the per-aircraft tracking on
+    g = torch.Generator(device='cpu').manual_seed(n)
+    for k in range(3):
+        a = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
+        outs = [e.step(a) for e in envs]
+        for x, y in zip(outs[0][:5], outs[1][:5]):
+            assert torch.equal(x, y), f'macro-step {k}'
+        assert torch.equal(envs[0].model.s, envs[1].model.s) and torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
+        assert torch.equal(envs[0].termination_reasons(), envs[1].termination_reasons())
+        assert torch.equal(envs[0].step_count, envs[1].step_count)
+    assert envs[0].termination_counts() == envs[1].termination_counts()
 
 
 def test_misaligned_recurrent_state(golden_dir):
