@@ -1595,7 +1595,11 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     // small batches: 32-row tiles (twice the workgroups, half the MFMA chain per tile); NP_ACTOR_TILE=32|64 overrides (benchmarks)
     const char *tile_str = std::getenv("NP_ACTOR_TILE");  // read per call: the tests switch it
     const int tile_env = tile_str ? atoi(tile_str) : 0;
-    if (tile_env == 32 || (tile_env != 64 && n <= NPACT_TILE32_MAX_N)) {
+    // which tiling: a round of the 32-row kernel is 512 tiles = 16 384 rows in ~60 us, of the 64-row kernel 32 768 rows in ~98 us; the
+    // 32-row kernel wins wherever it needs fewer or shorter rounds (tools/microbench/actor_bench.py, profiles/r03h_actor_tilings.log:
+    // n = 20 000 84.6 vs 98.7 us, 24 576 86.9 vs 98.3, 40 960 138.8 vs 149.2; 28 672 110.3 vs 98.5 and everything from 49 152 on the other way)
+    const bool tile32_auto = n <= NPACT_TILE32_MAX_N || (n <= 26624) || (n > 32768 && n <= 43008);
+    if (tile_env == 32 || (tile_env != 64 && tile32_auto)) {
         if ((uintptr_t)weights & 15) return fail("packed actor weights must be 16-byte aligned");
         const dim3 grid32((unsigned)((n + npact::T32 - 1) / npact::T32)), block32(npact::MTHREADS);
         hipLaunchKernelGGL(npact::actor_forward_mfma32_kernel, grid32, block32, 0, (hipStream_t)stream, weights, (long long)n, obs, h_in,
@@ -1638,10 +1642,11 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
     // automatic choice, measured per size (profiles/r03g_planning_groups.log; ms per PlanningEnv.step, one group -> the choice):
-    // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 6.43 -> 4.44, 24 576 6.74 -> 4.88, 32 768 6.90 -> 6.29, 49 152 10.7 -> 9.17,
-    // 65 536 12.75 -> 12.17; one group is the best up to 8 192 (one 32-row controller tile per CU) and from ~80 000 on (throughput)
+    // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 5.67 -> 4.39, 24 576 5.86 -> 4.89, 28 672 6.84 -> 5.64, 32 768 6.92 -> 6.29,
+    // 40 960 8.53 -> 7.76, 49 152 10.3 -> 9.2, 57 344 12.35 -> 10.45, 65 536 12.57 -> 11.81, 81 920 15.4 -> 14.9; one group is the
+    // best up to 8 192 (one 32-row controller tile per CU) and above ~82 000 (throughput)
     int groups = lp->groups ? lp->groups
-                 : n <= 8192 ? 1 : n <= 16384 ? 2 : n <= 28672 ? 3 : n <= 57344 ? 2 : n <= 81920 ? 3 : 1;
+                 : n <= 8192 ? 1 : n <= 16384 ? 2 : n <= 26624 ? 3 : n <= 36864 ? 4 : n <= 53248 ? 2 : n <= 81920 ? 3 : 1;
     if (stream_is_capturing(st)) groups = 1;  // a captured graph runs its branches one after the other
     const int64_t per = ((n + groups - 1) / groups + 63) / 64 * 64;  // rows per group: boundaries on cache / kernel tiles
     if (per * (groups - 1) >= n) groups = (int)((n + per - 1) / per);
