@@ -1638,6 +1638,8 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         !lp->flags[1] || !lp->ll_tgt)
         return fail("np_planning_loop: null buffer");
     if (lp->groups < 0 || lp->groups > 8) return fail("np_planning_loop: groups must be 0 (automatic) .. 8");
+    if (lp->rnn[0] == lp->rnn[1] || lp->ll_obs[0] == lp->ll_obs[1] || lp->flags[0] == lp->flags[1])
+        return fail("np_planning_loop: the two buffers of a ping-pong pair must differ");
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
@@ -1664,15 +1666,18 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         NP_HIP(hipEventRecord(ctx->group_events[0], st));
         for (int g = 1; g < groups; g++) NP_HIP(hipStreamWaitEvent(ctx->group_streams[g - 1], ctx->group_events[0], 0));
     }
-    for (int k = 0; k < lp->iterations; k++) {
+    int rc = 0;  // a launch that fails ends the enqueueing, but the streams are joined all the same
+    for (int k = 0; k < lp->iterations && !rc; k++) {
         const bool last = k == lp->iterations - 1;
         const int a = k & 1, b = a ^ 1;
-        for (int g = 0; g < groups; g++) {
+        for (int g = 0; g < groups && !rc; g++) {
             const int64_t r0 = g * per, m = (r0 + per <= n ? per : n - r0);
             hipStream_t sg = g == 0 ? st : ctx->group_streams[g - 1];
             if (np_actor_forward(lp->actor_weights, NP_ACTOR_NUM_FLOATS, m, lp->ll_obs[a] + r0 * npact::OBS, lp->rnn[a] + r0 * npact::HID, lp->masks + r0,
-                                 lp->ll_act + r0 * 4, lp->rnn[b] + r0 * npact::HID, ctx->device, (void *)sg))
-                return 1;
+                                 lp->ll_act + r0 * 4, lp->rnn[b] + r0 * npact::HID, ctx->device, (void *)sg)) {
+                rc = 1;
+                break;
+            }
             np_f16_io q = *io;
             q.s = io->s + r0; q.u = io->u + r0; q.tgt = io->tgt + r0;
             q.step_count = io->step_count + r0;
@@ -1691,14 +1696,14 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
             q.reward_task = io->reward_task ? io->reward_task + r0 : nullptr;
             q.ll_tgt = last ? nullptr : lp->ll_tgt + r0;
             q.ll_obs = last ? nullptr : lp->ll_obs[b] + r0 * npact::OBS;
-            if (launch_env<true>(ctx, m, &q, (void *)sg)) return 1;
+            if (launch_env<true>(ctx, m, &q, (void *)sg)) rc = 1;
         }
     }
     for (int g = 1; g < groups; g++) {
         NP_HIP(hipEventRecord(ctx->group_events[g], ctx->group_streams[g - 1]));
         NP_HIP(hipStreamWaitEvent(st, ctx->group_events[g], 0));
     }
-    return 0;
+    return rc;
 }
 
 int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int use_proper_time_limits,

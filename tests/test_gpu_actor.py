@@ -136,6 +136,28 @@ def test_planning_inner_loop_row_groups_equal_the_launch_by_launch_path(golden_d
     assert envs[0].termination_counts() == envs[1].termination_counts()
 
 
+def test_planning_inner_loop_rejects_bad_arguments(golden_dir):
+    """np_planning_inner_loop fails loudly (no launch) on aliased ping-pong buffers and on an impossible group count."""
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    w = pack_ppo_actor(_sd(np.load(f'{golden_dir}/actor_kat.npz')))
+    n = 128
+    env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=1, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+    b = env._batch
+    b.reset(want_obs=False)
+    tgt3 = torch.zeros((3, n), device='cuda')
+    ll = [b.lowlevel_obs(tgt3), torch.empty((n, 22), device='cuda')]
+    rnn = [torch.zeros((n, 128), device='cuda'), torch.zeros((n, 128), device='cuda')]
+    masks, act, fl = torch.ones(n, device='cuda'), torch.empty((n, 4), device='cuda'), torch.empty((3, n), dtype=torch.uint8, device='cuda')
+    s0 = b.s.clone()
+    with pytest.raises(RuntimeError, match='ping-pong'):
+        b.planning_inner_loop(env.controller.weights, ll, [rnn[0], rnn[0]], masks, act, tgt3, fl, 50)
+    with pytest.raises(RuntimeError, match='groups'):
+        b.planning_inner_loop(env.controller.weights, ll, rnn, masks, act, tgt3, fl, 50, groups=9)
+    torch.cuda.synchronize()
+    assert torch.equal(b.s, s0), 'a rejected call must not have launched anything'
+
+
 def test_misaligned_recurrent_state(golden_dir):
     """h_in / h_out are read and written 16 bytes at a time: the raw entry point rejects a misaligned pointer loudly, the
     FusedActor wrapper realigns a view at an odd storage offset and returns the same result."""
