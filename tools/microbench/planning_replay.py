@@ -31,6 +31,9 @@ rp.replay.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
 for G in groups_list:
     sizes = [n // G + (1 if g < n % G else 0) for g in range(G)]
+    if os.environ.get('NP_REPLAY_SIZES'):      # explicit group sizes, e.g. 8192,1808
+        sizes = [int(x) for x in os.environ['NP_REPLAY_SIZES'].split(',')]
+        n, G = sum(sizes), len(sizes)
     envs = [PlanningEnv(num_envs=m, config='tracking', model='F16', random_seed=g, device=dev, controller=FusedActor(w, dev)) for g, m in enumerate(sizes)]
     streams = [torch.cuda.Stream(device=dev) for _ in envs]
     keep, per_group = [], []
