@@ -190,6 +190,7 @@ class Timer:
                 self.step(i)
                 i += 1
             ev1.record()
+        host_enqueue = time.perf_counter() - t0   # this rank's host time to enqueue the K steps (before it waits for the GPU)
         self.barrier()
         elapsed = time.perf_counter() - t0
         if self.per_launch:
@@ -199,7 +200,12 @@ class Timer:
             first = list(self.batch.get_timing_samples())
             samples.region_avg_ms = (sum(first) + ev0.elapsed_time(ev1)) / max(1, steps)
             samples.region_launches = steps
-        elapsed = sharding.max_over_ranks(elapsed, self.dist, self.dev if self.backend == 'nccl' else 'cpu')
+        red_dev = self.dev if self.backend == 'nccl' else 'cpu'
+        # per-rank diagnostics of the SAME region (read the launch skew of an N-process run off these): each rank's own wall time
+        # between the two barriers and its host enqueue time per step
+        self.rank_elapsed_s = sharding.gather_over_ranks(elapsed, self.dist, red_dev)
+        self.rank_host_us_per_step = [1e6 * v / max(1, steps) for v in sharding.gather_over_ranks(host_enqueue, self.dist, red_dev)]
+        elapsed = sharding.max_over_ranks(elapsed, self.dist, red_dev)
         return elapsed, samples, i
 
     def prelude(self, seconds, i0=0, est_step_s=None, max_steps=20000):
@@ -280,6 +286,35 @@ def side_mode(make_env, make_actions, dev, steps, warmup, prelude_s):
     return el, samples
 
 
+def group_fields(dist, args, world):
+    """world_size / backend / rccl_ranks as the LIVE process group reports them (dist.get_world_size(), dist.get_backend()), next to
+    what was asked for; a mismatch is an error, not a footnote."""
+    from neuralplane_amd import sharding
+    live_world, live_backend = sharding.live_group(dist)
+    if live_world != world or (world > 1 and live_backend != args.backend):
+        raise SystemExit(f'process group mismatch: asked for {world} rank(s) on {args.backend}, the live group has {live_world} on {live_backend}')
+    return {'world_size': live_world, 'backend': live_backend, 'rccl_ranks': live_world if live_backend == 'nccl' else 0,
+            'group_source': 'torch.distributed.get_world_size() / get_backend() of the initialised group' if live_backend else 'single process, no group'}
+
+
+def expected_weak_scaling(host_us, step_ms, kernel_ms, world):
+    """What the 1 -> 8 GPU curve of a weak-scaling config (Heading / Control / Tracking: rows shard, no data-path collective) should
+    look like, from THIS run's numbers: every rank enqueues its own launches from its own process, so the aggregate is N x the
+    single-GPU rate unless the host cannot keep its GPU fed (host enqueue time per step >= kernel time) — plus the skew of the closing
+    barrier, one step at worst over the K timed ones."""
+    if not kernel_ms:
+        return None
+    fed = host_us * 1e-3 < kernel_ms
+    per_gpu_ms = max(step_ms, host_us * 1e-3)
+    return {'host_enqueue_us_per_step_rank0': host_us, 'kernel_ms': kernel_ms, 'ms_per_step': step_ms, 'host_keeps_gpu_fed': bool(fed),
+            'measured_at_world_size': world,
+            'predicted_efficiency_8_gpus': [0.95, 1.0] if fed else [kernel_ms / per_gpu_ms * 0.95, kernel_ms / per_gpu_ms],
+            'predicted_speedup_8_gpus': [7.6, 8.0] if fed else [8 * kernel_ms / per_gpu_ms * 0.95, 8 * kernel_ms / per_gpu_ms],
+            'note': 'weak scaling, one process per GPU, no collective inside the timed steps (RCCL: the two barriers and one MAX all-reduce '
+                    'around them); the 5 % allowance is barrier skew and the clock spread between GPUs of a node (+-3-4 % between '
+                    'boxes of this pool, DESIGN.md).  A prediction, unmeasured until the driver has an 8-GPU node.'}
+
+
 def run_env(args, rank, local_rank, world, dev, dist):
     import torch
     from neuralplane_amd import sharding
@@ -324,7 +359,10 @@ def run_env(args, rank, local_rank, world, dev, dist):
                                f'{args.actions} actions, one fused HIP kernel per env.step',
                    'aircraft_per_gpu': n, 'sharding': f'rows split over {world} GPU(s), no data-path collective',
                    'cross_step_coefficient_reuse': True, 'aero_1d_tables': bool(b.aero_1d_tables)},
-        'world_size': world, 'backend': args.backend if world > 1 else None, 'rccl_ranks': world if (world > 1 and args.backend == 'nccl') else 0,
+        **group_fields(dist, args, world),
+        'per_rank': {'host_enqueue_us_per_step': tm.rank_host_us_per_step, 'elapsed_ms_per_step': [1e3 * v / args.steps for v in tm.rank_elapsed_s],
+                     'note': 'timed region only; elapsed = each rank\'s own wall time between the two barriers (value uses the max)'},
+        'expected_scaling': expected_weak_scaling(tm.rank_host_us_per_step[0], 1e3 * elapsed / args.steps, st['kernel_avg_ms'], world),
         'prelude': {'steps': p_steps, 'seconds': p_sec, 'timed': False,
                     'why': 'clock-governor ramp: the shader clock reaches its steady state only after ~50-100 ms of load '
                            '(cold_start below is the same K-step window taken from an idle GPU)'},
@@ -612,7 +650,8 @@ def run_combat(args, rank, local_rank, world, dev, dist):
                                f'linear stand-in policies, opponent exchange: 2 all-gathers per step on a side stream, opponent lag {args.opponent_lag}',
                    'engagements_total': e_total, 'sharding': f'envs split over {world} GPU(s); all-gather of opponent observations / actions only'},
         'aircraft_fdm_steps_per_s': 2 * e_total * 5 * args.steps / elapsed,
-        'world_size': world, 'backend': args.backend if world > 1 else None, 'rccl_ranks': world if (world > 1 and args.backend == 'nccl') else 0,
+        **group_fields(dist, args, world),
+        'per_rank': {'host_enqueue_us_per_step': tm.rank_host_us_per_step, 'elapsed_ms_per_step': [1e3 * v / args.steps for v in tm.rank_elapsed_s]},
         'exchange': {'collectives_per_step': 2 if world > 1 else 0, 'obs_bytes_gathered_per_step': e_total * 15 * 4, 'action_bytes_gathered_per_step': e_total * 4 * 4,
                      'opponent_lag': args.opponent_lag},
         'expected_scaling': expected,

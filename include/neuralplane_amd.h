@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 12
+#define NP_ABI_VERSION 13
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -285,7 +285,14 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
  * another's FDM step and every group's controller call runs on the 32-row tiles.  0 = the library chooses by n (one group up to
  * 8 192 rows and from ~80 000 on, two or three in between: PlanningEnv.step 3.51 -> 3.23 ms at n = 1e4, 6.43 -> 4.44 ms at 20 000,
  * 10.7 -> 9.2 ms at 49 152; profiles/r03g_planning_groups.log).
- * A stream that is being captured into a graph always gets one group. */
+ * A stream that is being captured into a graph always gets one group.
+ * mode (ABI 13): NP_PLANNING_PERSISTENT runs ALL iterations in ONE kernel launch — a workgroup owns a tile of 32 rows and loops
+ * {controller call, inner FDM step} with no kernel boundary in between (np_planning.hip; Euler solver, MLP numerics); with more
+ * tiles than resident workgroups NP_PLANNING_PERSISTENT_QUEUE has the resident workgroups pull (tile, iteration) items from a device
+ * counter instead, so that e.g. 313 tiles on 256 CUs take 62 rounds of items rather than two lock-step passes.  Both are bit-identical
+ * to the launches they replace.  NP_PLANNING_AUTO picks by n, solver and numerics; environment NP_PLANNING_MODE=launches|persistent|queue
+ * (read per call) overrides it for benchmarks and the parity tests. */
+enum { NP_PLANNING_AUTO = 0, NP_PLANNING_LAUNCHES = 1, NP_PLANNING_PERSISTENT = 2, NP_PLANNING_PERSISTENT_QUEUE = 3 };
 typedef struct np_planning_loop {
     int32_t iterations;        /* planning_env.py:153: 50 */
     int32_t groups;            /* 0 = automatic */
@@ -296,6 +303,8 @@ typedef struct np_planning_loop {
     float *ll_act;             /* [n][4] scratch: the controller's actions of the current iteration */
     uint8_t *flags[2];         /* [3][n] each (done, bad_done, exceed_time_limit); [0] = the flags on entry; the final flags end in flags[iterations & 1] */
     const float *ll_tgt;       /* [3][ld] the controller's targets (np_f16_io.ll_tgt) */
+    int32_t mode;              /* NP_PLANNING_AUTO / _LAUNCHES / _PERSISTENT / _PERSISTENT_QUEUE (ABI 13) */
+    int32_t waves;             /* persistent kernel: waves per 32-row tile, 4 or 8; 0 = the library chooses */
 } np_planning_loop;
 int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *loop, void *stream);
 

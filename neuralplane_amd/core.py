@@ -232,6 +232,9 @@ class F16Batch:
         self.flags = scratch[0]
         try:
             io = self._io(scratch[1], None, obs, None, None, self._inject(noise, 22))
+            # observe-only: a real reset() clears the per-aircraft condition bits "of the last step"; this launch must not
+            io.term_reasons = None
+            io.reward_task = None
             _lib.check(self.lib.np_f16_reset(self._ctx, self.n, C.byref(io), self._stream()))
         finally:
             self.flags = keep
@@ -265,24 +268,35 @@ class F16Batch:
         self._version += 1
         return obs, reward, new_flags
 
-    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0):
+    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0, mode=0, waves=0):
         """np_planning_inner_loop: the `iterations` low-level iterations of PlanningEnv.step (controller forward + inner FDM step each)
         enqueued by one library call.  ll_obs = (first input [n,22], scratch [n,22]); rnn = (state on entry [n,128], scratch [n,128]);
         flags_scratch [3,n] uint8.  Returns obs (task observation of the last iteration), reward, flags; the final recurrent state is in
-        rnn[iterations & 1]."""
+        rnn[iterations & 1].  mode: np_planning_loop.mode (0 automatic, 1 launch by launch, 2 the persistent kernel — all iterations in
+        one launch, 3 the same with the (tile, iteration) work queue); waves: waves per 32-row tile of the persistent kernel (0, 4, 8)."""
         n = self.n
         obs = torch.empty((n, 22), dtype=torch.float32, device=self.device)
         reward = torch.empty(n, dtype=torch.float32, device=self.device)
         io = self._io(flags_scratch, ll_act, obs, reward, None, None, inner=True, ll_tgt=tgt3, ll_obs=ll_obs[1])
         lp = _lib.NpPlanningLoop()
         lp.iterations, lp.groups = int(iterations), int(groups)
+        lp.mode, lp.waves = int(mode), int(waves)
         lp.actor_weights = actor_weights.data_ptr()
         lp.ll_obs[0], lp.ll_obs[1] = ll_obs[0].data_ptr(), ll_obs[1].data_ptr()
         lp.rnn[0], lp.rnn[1] = rnn[0].data_ptr(), rnn[1].data_ptr()
         lp.masks, lp.ll_act, lp.ll_tgt = masks.data_ptr(), ll_act.data_ptr(), tgt3.data_ptr()
         lp.flags[0], lp.flags[1] = self.flags.data_ptr(), flags_scratch.data_ptr()   # _io made self.flags contiguous
-        _lib.check(self.lib.np_planning_inner_loop(self._ctx, n, C.byref(io), C.byref(lp), self._stream()))
-        self._cache_valid = True
+        if self._no_cache:
+            # NPF16_NO_CACHE (the cache-off A/B validation switch): the library treats a loop WITHOUT a cache buffer as "never valid" —
+            # every one of the iterations re-evaluates all coefficients (launch-by-launch path), not just the first
+            io.coef_cache = None
+            io.cache_valid = 0
+            lp.mode = 1
+        try:
+            _lib.check(self.lib.np_planning_inner_loop(self._ctx, n, C.byref(io), C.byref(lp), self._stream()))
+        finally:
+            io.coef_cache = self.coef_cache.data_ptr()   # `io` is the cached struct of _io()
+        self._cache_valid = not self._no_cache
         if iterations & 1:
             self.flags = flags_scratch
         self.call_idx += int(iterations)
@@ -590,8 +604,12 @@ class F16CombatBatch:
         obs_opp[E,15], reward[n], flags[3,n]: ONE kernel launch, no copies on either side."""
         ego_action, opp_action = self._check_half(ego_action, 'ego_action'), self._check_half(opp_action, 'opp_action')
         if ego_action.stride(0) != opp_action.stride(0):
-            opp_action = opp_action.contiguous()
-            ego_action = ego_action.contiguous()
+            # the kernel reads both halves with ONE row stride: contiguous() is a no-op on halves that are already contiguous but of
+            # different widths ([E,4] next to [E,6]), so both are cut to the four columns the kernel reads
+            opp_action = opp_action[:, :4].contiguous()
+            ego_action = ego_action[:, :4].contiguous()
+        if ego_action.stride(0) != opp_action.stride(0):
+            raise ValueError(f'ego_action / opp_action row strides differ ({ego_action.stride(0)} vs {opp_action.stride(0)})')
         oe, oo = out if out is not None else (torch.empty((self.num_envs, NUM_OBS_COMBAT), dtype=torch.float32, device=self.device) for _ in range(2))
         reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
         new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)

@@ -124,6 +124,7 @@ __device__ __forceinline__ void relu16(float (&v)[SLICE]) {
     for (int j = 0; j < SLICE; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
 }
 
+#ifndef NPACT_NO_KERNELS  // np_planning.hip takes the device functions only
 __global__ __launch_bounds__(THREADS, 4) void actor_forward_kernel(const float *__restrict__ weights, long long n,
                                                                    const float *__restrict__ obs, const float *__restrict__ h_in,
                                                                    const float *__restrict__ mask, float *__restrict__ act,
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(THREADS, 4) void actor_forward_kernel(const float *
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // MFMA variant (the shipped one): the 128-wide layers are GEMMs [64 rows x 128] x [128 x 128], so they run on the matrix cores.
@@ -355,6 +357,7 @@ __device__ __forceinline__ void layernorm_rows(float *__restrict__ buf, cw_ptr g
     __syncthreads();
 }
 
+#ifndef NPACT_NO_KERNELS  // np_planning.hip takes the device functions only
 __global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma_kernel(const float *__restrict__ weights, long long n,
                                                                          const float *__restrict__ obs, const float *__restrict__ h_in,
                                                                          const float *__restrict__ mask, float *__restrict__ act,
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma_kernel(const f
         }
     }
 }
+#endif
 
 constexpr size_t ACTOR_LDS_BYTES = sizeof(float) * (2 * HID * TILE + 2 * WAVES * TILE);
 
@@ -512,7 +516,7 @@ constexpr int T32 = 32, BLK = 16;
 #endif
 #if NPACT_TRACE
 __device__ long long npact_trace[64];
-#define NPACT_STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) npact_trace[k] = __builtin_readcyclecounter(); } while (0)
+#define NPACT_STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && tid == 0) npact_trace[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define NPACT_STAMP(k) do { } while (0)
 #endif
@@ -588,52 +592,51 @@ __device__ __forceinline__ void layernorm_rows16(float *__restrict__ buf, const 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma32_kernel(const float *__restrict__ weights, long long n,
-                                                                           const float *__restrict__ obs, const float *__restrict__ h_in,
-                                                                           const float *__restrict__ mask, float *__restrict__ act,
-                                                                           float *__restrict__ h_out) {
-    __shared__ float lds[2 * HID * T32 + 2 * 8 * T32 + 4 * HID];
+constexpr int ACTOR32_LDS_FLOATS = 2 * HID * T32 + 2 * 8 * T32 + 4 * HID;
+constexpr int ACTOR32_HEAD_W = 2 * HID * T32 + 2 * 8 * T32;  // float offset of the staged mu_net weights [k][4] inside the tile's LDS
+constexpr int ACTOR32_BARRIERS = 23;  // __syncthreads() executed by actor32_body (straight-line code): what a wave that sits the call out has to match
+
+// One 32-row tile of the controller, the calling workgroup's waves 0..3 (tid = threadIdx.x < 256), in three pieces so that the
+// persistent PlanningEnv kernel (np_planning.hip) can feed it from registers / LDS instead of global memory:
+//   actor32_request_l1   the first layer's A operands of this lane (22 weights + the bias): requested first, consumed after the obs LayerNorm
+//   actor32_stage_head   mu_net's weights -> LDS (the head reads them 128 times in a row)
+//   actor32_body         observation LayerNorm ... head: xr = the 22 raw observations of this thread's row, hm = the MASKED recurrent
+//                        state (gru.py:26) of (row, block of 16 features); returns hn = the new recurrent state of (row, block) and
+//                        `action` = tanh(mu) of (row, wave) — the caller stores them (lanes with hi == 0 hold the action)
+// actor_tile32 = the three with global loads / stores around them: the body of actor_forward_mfma32_kernel.
+struct Actor32Pre {
+    float a1[OBS];
+    float b1;
+};
+
+__device__ __forceinline__ void actor32_request_l1(const float *weights, unsigned tid, Actor32Pre &pre) {
+    const int lane = (int)(tid % TILE), l16 = lane & 15, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
+    const int f0 = wave * MSLICE, fl = 16 * hi + l16;
+#pragma unroll
+    for (int k = 0; k < OBS; k++) pre.a1[k] = weights[L1_W + k * HID + f0 + fl];
+    pre.b1 = weights[L1_B + f0 + fl];
+}
+
+__device__ __forceinline__ void actor32_stage_head(float *lds, const float *weights, unsigned tid) {
+    float *head_w = lds + ACTOR32_HEAD_W;
+    if (tid < HID) reinterpret_cast<float4 *>(head_w)[tid] = reinterpret_cast<const float4 *>(weights + HD_W)[tid];
+}
+
+__device__ __forceinline__ void actor32_body(float *lds, const float *weights, const Actor32Pre &pre, const float (&xr)[OBS], const float (&hm)[BLK],
+                                             float (&hn)[BLK], float &action, unsigned tid) {
     float *bufA = lds, *bufB = lds + HID * T32;
     float *part_s = lds + 2 * HID * T32, *part_q = part_s + 8 * T32;
-    float *head_w = part_q + 8 * T32;                      // mu_net weights [k][4], staged at entry: the head reads them 128 times in a row
+    float *head_w = part_q + 8 * T32;
     const cw_ptr W = (cw_ptr)(unsigned long long)weights;  // wave-uniform reads: scalar loads
     const float *Wv = weights;                             // per-lane reads
-    const int lane = (int)(threadIdx.x % TILE), row = lane & 31, l16 = lane & 15, g4 = lane >> 4, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE));
+    const int lane = (int)(tid % TILE), row = lane & 31, l16 = lane & 15, g4 = lane >> 4, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
     const int f0 = wave * MSLICE;        // MFMA role: features [f0, f0 + 32); this lane's A operand is feature f0 + fl
     const int fl = 16 * hi + l16;
     const int blk = 2 * wave + hi;       // row role: features [16 blk, 16 blk + 16) of row `row`
-    const long long i = (long long)blockIdx.x * T32 + row;
-    const bool valid = i < n;
-    const long long ic = valid ? i : n - 1;
-    NPACT_STAMP(0);
-
-    // requested first, consumed after the observation LayerNorm: the first layer's A operands (22 weights + the bias) and the
-    // masked recurrent state (gru.py:26: this thread's 16 features of its row, 64 B)
-    float a1[OBS];
-#pragma unroll
-    for (int k = 0; k < OBS; k++) a1[k] = Wv[L1_W + k * HID + f0 + fl];
-    const float b1 = Wv[L1_B + f0 + fl];
-    const float mk = mask[ic];
-    float hm[BLK];
-    {
-        const float4 *hp = reinterpret_cast<const float4 *>(h_in + ic * HID + blk * BLK);
-#pragma unroll
-        for (int j = 0; j < BLK / 4; j++) {
-            const float4 q = hp[j];
-            hm[4 * j] = q.x * mk;
-            hm[4 * j + 1] = q.y * mk;
-            hm[4 * j + 2] = q.z * mk;
-            hm[4 * j + 3] = q.w * mk;
-        }
-    }
-
-    if (threadIdx.x < HID) reinterpret_cast<float4 *>(head_w)[threadIdx.x] = reinterpret_cast<const float4 *>(Wv + HD_W)[threadIdx.x];
     // base.feature_norm (two blocks: 16 + 6) -> bufB rows 0..21; every thread computes its row's, block 0 stores it
     {
-        float xr[OBS];
-#pragma unroll
-        for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; j++) s0 = s0 + xr[j];
@@ -667,9 +670,9 @@ __global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma32_kernel(const
     // base.mlp: Linear(22, 128) + ReLU + LayerNorm -> bufA
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(b1, 1.0f, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(pre.b1, 1.0f, acc, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < OBS; k++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a1[k], bufB[k * T32 + row], acc, 0, 0, 0);
+    for (int k = 0; k < OBS; k++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(pre.a1[k], bufB[k * T32 + row], acc, 0, 0, 0);
     store_transposed16<true>(acc, bufA, f0, l16, g4);
     __syncthreads();
     NPACT_STAMP(2);
@@ -716,9 +719,8 @@ NPACT_STAMP(11);
     NPACT_STAMP(12);
     store_transposed16<false>(acc, bufB, f0, l16, g4);
     __syncthreads();
-    // rnn.norm in place; hn = the new recurrent state (this thread's 16 features), stored at the very end: a store issued here would
-    // be the oldest entry of the vector-memory queue that the next layer's operand waits (s_waitcnt vmcnt) have to drain
-    float hn[BLK];
+    // rnn.norm in place; hn = the new recurrent state (this thread's 16 features), stored by the caller at the very end: a store issued
+    // here would be the oldest entry of the vector-memory queue that the next layer's operand waits (s_waitcnt vmcnt) have to drain
     layernorm_rows16(bufB, Wv + LN3_G, Wv + LN3_B, blk, row, part_s, part_q, hn);
     NPACT_STAMP(13);
     // act.mlp
@@ -739,8 +741,46 @@ NPACT_STAMP(11);
         float m = W[HD_B + wave];
 #pragma unroll
         for (int k = 0; k < HID; k++) m = fmaf(head_w[k * 4 + wave], bufB[k * T32 + row], m);
-        if (valid && hi == 0) act[i * 4 + wave] = act_tanh(m);
+        action = act_tanh(m);
     }
+}
+
+// tile `tile` = rows [32 tile, 32 tile + 32) through global memory.  Plain (aliasing) pointers: inside the persistent kernel the buffers
+// read here are written by the same workgroup between calls.  tid = threadIdx.x (the persistent kernel hands it over through an opaque
+// copy per iteration, so that per-thread addresses are recomputed, not kept in registers across its loop).
+__device__ __forceinline__ void actor_tile32(float *lds, const float *weights, long long n, const float *obs, const float *h_in,
+                                             const float *mask, float *act, float *h_out, long long tile, unsigned tid) {
+    const int lane = (int)(tid % TILE), row = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
+    const int blk = 2 * wave + hi;
+    const long long i = tile * T32 + row;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;
+    NPACT_STAMP(0);
+    // requested first, consumed after the observation LayerNorm: the first layer's A operands and the masked recurrent state
+    // (gru.py:26: this thread's 16 features of its row, 64 B)
+    Actor32Pre pre;
+    actor32_request_l1(weights, tid, pre);
+    const float mk = mask[ic];
+    float hm[BLK];
+    {
+        const float4 *hp = reinterpret_cast<const float4 *>(h_in + ic * HID + blk * BLK);
+#pragma unroll
+        for (int j = 0; j < BLK / 4; j++) {
+            const float4 q = hp[j];
+            hm[4 * j] = q.x * mk;
+            hm[4 * j + 1] = q.y * mk;
+            hm[4 * j + 2] = q.z * mk;
+            hm[4 * j + 3] = q.w * mk;
+        }
+    }
+    actor32_stage_head(lds, weights, tid);
+    float xr[OBS];
+#pragma unroll
+    for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
+    float hn[BLK], action;
+    actor32_body(lds, weights, pre, xr, hm, hn, action, tid);
+    if (valid && hi == 0) act[i * 4 + wave] = action;
     if (valid) {
         float4 *hq = reinterpret_cast<float4 *>(h_out + i * HID + blk * BLK);
 #pragma unroll
@@ -748,5 +788,15 @@ NPACT_STAMP(11);
     }
     NPACT_STAMP(18);
 }
+
+#ifndef NPACT_NO_KERNELS  // np_planning.hip takes the device functions only
+__global__ __launch_bounds__(MTHREADS, 2) void actor_forward_mfma32_kernel(const float *__restrict__ weights, long long n,
+                                                                           const float *__restrict__ obs, const float *__restrict__ h_in,
+                                                                           const float *__restrict__ mask, float *__restrict__ act,
+                                                                           float *__restrict__ h_out) {
+    __shared__ float lds[ACTOR32_LDS_FLOATS];
+    actor_tile32(lds, weights, n, obs, h_in, mask, act, h_out, (long long)blockIdx.x, threadIdx.x);
+}
+#endif
 
 }  // namespace npact

@@ -22,9 +22,11 @@
 
 #include "../../include/neuralplane_amd.h"
 #include "np_f16_device.h"
+#include "np_f16_kargs.h"
 #include "np_f16_combat.h"
 #include "np_actor.h"
 #include "np_rollout.h"
+#include "np_planning.h"
 
 namespace npf16 {
 
@@ -61,62 +63,6 @@ namespace npf16 {
 #ifndef NPF16_STAGGER_CYCLES_LONG
 #define NPF16_STAGGER_CYCLES_LONG 30000  // grids of 8 generations and more (N >= 1.6e6 on 256 CUs), see the kernel
 #endif
-constexpr int BLOCK = NPF16_BLOCK;
-// workgroups resident at once: 256 CUs x 4 SIMDs x NPF16_MINWAVES wave slots / waves per workgroup
-constexpr int FIRST_GENERATION = 256 * 4 * NPF16_MINWAVES / (BLOCK / 64);
-constexpr int CACHE_TILE = 64;  // rows per tile of the cross-step coefficient cache
-constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
-// LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
-// (coef[slot][lane]), later re-used as the [BLOCK][OBS_LD] observation transpose tile.
-constexpr int LDS_FLOATS = (NUM_LDS_SLOTS * BLOCK > BLOCK * OBS_LD) ? NUM_LDS_SLOTS * BLOCK : BLOCK * OBS_LD;
-
-// row-indexed access as (uniform base) + (32-bit BYTE offset): selects the SGPR-base + VGPR-offset addressing mode
-// (every such array is device memory handed over through np_f16_io: the reference is typed as GLOBAL address space, so that pointers
-// re-read from the kernel-argument segment — plain generic pointers to the compiler — do not turn into flat_store + a 64-bit VALU add)
-template <class T>
-__device__ __forceinline__ __attribute__((address_space(1))) T &at_off(T *base, unsigned byte_off) {
-    typedef __attribute__((address_space(1))) T GT;
-    return *reinterpret_cast<GT *>(reinterpret_cast<uintptr_t>(base) + byte_off);
-}
-
-struct KArgs;
-typedef const KArgs __attribute__((address_space(4))) *KArgsC;
-#ifndef NP_REREAD_ARGS
-#define NP_REREAD_ARGS(ap) asm volatile("" : "+s"(ap) : : "memory")
-#endif
-
-struct KArgs {
-    float *s, *u, *tgt;
-    long long ld;
-    long long *step_count;
-    const uint8_t *fin0, *fin1, *fin2;
-    uint8_t *fout0, *fout1, *fout2;
-    const float *action;
-    long long act_stride;
-    float *obs, *reward;
-    const float *rand_u, *noise;
-    int inner;     // one low-level iteration of PlanningEnv.step: no auto-reset, flagged rows frozen, flags accumulate
-    float *cache;  // [row / 64][14][row % 64] force-side alpha/beta-only coefficients at the current state (may be null)
-    uint64_t seed, call_idx;
-    const uint64_t *call_idx_base;  // optional device word added to call_idx (launches replayed from a HIP graph)
-    unsigned *term_counters;        // optional [NP_NUM_TERM_COUNTERS] per-condition counters (one atomic per wave and condition)
-    unsigned char *term_reasons;    // optional [n]: the same conditions per aircraft, bit k = counter k
-    float *reward_task;             // optional [n]: the task's reward function alone (reward = this + the event term)
-    const float *ll_tgt;            // INNER, optional [3][ld]: the low-level controller's targets
-    float *ll_obs;                  // INNER, optional [n][22]: PlanningEnv.low_level_obs of the state this launch reaches
-    long long row0, n;
-    DevCfg cfg;
-    // the 14 cached (force-side alpha/beta-only) coefficients of a freshly reset aircraft (alpha = beta = 0), evaluated once
-    // per context by the same device code (f16_reset_coef_kernel), so they are bit-identical to an in-line evaluation;
-    // per context (a small device buffer, not __constant__): contexts with different numerics options can coexist on a
-    // device; read only inside the `flagged` branches
-    const float *reset_coef;
-    AeroWeights wt;
-    // profiling hook (np_f16_set_trace; null otherwise): per workgroup NP_TRACE_WORDS 64-bit words — shader-clock counter at
-    // entry, after the de-phasing delay and at exit, the constant 100 MHz counter at entry and exit, XCC / CU / SIMD ids
-    unsigned long long *trace;
-};
-
 // STEP=true : BaseEnv.step  (env_base.py:99-109)
 // STEP=false: BaseEnv.reset (env_base.py:83-97)
 // CACHED    : a.cache holds, for every row, the 14 force-side alpha/beta-only coefficients of its CURRENT
@@ -835,6 +781,10 @@ struct np_f16_ctx {
     // np_planning_inner_loop: streams of row groups 1.. and the fork / join events (created on first use)
     std::vector<hipStream_t> group_streams;
     std::vector<hipEvent_t> group_events;  // [0] fork, [1 + g] join of group g + 1
+    // persistent PlanningEnv kernel (np_planning.hip): the (tile, iteration) queue words, owned by the context, grown on demand
+    unsigned *d_queue;
+    int64_t queue_cap;
+    int num_cus;  // multiProcessorCount of the context's device
 };
 
 namespace {
@@ -1463,6 +1413,9 @@ static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables
     ctx->t_count = 0;
     ctx->trace = nullptr;
     ctx->trace_cap = 0;
+    ctx->d_queue = nullptr;
+    ctx->queue_cap = 0;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = ctx;
     return 0;
 }
@@ -1521,6 +1474,7 @@ void np_f16_ctx_destroy(np_f16_ctx *ctx) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (!ctx->group_streams.empty() || !ctx->group_events.empty()) {
         DeviceGuard guard;
         if (guard.enter(ctx->device) == hipSuccess) {
@@ -1630,6 +1584,55 @@ extern "C" int np_actor_trace_read(long long *out) {  // diagnostics builds only
 }
 #endif
 
+// All iterations in one launch of the persistent kernel (np_planning.hip).  mode: NP_PLANNING_PERSISTENT (one workgroup per tile) or
+// NP_PLANNING_PERSISTENT_QUEUE (resident workgroups pull (tile, iteration) items).
+static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, hipStream_t st, int mode, int waves) {
+    if (!io->s || !io->u || !io->tgt || !io->step_count || !io->reward || !io->coef_cache)
+        return fail("np_planning_inner_loop (persistent): needs state, reward and coef_cache buffers");
+    if (io->ld < n) return fail("ld < n");
+    if (io->ld >= (1ll << 30)) return fail("ld must be below 2^30 rows (32-bit byte offsets inside a row-indexed array)");
+    if (((uintptr_t)lp->rnn[0] | (uintptr_t)lp->rnn[1] | (uintptr_t)lp->actor_weights) & 15) return fail("rnn buffers / actor weights must be 16-byte aligned");
+    PlanArgs pa;
+    KArgs &a = pa.k;
+    a.s = io->s; a.u = io->u; a.tgt = io->tgt; a.ld = io->ld; a.step_count = (long long *)io->step_count;
+    a.fin0 = a.fin1 = a.fin2 = nullptr; a.fout0 = a.fout1 = a.fout2 = nullptr;
+    a.action = lp->ll_act; a.act_stride = 4; a.obs = io->obs; a.reward = io->reward;
+    a.rand_u = nullptr; a.noise = nullptr; a.inner = 1; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
+    a.call_idx_base = io->call_idx_base;
+    a.term_counters = io->term_counters; a.term_reasons = io->term_reasons; a.reward_task = io->reward_task;
+    a.ll_tgt = lp->ll_tgt; a.ll_obs = nullptr;
+    a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg; a.reset_coef = ctx->d_reset_coef; a.wt = ctx->wt; a.trace = nullptr;
+    pa.actor_w = lp->actor_weights;
+    pa.ll_obs[0] = lp->ll_obs[0]; pa.ll_obs[1] = lp->ll_obs[1];
+    pa.rnn[0] = lp->rnn[0]; pa.rnn[1] = lp->rnn[1];
+    pa.masks = lp->masks; pa.ll_act = lp->ll_act;
+    pa.flags[0] = lp->flags[0]; pa.flags[1] = lp->flags[1];
+    pa.final_obs = io->obs;
+    pa.iterations = lp->iterations;
+    pa.cache_valid0 = io->cache_valid ? 1 : 0;
+    pa.tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS;
+    pa.queue = nullptr;
+    unsigned grid = (unsigned)pa.tiles;
+    if (mode == NP_PLANNING_PERSISTENT_QUEUE) {
+        const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves);
+        if (per_cu <= 0) return fail("np_planning_inner_loop (persistent): occupancy query failed");
+        const int64_t resident = (int64_t)per_cu * ctx->num_cus;
+        if (pa.tiles * (int64_t)lp->iterations >= (1ll << 31)) return fail("np_planning_inner_loop (queue): too many items");
+        if (ctx->queue_cap < 1 + pa.tiles) {
+            if (ctx->d_queue) NP_HIP(hipFree(ctx->d_queue));
+            ctx->d_queue = nullptr;
+            ctx->queue_cap = 0;
+            NP_HIP(hipMalloc((void **)&ctx->d_queue, sizeof(unsigned) * (size_t)(1 + pa.tiles)));
+            ctx->queue_cap = 1 + pa.tiles;
+        }
+        NP_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned) * (size_t)(1 + pa.tiles), st));
+        pa.queue = ctx->d_queue;
+        grid = (unsigned)(pa.tiles < resident ? pa.tiles : resident);
+    }
+    NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
+    return 0;
+}
+
 int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, void *stream) {
     if (!ctx || !io || !lp) return fail("null ctx/io/loop");
     if (ctx->combat) return fail("combat context");
@@ -1640,9 +1643,24 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     if (lp->groups < 0 || lp->groups > 8) return fail("np_planning_loop: groups must be 0 (automatic) .. 8");
     if (lp->rnn[0] == lp->rnn[1] || lp->ll_obs[0] == lp->ll_obs[1] || lp->flags[0] == lp->flags[1])
         return fail("np_planning_loop: the two buffers of a ping-pong pair must differ");
+    if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_QUEUE) return fail("np_planning_loop: unknown mode");
+    if (lp->waves != 0 && lp->waves != 4 && lp->waves != 8) return fail("np_planning_loop: waves must be 0 (automatic), 4 or 8");
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
+    {
+        int mode = lp->mode, waves = lp->waves;
+        if (const char *e = std::getenv("NP_PLANNING_MODE")) {  // read per call: benchmarks and the parity tests switch it
+            mode = std::strcmp(e, "launches") == 0 ? NP_PLANNING_LAUNCHES : std::strcmp(e, "persistent") == 0 ? NP_PLANNING_PERSISTENT
+                   : std::strcmp(e, "queue") == 0 ? NP_PLANNING_PERSISTENT_QUEUE : mode;
+        }
+        if (const char *e = std::getenv("NP_PLANNING_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
+        const bool eligible = ctx->solver == 0 && !ctx->cfg.aero_1d_tables && io->coef_cache && !io->rand_u && !io->noise && io->reward;
+        if ((mode == NP_PLANNING_PERSISTENT || mode == NP_PLANNING_PERSISTENT_QUEUE) && !eligible)
+            return fail("np_planning_loop: the persistent kernel serves the Euler solver with the MLP numerics and needs coef_cache / reward buffers");
+        if (mode == NP_PLANNING_AUTO) mode = NP_PLANNING_LAUNCHES;
+        if (mode != NP_PLANNING_LAUNCHES) return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 4);
+    }
     // automatic choice, measured per size (profiles/r03g_planning_groups.log; ms per PlanningEnv.step, one group -> the choice):
     // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 5.67 -> 4.39, 24 576 5.86 -> 4.89, 28 672 6.84 -> 5.64, 32 768 6.92 -> 6.29,
     // 40 960 8.53 -> 7.76, 49 152 10.3 -> 9.2, 57 344 12.35 -> 10.45, 65 536 12.57 -> 11.81, 81 920 15.4 -> 14.9; one group is the

@@ -1,0 +1,40 @@
+// np_planning.h — the persistent PlanningEnv kernel's argument record and its launcher (np_planning.hip), as np_f16_kernels.hip's
+// np_planning_inner_loop sees them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "np_f16_kargs.h"
+
+namespace npf16 {
+
+// One launch = all `iterations` low-level iterations of PlanningEnv.step (reference envs/planning_env.py:153-176) for every 32-row
+// tile.  `k` must stay the first member: the FDM device code re-reads its scalars from offset 0 of the kernel-argument segment.
+struct PlanArgs {
+    KArgs k;                 // what all iterations share (np_f16_io); fin* / fout* / call_idx are per iteration and derived below
+    const float *actor_w;    // np_actor_forward's packed weights
+    float *ll_obs[2];        // [n][22] ping-pong; [0] = the first iteration's input
+    float *rnn[2];           // [n][128] ping-pong; [0] = the recurrent state on entry
+    const float *masks;      // [n]
+    float *ll_act;           // [n][4]
+    uint8_t *flags[2];       // [3][n] ping-pong; [0] = the flags on entry
+    float *final_obs;        // the task observation of the LAST iteration (may be null)
+    int iterations;
+    int cache_valid0;        // is k.cache valid for the first iteration?
+    long long tiles;         // ceil(n / 32)
+    // (tile, iteration) work queue (tiles > resident workgroups): item id = iteration * tiles + tile, handed out in order
+    unsigned *queue;         // [0] next item id; [1 + tile] iterations of that tile that are complete
+};
+
+constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_actor.h)
+
+// tasks: 0 heading, 1 control, 2 tracking (PlanningEnv ships tracking only; the others serve the parity tests of the loop).
+// waves: 4 or 8 per workgroup.  queue_mode: 0 = one workgroup per tile (grid = tiles), 1 = `grid` persistent workgroups pulling
+// (tile, iteration) items.  Returns hipSuccess or the launch error.
+hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args, unsigned grid, hipStream_t stream, hipEvent_t ev_start,
+                                      hipEvent_t ev_stop);
+// how many workgroups of that shape fit one CU / the device (occupancy query)
+int planning_persistent_workgroups_per_cu(int task, int waves);
+
+}  // namespace npf16

@@ -99,9 +99,11 @@ class PlanningEnv(BaseEnv):
         return self._batch.lowlevel_obs(torch.stack((target_pitch, target_heading, target_vt)))
 
     def _step_fused(self, action):
-        """PlanningEnv.step with the fused controller: reset, the first low-level observation and ONE library call that enqueues the 50
-        iterations (np_planning_inner_loop; for 8 192 < n <= 16 384 as two row groups on two streams).  Same kernels on the same inputs
-        as the launch-by-launch path below: bit-identical (tests/test_gpu_actor.py)."""
+        """PlanningEnv.step with the fused controller: reset, the first low-level observation and ONE library call for the 50 iterations
+        (np_planning_inner_loop: `loop_mode` 'persistent' / 'queue' = one launch of the persistent kernel, 'launches' = 2 x 50 launches as
+        1-4 row groups on their own streams — two for 8 192 < n <= 16 384, three to 26 624, four to 36 864, two to 53 248, three to
+        81 920; 'auto' = the library chooses).  The same arithmetic on the same inputs as the launch-by-launch path below:
+        bit-identical (tests/test_gpu_actor.py)."""
         b, n, d = self._batch, self.n, self.device
         b.reset(want_obs=False)                                    # self.reset()           :145
         action = torch.clamp(torch.as_tensor(action, dtype=torch.float32, device=d), -1, 1)
@@ -120,19 +122,24 @@ class PlanningEnv(BaseEnv):
             p['rnn'][0].copy_(torch.as_tensor(h, dtype=torch.float32, device=d).reshape(n, 128))
         flags_scratch = p['flags'] if p['flags'].data_ptr() != b.flags.data_ptr() else torch.empty((3, n), dtype=torch.uint8, device=d)
         obs, reward, flags = b.planning_inner_loop(self.controller.weights, p['ll'], p['rnn'], p['masks'], p['act'], tgt3, flags_scratch,
-                                                   INNER_STEPS, groups=self.loop_groups)
+                                                   INNER_STEPS, groups=self.loop_groups, mode=self.LOOP_MODES[self.loop_mode],
+                                                   waves=self.loop_waves)
         self.ego_rnn_states = p['rnn'][INNER_STEPS & 1].view(n, 1, 128)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
 
     loop_groups = 0          # np_planning_loop.groups (0 = the library chooses)
+    LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3}
+    loop_mode = 'auto'       # np_planning_loop.mode: 'launches' = 2 x 50 launches, 'persistent' / 'queue' = ONE launch (np_planning.hip)
+    loop_waves = 0           # persistent kernel: waves per 32-row tile (0 = the library chooses, 4, 8)
     use_inner_loop = True    # False: the launch-by-launch path (tests compare the two)
 
     def step(self, action, render=False, count=0):
-        if self.use_inner_loop and isinstance(self.controller, FusedActor) and not render:
-            return self._step_fused(action)
+        # an explicit enable_graph() wins over the default single-call path (it used to be silently ignored)
         if self._graph_enabled and not render:
             return self._step_graph(action)
+        if self.use_inner_loop and isinstance(self.controller, FusedActor) and not render:
+            return self._step_fused(action)
         b = self._batch
         b.reset(want_obs=False)                                    # self.reset()           :145
         action = torch.clamp(torch.as_tensor(action, dtype=torch.float32, device=self.device), -1, 1)
@@ -163,7 +170,8 @@ class PlanningEnv(BaseEnv):
         launches of this library plus the controller's own) from a single captured HIP graph: the step is launch-bound
         for small and medium batches.  Requirements: the controller is a pure torch module on this device (capturable),
         and nobody replaces `env.ego_rnn_states` / the state tensors between steps (in-place edits are fine).
-        Results are bit-identical to the eager path (same kernels, RNG counter kept on the device)."""
+        Results are bit-identical to the eager path (same kernels, RNG counter kept on the device).  Takes precedence over the
+        fused controller's single-call path (`use_inner_loop`), which needs no graph: with a FusedActor leave it off."""
         self._graph_enabled = bool(enable)
         if not enable:
             self._graph = None

@@ -44,6 +44,24 @@ def max_over_ranks(value, dist, device='cpu'):
     return float(t.item())
 
 
+def gather_over_ranks(value, dist, device='cpu'):
+    """One float per rank -> the list of all ranks' values, in rank order (a timing diagnostic: launch skew between the ranks)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist is None:
+        return [float(t.item())]
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
+def live_group(dist):
+    """What the LIVE process group says about itself (not what the command line asked for): world size and backend string;
+    (1, None) without a group."""
+    if dist is None or not dist.is_initialized():
+        return 1, None
+    return int(dist.get_world_size()), str(dist.get_backend())
+
+
 # ---------------------------------------------------------------------------------------------------
 # SingleCombat: partition by ENV (both aircraft of an engagement stay on one rank, so physics, reward and
 # terminations need no exchange).  The one real exchange of the self-play setup is between the rank that

@@ -136,6 +136,44 @@ def test_planning_inner_loop_row_groups_equal_the_launch_by_launch_path(golden_d
     assert envs[0].termination_counts() == envs[1].termination_counts()
 
 
+@pytest.mark.parametrize('n,mode,waves', [(200, 'persistent', 4), (200, 'persistent', 8), (1, 'persistent', 4), (33, 'persistent', 8),
+                                          (8_192, 'persistent', 8), (10_037, 'persistent', 4), (10_037, 'queue', 8), (10_037, 'queue', 4),
+                                          (20_011, 'queue', 4), (95, 'queue', 8)])
+def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir, n, mode, waves):
+    """np_planning_loop.mode = persistent / queue: all 50 iterations in ONE launch of the persistent kernel (np_planning.hip; a
+    workgroup per 32-row tile, or resident workgroups pulling (tile, iteration) items) — states, observation, reward, flags, recurrent
+    state, step counters and termination statistics equal the launch-by-launch path bit for bit over several macro-steps (rows that
+    terminate mid-step and stay frozen included); ragged last tile; the first macro-step starts from an invalid coefficient cache."""
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    w = pack_ppo_actor(_sd(np.load(f'{golden_dir}/actor_kat.npz')))
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=13, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+            for _ in range(2)]
+    envs[0].use_inner_loop = False
+    envs[1].loop_mode, envs[1].loop_waves = mode, waves
+    for e in envs:
+        e.termination_reasons()
+        e._batch.track_reward_terms()
+    g = torch.Generator(device='cpu').manual_seed(n)
+    for k in range(4):
+        a = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
+        if k == 2:   # the caller edits the state between macro-steps: the cached coefficients are stale for both paths
+            for e in envs:
+                e.model.s[: max(1, n // 3), 7] += 0.01
+        outs = [e.step(a) for e in envs]
+        for x, y in zip(outs[0][:5], outs[1][:5]):
+            assert torch.equal(x, y), f'macro-step {k}'
+        assert torch.equal(envs[0].model.s, envs[1].model.s) and torch.equal(envs[0].model.u, envs[1].model.u)
+        assert torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
+        assert torch.equal(envs[0].termination_reasons(), envs[1].termination_reasons())
+        assert torch.equal(envs[0]._batch.reward_task, envs[1]._batch.reward_task)
+        assert torch.equal(envs[0].step_count, envs[1].step_count)
+        m = (n // 64) * 14 * 64   # whole 64-row tiles of the cache (the rows beyond n of a last tile are never written)
+        assert torch.equal(envs[0]._batch.coef_cache[: m], envs[1]._batch.coef_cache[: m])
+    assert envs[0].termination_counts() == envs[1].termination_counts()
+    assert any(v > 0 for v in envs[0].termination_counts().values()), 'the comparison should include rows that terminated'
+
+
 def test_planning_inner_loop_rejects_bad_arguments(golden_dir):
     """np_planning_inner_loop fails loudly (no launch) on aliased ping-pong buffers and on an impossible group count."""
     from neuralplane_amd.actor import FusedActor, pack_ppo_actor

@@ -326,3 +326,30 @@ def test_termination_condition_objects_read_the_step_kernels_verdict():
             env.reward_terms()
         fired += int(bad.sum()) + int(done.sum())
     assert fired > 50
+
+
+def test_obs_after_step_leaves_the_reason_bits_of_the_last_step_alone():
+    """env.obs() (one np_f16_reset launch on an all-clear flag input) is observe-only: the per-aircraft condition bits "of the LAST
+    step" and the task reward term survive it; only a real reset() clears the bits (ADVICE r3)."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    n = 400
+    env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=9, device='cuda:0')
+    env.termination_reasons()
+    env.reward_terms()
+    env.reset()
+    a = torch.zeros((n, 4), device='cuda')
+    a[:, 1] = 1.0                                         # full elevator: overload / extreme-state trips within a few dozen steps
+    seen = False
+    for t in range(120):
+        env.step(a)
+        bits = env.termination_reasons().clone()
+        if int((bits != 0).sum()) > 0:
+            terms = env._batch.reward_task.clone()
+            env.obs()
+            assert torch.equal(env.termination_reasons(), bits), 'obs() cleared the reason bits of the last step'
+            assert torch.equal(env._batch.reward_task, terms)
+            seen = True
+            break
+    assert seen, 'no condition fired: the test did not exercise anything'
+    env.reset()
+    assert int(env.termination_reasons().sum()) == 0, 'a real reset() clears the bits'

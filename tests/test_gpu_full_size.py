@@ -215,6 +215,8 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert r['traffic'] is None or r['traffic_source'].startswith('profiles/')
     assert 1500 < r['effective_shader_mhz'] < 2600
     assert d['n_gpus'] == 1 and d['rccl_ranks'] == 0 and d['steps'] == 20 and d['warmup'] == 5
+    assert d['world_size'] == 1 and d['backend'] is None and len(d['per_rank']['host_enqueue_us_per_step']) == 1
+    assert d['expected_scaling']['host_keeps_gpu_fed'] in (True, False) and d['expected_scaling']['measured_at_world_size'] == 1
 
 
 @pytest.mark.parametrize('task', ['tracking', 'combat'])
@@ -226,6 +228,32 @@ def test_bench_other_configs_multi_rank(task):
     assert d['n_gpus'] == 2 and d['state_finite'] is True and d['value'] > 0
     if task == 'combat':
         assert d['scaling'] == 'strong' and d['exchange']['collectives_per_step'] == 2 and d['unit'] == 'engagement-steps/s'
+
+
+def test_bench_eight_ranks_on_one_gpu_heading():
+    """The command the driver's SCALE run issues at N = 8 (`bench.py --gpus 8 ...`), with eight gloo ranks sharing this box's one GPU:
+    rendezvous on 127.0.0.1, per-rank row shards, the barriers, the max-over-ranks, ONE JSON line from rank 0 — and the fields that
+    let the launch skew of an 8-process run be read off the line: the live group's size / backend and every rank's own host time."""
+    d = _bench_json(['--gpus', '8', '--steps', '10', '--warmup', '2', '--n', '20000', '--backend', 'gloo', '--prelude-ms', '20', '--headline-only'], timeout=600)
+    assert d['n_gpus'] == 8 and d['world_size'] == 8 and d['backend'] == 'gloo' and d['rccl_ranks'] == 0 and d['scaling'] == 'weak'
+    assert 'get_world_size' in d['group_source'] and d['state_finite'] is True
+    assert d['value'] == pytest.approx(8 * 20000 * 10 / (d['ms_per_step'] * 1e-3 * 10), rel=1e-6)
+    pr = d['per_rank']
+    assert len(pr['host_enqueue_us_per_step']) == 8 and len(pr['elapsed_ms_per_step']) == 8
+    assert all(v > 0 for v in pr['host_enqueue_us_per_step']) and max(pr['elapsed_ms_per_step']) == pytest.approx(d['ms_per_step'], rel=1e-6)
+    es = d['expected_scaling']
+    assert es['measured_at_world_size'] == 8 and len(es['predicted_speedup_8_gpus']) == 2
+
+
+@pytest.mark.parametrize('lag', [0, 1])
+def test_bench_eight_ranks_on_one_gpu_combat(lag):
+    """BASELINE.json configs[4] at eight ranks (gloo, one GPU): envs sharded by engagement, two all-gathers per step on the side
+    stream, opponent lag 0 (the reference runner's semantics) and 1 (the exchange overlaps the env kernel)."""
+    d = _bench_json(['--gpus', '8', '--task', 'combat', '--engagements', '8000', '--steps', '6', '--warmup', '2', '--backend', 'gloo',
+                     '--prelude-ms', '20', '--opponent-lag', str(lag), '--headline-only'], timeout=600)
+    assert d['n_gpus'] == 8 and d['world_size'] == 8 and d['backend'] == 'gloo' and d['state_finite'] is True and d['value'] > 0
+    assert d['scaling'] == 'strong' and d['exchange']['collectives_per_step'] == 2 and d['exchange']['opponent_lag'] == lag
+    assert len(d['per_rank']['host_enqueue_us_per_step']) == 8
 
 
 @pytest.mark.parametrize('task', ['heading', 'tracking'])

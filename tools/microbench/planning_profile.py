@@ -11,6 +11,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 w = np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32)
 env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
 env.loop_groups = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # np_planning_loop.groups (0 = the library chooses)
+env.loop_mode = sys.argv[4] if len(sys.argv) > 4 else 'auto'        # auto | launches | persistent | queue
+env.loop_waves = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 a = torch.rand(n, 3, device='cuda') * 2 - 1
 t_end = time.perf_counter() + 0.3
 while time.perf_counter() < t_end:
@@ -19,4 +21,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     env.step(a)
 torch.cuda.synchronize()
-print(f'n={n} groups={env.loop_groups}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per PlanningEnv.step (np_planning_inner_loop)')
+print(f'n={n} groups={env.loop_groups} mode={env.loop_mode} waves={env.loop_waves}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per PlanningEnv.step (np_planning_inner_loop)')
