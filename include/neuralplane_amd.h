@@ -305,6 +305,8 @@ typedef struct np_planning_loop {
     const float *ll_tgt;       /* [3][ld] the controller's targets (np_f16_io.ll_tgt) */
     int32_t mode;              /* NP_PLANNING_AUTO / _LAUNCHES / _PERSISTENT / _PERSISTENT_QUEUE (ABI 13) */
     int32_t waves;             /* persistent kernel: waves per 32-row tile, 4 or 8; 0 = the library chooses */
+    int32_t block;             /* queue schedule: iterations per (tile, block) item, 1 .. iterations; 0 = the library chooses */
+    int32_t reserved_loop_;
 } np_planning_loop;
 int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *loop, void *stream);
 

@@ -66,7 +66,7 @@ class NpF16CombatCfg(C.Structure):
 class NpPlanningLoop(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('groups', C.c_int32), ('actor_weights', C.c_void_p),
                 ('ll_obs', C.c_void_p * 2), ('rnn', C.c_void_p * 2), ('masks', C.c_void_p), ('ll_act', C.c_void_p),
-                ('flags', C.c_void_p * 2), ('ll_tgt', C.c_void_p), ('mode', C.c_int32), ('waves', C.c_int32)]
+                ('flags', C.c_void_p * 2), ('ll_tgt', C.c_void_p), ('mode', C.c_int32), ('waves', C.c_int32), ('block', C.c_int32), ('reserved_loop_', C.c_int32)]
 
 
 class NpF16CombatIo(C.Structure):

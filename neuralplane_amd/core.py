@@ -268,7 +268,7 @@ class F16Batch:
         self._version += 1
         return obs, reward, new_flags
 
-    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0, mode=0, waves=0):
+    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0, mode=0, waves=0, block=0):
         """np_planning_inner_loop: the `iterations` low-level iterations of PlanningEnv.step (controller forward + inner FDM step each)
         enqueued by one library call.  ll_obs = (first input [n,22], scratch [n,22]); rnn = (state on entry [n,128], scratch [n,128]);
         flags_scratch [3,n] uint8.  Returns obs (task observation of the last iteration), reward, flags; the final recurrent state is in
@@ -280,7 +280,7 @@ class F16Batch:
         io = self._io(flags_scratch, ll_act, obs, reward, None, None, inner=True, ll_tgt=tgt3, ll_obs=ll_obs[1])
         lp = _lib.NpPlanningLoop()
         lp.iterations, lp.groups = int(iterations), int(groups)
-        lp.mode, lp.waves = int(mode), int(waves)
+        lp.mode, lp.waves, lp.block = int(mode), int(waves), int(block)
         lp.actor_weights = actor_weights.data_ptr()
         lp.ll_obs[0], lp.ll_obs[1] = ll_obs[0].data_ptr(), ll_obs[1].data_ptr()
         lp.rnn[0], lp.rnn[1] = rnn[0].data_ptr(), rnn[1].data_ptr()

@@ -28,6 +28,9 @@
 #ifndef NPACT_TILE32_MAX_N
 #define NPACT_TILE32_MAX_N 16384  // up to here the 32-row tile kernel (actor_forward_mfma32_kernel), above it the 64-row one
 #endif
+#ifndef NPACT_PRIO
+#define NPACT_PRIO 0  // > 0: wave priority outside the MFMA chains of the 32-row tile (the chains themselves run at 0)
+#endif
 #ifndef NPACT_EXP
 #define NPACT_EXP 0  // timing-only experiment switches (tools/microbench/README.md); 0 in every shipped build
 #endif
@@ -535,7 +538,13 @@ template <int LD_W, int LD_NEXT>
 __device__ __forceinline__ void dense_mfma16(const float *__restrict__ wt, const float *__restrict__ wnext, const float *__restrict__ bnext,
                                              const float *__restrict__ xin, int fl, float (&pa)[33], f32x16 &acc) {
     const unsigned xaddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)xin;
+#if NPACT_PRIO   // two tiles on one CU: a dependent MFMA chain otherwise starves the other wave of the SIMD (tools/microbench/mfma_coissue.hip)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     actor_dense_mfma16_asm<LD_W, LD_NEXT>(wt, wnext, bnext, 4u * (unsigned)fl, xaddr, pa, acc);
+#if NPACT_PRIO
+    __builtin_amdgcn_s_setprio(NPACT_PRIO);
+#endif
 }
 
 template <bool RELU>

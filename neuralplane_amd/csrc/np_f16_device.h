@@ -612,10 +612,14 @@ struct StateScalars {
     float tt, spsi, cpsi, powv;  // tan(theta), sin / cos(psi), (1 - 0.703e-5 alt)^4.14
 };
 constexpr int NUM_SHARED_SCALARS = 12;
-template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0, bool HAVE_POW = false>
+// STAGE (SHARE only; the persistent PlanningEnv kernel splits an evaluation in time): 0 = everything; 1 = this wave's share of the state's
+// serial chains -> LDS and nothing else (no barrier: the caller publishes them); 2 = everything BUT the share computation (the set is
+// already in LDS and published).
+template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0, bool HAVE_POW = false, int STAGE = 0>
 __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], StateScalars &sc,
                                         float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
     static_assert(!SHARE || WPT == 4 || WPT == 8 || WPT == WPT_LAT2, "shared state scalars belong to the latency variants");
+    static_assert(STAGE == 0 || SHARE, "stages split the shared-scalar evaluation");
     const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
     const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
     const float xc = (float)(0.35 - 0.30);
@@ -634,7 +638,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     const float T = u[0], el = u[1], ail = u[2], rud = u[3];
     const float tfac = 1.0f - 0.703e-5f * alt;
 
-    if constexpr (SHARE) {  // this wave's share of the state's serial chains -> LDS (published by the barrier inside eval_nets)
+    if constexpr (SHARE && STAGE != 2) {  // this wave's share of the state's serial chains -> LDS (published by the barrier inside eval_nets)
         float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
         if constexpr (WPT == WPT_LAT2) {  // two waves: wave 0 alpha, theta (+ tan), psi; wave 1 beta, phi, tfac^4.14
             float a_, b_, c_ = 0.0f;
@@ -694,6 +698,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         }
     }
 
+    if constexpr (STAGE == 1) return;
     float xn[NUM_NORM_GROUPS];
     normalise_inputs(wt, alpha, beta, el, xn);
     // non-finite inputs poison every coefficient (numerics spec, "non-finite inputs")

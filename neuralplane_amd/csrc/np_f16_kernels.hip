@@ -1586,7 +1586,7 @@ extern "C" int np_actor_trace_read(long long *out) {  // diagnostics builds only
 
 // All iterations in one launch of the persistent kernel (np_planning.hip).  mode: NP_PLANNING_PERSISTENT (one workgroup per tile) or
 // NP_PLANNING_PERSISTENT_QUEUE (resident workgroups pull (tile, iteration) items).
-static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, hipStream_t st, int mode, int waves) {
+static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, hipStream_t st, int mode, int waves, int block) {
     if (!io->s || !io->u || !io->tgt || !io->step_count || !io->reward || !io->coef_cache)
         return fail("np_planning_inner_loop (persistent): needs state, reward and coef_cache buffers");
     if (io->ld < n) return fail("ld < n");
@@ -1612,6 +1612,7 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     pa.cache_valid0 = io->cache_valid ? 1 : 0;
     pa.tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS;
     pa.queue = nullptr;
+    pa.block = block > 0 ? (block < lp->iterations ? block : lp->iterations) : 1;
     unsigned grid = (unsigned)pa.tiles;
     if (mode == NP_PLANNING_PERSISTENT_QUEUE) {
         const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves);
@@ -1645,6 +1646,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         return fail("np_planning_loop: the two buffers of a ping-pong pair must differ");
     if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_QUEUE) return fail("np_planning_loop: unknown mode");
     if (lp->waves != 0 && lp->waves != 4 && lp->waves != 8) return fail("np_planning_loop: waves must be 0 (automatic), 4 or 8");
+    if (lp->block < 0) return fail("np_planning_loop: block must be >= 0");
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
@@ -1659,7 +1661,9 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         if ((mode == NP_PLANNING_PERSISTENT || mode == NP_PLANNING_PERSISTENT_QUEUE) && !eligible)
             return fail("np_planning_loop: the persistent kernel serves the Euler solver with the MLP numerics and needs coef_cache / reward buffers");
         if (mode == NP_PLANNING_AUTO) mode = NP_PLANNING_LAUNCHES;
-        if (mode != NP_PLANNING_LAUNCHES) return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 4);
+        int block = lp->block;
+        if (const char *e = std::getenv("NP_PLANNING_BLOCK")) block = atoi(e) > 0 ? atoi(e) : block;
+        if (mode != NP_PLANNING_LAUNCHES) return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 8, block > 0 ? block : 5);
     }
     // automatic choice, measured per size (profiles/r03g_planning_groups.log; ms per PlanningEnv.step, one group -> the choice):
     // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 5.67 -> 4.39, 24 576 5.86 -> 4.89, 28 672 6.84 -> 5.64, 32 768 6.92 -> 6.29,

@@ -23,8 +23,9 @@ struct PlanArgs {
     int iterations;
     int cache_valid0;        // is k.cache valid for the first iteration?
     long long tiles;         // ceil(n / 32)
-    // (tile, iteration) work queue (tiles > resident workgroups): item id = iteration * tiles + tile, handed out in order
-    unsigned *queue;         // [0] next item id; [1 + tile] iterations of that tile that are complete
+    int block;               // queue schedule: iterations per item (a tile stays on its workgroup for a block)
+    // (tile, block of iterations) work queue (tiles > resident workgroups): item id = block index * tiles + tile, handed out in order
+    unsigned *queue;         // [0] next item id; [1 + tile] blocks of that tile that are complete
 };
 
 constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_actor.h)

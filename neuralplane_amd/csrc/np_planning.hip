@@ -3,21 +3,26 @@
 // Reference: envs/planning_env.py:153-176 — per iteration: ego_actions = controller(low_level_obs, rnn_states, masks);
 // model.update(ego_actions); step_count += 1; terminations / reward; the next low_level_obs.  np_planning_inner_loop
 // (np_f16_kernels.hip) enqueues that as 2 x 50 launches (np_actor_forward + np_f16_step with inner_step); here a workgroup owns a
-// tile of 32 aircraft — one 32-row tile of the controller's MFMA kernel (np_actor.h::actor_tile32) — and runs
+// tile of 32 aircraft — one 32-row tile of the controller's MFMA kernel (np_actor.h::actor32_body) — and runs
 //     controller call  ->  barrier  ->  inner FDM step (np_f16_device.h, the latency variant's device code on the tile's rows)  ->  barrier
-// for every iteration inside one launch: no kernel boundary (dispatch + first loads, ~9 us of a 50 us iteration at n <= 8 192).
+// for every iteration inside one launch.  The tile's data never leaves the CU between the two halves of an iteration nor between
+// iterations: the recurrent state stays in registers (16 per thread), the low-level observation, the actions, the aircraft state,
+// counters, flags and the 14 cross-step aero coefficients stay in LDS (the "tile context" below).  Global memory is touched when a
+// tile is IMPORTED (before its first iteration on this workgroup) and EXPORTED (after its last).
 // The arithmetic is the launch-by-launch path's, operation by operation (same device functions, same generated statements, same
 // order): results are bit-identical (tests/test_gpu_actor.py).
 //
 // Two schedules:
-//   static : grid = tiles, workgroup b runs all iterations of tile b (tiles <= resident workgroups: n <= 8 192 at one per CU);
+//   static : grid = tiles, workgroup b runs all iterations of tile b: one import, one export;
 //   queue  : `grid` resident workgroups pull (tile, iteration) items, id = iteration * tiles + tile, from an atomic counter; an item
-//            waits until its tile's previous iteration is published (release / acquire at agent scope through queue[1 + tile]).  The
-//            lowest outstanding id never waits on anything unfinished, so the schedule cannot deadlock as long as the grid is
-//            resident (the launcher sizes it by the occupancy query).  313 tiles on 256 CUs then take 62 rounds of items instead
-//            of 2 x 50 lock-step iterations.
-// The tile's data (recurrent state, low-level observation, actions, aircraft state, coefficient cache) travels through global memory
-// between the two halves of an iteration exactly as between the launches it replaces — L2-resident at these sizes.
+//            waits until its tile's previous iteration is published in queue[1 + tile].  A tile then moves between CUs (and XCDs,
+//            whose L2s are not coherent with each other), so every item imports and exports, and these accesses are agent-scope
+//            relaxed atomics (global_load / global_store ... sc1: they bypass the non-coherent cache levels) ordered by
+//            s_waitcnt vmcnt(0) + the workgroup barrier before the flag store — a full agent-scope release / acquire pair per item
+//            (buffer_wbl2 / buffer_inv) measured ~50 us per item, more than the item itself.  The lowest outstanding id never
+//            waits on anything unfinished, so the schedule cannot deadlock as long as the grid is resident (the launcher sizes it by
+//            the occupancy query).  313 tiles (n = 1e4) on 512 slots of two 4-wave workgroups per CU: whichever slot is free takes
+//            the next item, and the two workgroups of a CU hide each other's barriers and load latencies.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -26,57 +31,145 @@
 #define NPACT_NO_KERNELS 1
 #include "np_actor.h"
 
+#ifndef NP_PLAN_PIPE
+#define NP_PLAN_PIPE 1  // 0: eight-wave tiles run the inner step sequentially like the four-wave ones (A/B)
+#endif
+#ifndef NP_PLAN_TRACE
+#define NP_PLAN_TRACE 0  // 1: the last workgroup stamps the shader clock at the phase boundaries of its last-but-one iteration (tools/microbench/planning_phases.py); never shipped
+#endif
+
 namespace npf16 {
 
 typedef const PlanArgs __attribute__((address_space(4))) *PlanArgsC;
 
-constexpr int PLAN_TILE = 64;  // lanes per wave = LDS column pitch of the FDM device code; lanes 32..63 shadow rows 0..31 (stores masked)
-constexpr int PLAN_STATE_WAVE = 1;  // as the latency variant: wave 1 evaluates terminations / reward and stores the state
-constexpr int PLAN_NOISE_COL0 = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS;
-constexpr int PLAN_COLS = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS + 33;
-constexpr int PLAN_FDM_LDS = (PLAN_COLS * PLAN_TILE > PLAN_TILE * OBS_LD) ? PLAN_COLS * PLAN_TILE : PLAN_TILE * OBS_LD;
+#if NP_PLAN_TRACE
+__device__ unsigned long long np_plan_trace_buf[8 * 16];   // [wave][stamp]
+#define NP_PSTAMP(k) do { if (blockIdx.x == gridDim.x - 1 && (tid & 63) == 0 && it == ap->iterations - 2) np_plan_trace_buf[(tid >> 6) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NP_PSTAMP(k) do { } while (0)
+#endif
 
-// One inner FDM step (np_f16_step with inner_step: f16_env_kernel<TASK, 0, true, true, 64, W, true>) of rows [i0, i0 + 32):
-// no auto-reset, flagged rows frozen, flags accumulate; writes the controller's next observation unless `last`, the task
-// observation if `last`.  fin / fout: the flag planes [3][n] read / written by this iteration.
-template <int TASK, int W>
-__device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds, long long i0, int it, bool last, unsigned tid) {
+constexpr int PLAN_TILE = 64;  // lanes per wave = LDS column pitch of the FDM device code; lanes 32..63 shadow rows 0..31 (stores masked)
+constexpr int PLAN_STATE_WAVE = 1;  // as the latency variant: wave 1 evaluates terminations / reward and owns the state
+constexpr int PLAN_COLS = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS;  // coefficient columns + the two sets of shared state scalars
+// tile context (floats): [row][22] low-level observation | [row][4] actions | [18][32] state rows: s 0..11, u 12..15, step_count (int
+// bits), flag / reason bits (bit 0 done, 1 bad_done, 2 exceed_time_limit, 8..14 the termination reasons accumulated over the iterations)
+constexpr int CTX_OBS = 0, CTX_ACT = CTX_OBS + PLAN_ROWS * 22, CTX_ST = CTX_ACT + PLAN_ROWS * 4, CTX_ROWS = 18, CTX_SC = 16, CTX_FL = 17;
+constexpr int CTX_FLOATS = CTX_ST + CTX_ROWS * PLAN_ROWS;
+constexpr int PLAN_LDS_FLOATS = npact::ACTOR32_LDS_FLOATS + PLAN_COLS * PLAN_TILE + CTX_FLOATS;
+static_assert(PLAN_LDS_FLOATS * sizeof(float) <= 65536, "static LDS of the persistent kernel");
+static_assert(33 * PLAN_TILE <= npact::ACTOR32_HEAD_W && PLAN_ROWS * OBS_LD <= npact::ACTOR32_HEAD_W,
+              "noise columns / observation tile borrow the controller's LDS below its staged head weights");
+
+// global loads / stores of tile data: plain, or (queue schedule) agent-scope relaxed atomics = `sc1` accesses that bypass the cache
+// levels which are not coherent between CUs / XCDs
+template <bool COH, class T>
+__device__ __forceinline__ T gld(const T *p) {
+    if constexpr (COH) return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH, class T>
+__device__ __forceinline__ void gst(T *p, T v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// tile -> LDS context + coefficient columns (waves 0 / STATE_WAVE); the recurrent state of (row, block) -> hm, masked (gru.py:26)
+template <int W, bool COH>
+__device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK]) {
+    NP_REREAD_ARGS(ap);
+    const PlanArgsC a = ap;
+    const int t = (int)(tid % PLAN_TILE), r = t & (PLAN_ROWS - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid / PLAN_TILE));
+    const long long n = a->k.n;
+    const long long i = i0 + r;
+    const long long ic = i < n ? i : n - 1;   // rows beyond the batch shadow its last row; nothing of them is exported
+    if (wave < 4) {   // the controller's waves: this thread's 16 features of its row
+        const int blk = 2 * wave + (t >> 5);
+        const float mk = a->masks[ic];
+        const float *hp = a->rnn[it & 1] + ic * npact::HID + blk * npact::BLK;
+        if constexpr (COH) {
+#pragma unroll
+            for (int j = 0; j < npact::BLK; j++) hm[j] = gld<true>(hp + j) * mk;
+        } else {
+#pragma unroll
+            for (int j = 0; j < npact::BLK / 4; j++) {
+                const float4 q = reinterpret_cast<const float4 *>(hp)[j];
+                hm[4 * j] = q.x * mk;
+                hm[4 * j + 1] = q.y * mk;
+                hm[4 * j + 2] = q.z * mk;
+                hm[4 * j + 3] = q.w * mk;
+            }
+        }
+    }
+    if (wave == 0) {  // low-level observation rows [32][22]: 704 dwords, 11 per lane
+        const float *src = a->ll_obs[it & 1] + i0 * 22;
+        const long long avail = (n - i0) * 22;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const int L = k * 64 + t;
+            ctx[CTX_OBS + L] = gld<COH>(src + (L < avail ? L : 0));
+        }
+    }
+    if (wave == PLAN_STATE_WAVE && t < PLAN_ROWS) {
+        float *st = ctx + CTX_ST + r;
+#pragma unroll
+        for (int k = 0; k < 12; k++) st[k * PLAN_ROWS] = gld<COH>(a->k.s + k * a->k.ld + ic);
+#pragma unroll
+        for (int k = 0; k < 4; k++) st[(12 + k) * PLAN_ROWS] = gld<COH>(a->k.u + k * a->k.ld + ic);
+        st[CTX_SC * PLAN_ROWS] = __int_as_float((int)gld<COH>(a->k.step_count + ic));
+        const uint8_t *fin = a->flags[it & 1];
+        unsigned fl = (gld<COH>(fin + ic) ? 1u : 0u) | (gld<COH>(fin + n + ic) ? 2u : 0u) | (gld<COH>(fin + 2 * n + ic) ? 4u : 0u);
+        if (a->k.term_reasons) fl |= (unsigned)gld<COH>(a->k.term_reasons + ic) << 8;
+        st[CTX_FL * PLAN_ROWS] = __uint_as_float(fl);
+    }
+    if (wave == PLAN_STATE_WAVE) {  // coefficient columns <- the cross-step cache (layout [row / 64][NUM_CACHE_ROWS][row % 64]); all 64 lanes
+        const float *cache_blk = a->k.cache + ((ic >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (ic & (CACHE_TILE - 1));
+        float *coef = lds_fdm + t;
+#pragma unroll
+        for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * PLAN_TILE] = gld<COH>(cache_blk + k * CACHE_TILE);
+    }
+}
+
+// One inner FDM step (np_f16_step with inner_step: f16_env_kernel<TASK, 0, true, true, 64, W, true>) of the tile in the context:
+// no auto-reset, flagged rows frozen, flags accumulate; leaves the controller's next observation in the context unless `last`, writes the
+// task observation and the reward if `last`; `do_export`: state, counters, flags, reason bits and cached coefficients -> global.
+template <int TASK, int W, bool COH>
+__device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, bool last, bool do_export,
+                                              unsigned tid) {
     // every scalar is (re-)read from the kernel-argument segment where it is used: read through the by-value parameter the compiler
     // hoists the loads out of the iteration loop and keeps ~60 SGPRs alive across the asm phases (parked in VGPR lanes, then scratch)
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
-    const uint8_t *fin = a->flags[it & 1];
     constexpr int TILE = PLAN_TILE;
-    float *obs_tile = lds;
-    const int t = (int)(tid % TILE);
+    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
     const int part = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
-    float *coef = lds + t;
+    float *coef = lds_fdm + t;
     const long long n = a->k.n;
-    const long long i = i0 + (t & (PLAN_ROWS - 1));
+    const long long i = i0 + r;
     const bool valid = t < PLAN_ROWS && i < n;
     const long long ic = i < n ? i : n - 1;
     const bool tables = false;  // the persistent kernel serves the MLP numerics (the launcher falls back otherwise)
     const bool want_obs = last && a->final_obs != nullptr;
+    const unsigned o4 = (unsigned)ic * 4u;
 
-    const unsigned r32 = (unsigned)ic, o4 = r32 * 4u, o8 = r32 * 8u;
-    const unsigned nn = (unsigned)n;
     float s[12], u[4], tgt[3];
+    const float *st = ctx + CTX_ST + r;
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = at_off(a->k.s + k * a->k.ld, o4);
+    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) u[k] = at_off(a->k.u + k * a->k.ld, o4);
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
 #pragma unroll
-    for (int k = 0; k < 3; k++) tgt[k] = at_off(a->k.tgt + k * a->k.ld, o4);
-    long long sc = at_off(a->k.step_count, o8);
-    const unsigned f0 = at_off(fin, r32), f1 = at_off(fin, r32 + nn), f2 = at_off(fin, r32 + 2u * nn);
-    const unsigned fl_in = f0 | f1 | f2;
+    for (int k = 0; k < 3; k++) tgt[k] = at_off(a->k.tgt + k * a->k.ld, o4);   // constant during the loop
+    long long sc = (long long)__float_as_int(st[CTX_SC * PLAN_ROWS]);
+    const unsigned fl_in = __float_as_uint(st[CTX_FL * PLAN_ROWS]);
+    float *nz = lds_act + t;  // 33 noise columns, in the controller's (idle) LDS
     if (want_obs && !a->k.noise && a->k.cfg.noise_scale != 0.0f) {  // this wave's share of the observation noise (f16_env_kernel, SHARED)
         const int nb = W == 8 ? part - 4 : part;
         if (nb >= 0) {
             uint32_t blk[4], k1[3], k2[3];
             rng_block(a->k.seed, a->k.call_idx + (uint64_t)it + (a->k.call_idx_base ? *a->k.call_idx_base : 0ull), a->k.row0 + ic, 2u + (uint32_t)nb, blk);
             noise_block_indices(blk, k1, k2);
-            float *nz = coef + PLAN_NOISE_COL0 * TILE;
             const float scale = a->k.cfg.noise_scale;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -91,22 +184,13 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds, long lo
             }
         }
     }
-    const bool flagged = fl_in != 0;
-    const bool frozen = flagged;  // planning_env.py:162-166
-    const bool tmo_prev = f2 != 0;
-
-    // coefficient columns <- the cross-step cache (layout [row / 64][NUM_CACHE_ROWS][row % 64])
-    {
-        const float *cache_blk = a->k.cache + ((ic >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (ic & (CACHE_TILE - 1));
-#pragma unroll
-        for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * TILE] = cache_blk[k * CACHE_TILE];
-    }
+    const bool frozen = (fl_in & 7u) != 0;  // planning_env.py:162-166
 
     // ---- F16Model.update (F16_model.py:51-67) ----
     float act[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        float v = a->ll_act[ic * 4 + k];
+        float v = ctx[CTX_ACT + r * 4 + k];
         v = v < -1.0f ? -1.0f : v;
         v = v > 1.0f ? 1.0f : v;
         act[k] = v;
@@ -115,6 +199,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds, long lo
     u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
     u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
     u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
+    NP_PSTAMP(4);
     {
         float k1[12];
         StateScalars sc0;
@@ -126,6 +211,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds, long lo
         for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
     }
     sc += 1;  // env_base.py:102
+    NP_PSTAMP(5);
 
     // ---- Overload evaluation at the new state (overload.py:37-42) + the 14 coefficients of the next iteration ----
     StateScalars sc1;
@@ -136,20 +222,19 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds, long lo
     }
     const Trig tr = sc1.tr;
     NP_REREAD_ARGS(ap);
-    bool done = false, bad = false;
-    float reward = 0.0f;
+    NP_PSTAMP(6);
     if (part == PLAN_STATE_WAVE) {
+        const unsigned fl0 = __float_as_uint(ctx[CTX_ST + CTX_FL * PLAN_ROWS + r]);
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
-        const bool done_prev = f0 != 0, bad_prev = f1 != 0;
+        const bool done_prev = (fl0 & 1u) != 0, bad_prev = (fl0 & 2u) != 0;
+        bool done = false, bad = false;
+        float reward = 0.0f, reward_task = 0.0f;
         unsigned reasons = 0;
-        float reward_task = 0.0f;
         done_and_reward<TASK>(ap->k.cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons, reward_task);
-        if (ap->k.reward_task && valid) ap->k.reward_task[i] = reward_task;
-        if (ap->k.term_reasons && valid) {
-            reasons |= ap->k.term_reasons[i];  // inner iterations: the bits accumulate like the flags they explain
-            ap->k.term_reasons[i] = (unsigned char)reasons;
-        }
+        // as the launch-by-launch kernel: with the per-aircraft bits tracked, the bits accumulated over the earlier inner iterations are
+        // OR-ed in BEFORE the counters are fed (so a condition that fired earlier in the macro-step is counted in every later iteration)
+        if (ap->k.term_reasons) reasons |= (fl0 >> 8) & 0x7Fu;
         if (ap->k.term_counters) {
 #pragma unroll
             for (int k = 0; k < NP_NUM_TERM_COUNTERS; k++) {
@@ -157,157 +242,355 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds, long lo
                 if (m != 0 && (tid & 63) == 0) atomicAdd(ap->k.term_counters + k, (unsigned)__popcll(m));
             }
         }
-    }
-    float o[22];
-    if (part == 0 && want_obs) {
-        observe<TASK, true>(ap->k.cfg, s, u, tgt, tr, o, sc1.powv);
-        if (ap->k.noise) {
+        // inner iterations: the reason bits accumulate like the flags they explain; exceed_time_limit is carried (no Timeout condition fires inside)
+        const unsigned fl1 = (done ? 1u : 0u) | (bad ? 2u : 0u) | (fl0 & 4u) | (fl0 & 0x7F00u) | (reasons << 8);
+        if (t < PLAN_ROWS) {
+            float *sw = ctx + CTX_ST + r;
 #pragma unroll
-            for (int k = 0; k < 22; k++) o[k] = o[k] + ap->k.noise[ic * 22 + k] * ap->k.cfg.noise_scale;
-        } else if (ap->k.cfg.noise_scale != 0.0f) {
-            const float *nz = coef + PLAN_NOISE_COL0 * TILE;
+            for (int k = 0; k < 12; k++) sw[k * PLAN_ROWS] = s[k];
 #pragma unroll
-            for (int pair = 0; pair < 11; pair++) {
-                const float rs = nz[(3 * pair) * TILE], cs = nz[(3 * pair + 1) * TILE], sn = nz[(3 * pair + 2) * TILE];
-                o[2 * pair] = fmaf(rs, cs, o[2 * pair]);
-                o[2 * pair + 1] = fmaf(rs, sn, o[2 * pair + 1]);
-            }
+            for (int k = 0; k < 4; k++) sw[(12 + k) * PLAN_ROWS] = u[k];
+            sw[CTX_SC * PLAN_ROWS] = __int_as_float((int)sc);
+            sw[CTX_FL * PLAN_ROWS] = __uint_as_float(fl1);
+        }
+        if (valid && last) {   // every iteration overwrites these: the last one's survive (planning_env.py:153-176)
+            ap->k.reward[i] = reward;
+            if (ap->k.reward_task) ap->k.reward_task[i] = reward_task;
+        }
+        if (valid && do_export) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) gst<COH>(ap->k.s + k * ap->k.ld + i, s[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) gst<COH>(ap->k.u + k * ap->k.ld + i, u[k]);
+            gst<COH>(ap->k.step_count + i, sc);
+            uint8_t *fout = ap->flags[(it & 1) ^ 1];
+            gst<COH>(fout + i, (uint8_t)(fl1 & 1u));
+            gst<COH>(fout + n + i, (uint8_t)((fl1 >> 1) & 1u));
+            gst<COH>(fout + 2 * n + i, (uint8_t)((fl1 >> 2) & 1u));
+            if (ap->k.term_reasons) gst<COH>(ap->k.term_reasons + i, (unsigned char)((fl1 >> 8) & 0x7Fu));
+            float *cache_w = ap->k.cache + ((i >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (i & (CACHE_TILE - 1));
+#pragma unroll
+            for (int k = 0; k < NUM_CACHED; k++) gst<COH>(cache_w + k * CACHE_TILE, coef[cached_slot(k) * TILE]);
         }
     }
-
-    if (valid && part == PLAN_STATE_WAVE) {
-        unsigned iw = (unsigned)i;
-        asm volatile("" : "+v"(iw));
-        const unsigned w4 = iw * 4u;
+    if (part == 0 && !last && t < PLAN_ROWS) {
+        // PlanningEnv.low_level_obs (planning_env.py:60-142) of the state just reached, for the controller's next call: straight into the context
+        float o2[22], t3[3];
 #pragma unroll
-        for (int k = 0; k < 12; k++) at_off(ap->k.s + k * ap->k.ld, w4) = s[k];
+        for (int k = 0; k < 3; k++) t3[k] = at_off(ap->k.ll_tgt + k * ap->k.ld, o4);
+        observe<1, true>(ap->k.cfg, s, u, t3, tr, o2, sc1.powv);
+        float2 *row = reinterpret_cast<float2 *>(ctx + CTX_OBS + t * 22);
 #pragma unroll
-        for (int k = 0; k < 4; k++) at_off(ap->k.u + k * ap->k.ld, w4) = u[k];
-        at_off(ap->k.step_count, iw * 8u) = sc;
-        uint8_t *fout = ap->flags[(it & 1) ^ 1];
-        at_off(fout, iw) = done ? 1 : 0;
-        at_off(fout, iw + nn) = bad ? 1 : 0;
-        at_off(fout, iw + 2u * nn) = tmo_prev ? 1 : 0;
-        at_off(ap->k.reward, w4) = reward;
-        float *cache_w = ap->k.cache + ((long long)(iw >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (iw & (CACHE_TILE - 1));
-#pragma unroll
-        for (int k = 0; k < NUM_CACHED; k++) cache_w[k * CACHE_TILE] = coef[cached_slot(k) * TILE];
+        for (int k = 0; k < 11; k++) row[k] = make_float2(o2[2 * k], o2[2 * k + 1]);
     }
-
-    // ---- [rows][22] observation rows: transpose through LDS, store coalesced ----
-    auto store_rows22 = [&](float *out_base, const float (&ov)[22]) {
-        __syncthreads();  // every lane is done with its coefficient column before the tile overwrites it
-        const long long rows = (n - i0) < PLAN_ROWS ? (n - i0) : PLAN_ROWS;
-        float *dst = out_base + i0 * 22;
-        constexpr int THREADS = TILE * W;
-        if (rows == PLAN_ROWS && ((uintptr_t)dst & 15) == 0) {
-            if (part == 0 && t < PLAN_ROWS) {
-                float2 *row = reinterpret_cast<float2 *>(obs_tile + t * 22);
+    NP_PSTAMP(7);
+    if (want_obs) {   // the task observation of the last iteration: [rows][22] through an LDS tile (the controller's, idle), stored coalesced
+        float o[22];
+        if (part == 0) {
+            observe<TASK, true>(ap->k.cfg, s, u, tgt, tr, o, sc1.powv);
+            if (ap->k.noise) {
 #pragma unroll
-                for (int k = 0; k < 11; k++) row[k] = make_float2(ov[2 * k], ov[2 * k + 1]);
-            }
-            __syncthreads();
-            constexpr int VECS = PLAN_ROWS * 22 / 4;
-            static_assert(VECS <= THREADS, "one 16-byte vector per thread");
-            const float4 *src4 = reinterpret_cast<const float4 *>(obs_tile);
-            float4 *dst4 = reinterpret_cast<float4 *>(dst);
-            if ((int)tid < VECS) dst4[tid] = src4[tid];
-        } else {
-            if (part == 0 && t < PLAN_ROWS) {
+                for (int k = 0; k < 22; k++) o[k] = o[k] + ap->k.noise[ic * 22 + k] * ap->k.cfg.noise_scale;
+            } else if (ap->k.cfg.noise_scale != 0.0f) {
 #pragma unroll
-                for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = ov[k];
-            }
-            __syncthreads();
-            const int total = (int)rows * 22;
-#pragma nounroll
-            for (int base = 0; base < 22 * PLAN_ROWS; base += THREADS) {
-                const int L = base + (int)tid;
-                if (L < total) {
-                    const unsigned r = ((unsigned)L * 2979u) >> 16;  // L / 22 for every L < 22 * 256
-                    dst[L] = obs_tile[(unsigned)L + r];
+                for (int pair = 0; pair < 11; pair++) {
+                    const float rs = nz[(3 * pair) * TILE], cs = nz[(3 * pair + 1) * TILE], sn = nz[(3 * pair + 2) * TILE];
+                    o[2 * pair] = fmaf(rs, cs, o[2 * pair]);
+                    o[2 * pair + 1] = fmaf(rs, sn, o[2 * pair + 1]);
                 }
             }
         }
-    };
-    if (want_obs) store_rows22(ap->final_obs, o);
-    if (!last) {
-        // PlanningEnv.low_level_obs (planning_env.py:60-142) of the state just reached, for the controller's next call
-        float o2[22];
-        if (part == 0) {
-            float t3[3];
+        __syncthreads();  // wave 0 is done reading the noise columns before the tile overwrites them
+        float *obs_tile = lds_act;
+        const long long rows = (n - i0) < PLAN_ROWS ? (n - i0) : PLAN_ROWS;
+        float *dst = ap->final_obs + i0 * 22;
+        if (part == 0 && t < PLAN_ROWS) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) t3[k] = at_off(ap->k.ll_tgt + k * ap->k.ld, o4);
-            observe<1, true>(ap->k.cfg, s, u, t3, tr, o2, sc1.powv);
+            for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
         }
-        store_rows22(ap->ll_obs[(it & 1) ^ 1], o2);
+        __syncthreads();
+        const int total = (int)rows * 22;
+#pragma nounroll
+        for (int base = 0; base < 22 * PLAN_ROWS; base += TILE * W) {
+            const int L = base + (int)tid;
+            if (L < total) {
+                const unsigned rr = ((unsigned)L * 2979u) >> 16;  // L / 22 for every L < 22 * 256
+                dst[L] = obs_tile[(unsigned)L + rr];
+            }
+        }
+    }
+}
+
+// ---- pipelined schedule (eight waves per tile, static): an iteration's Overload evaluation, terminations and reward do not feed the
+// controller's next call — that needs only the next low-level observation, i.e. the new state and its trigonometry.  So an inner step is
+// split: the FRONT (all eight waves: integrator evaluation + Euler; waves 4..7: the new state's fp64 chains; wave 0: the next
+// observation) stays on the critical path, the BACK (Overload evaluation on the four-wave plan, terminations, counters, flags) runs on
+// waves 4..7 WHILE waves 0..3 run the next controller call.  The two groups meet only at workgroup barriers (gfx950 has no named
+// barriers): the back's two barriers — "coefficient columns free / inputs visible" and "columns complete" — are the controller call's
+// barriers 10 and 11, which bracket its six GRU layers (33 K cycles without a barrier); before and after, waves 4..7 execute the call's
+// other 21 barriers back to back.  Same evaluations on the same inputs as the sequential step: bit-identical.
+constexpr int ACTOR32_BARRIERS_BEFORE_GRU = 9;   // barriers of actor32_body before "h -> LDS" (np_actor.h): obs LN 1, L1 1 + LN1 3, L2 1 + LN2 3
+static_assert(npact::ACTOR32_BARRIERS == ACTOR32_BARRIERS_BEFORE_GRU + 2 + 12, "barrier plan of the pipelined schedule");
+
+template <int W>
+__device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, float *ctx, long long i0, int it, unsigned tid) {
+    static_assert(W == 8, "the pipelined schedule needs the four helper waves");
+    NP_REREAD_ARGS(ap);
+    const PlanArgsC a = ap;
+    constexpr int TILE = PLAN_TILE;
+    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
+    const int part = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
+    float *coef = lds_fdm + t;
+    const long long n = a->k.n;
+    const long long i = i0 + r;
+    const long long ic = i < n ? i : n - 1;
+    const unsigned o4 = (unsigned)ic * 4u;
+    float s[12], u[4];
+    const float *st = ctx + CTX_ST + r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
+    long long sc = (long long)__float_as_int(st[CTX_SC * PLAN_ROWS]);
+    const bool frozen = (__float_as_uint(st[CTX_FL * PLAN_ROWS]) & 7u) != 0;  // planning_env.py:162-166
+    float act[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float v = ctx[CTX_ACT + r * 4 + k];
+        v = v < -1.0f ? -1.0f : v;
+        v = v > 1.0f ? 1.0f : v;
+        act[k] = v;
+    }
+    u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);
+    u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
+    u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
+    u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
+    NP_PSTAMP(4);
+    {
+        float k1[12];
+        StateScalars sc0;
+        const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
+        nlplant<true, AB_REST, TILE, W, true, 0>(wt1, s, u, sc0, coef, false, k1, part);
+        NP_REREAD_ARGS(ap);
+        const float dt = ap->k.cfg.dt;
+#pragma unroll
+        for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : s[k] + dt * k1[k];
+    }
+    sc += 1;  // env_base.py:102
+    NP_PSTAMP(5);
+    if (part >= 4) {   // the new state's serial chains (set 1), one per helper wave as the four-wave plan splits them
+        StateScalars scx;
+        float xd[12];
+        const AeroWeights wt2 = {ap->k.wt.kblob, ap->k.wt.kblob_dual, ap->k.wt.pwl, ap->k.wt.pwl_unnorm};
+        nlplant<false, AB_FORCE, TILE, 4, true, 1, false, 1>(wt2, s, u, scx, coef, false, xd, part - 4);
+    }
+    if (part == 4 + PLAN_STATE_WAVE && t < PLAN_ROWS) {   // the state the back (and the next front) start from
+        float *sw = ctx + CTX_ST + r;
+#pragma unroll
+        for (int k = 0; k < 12; k++) sw[k * PLAN_ROWS] = s[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sw[(12 + k) * PLAN_ROWS] = u[k];
+        sw[CTX_SC * PLAN_ROWS] = __int_as_float((int)sc);
+    }
+    __syncthreads();   // the shared scalars of the new state are published
+    NP_PSTAMP(6);
+    if (part == 0 && t < PLAN_ROWS) {
+        // PlanningEnv.low_level_obs (planning_env.py:60-142) of the state just reached, for the controller's next call: straight into the context
+        const float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * 1) * TILE;
+        Trig tr;
+        tr.sa = shr[0 * TILE]; tr.ca = shr[1 * TILE]; tr.sb = shr[2 * TILE]; tr.cb = shr[3 * TILE];
+        tr.st = shr[4 * TILE]; tr.ct = shr[5 * TILE]; tr.sphi = shr[6 * TILE]; tr.cphi = shr[7 * TILE];
+        const float powv = shr[11 * TILE];
+        float o2[22], t3[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t3[k] = at_off(ap->k.ll_tgt + k * ap->k.ld, o4);
+        observe<1, true>(ap->k.cfg, s, u, t3, tr, o2, powv);
+        float2 *row = reinterpret_cast<float2 *>(ctx + CTX_OBS + t * 22);
+#pragma unroll
+        for (int k = 0; k < 11; k++) row[k] = make_float2(o2[2 * k], o2[2 * k + 1]);
+    }
+    NP_PSTAMP(7);
+}
+
+// the BACK of an inner step on waves 4..7 (part4 = wave - 4), during the controller call that follows it: executes exactly two workgroup barriers
+template <int TASK>
+__device__ __forceinline__ void plan_fdm_back(PlanArgsC &ap, float *lds_fdm, float *ctx, long long i0, unsigned tid, int part4) {
+    NP_REREAD_ARGS(ap);
+    const PlanArgsC a = ap;
+    constexpr int TILE = PLAN_TILE;
+    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
+    float *coef = lds_fdm + t;
+    const long long n = a->k.n;
+    const long long i = i0 + r;
+    const bool valid = t < PLAN_ROWS && i < n;
+    const long long ic = i < n ? i : n - 1;
+    const unsigned o4 = (unsigned)ic * 4u;
+    float s[12], u[4], tgt[3];
+    const float *st = ctx + CTX_ST + r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
+    StateScalars sc1;
+    float xd[12];
+    {
+        const AeroWeights wt2 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
+        nlplant<false, AB_FORCE, TILE, 4, true, 1, false, 2>(wt2, s, u, sc1, coef, false, xd, part4);   // two barriers inside (eval_nets)
+    }
+    NP_REREAD_ARGS(ap);
+    if (part4 == PLAN_STATE_WAVE) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) tgt[k] = at_off(ap->k.tgt + k * ap->k.ld, o4);
+        const long long sc = (long long)__float_as_int(st[CTX_SC * PLAN_ROWS]);
+        const unsigned fl0 = __float_as_uint(st[CTX_FL * PLAN_ROWS]);
+        float acc3[3];
+        body_acceleration(s, sc1.tr, xd, acc3);
+        const bool done_prev = (fl0 & 1u) != 0, bad_prev = (fl0 & 2u) != 0;
+        bool done = false, bad = false;
+        float reward = 0.0f, reward_task = 0.0f;
+        unsigned reasons = 0;
+        done_and_reward<TASK>(ap->k.cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons, reward_task);
+        if (ap->k.term_reasons) reasons |= (fl0 >> 8) & 0x7Fu;   // as plan_fdm_step
+        if (ap->k.term_counters) {
+#pragma unroll
+            for (int k = 0; k < NP_NUM_TERM_COUNTERS; k++) {
+                const unsigned long long m = __ballot(valid && ((reasons >> k) & 1u));
+                if (m != 0 && (tid & 63) == 0) atomicAdd(ap->k.term_counters + k, (unsigned)__popcll(m));
+            }
+        }
+        const unsigned fl1 = (done ? 1u : 0u) | (bad ? 2u : 0u) | (fl0 & 4u) | (fl0 & 0x7F00u) | (reasons << 8);
+        if (t < PLAN_ROWS) ctx[CTX_ST + CTX_FL * PLAN_ROWS + r] = __uint_as_float(fl1);
     }
 }
 
 // the cached coefficients of the tile's CURRENT state when the caller's cache is not valid for the first iteration: the force-side
 // evaluation the previous step would have left (same nets, same inputs, same statements as the Overload evaluation that fills the
-// cache in every step), written to the cache rows of the tile
+// cache in every step) -> the coefficient columns
 template <int W>
-__device__ __forceinline__ void plan_fill_cache(PlanArgsC &ap, float *lds, long long i0, unsigned tid) {
+__device__ __forceinline__ void plan_fill_cache(PlanArgsC &ap, float *lds_fdm, const float *ctx, unsigned tid) {
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
     constexpr int TILE = PLAN_TILE;
-    const int t = (int)(tid % TILE);
+    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
     const int part = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
-    float *coef = lds + t;
-    const long long n = a->k.n;
-    const long long i = i0 + (t & (PLAN_ROWS - 1));
-    const bool valid = t < PLAN_ROWS && i < n;
-    const long long ic = i < n ? i : n - 1;
-    const unsigned o4 = (unsigned)ic * 4u;
+    float *coef = lds_fdm + t;
     float s[12], u[4];
+    const float *st = ctx + CTX_ST + r;
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = at_off(a->k.s + k * a->k.ld, o4);
+    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) u[k] = at_off(a->k.u + k * a->k.ld, o4);
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
     StateScalars sc1;
     float xd[12];
     const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
     nlplant<false, AB_FORCE, TILE, W, true, 1>(wt1, s, u, sc1, coef, false, xd, part);
     NP_REREAD_ARGS(ap);
-    if (valid && part == PLAN_STATE_WAVE) {
-        const unsigned iw = (unsigned)i;
-        float *cache_w = ap->k.cache + ((long long)(iw >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (iw & (CACHE_TILE - 1));
-#pragma unroll
-        for (int k = 0; k < NUM_CACHED; k++) cache_w[k * CACHE_TILE] = coef[cached_slot(k) * TILE];
-    }
-    __syncthreads();  // the cache rows are written (same workgroup reads them back) and the columns are free
 }
 
 template <int TASK, int W, bool QUEUE>
 __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const PlanArgs a) {
     static_assert(W == 4 || W == 8, "four or eight waves per tile");
-    __shared__ __attribute__((aligned(16))) float lds_all[npact::ACTOR32_LDS_FLOATS + PLAN_FDM_LDS];
+    constexpr bool PIPE = NP_PLAN_PIPE && W == 8;   // the pipelined schedule (plan_fdm_front / plan_fdm_back) inside a tile's stay on this workgroup
+    __shared__ __attribute__((aligned(16))) float lds_all[PLAN_LDS_FLOATS];
     __shared__ unsigned item_s;
-    float *lds_act = lds_all, *lds_fdm = lds_all + npact::ACTOR32_LDS_FLOATS;
+    float *lds_act = lds_all, *lds_fdm = lds_all + npact::ACTOR32_LDS_FLOATS, *ctx = lds_fdm + PLAN_COLS * PLAN_TILE;
     PlanArgsC ap = (PlanArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
+#if NPACT_PRIO
+    __builtin_amdgcn_s_setprio(NPACT_PRIO);
+#endif
+    float h[npact::BLK];  // the recurrent state of (row, block of 16 features): masked on the way into a controller call, new on the way out
+#pragma unroll
+    for (int j = 0; j < npact::BLK; j++) h[j] = 0.0f;
 
-    auto run_item = [&](long long tile, int it, bool first_of_tile) {
+    // one (tile, iteration) item.  do_import: the tile is not in this workgroup's registers / LDS yet; do_export: it leaves afterwards
+    auto run_item = [&](long long tile, int it, bool do_import, bool do_export) {
         const long long i0 = tile * PLAN_ROWS;
         // per-thread indices and LDS addresses are recomputed from this opaque copy in every iteration: kept across the loop they
         // are ~25 registers the allocator parks in scratch
         unsigned tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         NP_REREAD_ARGS(ap);
-        if (first_of_tile && !ap->cache_valid0) plan_fill_cache<W>(ap, lds_fdm, i0, tid);
-        // ---- controller (ppo_actor.py:38-64): ll_obs[ia], rnn[ia] -> ll_act, rnn[ib] ----
+        const bool last = it == ap->iterations - 1;
+        NP_PSTAMP(0);
+        npact::Actor32Pre pre;
+        if (W == 4 || wave < 4) {
+            npact::actor32_request_l1(ap->actor_w, tid, pre);
+            if (do_import) npact::actor32_stage_head(lds_act, ap->actor_w, tid);  // stays staged while the workgroup lives
+        }
+        if (do_import) {
+            plan_import<W, QUEUE>(ap, lds_fdm, ctx, i0, it, tid, h);
+            __syncthreads();
+            if (it == 0 && !ap->cache_valid0) plan_fill_cache<W>(ap, lds_fdm, ctx, tid);
+        } else if (W == 4 || wave < 4) {   // resident: h holds the previous call's new state; gru.py:26 masks it
+            NP_REREAD_ARGS(ap);
+            const int row = (int)(tid & 31);
+            const long long i = i0 + row;
+            const float mk = ap->masks[i < ap->k.n ? i : ap->k.n - 1];
+#pragma unroll
+            for (int j = 0; j < npact::BLK; j++) h[j] = h[j] * mk;
+        }
+        // ---- controller (ppo_actor.py:38-64): context observation, h -> context actions, h ----
+        NP_PSTAMP(1);
         if (W == 4 || wave < 4) {
             NP_REREAD_ARGS(ap);
-            const int ia = it & 1, ib = ia ^ 1;
-            npact::actor_tile32(lds_act, ap->actor_w, ap->k.n, ap->ll_obs[ia], ap->rnn[ia], ap->masks, ap->ll_act, ap->rnn[ib], tile, tid);
-        } else {
+            const int row = (int)(tid & 31), hi = (int)((tid >> 5) & 1), w4 = (int)(tid >> 6);
+            float xr[npact::OBS];
+#pragma unroll
+            for (int j = 0; j < npact::OBS; j++) xr[j] = ctx[CTX_OBS + row * 22 + j];
+            float hn[npact::BLK], action;
+            npact::actor32_body(lds_act, ap->actor_w, pre, xr, h, hn, action, tid);
+            if (hi == 0) ctx[CTX_ACT + row * 4 + w4] = action;
+#pragma unroll
+            for (int j = 0; j < npact::BLK; j++) h[j] = hn[j];
+            if (do_export) {   // the recurrent state leaves: rnn[(it + 1) & 1]
+                NP_REREAD_ARGS(ap);
+                const long long i = i0 + row;
+                if (i < ap->k.n) {
+                    float *hq = ap->rnn[(it & 1) ^ 1] + i * npact::HID + (2 * w4 + hi) * npact::BLK;
+                    if constexpr (QUEUE) {
+#pragma unroll
+                        for (int j = 0; j < npact::BLK; j++) gst<true>(hq + j, h[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < npact::BLK / 4; j++) reinterpret_cast<float4 *>(hq)[j] = make_float4(h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]);
+                    }
+                }
+            }
+        } else if constexpr (W == 8) {
+            // waves 4..7 match the call's 23 barriers; in the pipelined schedule they run the BACK of the previous inner step meanwhile
+            const bool back = PIPE && !do_import;   // a front ran in this workgroup's previous iteration
 #pragma unroll 1
-            for (int b = 0; b < npact::ACTOR32_BARRIERS; b++) __builtin_amdgcn_s_barrier();
+            for (int b = 0; b < ACTOR32_BARRIERS_BEFORE_GRU; b++) __builtin_amdgcn_s_barrier();
+            if (back) {
+                plan_fdm_back<TASK>(ap, lds_fdm, ctx, i0, tid, wave - 4);
+            } else {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll 1
+            for (int b = 0; b < npact::ACTOR32_BARRIERS - ACTOR32_BARRIERS_BEFORE_GRU - 2; b++) __builtin_amdgcn_s_barrier();
         }
-        __syncthreads();  // the tile's actions are written
+        NP_PSTAMP(2);
+        __syncthreads();  // the tile's actions are in the context (and the previous step's flags, pipelined schedule)
         NP_REREAD_ARGS(ap);
-        plan_fdm_step<TASK, W>(ap, lds_fdm, i0, it, it == ap->iterations - 1, tid);
-        __syncthreads();  // the tile's next observation / state are written
+        NP_PSTAMP(3);
+        if (PIPE && !do_export) {   // the tile's next iteration runs here too: its controller call hides this step's back
+            if constexpr (W == 8) plan_fdm_front<W>(ap, lds_fdm, ctx, i0, it, tid);
+        } else {
+            plan_fdm_step<TASK, W, QUEUE>(ap, lds_fdm, lds_act, ctx, i0, it, last, do_export, tid);
+        }
+        __syncthreads();  // the context holds the tile's next observation / state
+        NP_PSTAMP(8);
+        if (QUEUE && do_export && !last) {   // the next observation leaves too: ll_obs[(it + 1) & 1], 704 dwords
+            NP_REREAD_ARGS(ap);
+            float *dst = ap->ll_obs[(it & 1) ^ 1] + i0 * 22;
+            const long long avail = (ap->k.n - i0) * 22;
+#pragma unroll 1
+            for (int L = (int)tid; L < PLAN_ROWS * 22; L += 64 * W) {
+                if (L < avail) gst<true>(dst + L, ctx[CTX_OBS + L]);
+            }
+        }
     };
 
     if (!QUEUE) {
@@ -315,10 +598,13 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 #pragma nounroll
         for (int it = 0;; it++) {
             NP_REREAD_ARGS(ap);
-            if (it >= ap->iterations) break;
-            run_item(tile, it, it == 0);
+            const int iters = ap->iterations;
+            if (it >= iters) break;
+            run_item(tile, it, it == 0, it == iters - 1);
         }
     } else {
+        // items = (tile, block of `block` consecutive iterations): id = block index * tiles + tile, handed out in order; queue[1 + tile] =
+        // blocks of that tile that are complete.  Inside a block the tile is resident (one import, one export).
 #pragma nounroll
         for (;;) {
             NP_REREAD_ARGS(ap);
@@ -326,21 +612,31 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             __syncthreads();
             const unsigned id = item_s;
             const unsigned tiles = (unsigned)ap->tiles;
-            if (id >= tiles * (unsigned)ap->iterations) break;
-            const int it = (int)(id / tiles);
+            const int iters = ap->iterations, per = ap->block;
+            const unsigned nblk = (unsigned)((iters + per - 1) / per);
+            if (id >= tiles * nblk) break;
+            const int blk = (int)(id / tiles);
             const long long tile = (long long)(id % tiles);
-            if (it > 0) {
+            if (blk > 0) {
                 if (threadIdx.x == 0) {
-                    while (__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it) __builtin_amdgcn_s_sleep(16);
+                    while (__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)blk) __builtin_amdgcn_s_sleep(8);
                 }
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: what the previous owner of the tile published is visible
+                __syncthreads();   // what the tile's previous owner exported was complete before it raised the flag; the imports are sc1 loads
             }
-            run_item(tile, it, it == 0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // every wave: its stores of this item are out
+            asm volatile("" ::: "memory");
+            const int it0 = blk * per;
+#pragma nounroll
+            for (int it = it0;; it++) {
+                NP_REREAD_ARGS(ap);
+                const int end = (it0 + ap->block < ap->iterations ? it0 + ap->block : ap->iterations);
+                if (it >= end) break;
+                run_item(tile, it, it == it0, it == end - 1);
+            }
+            // every wave: its exports (sc1 stores) have completed; then the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             NP_REREAD_ARGS(ap);
-            if (threadIdx.x == 0) __hip_atomic_store(ap->queue + 1 + tile, (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) __hip_atomic_store(ap->queue + 1 + tile, (unsigned)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -396,3 +692,13 @@ int planning_persistent_workgroups_per_cu(int task, int waves) {
 }
 
 }  // namespace npf16
+
+#if NP_PLAN_TRACE
+extern "C" int np_plan_trace_read(unsigned long long *out128, long long *actor64) {  // diagnostics builds only (tools/microbench/planning_phases.py)
+    if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(npf16::np_plan_trace_buf), sizeof(unsigned long long) * 128) != hipSuccess) return 1;
+#if NPACT_TRACE
+    if (actor64 && hipMemcpyFromSymbol(actor64, HIP_SYMBOL(npact::npact_trace), sizeof(long long) * 64) != hipSuccess) return 1;
+#endif
+    return 0;
+}
+#endif

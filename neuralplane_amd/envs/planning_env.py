@@ -123,7 +123,7 @@ class PlanningEnv(BaseEnv):
         flags_scratch = p['flags'] if p['flags'].data_ptr() != b.flags.data_ptr() else torch.empty((3, n), dtype=torch.uint8, device=d)
         obs, reward, flags = b.planning_inner_loop(self.controller.weights, p['ll'], p['rnn'], p['masks'], p['act'], tgt3, flags_scratch,
                                                    INNER_STEPS, groups=self.loop_groups, mode=self.LOOP_MODES[self.loop_mode],
-                                                   waves=self.loop_waves)
+                                                   waves=self.loop_waves, block=self.loop_block)
         self.ego_rnn_states = p['rnn'][INNER_STEPS & 1].view(n, 1, 128)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
@@ -132,6 +132,7 @@ class PlanningEnv(BaseEnv):
     LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3}
     loop_mode = 'auto'       # np_planning_loop.mode: 'launches' = 2 x 50 launches, 'persistent' / 'queue' = ONE launch (np_planning.hip)
     loop_waves = 0           # persistent kernel: waves per 32-row tile (0 = the library chooses, 4, 8)
+    loop_block = 0           # queue schedule: iterations per (tile, block) work item (0 = the library chooses)
     use_inner_loop = True    # False: the launch-by-launch path (tests compare the two)
 
     def step(self, action, render=False, count=0):

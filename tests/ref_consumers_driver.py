@@ -39,6 +39,9 @@ def setup(side):
         sys.modules['envs.env_wrappers'] = npe.env_wrappers
         sys.modules['envs.utils'] = npe.utils
         sys.modules['envs.utils.utils'] = npe.utils.utils
+    import numpy as np
+    if not hasattr(np, 'product'):       # the reference targets numpy < 2 (algorithms/utils/flatten.py:83); this image has numpy 2.2
+        np.product = np.prod
     import torch
     torch.set_num_threads(4)
     torch.manual_seed(0)
@@ -101,7 +104,9 @@ def run_render(torch, out_dir, cap=300):
 
     def reset(self, *a, **k):
         obs = orig_reset(self, *a, **k)
-        pin_state(self, torch)
+        if not counter.get('pinned'):                 # the reference's BaseEnv.step() calls self.reset() every step: pin the FIRST reset only
+            pin_state(self, torch)
+            counter['pinned'] = True
         return obs
 
     def step(self, action, *a, **k):

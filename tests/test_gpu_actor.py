@@ -136,12 +136,13 @@ def test_planning_inner_loop_row_groups_equal_the_launch_by_launch_path(golden_d
     assert envs[0].termination_counts() == envs[1].termination_counts()
 
 
-@pytest.mark.parametrize('n,mode,waves', [(200, 'persistent', 4), (200, 'persistent', 8), (1, 'persistent', 4), (33, 'persistent', 8),
-                                          (8_192, 'persistent', 8), (10_037, 'persistent', 4), (10_037, 'queue', 8), (10_037, 'queue', 4),
-                                          (20_011, 'queue', 4), (95, 'queue', 8)])
-def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir, n, mode, waves):
+@pytest.mark.parametrize('n,mode,waves,block', [(200, 'persistent', 4, 0), (200, 'persistent', 8, 0), (1, 'persistent', 4, 0), (33, 'persistent', 8, 0),
+                                                (8_192, 'persistent', 8, 0), (10_037, 'persistent', 4, 0), (10_037, 'queue', 8, 0), (10_037, 'queue', 4, 1),
+                                                (20_011, 'queue', 4, 7), (95, 'queue', 8, 1), (95, 'queue', 8, 50), (700, 'queue', 8, 3)])
+def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir, n, mode, waves, block):
     """np_planning_loop.mode = persistent / queue: all 50 iterations in ONE launch of the persistent kernel (np_planning.hip; a
-    workgroup per 32-row tile, or resident workgroups pulling (tile, iteration) items) — states, observation, reward, flags, recurrent
+    workgroup per 32-row tile, or resident workgroups pulling (tile, block of iterations) items; eight-wave tiles run the pipelined
+    schedule: an inner step's Overload evaluation on waves 4..7 during the next controller call) — states, observation, reward, flags, recurrent
     state, step counters and termination statistics equal the launch-by-launch path bit for bit over several macro-steps (rows that
     terminate mid-step and stay frozen included); ragged last tile; the first macro-step starts from an invalid coefficient cache."""
     from neuralplane_amd.actor import FusedActor, pack_ppo_actor
@@ -150,7 +151,7 @@ def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir,
     envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=13, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
             for _ in range(2)]
     envs[0].use_inner_loop = False
-    envs[1].loop_mode, envs[1].loop_waves = mode, waves
+    envs[1].loop_mode, envs[1].loop_waves, envs[1].loop_block = mode, waves, block
     for e in envs:
         e.termination_reasons()
         e._batch.track_reward_terms()

@@ -13,6 +13,7 @@ env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, dev
 env.loop_groups = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # np_planning_loop.groups (0 = the library chooses)
 env.loop_mode = sys.argv[4] if len(sys.argv) > 4 else 'auto'        # auto | launches | persistent | queue
 env.loop_waves = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+env.loop_block = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 a = torch.rand(n, 3, device='cuda') * 2 - 1
 t_end = time.perf_counter() + 0.3
 while time.perf_counter() < t_end:
@@ -21,4 +22,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     env.step(a)
 torch.cuda.synchronize()
-print(f'n={n} groups={env.loop_groups} mode={env.loop_mode} waves={env.loop_waves}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per PlanningEnv.step (np_planning_inner_loop)')
+print(f'n={n} groups={env.loop_groups} mode={env.loop_mode} waves={env.loop_waves} block={env.loop_block}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per PlanningEnv.step (np_planning_inner_loop)')
