@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 13
+#define NP_ABI_VERSION 14
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -183,6 +183,11 @@ int np_f16_aero_coefficients(np_f16_ctx *ctx, int64_t n, const float *alpha_deg,
  * targets tgt3[3][ld].  obs: [n][22] row-major. */
 int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, const float *tgt3, int64_t ld,
                         float *obs, void *stream);
+/* The prelude of PlanningEnv.step — envs/planning_env.py:146-152 — in one launch (ABI 14): action [n][act_stride >= 3] is clamped to
+ * [-1, 1], tgt3[3][ld] = (pitch, heading, vt) + action * (0.3, 0.3, 30) (one fp32 product and one fp32 sum per element, as the reference's
+ * torch expressions) is written, and obs [n][22] = low_level_obs(tgt3) as np_f16_lowlevel_obs computes it. */
+int np_planning_targets_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, const float *action, int64_t act_stride, float *tgt3,
+                            int64_t ld, float *obs, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * SingleCombat 1v1 (envs/singlecombat_env.py).  n = 2*num_envs aircraft; rows 2k / 2k+1 are the ego /
@@ -290,9 +295,12 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
  * {controller call, inner FDM step} with no kernel boundary in between (np_planning.hip; Euler solver, MLP numerics); with more
  * tiles than resident workgroups NP_PLANNING_PERSISTENT_QUEUE has the resident workgroups pull (tile, iteration) items from a device
  * counter instead, so that e.g. 313 tiles on 256 CUs take 62 rounds of items rather than two lock-step passes.  Both are bit-identical
- * to the launches they replace.  NP_PLANNING_AUTO picks by n, solver and numerics; environment NP_PLANNING_MODE=launches|persistent|queue
- * (read per call) overrides it for benchmarks and the parity tests. */
-enum { NP_PLANNING_AUTO = 0, NP_PLANNING_LAUNCHES = 1, NP_PLANNING_PERSISTENT = 2, NP_PLANNING_PERSISTENT_QUEUE = 3 };
+ * to the launches they replace.  NP_PLANNING_PERSISTENT_GUESTS (ABI 14) is the static counterpart of the queue for resident < tiles <= 2 x
+ * resident: every resident workgroup owns a tile, the remaining "guest" tiles are cut into blocks of iterations and each block is hosted
+ * by a different workgroup between two stretches of its own tile (makespan = iterations + one block instead of 2 x iterations; `block`
+ * = the slack in iterations per block index, 0 = the library chooses).  NP_PLANNING_AUTO picks by n, solver and numerics; environment
+ * NP_PLANNING_MODE=launches|persistent|queue|guests (read per call) overrides it for benchmarks and the parity tests. */
+enum { NP_PLANNING_AUTO = 0, NP_PLANNING_LAUNCHES = 1, NP_PLANNING_PERSISTENT = 2, NP_PLANNING_PERSISTENT_QUEUE = 3, NP_PLANNING_PERSISTENT_GUESTS = 4 };
 typedef struct np_planning_loop {
     int32_t iterations;        /* planning_env.py:153: 50 */
     int32_t groups;            /* 0 = automatic */
@@ -303,7 +311,7 @@ typedef struct np_planning_loop {
     float *ll_act;             /* [n][4] scratch: the controller's actions of the current iteration */
     uint8_t *flags[2];         /* [3][n] each (done, bad_done, exceed_time_limit); [0] = the flags on entry; the final flags end in flags[iterations & 1] */
     const float *ll_tgt;       /* [3][ld] the controller's targets (np_f16_io.ll_tgt) */
-    int32_t mode;              /* NP_PLANNING_AUTO / _LAUNCHES / _PERSISTENT / _PERSISTENT_QUEUE (ABI 13) */
+    int32_t mode;              /* NP_PLANNING_AUTO / _LAUNCHES / _PERSISTENT / _PERSISTENT_QUEUE (ABI 13) / _PERSISTENT_GUESTS (ABI 14) */
     int32_t waves;             /* persistent kernel: waves per 32-row tile, 4 or 8; 0 = the library chooses */
     int32_t block;             /* queue schedule: iterations per (tile, block) item, 1 .. iterations; 0 = the library chooses */
     int32_t reserved_loop_;
@@ -335,6 +343,22 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
  * throughput. */
 enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4, NP_KERNEL_LATENCY2 = 5, NP_KERNEL_LATENCY4W = 6 };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
+
+/* Which variant / tiling / row grouping a launch of n rows gets on a device with num_cus compute units (ABI 14): the selection
+ * np_f16_step, np_f16_combat_step, np_actor_forward and np_planning_inner_loop apply, as a pure function (no device needed, the NPF16_*
+ * environment overrides not applied).  Every threshold is a number of tiles per CU or wave slots per SIMD, measured on the 256-CU device
+ * and scaled by multiProcessorCount (csrc/np_dispatch.h), so a partitioned MI355X (CPX 32 CUs, DPX 128) takes the same decisions per CU.
+ * step: 1 = np_f16_step, 0 = np_f16_reset; solver: 0 euler, 1 rk4; tables: the 1-D table numerics; variant: NP_KERNEL_*. */
+typedef struct np_dispatch_info {
+    int32_t pair, pair3, latency, latency8, latency2, latency4w;  /* np_f16_step: which kernel family / build */
+    int32_t block;            /* threads per workgroup */
+    int32_t planning_groups;  /* np_planning_inner_loop, launch-by-launch mode: row groups */
+    int32_t actor_tile32;     /* np_actor_forward: 32-row tiles (1) or 64-row tiles (0) */
+    int32_t combat_latency;   /* np_f16_combat_step with n aircraft: latency variant (1) or pair / throughput (0) */
+    int64_t grid;             /* workgroups of the np_f16_step launch */
+    int64_t reserved_;
+} np_dispatch_info;
+int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, int32_t tables, int32_t variant, np_dispatch_info *out);
 
 /* Average duration in ms of the `count` most recent np_f16_step / np_f16_combat_step launches on this context, measured with
  * HIP events on the launch stream: a start / stop pair attached to each kernel's own dispatch (hipExtLaunchKernelGGL — the

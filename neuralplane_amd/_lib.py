@@ -13,7 +13,7 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class NpF16Cfg(C.Structure):
@@ -80,9 +80,23 @@ class NpF16CombatIo(C.Structure):
                 ('action_opp', C.c_void_p), ('obs_opp', C.c_void_p)]
 
 
+class NpDispatchInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ('pair', 'pair3', 'latency', 'latency8', 'latency2', 'latency4w', 'block', 'planning_groups', 'actor_tile32',
+                                          'combat_latency')] + [('grid', C.c_int64), ('reserved_', C.c_int64)]
+
+
+def dispatch_plan(n, num_cus, step=True, solver=0, tables=False, variant=0):
+    """np_dispatch_plan as a dict: the variant / tiling / row-group selection for n rows on a device with num_cus CUs (no GPU needed)."""
+    info = NpDispatchInfo()
+    lib = load()
+    lib.np_dispatch_plan.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(NpDispatchInfo)]
+    check(lib.np_dispatch_plan(int(n), int(num_cus), int(bool(step)), int(solver), int(bool(tables)), int(variant), C.byref(info)))
+    return {k: getattr(info, k) for k, _ in NpDispatchInfo._fields_ if k != 'reserved_'}
+
+
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
            'np_f16_step', 'np_f16_derived', 'np_f16_aero_coefficients', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace', 'np_selfcheck_divc',
-           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop')
+           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop', 'np_planning_targets_obs', 'np_dispatch_plan')
 KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4, 'latency2': 5, 'latency4w': 6}
 
 _lib = None
@@ -123,6 +137,7 @@ def load():
                                    C.c_void_p]
     lib.np_f16_aero_coefficients.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.np_f16_lowlevel_obs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.np_planning_targets_obs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.np_f16_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.np_f16_set_kernel_variant.argtypes = [C.c_void_p, C.c_int]
     lib.np_actor_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -313,6 +313,17 @@ class F16Batch:
                                                 obs.data_ptr(), self._stream()))
         return obs
 
+    def planning_targets_obs(self, action, tgt3):
+        """PlanningEnv.step's prelude (planning_env.py:146-152) in one launch: tgt3[3,n] <- (pitch, heading, vt) + clamp(action, -1, 1) *
+        (0.3, 0.3, 30); returns low_level_obs(tgt3) [n,22].  action: float32 [n, >=3] on this device, rows contiguous."""
+        if action.dtype != torch.float32 or action.device != self.s.device or action.dim() != 2 or action.shape[0] != self.n or action.shape[1] < 3 \
+                or action.stride(1) != 1 or tuple(tgt3.shape) != (3, self.n) or not tgt3.is_contiguous():
+            raise ValueError('planning_targets_obs: action must be float32 [n, >=3] with contiguous rows on the env device, tgt3 contiguous [3, n]')
+        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.np_planning_targets_obs(self._ctx, self.n, self.s.data_ptr(), self.u.data_ptr(), action.data_ptr(), action.stride(0),
+                                                    tgt3.data_ptr(), self.n, obs.data_ptr(), self._stream()))
+        return obs
+
     def aero_coefficients(self, alpha_deg, beta_deg, el):
         """The 43 aero coefficient surrogates at arbitrary inputs in degrees (hifi_F16_AeroData.py:745-822) -> [43, m] in the
         reference's evaluation order, through the same device code the step kernels run (np_f16_aero_coefficients).  Row 24

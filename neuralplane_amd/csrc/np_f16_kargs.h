@@ -17,8 +17,6 @@
 namespace npf16 {
 
 constexpr int BLOCK = NPF16_BLOCK;
-// workgroups resident at once: 256 CUs x 4 SIMDs x NPF16_MINWAVES wave slots / waves per workgroup
-constexpr int FIRST_GENERATION = 256 * 4 * NPF16_MINWAVES / (BLOCK / 64);
 constexpr int CACHE_TILE = 64;  // rows per tile of the cross-step coefficient cache
 constexpr int OBS_LD = 23;  // odd row pitch: conflict-free ds_write_b32 of a 22-float row per lane
 // LDS scratch of a workgroup: first the per-lane columns of the 42 aero coefficients
@@ -51,6 +49,7 @@ struct KArgs {
     float *obs, *reward;
     const float *rand_u, *noise;
     int inner;     // one low-level iteration of PlanningEnv.step: no auto-reset, flagged rows frozen, flags accumulate
+    int cus;       // multiProcessorCount of the launching context's device: the de-phasing rules count generations of resident workgroups
     float *cache;  // [row / 64][14][row % 64] force-side alpha/beta-only coefficients at the current state (may be null)
     uint64_t seed, call_idx;
     const uint64_t *call_idx_base;  // optional device word added to call_idx (launches replayed from a HIP graph)

@@ -27,6 +27,7 @@
 #include "np_actor.h"
 #include "np_rollout.h"
 #include "np_planning.h"
+#include "np_dispatch.h"
 
 namespace npf16 {
 
@@ -135,18 +136,21 @@ void f16_env_kernel(const KArgs a) {
     // worse: 0.45 ms); later workgroups inherit the phase of the workgroup whose slot they take.  Only done
     // for grids that run several generations (large N), where 20 us is noise; dispatch order is an
     // assumption that affects speed only, never results.
-    constexpr int FIRST_GEN = WPT == 2 ? 256 * 4 * PW / (BLOCK / 64) : FIRST_GENERATION;
+    // workgroups resident at once = CUs (a.cus: multiProcessorCount of the launching context's device) x 4 SIMDs x wave slots / waves per workgroup
+    const int cus = a.cus;
+    const int FIRST_GEN = cus * 4 * (WPT == 2 ? PW : NPF16_MINWAVES) / (BLOCK / 64);
+    const int FIRST_GENERATION_RT = cus * 4 * NPF16_MINWAVES / (BLOCK / 64);
     // Round 3 (profiles/r03f_mid_large_n.log, one session): the three-wave pair build gains from the delay on EVERY grid it is used
     // for, also a single or a partial generation that fills the chip (1 025 .. 3 071 workgroups: 163 840 aircraft 73.2 -> 70.6 us,
     // 196 608 86.4 -> 82.6, 229 376 124.2 -> 88.9, 262 144 106.5 -> 102.4, 327 680 126.4 -> 118.9) — unlike the two-wave build
     // on its half-filled chip (profiles/r03a_one_generation_dephasing.json: nothing).
     constexpr bool ALWAYS = WPT == 2 && PW == 3;
-    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && (ALWAYS ? gridDim.x > 1024 : gridDim.x >= NPF16_STAGGER_MIN_GENS * FIRST_GEN) &&
-        blockIdx.x < FIRST_GEN) {
+    if (WPT < 4 && STEP && NPF16_STAGGER_CYCLES > 0 && (ALWAYS ? (int)gridDim.x > 4 * cus : (int)gridDim.x >= NPF16_STAGGER_MIN_GENS * FIRST_GEN) &&
+        (int)blockIdx.x < FIRST_GEN) {
         // The phase pattern has to survive the whole grid: measured on the current build (A/B in one session, 20 000 / 30 000 /
         // 40 000 cycles): N = 1e6 (5 generations) 0.393 / 0.398 / 0.399 ms — the delay itself is visible — but N = 3e6
         // 1.257 / 1.115 / 1.111 ms and N = 1e7 3.78-4.04 / 3.37-3.40 / 3.36-3.38 ms; the curves cross at ~8 generations.
-        const long long unit = gridDim.x >= 8 * FIRST_GENERATION ? NPF16_STAGGER_CYCLES_LONG : NPF16_STAGGER_CYCLES;
+        const long long unit = (int)gridDim.x >= 8 * FIRST_GENERATION_RT ? NPF16_STAGGER_CYCLES_LONG : NPF16_STAGGER_CYCLES;
         // pair variant: NPF16_PAIR_GROUPS phase groups, NPF16_PAIR_STAGGER cycles apart
         const long long wait = WPT != 2 ? (long long)(blockIdx.x % 3) * unit
                                : PW == 3 ? (long long)(blockIdx.x % NPF16_PAIR3_GROUPS) * NPF16_PAIR3_STAGGER
@@ -157,7 +161,8 @@ void f16_env_kernel(const KArgs a) {
     // a grid that fills the chip exactly once with the two-wave pair variant (897..1024 workgroups, four per CU: e.g. N = 131 072)
     // runs its co-resident workgroups in lock-step (all load, all compute, all store); every second generation of 256 starts
     // NPF16_ONEGEN_DELAY cycles late: 64.8 -> 60.0 us at N = 131 072, nothing below 897 workgroups (profiles/r03e_onegen_phase_ab.log)
-    if (WPT == 2 && PW == 2 && STEP && NPF16_ONEGEN_DELAY > 0 && gridDim.x > 896 && gridDim.x <= 1024 && (blockIdx.x & 256)) {
+    // (on 256 CUs: 897..1 024 workgroups, blockIdx & 256)
+    if (WPT == 2 && PW == 2 && STEP && NPF16_ONEGEN_DELAY > 0 && 2 * (int)gridDim.x > 7 * cus && (int)gridDim.x <= 4 * cus && (((int)blockIdx.x / cus) & 1)) {
         const long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < NPF16_ONEGEN_DELAY) __builtin_amdgcn_s_sleep(32);
     }
@@ -663,9 +668,13 @@ __global__ __launch_bounds__(BLOCK) void f16_aero_kernel(const float *__restrict
 }
 
 // PlanningEnv.low_level_obs (planning_env.py:60-142): ControlTask-style observation for caller-supplied targets, no noise
+// ACTION = false: targets from tp[3][ld].  ACTION = true (PlanningEnv.step's prelude, planning_env.py:146-152): targets = (pitch, heading,
+// vt) + clamp(action, -1, 1) * (0.3, 0.3, 30) — one product and one sum per element as the reference's torch expressions — written to
+// tgt_out[3][ld] as well
+template <bool ACTION>
 __global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                                  const float *__restrict__ tp, long long ld, float *__restrict__ obs,
-                                                                 long long n, DevCfg cfg) {
+                                                                 long long n, DevCfg cfg, long long act_stride, float *__restrict__ tgt_out) {
     __shared__ float tile[BLOCK * OBS_LD];
     const int t = threadIdx.x;
     const long long i0 = (long long)blockIdx.x * BLOCK, i = i0 + t;
@@ -675,8 +684,19 @@ __global__ __launch_bounds__(BLOCK) void f16_lowlevel_obs_kernel(const float *__
     for (int k = 0; k < 12; k++) s[k] = sp[k * ld + ic];
 #pragma unroll
     for (int k = 0; k < 4; k++) u[k] = up[k * ld + ic];
+    if constexpr (ACTION) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) tgt[k] = tp[k * ld + ic];
+        for (int k = 0; k < 3; k++) {
+            float a = tp[ic * act_stride + k];
+            a = a < -1.0f ? -1.0f : a;   // torch.clamp: NaN stays NaN
+            a = a > 1.0f ? 1.0f : a;
+            tgt[k] = s[4 + k] + a * (k == 2 ? 30.0f : 0.3f);
+            if (i < n) tgt_out[k * ld + i] = tgt[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) tgt[k] = tp[k * ld + ic];
+    }
     Trig tr;
     float tt;
     trig_of(s, tr, tt);
@@ -784,6 +804,8 @@ struct np_f16_ctx {
     // persistent PlanningEnv kernel (np_planning.hip): the (tile, iteration) queue words, owned by the context, grown on demand
     unsigned *d_queue;
     int64_t queue_cap;
+    unsigned queue_next = 0, flag_base = 0;   // where the item counter stands / the base of the progress words for the next launch
+    bool queue_dirty = true;
     int num_cus;  // multiProcessorCount of the context's device
 };
 
@@ -1065,50 +1087,31 @@ bool stream_is_capturing(hipStream_t st) {
     return status != hipStreamCaptureStatusNone;
 }
 
-constexpr int LAT_TILE = 64;
-constexpr int64_t LAT8_MAX_N = 16384;  // eight waves per tile while every tile still gets a CU of its own (256 tiles)
-constexpr int64_t COMBAT_LAT_MAX_N = 40000;  // aircraft; against the pair variant (round 2): 16 384 engagements 0.116 vs 0.127 ms, 20 000 a tie (0.197), 24 576 0.213 vs 0.198
-// latency family up to LAT_MAX_N, the pair variant above.  Round 3 (profiles/r03_n_sweep.json): four waves per tile fill one generation
-// of 768 tiles at three waves per SIMD up to LAT4_MAX_N (49 152: 30.6 us; 65 536 needs a second round: 45.6 us); two waves per
-// tile (latency2) keep 1 024 - 1 536 tiles in ONE generation of two to three waves per SIMD up to 98 304 aircraft
-#ifndef NPF16_LAT4_MAX_N
-#define NPF16_LAT4_MAX_N 49152
-#endif
-#ifndef NPF16_LAT_MAX_N
-#define NPF16_LAT_MAX_N 98304
-#endif
-// between the two: the four-wave variant built for FOUR waves per SIMD (128 VGPRs: it needs 132, a handful of dwords in scratch) holds
-// 1 024 tiles in one generation: 65 536 aircraft in 34.6 us against 38.1 with two waves per tile (profiles/r03d_mid_n_lat4w.json)
-#ifndef NPF16_LAT4W_MAX_N
-#define NPF16_LAT4W_MAX_N 65536
-#endif
-constexpr int64_t LAT4W_MAX_N = NPF16_LAT4W_MAX_N;
-constexpr int64_t LAT4_MAX_N = NPF16_LAT4_MAX_N;
-constexpr int64_t LAT_MAX_N = NPF16_LAT_MAX_N;
-bool use_latency_kernel(const np_f16_ctx *ctx, int64_t n) {
-    static const int forced = [] {  // process-wide override for experiments: NPF16_KERNEL=latency|throughput
+constexpr int LAT_TILE = npdispatch::LAT_TILE;
+static_assert(NP_KERNEL_AUTO == npdispatch::K_AUTO && NP_KERNEL_LATENCY == npdispatch::K_LATENCY && NP_KERNEL_THROUGHPUT == npdispatch::K_THROUGHPUT &&
+                  NP_KERNEL_PAIR == npdispatch::K_PAIR && NP_KERNEL_LATENCY8 == npdispatch::K_LATENCY8 && NP_KERNEL_LATENCY2 == npdispatch::K_LATENCY2 &&
+                  NP_KERNEL_LATENCY4W == npdispatch::K_LATENCY4W,
+              "np_dispatch.h mirrors the NP_KERNEL_* numbers");
+// Which variant a launch gets is a pure function of (n, CU count of the context's device, options): np_dispatch.h, where every threshold is
+// written per CU.  What they mean on the 256-CU device they were measured on (profiles/r03_n_sweep.json, r03d_mid_n_lat4w.json,
+// tools/microbench/ab_pair.sh): latency family up to 98 304 aircraft, the pair variant above (N = 1e5 0.060 / 0.062 ms against the
+// throughput variant, 2e5 0.112 / 0.170, 1e6 0.384 / 0.402, 1e7 3.31 / 3.37); eight waves per tile up to 16 384 (a CU per tile); four waves
+// per tile fill one generation of 768 tiles at three waves per SIMD up to 49 152 (30.6 us; 65 536 needs a second round: 45.6 us), built
+// for FOUR waves per SIMD (128 VGPRs: it needs 132, a handful of dwords in scratch) 1 024 tiles up to 65 536 (34.6 us against 38.1 with
+// two waves per tile); two waves per tile keep 1 024 - 1 536 tiles in ONE generation up to 98 304.  SingleCombat: latency variant up to
+// 40 000 aircraft (16 384 engagements 0.116 vs 0.127 ms, 20 000 a tie, 24 576 0.213 vs 0.198).
+int env_kernel_override() {  // process-wide override for experiments: NPF16_KERNEL=latency|throughput|pair
+    static const int forced = [] {
         const char *e = std::getenv("NPF16_KERNEL");
         if (!e) return (int)NP_KERNEL_AUTO;
-        return std::strcmp(e, "latency") == 0 ? (int)NP_KERNEL_LATENCY : std::strcmp(e, "throughput") == 0 ? (int)NP_KERNEL_THROUGHPUT : (int)NP_KERNEL_AUTO;
+        return std::strcmp(e, "latency") == 0 ? (int)NP_KERNEL_LATENCY : std::strcmp(e, "throughput") == 0 ? (int)NP_KERNEL_THROUGHPUT
+               : std::strcmp(e, "pair") == 0 ? (int)NP_KERNEL_PAIR : (int)NP_KERNEL_AUTO;
     }();
-    const int v = ctx->variant != NP_KERNEL_AUTO ? ctx->variant : forced;
-    if (v != NP_KERNEL_AUTO) return v == NP_KERNEL_LATENCY || v == NP_KERNEL_LATENCY8 || v == NP_KERNEL_LATENCY2 || v == NP_KERNEL_LATENCY4W;
-    return n <= LAT_MAX_N;
+    return forced;
 }
-// pair variant (two waves split the nets and evaluate them for each other's aircraft): Euler, MLP numerics (no 1-D tables)
-bool use_pair_kernel(const np_f16_ctx *ctx, int64_t n) {
-    static const bool forced = [] {  // NPF16_KERNEL=pair
-        const char *e = std::getenv("NPF16_KERNEL");
-        return e && std::strcmp(e, "pair") == 0;
-    }();
-    // measured against the throughput variant (tools/microbench/ab_pair.sh, one session): N = 1e5 0.060 / 0.062 ms, 2e5 0.112 /
-    // 0.170, 4e5 0.180 / 0.187, 1e6 0.384 / 0.402, 1e7 3.31 / 3.37 — the default above the latency variant's range
-    if (ctx->variant != NP_KERNEL_AUTO) return ctx->variant == NP_KERNEL_PAIR;
-    static const bool off = [] {  // NPF16_KERNEL=throughput|latency pins the others process-wide
-        const char *e = std::getenv("NPF16_KERNEL");
-        return e && (std::strcmp(e, "throughput") == 0 || std::strcmp(e, "latency") == 0);
-    }();
-    return forced || (!off && n > LAT_MAX_N);
+int pair_waves_override() {
+    static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
+    return pw_env;
 }
 
 // One kernel launch; when the context is being timed, the start / stop events are attached to the dispatch itself
@@ -1161,19 +1164,15 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
         a.trace = ctx->trace;
     }
     // small batches: four waves per 64-aircraft tile (latency variant); NPF16_KERNEL=throughput|latency overrides
-    const bool pair = STEP && use_pair_kernel(ctx, n);  // both numerics (round 3: the table mode's multi-input nets on the two-set bodies)
-    const bool latency = !pair && STEP && ctx->solver == 0 && use_latency_kernel(ctx, n);
-    // eight waves per tile: small batches of the MLP numerics (the table mode's classes are too short to split further)
-    const bool latency8 = latency && !ctx->cfg.aero_1d_tables &&
-                          (ctx->variant == NP_KERNEL_LATENCY8 || (ctx->variant == NP_KERNEL_AUTO && n <= LAT8_MAX_N));
-    // two waves per tile: above the four-wave variant's single generation (both numerics; Euler)
-    const bool latency2 = latency && !latency8 &&
-                          (ctx->variant == NP_KERNEL_LATENCY2 || (ctx->variant == NP_KERNEL_AUTO && n > LAT4W_MAX_N));
-    // four waves per tile at four waves per SIMD: one generation of 1 024 tiles (MLP numerics; the table mode's kernels are not built for it)
-    const bool latency4w = latency && !latency8 && !latency2 && !ctx->cfg.aero_1d_tables &&
-                           (ctx->variant == NP_KERNEL_LATENCY4W || (ctx->variant == NP_KERNEL_AUTO && n > LAT4_MAX_N));
-    const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + BLOCK - 1) / BLOCK)),
-        block(latency8 ? LAT_TILE * 8 : latency2 ? LAT_TILE * 2 : latency ? LAT_TILE * 4 : BLOCK);
+    // pair: both numerics (round 3: the table mode's multi-input nets on the two-set bodies).  latency8: eight waves per tile, small
+    // batches of the MLP numerics (the table mode's classes are too short to split further).  latency2: two waves per tile, above the
+    // four-wave variant's single generation (both numerics; Euler).  latency4w: four waves per tile at four waves per SIMD, one generation
+    // of four tiles per CU (MLP numerics; the table mode's kernels are not built for it).
+    const npdispatch::EnvChoice ch = npdispatch::env_choice(n, ctx->num_cus, STEP, ctx->solver, ctx->cfg.aero_1d_tables != 0, ctx->variant,
+                                                            env_kernel_override(), pair_waves_override(), BLOCK);
+    const bool pair = ch.pair, latency = ch.latency, latency8 = ch.latency8, latency2 = ch.latency2, latency4w = ch.latency4w;
+    const dim3 grid((unsigned)ch.grid), block((unsigned)ch.block);
+    a.cus = ctx->num_cus;
     hipStream_t st = (hipStream_t)stream;
     // Pair variant at three waves per SIMD (six workgroups per CU) or at two (four per CU)?  Measured per grid size (heading,
     // one session, profiles/r02b_ab_sessions.md s25): long grids gain 5-9 % from the third wave; grids of up to three generations
@@ -1183,8 +1182,7 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     // to every three-wave grid (round 3, see the kernel) it wins there too (229 376 aircraft 124.2 -> 88.9 us, 327 680 126.4 ->
     // 118.9; profiles/r03f_mid_large_n.log).  PlanningEnv's inner steps take the same rule since the end of round 3 (165 VGPRs, no
     // scratch; the macro-step at n = 150 000: 29.2 -> 27.6 ms, 262 144: 45.8 -> 44.2 ms, profiles/r03f_planning_inner_pair3.log).
-    static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
-    const bool pair3 = pair && (pw_env ? pw_env == 3 : grid.x > 1024);
+    const bool pair3 = ch.pair3;
     const unsigned lds_pad = 0;
     if (io->cache_valid && !io->coef_cache) return fail("cache_valid set without a coef_cache buffer");
     const bool cached = STEP && io->coef_cache && io->cache_valid;
@@ -1320,8 +1318,9 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     a.obs_opp = io->obs_opp;
     if (io->obs_opp && !io->obs) return fail("obs_opp needs obs (the ego half)");
     // small batches: the latency variant (one generation of 4-wave workgroups at 2 waves per SIMD = 512 x 64 aircraft)
+    const npdispatch::Limits lim = npdispatch::limits_for(ctx->num_cus);
     const bool latency = STEP && ctx->solver == 0 &&
-                         (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= COMBAT_LAT_MAX_N));
+                         (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= lim.combat_lat_max_n));
     const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)),
         block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
@@ -1336,8 +1335,8 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     // three waves per SIMD (168 VGPRs, 4 dwords per lane in scratch since the state is pinned before the Overload phase — round 2: 46)
     // from 1 025 workgroups on: 70 000 engagements 0.275 vs 0.290 ms, 100 000 0.355 vs 0.379, 500 000 1.294 vs 1.412; a tie below
     // (profiles/r03b_combat_pair_waves.log)
-    static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
-    const bool pair3 = pair && (pw_env ? pw_env == 3 : grid.x > 1024);
+    const int pw_env = pair_waves_override();
+    const bool pair3 = pair && (pw_env ? pw_env == 3 : (int64_t)grid.x > lim.pair3_min_grid);
     if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
     else if (pair3) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2, 3>);
     else if (pair) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>);
@@ -1353,6 +1352,21 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
 extern "C" {
 
 int np_abi_version(void) { return NP_ABI_VERSION; }
+
+int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, int32_t tables, int32_t variant, np_dispatch_info *out) {
+    if (!out) return fail("null argument");
+    if (n <= 0 || num_cus <= 0) return fail("np_dispatch_plan: n and num_cus must be positive");
+    if (variant < NP_KERNEL_AUTO || variant > NP_KERNEL_LATENCY4W) return fail("np_dispatch_plan: unknown variant");
+    const npdispatch::EnvChoice c = npdispatch::env_choice(n, num_cus, step != 0, solver, tables != 0, variant, NP_KERNEL_AUTO, 0, BLOCK);
+    const npdispatch::Limits l = npdispatch::limits_for(num_cus);
+    out->pair = c.pair; out->pair3 = c.pair3; out->latency = c.latency; out->latency8 = c.latency8; out->latency2 = c.latency2;
+    out->latency4w = c.latency4w; out->block = c.block; out->grid = c.grid;
+    out->planning_groups = npdispatch::planning_groups(n, num_cus);
+    out->actor_tile32 = npdispatch::actor_tile32(n, num_cus) ? 1 : 0;
+    out->combat_latency = n <= l.combat_lat_max_n ? 1 : 0;
+    out->reserved_ = 0;
+    return 0;
+}
 int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHE_ROWS; }
 const char *np_last_error(void) { return g_err.c_str(); }
 
@@ -1528,8 +1542,23 @@ int np_f16_lowlevel_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float 
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
-    hipLaunchKernelGGL(f16_lowlevel_obs_kernel, grid, block, 0, (hipStream_t)stream, s, u, tgt3, (long long)ld, obs, (long long)n,
-                       ctx->cfg);
+    hipLaunchKernelGGL(f16_lowlevel_obs_kernel<false>, grid, block, 0, (hipStream_t)stream, s, u, tgt3, (long long)ld, obs, (long long)n,
+                       ctx->cfg, 0ll, (float *)nullptr);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_planning_targets_obs(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, const float *action, int64_t act_stride, float *tgt3,
+                            int64_t ld, float *obs, void *stream) {
+    if (!ctx || !s || !u || !action || !tgt3 || !obs) return fail("null argument");
+    if (n <= 0) return 0;
+    if (ld < n) return fail("leading dimension < n");
+    if (act_stride < 3) return fail("act_stride < 3");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipLaunchKernelGGL(f16_lowlevel_obs_kernel<true>, grid, block, 0, (hipStream_t)stream, s, u, action, (long long)ld, obs, (long long)n,
+                       ctx->cfg, (long long)act_stride, tgt3);
     NP_HIP(hipGetLastError());
     return 0;
 }
@@ -1552,7 +1581,18 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     // which tiling: a round of the 32-row kernel is 512 tiles = 16 384 rows in ~60 us, of the 64-row kernel 32 768 rows in ~98 us; the
     // 32-row kernel wins wherever it needs fewer or shorter rounds (tools/microbench/actor_bench.py, profiles/r03h_actor_tilings.log:
     // n = 20 000 84.6 vs 98.7 us, 24 576 86.9 vs 98.3, 40 960 138.8 vs 149.2; 28 672 110.3 vs 98.5 and everything from 49 152 on the other way)
-    const bool tile32_auto = n <= NPACT_TILE32_MAX_N || (n <= 26624) || (n > 32768 && n <= 43008);
+    // (the bounds are per CU in np_dispatch.h; NPACT_TILE32_MAX_N pins the first for experiments)
+    static int cus_of[64] = {};
+    int cus = npdispatch::REF_CUS;
+    if (device < 64) {
+        if (cus_of[device] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = npdispatch::REF_CUS;
+            cus_of[device] = v;
+        }
+        cus = cus_of[device];
+    }
+    const bool tile32_auto = npdispatch::actor_tile32(n, cus);
     if (tile_env == 32 || (tile_env != 64 && tile32_auto)) {
         if ((uintptr_t)weights & 15) return fail("packed actor weights must be 16-byte aligned");
         const dim3 grid32((unsigned)((n + npact::T32 - 1) / npact::T32)), block32(npact::MTHREADS);
@@ -1602,6 +1642,7 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     a.term_counters = io->term_counters; a.term_reasons = io->term_reasons; a.reward_task = io->reward_task;
     a.ll_tgt = lp->ll_tgt; a.ll_obs = nullptr;
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg; a.reset_coef = ctx->d_reset_coef; a.wt = ctx->wt; a.trace = nullptr;
+    a.cus = ctx->num_cus;
     pa.actor_w = lp->actor_weights;
     pa.ll_obs[0] = lp->ll_obs[0]; pa.ll_obs[1] = lp->ll_obs[1];
     pa.rnn[0] = lp->rnn[0]; pa.rnn[1] = lp->rnn[1];
@@ -1612,9 +1653,25 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     pa.cache_valid0 = io->cache_valid ? 1 : 0;
     pa.tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS;
     pa.queue = nullptr;
+    pa.queue_base = pa.flag_base = 0;
     pa.block = block > 0 ? (block < lp->iterations ? block : lp->iterations) : 1;
+    pa.guest_blocks = 0;
     unsigned grid = (unsigned)pa.tiles;
-    if (mode == NP_PLANNING_PERSISTENT_QUEUE) {
+    if (mode == NP_PLANNING_PERSISTENT_GUESTS) {
+        // tiles beyond the resident workgroups are guests: cut into as many blocks as there are hosts to go round (np_planning.hip)
+        const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves);
+        if (per_cu <= 0) return fail("np_planning_inner_loop (persistent): occupancy query failed");
+        const int64_t resident = (int64_t)per_cu * ctx->num_cus;
+        const int64_t guests = pa.tiles - resident;
+        if (guests <= 0) mode = NP_PLANNING_PERSISTENT;
+        else if (guests > resident) return fail("np_planning_inner_loop (guests): more than two tiles per resident workgroup; use the queue schedule");
+        else {
+            const int64_t b = resident / guests;
+            pa.guest_blocks = (int)(b < lp->iterations ? b : lp->iterations);
+            pa.block = block >= 0 && block <= lp->iterations ? block : 1;   // slack (iterations) per block index
+        }
+    }
+    if (mode == NP_PLANNING_PERSISTENT_QUEUE || mode == NP_PLANNING_PERSISTENT_GUESTS) {
         const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves);
         if (per_cu <= 0) return fail("np_planning_inner_loop (persistent): occupancy query failed");
         const int64_t resident = (int64_t)per_cu * ctx->num_cus;
@@ -1625,12 +1682,27 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
             ctx->queue_cap = 0;
             NP_HIP(hipMalloc((void **)&ctx->d_queue, sizeof(unsigned) * (size_t)(1 + pa.tiles)));
             ctx->queue_cap = 1 + pa.tiles;
+            ctx->queue_dirty = true;
         }
-        NP_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned) * (size_t)(1 + pa.tiles), st));
+        // the queue words are cleared once, not per call (a memset node in front of every macro-step costs ~10 us): the item counter runs
+        // on and the progress words carry a base that moves past whatever the previous launch left (np_planning.hip); cleared again after a
+        // failed launch and long before the bases could wrap
+        if (ctx->queue_dirty || ctx->flag_base > (1u << 30) || ctx->queue_next > (1u << 30)) {
+            NP_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned) * (size_t)ctx->queue_cap, st));
+            ctx->queue_dirty = false;
+            ctx->queue_next = ctx->flag_base = 0;
+        }
         pa.queue = ctx->d_queue;
+        pa.queue_base = ctx->queue_next;
+        pa.flag_base = ctx->flag_base;
         grid = (unsigned)(pa.tiles < resident ? pa.tiles : resident);
+        const int per = pa.block > 0 ? pa.block : 1;
+        if (pa.guest_blocks == 0) ctx->queue_next += (unsigned)(pa.tiles * ((lp->iterations + per - 1) / per)) + grid;   // every workgroup draws one id past the end
+        ctx->flag_base += (unsigned)lp->iterations + 1u;
+        ctx->queue_dirty = true;   // until the launch below is enqueued
     }
     NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
+    ctx->queue_dirty = false;
     return 0;
 }
 
@@ -1644,7 +1716,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     if (lp->groups < 0 || lp->groups > 8) return fail("np_planning_loop: groups must be 0 (automatic) .. 8");
     if (lp->rnn[0] == lp->rnn[1] || lp->ll_obs[0] == lp->ll_obs[1] || lp->flags[0] == lp->flags[1])
         return fail("np_planning_loop: the two buffers of a ping-pong pair must differ");
-    if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_QUEUE) return fail("np_planning_loop: unknown mode");
+    if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_GUESTS) return fail("np_planning_loop: unknown mode");
     if (lp->waves != 0 && lp->waves != 4 && lp->waves != 8) return fail("np_planning_loop: waves must be 0 (automatic), 4 or 8");
     if (lp->block < 0) return fail("np_planning_loop: block must be >= 0");
     hipStream_t st = (hipStream_t)stream;
@@ -1654,23 +1726,34 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         int mode = lp->mode, waves = lp->waves;
         if (const char *e = std::getenv("NP_PLANNING_MODE")) {  // read per call: benchmarks and the parity tests switch it
             mode = std::strcmp(e, "launches") == 0 ? NP_PLANNING_LAUNCHES : std::strcmp(e, "persistent") == 0 ? NP_PLANNING_PERSISTENT
-                   : std::strcmp(e, "queue") == 0 ? NP_PLANNING_PERSISTENT_QUEUE : mode;
+                   : std::strcmp(e, "queue") == 0 ? NP_PLANNING_PERSISTENT_QUEUE : std::strcmp(e, "guests") == 0 ? NP_PLANNING_PERSISTENT_GUESTS : mode;
         }
         if (const char *e = std::getenv("NP_PLANNING_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
         const bool eligible = ctx->solver == 0 && !ctx->cfg.aero_1d_tables && io->coef_cache && !io->rand_u && !io->noise && io->reward;
-        if ((mode == NP_PLANNING_PERSISTENT || mode == NP_PLANNING_PERSISTENT_QUEUE) && !eligible)
+        if (mode >= NP_PLANNING_PERSISTENT && !eligible)
             return fail("np_planning_loop: the persistent kernel serves the Euler solver with the MLP numerics and needs coef_cache / reward buffers");
-        if (mode == NP_PLANNING_AUTO) mode = NP_PLANNING_LAUNCHES;
+        if (mode == NP_PLANNING_AUTO) {
+            // measured per size (profiles/r04_planning_modes.log, ms per PlanningEnv.step): up to one 32-row tile per resident workgroup the
+            // persistent kernel with eight waves per tile (n = 8 192: 2.49 -> 2.07); up to 1.5 tiles per workgroup its guest schedule
+            // (n = 1e4: 3.16 -> 2.6); beyond that the launches, whose 64-row controller tiles and row groups fill the chip better
+            mode = NP_PLANNING_LAUNCHES;
+            if (eligible && !stream_is_capturing(st)) {
+                const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, 8);
+                const int64_t resident = (int64_t)per_cu * ctx->num_cus, tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS;
+                if (per_cu > 0 && tiles <= resident) mode = NP_PLANNING_PERSISTENT, waves = 8;
+                else if (per_cu > 0 && tiles - resident <= resident / 2) mode = NP_PLANNING_PERSISTENT_GUESTS, waves = 8;
+            }
+        }
         int block = lp->block;
         if (const char *e = std::getenv("NP_PLANNING_BLOCK")) block = atoi(e) > 0 ? atoi(e) : block;
-        if (mode != NP_PLANNING_LAUNCHES) return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 8, block > 0 ? block : 5);
+        if (mode != NP_PLANNING_LAUNCHES)
+            return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 8, mode == NP_PLANNING_PERSISTENT_GUESTS ? (block > 0 ? block : 1) : block > 0 ? block : 5);
     }
     // automatic choice, measured per size (profiles/r03g_planning_groups.log; ms per PlanningEnv.step, one group -> the choice):
     // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 5.67 -> 4.39, 24 576 5.86 -> 4.89, 28 672 6.84 -> 5.64, 32 768 6.92 -> 6.29,
     // 40 960 8.53 -> 7.76, 49 152 10.3 -> 9.2, 57 344 12.35 -> 10.45, 65 536 12.57 -> 11.81, 81 920 15.4 -> 14.9; one group is the
     // best up to 8 192 (one 32-row controller tile per CU) and above ~82 000 (throughput)
-    int groups = lp->groups ? lp->groups
-                 : n <= 8192 ? 1 : n <= 16384 ? 2 : n <= 26624 ? 3 : n <= 36864 ? 4 : n <= 53248 ? 2 : n <= 81920 ? 3 : 1;
+    int groups = lp->groups ? lp->groups : npdispatch::planning_groups(n, ctx->num_cus);
     if (stream_is_capturing(st)) groups = 1;  // a captured graph runs its branches one after the other
     const int64_t per = ((n + groups - 1) / groups + 63) / 64 * 64;  // rows per group: boundaries on cache / kernel tiles
     if (per * (groups - 1) >= n) groups = (int)((n + per - 1) / per);

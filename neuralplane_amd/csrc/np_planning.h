@@ -25,7 +25,10 @@ struct PlanArgs {
     long long tiles;         // ceil(n / 32)
     int block;               // queue schedule: iterations per item (a tile stays on its workgroup for a block)
     // (tile, block of iterations) work queue (tiles > resident workgroups): item id = block index * tiles + tile, handed out in order
-    unsigned *queue;         // [0] next item id; [1 + tile] blocks of that tile that are complete
+    unsigned *queue;         // [0] next item id + queue_base; [1 + tile] flag_base + iterations of that tile that are complete
+    unsigned queue_base, flag_base;   // the words are not cleared between launches: the launcher moves the bases past what the last launch left
+    int guest_blocks;        // 0: the dynamic queue above.  B > 0: the static guest schedule (np_planning.hip) — grid = resident workgroups C,
+                             // the tiles - C guest tiles are cut into B blocks each, hosted by workgroups 0 .. (tiles - C) * B - 1; `block` = slack
 };
 
 constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_actor.h)

@@ -53,8 +53,10 @@ constexpr int PLAN_TILE = 64;  // lanes per wave = LDS column pitch of the FDM d
 constexpr int PLAN_STATE_WAVE = 1;  // as the latency variant: wave 1 evaluates terminations / reward and owns the state
 constexpr int PLAN_COLS = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS;  // coefficient columns + the two sets of shared state scalars
 // tile context (floats): [row][22] low-level observation | [row][4] actions | [18][32] state rows: s 0..11, u 12..15, step_count (int
-// bits), flag / reason bits (bit 0 done, 1 bad_done, 2 exceed_time_limit, 8..14 the termination reasons accumulated over the iterations)
-constexpr int CTX_OBS = 0, CTX_ACT = CTX_OBS + PLAN_ROWS * 22, CTX_ST = CTX_ACT + PLAN_ROWS * 4, CTX_ROWS = 18, CTX_SC = 16, CTX_FL = 17;
+// bits), flag / reason bits (bit 0 done, 1 bad_done, 2 exceed_time_limit, 8..14 the termination reasons accumulated over the iterations),
+// then what the iterations only read: the controller's mask and its three targets (a global load per iteration otherwise, its latency
+// exposed on wave 0 right after a barrier)
+constexpr int CTX_OBS = 0, CTX_ACT = CTX_OBS + PLAN_ROWS * 22, CTX_ST = CTX_ACT + PLAN_ROWS * 4, CTX_ROWS = 22, CTX_SC = 16, CTX_FL = 17, CTX_MK = 18, CTX_LT = 19;
 constexpr int CTX_FLOATS = CTX_ST + CTX_ROWS * PLAN_ROWS;
 constexpr int PLAN_LDS_FLOATS = npact::ACTOR32_LDS_FLOATS + PLAN_COLS * PLAN_TILE + CTX_FLOATS;
 static_assert(PLAN_LDS_FLOATS * sizeof(float) <= 65536, "static LDS of the persistent kernel");
@@ -75,8 +77,37 @@ __device__ __forceinline__ void gst(T *p, T v) {
 }
 
 // tile -> LDS context + coefficient columns (waves 0 / STATE_WAVE); the recurrent state of (row, block) -> hm, masked (gru.py:26)
+// The recurrent state of a tile, [32 rows][128] floats = 16 KB contiguous in global memory, moved coherently (queue / guest schedules):
+// thread (row, block) owns 64 B of a row, so per-thread sc1 accesses put 64 lanes on 64 different lines — and, bypassing the caches, fetch
+// or write each line sixteen times over, 4 bytes at a time (measured: ~30 us per export / import pair).  Instead every wave of the workgroup moves
+// 8-byte pieces that are consecutive across its lanes (512 B per instruction) between global memory and a stage in the controller's idle
+// bufA, and the owners read / write the stage.  Stage layout: 8-byte piece c (0..63) of row r at float offset 128 r + 2 (c ^ 2 r): the xor
+// spreads a block's 32 rows over the banks.
+__device__ __forceinline__ int h_stage_off(int row, int piece) { return 128 * row + 2 * ((piece ^ (2 * row)) & 63); }
+
+template <int W>
+__device__ __forceinline__ void h_global_to_stage(const float *src, long long i0, long long n, float *stage, unsigned tid) {
+#pragma unroll
+    for (int q = 0; q < 2048 / (64 * W); q++) {
+        const int idx = q * 64 * W + (int)tid, row = idx >> 6, piece = idx & 63;
+        const long long i = i0 + row < n ? i0 + row : n - 1;
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src + i * npact::HID) + piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<unsigned long long *>(stage + h_stage_off(row, piece)) = v;
+    }
+}
+template <int W>
+__device__ __forceinline__ void h_stage_to_global(float *dst, long long i0, long long n, const float *stage, unsigned tid) {
+#pragma unroll
+    for (int q = 0; q < 2048 / (64 * W); q++) {
+        const int idx = q * 64 * W + (int)tid, row = idx >> 6, piece = idx & 63;
+        if (i0 + row < n)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + (i0 + row) * npact::HID) + piece,
+                               *reinterpret_cast<const unsigned long long *>(stage + h_stage_off(row, piece)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int W, bool COH>
-__device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK]) {
+__device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK]) {
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
     const int t = (int)(tid % PLAN_TILE), r = t & (PLAN_ROWS - 1);
@@ -84,14 +115,12 @@ __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float
     const long long n = a->k.n;
     const long long i = i0 + r;
     const long long ic = i < n ? i : n - 1;   // rows beyond the batch shadow its last row; nothing of them is exported
-    if (wave < 4) {   // the controller's waves: this thread's 16 features of its row
+    if constexpr (COH) h_global_to_stage<W>(a->rnn[it & 1], i0, n, lds_act, tid);   // the owners read the stage after the caller's barrier
+    if (!COH && wave < 4) {   // the controller's waves: this thread's 16 features of its row
         const int blk = 2 * wave + (t >> 5);
         const float mk = a->masks[ic];
         const float *hp = a->rnn[it & 1] + ic * npact::HID + blk * npact::BLK;
-        if constexpr (COH) {
-#pragma unroll
-            for (int j = 0; j < npact::BLK; j++) hm[j] = gld<true>(hp + j) * mk;
-        } else {
+        {
 #pragma unroll
             for (int j = 0; j < npact::BLK / 4; j++) {
                 const float4 q = reinterpret_cast<const float4 *>(hp)[j];
@@ -122,6 +151,9 @@ __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float
         unsigned fl = (gld<COH>(fin + ic) ? 1u : 0u) | (gld<COH>(fin + n + ic) ? 2u : 0u) | (gld<COH>(fin + 2 * n + ic) ? 4u : 0u);
         if (a->k.term_reasons) fl |= (unsigned)gld<COH>(a->k.term_reasons + ic) << 8;
         st[CTX_FL * PLAN_ROWS] = __uint_as_float(fl);
+        st[CTX_MK * PLAN_ROWS] = a->masks[ic];
+#pragma unroll
+        for (int k = 0; k < 3; k++) st[(CTX_LT + k) * PLAN_ROWS] = a->k.ll_tgt[k * a->k.ld + ic];
     }
     if (wave == PLAN_STATE_WAVE) {  // coefficient columns <- the cross-step cache (layout [row / 64][NUM_CACHE_ROWS][row % 64]); all 64 lanes
         const float *cache_blk = a->k.cache + ((ic >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (ic & (CACHE_TILE - 1));
@@ -277,7 +309,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
         // PlanningEnv.low_level_obs (planning_env.py:60-142) of the state just reached, for the controller's next call: straight into the context
         float o2[22], t3[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) t3[k] = at_off(ap->k.ll_tgt + k * ap->k.ld, o4);
+        for (int k = 0; k < 3; k++) t3[k] = ctx[CTX_ST + (CTX_LT + k) * PLAN_ROWS + r];
         observe<1, true>(ap->k.cfg, s, u, t3, tr, o2, sc1.powv);
         float2 *row = reinterpret_cast<float2 *>(ctx + CTX_OBS + t * 22);
 #pragma unroll
@@ -341,10 +373,6 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
     const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
     const int part = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
     float *coef = lds_fdm + t;
-    const long long n = a->k.n;
-    const long long i = i0 + r;
-    const long long ic = i < n ? i : n - 1;
-    const unsigned o4 = (unsigned)ic * 4u;
     float s[12], u[4];
     const float *st = ctx + CTX_ST + r;
 #pragma unroll
@@ -403,7 +431,7 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
         const float powv = shr[11 * TILE];
         float o2[22], t3[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) t3[k] = at_off(ap->k.ll_tgt + k * ap->k.ld, o4);
+        for (int k = 0; k < 3; k++) t3[k] = ctx[CTX_ST + (CTX_LT + k) * PLAN_ROWS + r];
         observe<1, true>(ap->k.cfg, s, u, t3, tr, o2, powv);
         float2 *row = reinterpret_cast<float2 *>(ctx + CTX_OBS + t * 22);
 #pragma unroll
@@ -519,14 +547,23 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             if (do_import) npact::actor32_stage_head(lds_act, ap->actor_w, tid);  // stays staged while the workgroup lives
         }
         if (do_import) {
-            plan_import<W, QUEUE>(ap, lds_fdm, ctx, i0, it, tid, h);
+            plan_import<W, QUEUE>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h);
             __syncthreads();
+            if constexpr (QUEUE) {
+                if (W == 4 || wave < 4) {   // the masked recurrent state (gru.py:26) of (row, block) from the stage
+                    const int row = (int)(tid & 31), blk = (int)(tid >> 5) & 7;
+                    const float mk = ctx[CTX_ST + CTX_MK * PLAN_ROWS + row];
+#pragma unroll
+                    for (int j = 0; j < npact::BLK / 2; j++) {
+                        const float2 v = *reinterpret_cast<const float2 *>(lds_act + h_stage_off(row, 8 * blk + j));
+                        h[2 * j] = v.x * mk;
+                        h[2 * j + 1] = v.y * mk;
+                    }
+                }
+            }
             if (it == 0 && !ap->cache_valid0) plan_fill_cache<W>(ap, lds_fdm, ctx, tid);
         } else if (W == 4 || wave < 4) {   // resident: h holds the previous call's new state; gru.py:26 masks it
-            NP_REREAD_ARGS(ap);
-            const int row = (int)(tid & 31);
-            const long long i = i0 + row;
-            const float mk = ap->masks[i < ap->k.n ? i : ap->k.n - 1];
+            const float mk = ctx[CTX_ST + CTX_MK * PLAN_ROWS + (int)(tid & 31)];
 #pragma unroll
             for (int j = 0; j < npact::BLK; j++) h[j] = h[j] * mk;
         }
@@ -543,18 +580,13 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             if (hi == 0) ctx[CTX_ACT + row * 4 + w4] = action;
 #pragma unroll
             for (int j = 0; j < npact::BLK; j++) h[j] = hn[j];
-            if (do_export) {   // the recurrent state leaves: rnn[(it + 1) & 1]
+            if (!QUEUE && do_export) {   // the recurrent state leaves: rnn[(it + 1) & 1] (the coherent variants: after the inner step, below)
                 NP_REREAD_ARGS(ap);
                 const long long i = i0 + row;
                 if (i < ap->k.n) {
                     float *hq = ap->rnn[(it & 1) ^ 1] + i * npact::HID + (2 * w4 + hi) * npact::BLK;
-                    if constexpr (QUEUE) {
 #pragma unroll
-                        for (int j = 0; j < npact::BLK; j++) gst<true>(hq + j, h[j]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < npact::BLK / 4; j++) reinterpret_cast<float4 *>(hq)[j] = make_float4(h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]);
-                    }
+                    for (int j = 0; j < npact::BLK / 4; j++) reinterpret_cast<float4 *>(hq)[j] = make_float4(h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]);
                 }
             }
         } else if constexpr (W == 8) {
@@ -582,6 +614,18 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         }
         __syncthreads();  // the context holds the tile's next observation / state
         NP_PSTAMP(8);
+        if constexpr (QUEUE) {
+            if (do_export) {   // the recurrent state leaves through the stage (the controller's LDS is idle; the last barrier covers the observation tile)
+                if (W == 4 || wave < 4) {
+                    const int row = (int)(tid & 31), blk = (int)(tid >> 5) & 7;
+#pragma unroll
+                    for (int j = 0; j < npact::BLK / 2; j++) *reinterpret_cast<float2 *>(lds_act + h_stage_off(row, 8 * blk + j)) = make_float2(h[2 * j], h[2 * j + 1]);
+                }
+                __syncthreads();
+                NP_REREAD_ARGS(ap);
+                h_stage_to_global<W>(ap->rnn[(it & 1) ^ 1], i0, ap->k.n, lds_act, tid);
+            }
+        }
         if (QUEUE && do_export && !last) {   // the next observation leaves too: ll_obs[(it + 1) & 1], 704 dwords
             NP_REREAD_ARGS(ap);
             float *dst = ap->ll_obs[(it & 1) ^ 1] + i0 * 22;
@@ -603,40 +647,67 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             run_item(tile, it, it == 0, it == iters - 1);
         }
     } else {
-        // items = (tile, block of `block` consecutive iterations): id = block index * tiles + tile, handed out in order; queue[1 + tile] =
-        // blocks of that tile that are complete.  Inside a block the tile is resident (one import, one export).
+        // SEGMENTS: (tile, iterations [it0, it1)) — the tile is imported, stays resident for the segment, is exported, and
+        // queue[1 + tile] = it1 publishes how far it has come; a segment with it0 > 0 first waits for that word to reach it0.
+        //   dynamic (ap->guest_blocks == 0): segment id = block index * tiles + tile from the atomic counter queue[0], blocks of
+        //       ap->block iterations, handed out in order;
+        //   guests  (ap->guest_blocks = B > 0): no counter.  grid = C resident workgroups, tiles = C + G.  Workgroup w owns tile w; the
+        //       G guest tiles' iterations are cut into B blocks each and block j of guest g is hosted by workgroup g * B + j, which runs
+        //       own [0, p) | guest [b_j, b_j+1) | own [p, iterations) with p = b_j + j * ap->block ("slack": by then block j - 1,
+        //       which started `slack` earlier on its host, is through).  Every workgroup hosts at most one block: the makespan is
+        //       iterations + the longest block instead of 2 x iterations, with four exports / imports per host instead of one per item.
+        int seg = 0;
 #pragma nounroll
         for (;;) {
             NP_REREAD_ARGS(ap);
-            if (threadIdx.x == 0) item_s = __hip_atomic_fetch_add(ap->queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const unsigned id = item_s;
-            const unsigned tiles = (unsigned)ap->tiles;
-            const int iters = ap->iterations, per = ap->block;
-            const unsigned nblk = (unsigned)((iters + per - 1) / per);
-            if (id >= tiles * nblk) break;
-            const int blk = (int)(id / tiles);
-            const long long tile = (long long)(id % tiles);
-            if (blk > 0) {
+            const int iters = ap->iterations;
+            const int B = ap->guest_blocks;
+            long long tile;
+            int it0, it1;
+            if (B == 0) {
+                if (threadIdx.x == 0) item_s = __hip_atomic_fetch_add(ap->queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const unsigned id = item_s - ap->queue_base;   // the counter is never reset: it runs on from launch to launch
+                const unsigned tiles = (unsigned)ap->tiles;
+                const int per = ap->block;
+                const unsigned nblk = (unsigned)((iters + per - 1) / per);
+                if (id >= tiles * nblk) break;
+                tile = (long long)(id % tiles);
+                it0 = (int)(id / tiles) * per;
+                it1 = it0 + per < iters ? it0 + per : iters;
+            } else {
+                const int w = (int)blockIdx.x, C = (int)gridDim.x;
+                const int G = (int)ap->tiles - C;
+                const bool host = w < G * B;
+                const int j = host ? w % B : 0;
+                const int b0 = host ? (int)((long long)j * iters / B) : 0, b1 = host ? (int)((long long)(j + 1) * iters / B) : 0;
+                int p = host ? b0 + j * ap->block : iters;
+                p = p < iters ? p : iters;
+                // segments in order: own [0, p) (if any), guest [b0, b1) (if hosting), own [p, iters) (if any)
+                if (seg == 0 && p == 0) seg = 1;
+                if (seg == 1 && !host) seg = 2;
+                if (seg == 2 && p >= iters) seg = 3;
+                if (seg >= 3) break;
+                tile = seg == 1 ? (long long)(C + w / B) : (long long)w;
+                it0 = seg == 0 ? 0 : seg == 1 ? b0 : p;
+                it1 = seg == 0 ? p : seg == 1 ? b1 : iters;
+                seg++;
+            }
+            if (it0 > 0) {
                 if (threadIdx.x == 0) {
-                    while (__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)blk) __builtin_amdgcn_s_sleep(8);
+                    // progress words carry flag_base + iterations done; what an earlier launch left is below flag_base
+                    while ((int)(__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ap->flag_base) < it0) __builtin_amdgcn_s_sleep(8);
                 }
                 __syncthreads();   // what the tile's previous owner exported was complete before it raised the flag; the imports are sc1 loads
             }
             asm volatile("" ::: "memory");
-            const int it0 = blk * per;
 #pragma nounroll
-            for (int it = it0;; it++) {
-                NP_REREAD_ARGS(ap);
-                const int end = (it0 + ap->block < ap->iterations ? it0 + ap->block : ap->iterations);
-                if (it >= end) break;
-                run_item(tile, it, it == it0, it == end - 1);
-            }
+            for (int it = it0; it < it1; it++) run_item(tile, it, it == it0, it == it1 - 1);
             // every wave: its exports (sc1 stores) have completed; then the flag
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             NP_REREAD_ARGS(ap);
-            if (threadIdx.x == 0) __hip_atomic_store(ap->queue + 1 + tile, (unsigned)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) __hip_atomic_store(ap->queue + 1 + tile, ap->flag_base + (unsigned)it1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -679,7 +750,15 @@ hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args,
     return hipErrorInvalidValue;
 }
 
+static int workgroups_per_cu_uncached(int task, int waves);
 int planning_persistent_workgroups_per_cu(int task, int waves) {
+    static int cached[3][2] = {};   // the occupancy query costs a driver call; its answer belongs to the code object
+    if (task < 0 || task > 2) return 0;
+    int &c = cached[task][waves == 8];
+    if (c == 0) c = workgroups_per_cu_uncached(task, waves);
+    return c;
+}
+static int workgroups_per_cu_uncached(int task, int waves) {
 #define NP_PLAN_CASE(T)                                                       \
     if constexpr (((NP_PLAN_TASKS >> T) & 1) != 0) {                        \
         if (task == T) return waves == 8 ? occupancy_of<T, 8>() : occupancy_of<T, 4>(); \

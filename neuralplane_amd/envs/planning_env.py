@@ -106,17 +106,19 @@ class PlanningEnv(BaseEnv):
         bit-identical (tests/test_gpu_actor.py)."""
         b, n, d = self._batch, self.n, self.device
         b.reset(want_obs=False)                                    # self.reset()           :145
-        action = torch.clamp(torch.as_tensor(action, dtype=torch.float32, device=d), -1, 1)
-        roll, pitch, yaw = self.model.get_posture()
-        vt = self.model.get_vt()
-        tgt3 = torch.stack((pitch + action[:, 0] * 0.3, yaw + action[:, 1] * 0.3, vt + action[:, 2] * 30)).contiguous()  # :150-152
+        action = torch.as_tensor(action, dtype=torch.float32, device=d)
+        if action.dim() != 2 or action.stride(1) != 1:
+            action = action.reshape(n, -1).contiguous()
         p = getattr(self, '_loop_buf', None)
         if p is None:
             p = self._loop_buf = {'ll': [None, torch.empty((n, 22), dtype=torch.float32, device=d)],
+                                  'tgt3': torch.empty((3, n), dtype=torch.float32, device=d),
                                   'rnn': [torch.empty((n, 128), dtype=torch.float32, device=d), torch.empty((n, 128), dtype=torch.float32, device=d)],
                                   'masks': torch.ones(n, dtype=torch.float32, device=d), 'act': torch.empty((n, 4), dtype=torch.float32, device=d),
                                   'flags': torch.empty((3, n), dtype=torch.uint8, device=d)}
-        p['ll'][0] = b.lowlevel_obs(tgt3)
+        # clamp, (pitch, yaw, vt) + action * (0.3, 0.3, 30)  (:146-152) and the controller's first observation: one launch
+        tgt3 = p['tgt3']
+        p['ll'][0] = b.planning_targets_obs(action, tgt3)
         h = self.ego_rnn_states
         if h.data_ptr() != p['rnn'][0].data_ptr():   # somebody replaced the recurrent state (load_state_dict, the caller): take it over
             p['rnn'][0].copy_(torch.as_tensor(h, dtype=torch.float32, device=d).reshape(n, 128))
@@ -129,7 +131,7 @@ class PlanningEnv(BaseEnv):
         return obs, reward, f[0], f[1], f[2], self.info()
 
     loop_groups = 0          # np_planning_loop.groups (0 = the library chooses)
-    LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3}
+    LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3, 'guests': 4}
     loop_mode = 'auto'       # np_planning_loop.mode: 'launches' = 2 x 50 launches, 'persistent' / 'queue' = ONE launch (np_planning.hip)
     loop_waves = 0           # persistent kernel: waves per 32-row tile (0 = the library chooses, 4, 8)
     loop_block = 0           # queue schedule: iterations per (tile, block) work item (0 = the library chooses)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.np_abi_version() == _lib.ABI_VERSION == 13
+    assert lib.np_abi_version() == _lib.ABI_VERSION == 14
 
 
 def _flat_fields(struct, prefix=''):
@@ -50,7 +50,8 @@ def test_struct_layout_matches_ctypes(tmp_path):
     """Compile a tiny C program against the public header and compare sizeof/offsetof with ctypes."""
     from neuralplane_amd import _lib
     pairs = [('np_f16_cfg', _lib.NpF16Cfg), ('np_f16_io', _lib.NpF16Io), ('np_pid_gains', _lib.NpPidGains),
-             ('np_f16_combat_cfg', _lib.NpF16CombatCfg), ('np_f16_combat_io', _lib.NpF16CombatIo), ('np_planning_loop', _lib.NpPlanningLoop)]
+             ('np_f16_combat_cfg', _lib.NpF16CombatCfg), ('np_f16_combat_io', _lib.NpF16CombatIo), ('np_planning_loop', _lib.NpPlanningLoop),
+             ('np_dispatch_info', _lib.NpDispatchInfo)]
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     exp = []
     for cname, st in pairs:
@@ -120,3 +121,51 @@ def test_product_never_touches_the_oracle():
     so = os.path.join(ROOT, 'neuralplane_amd', 'csrc', 'libneuralplane_hip.so')
     syms = subprocess.run(['nm', '-D', so], capture_output=True, text=True).stdout
     assert 'f16o_' not in syms
+
+
+def test_dispatch_plan_scales_with_the_cu_count(lib):
+    """np_dispatch_plan (csrc/np_dispatch.h): the variant / tiling / row-group selection is a pure function of (n, CU count).  On 256 CUs it
+    reproduces the measured thresholds of the full MI355X exactly; on a partitioned device (CPX: 32 CUs, DPX: 128) the same decision is
+    taken at the same number of rows PER CU (the literals used to assume 256 CUs)."""
+    from neuralplane_amd import _lib
+    P = _lib.dispatch_plan
+    # ---- 256 CUs: the shipped choices, boundary by boundary (np_f16_step, Euler, MLP numerics)
+    def fam(d):
+        return ('pair3' if d['pair3'] else 'pair' if d['pair'] else 'lat8' if d['latency8'] else 'lat2' if d['latency2'] else
+                'lat4w' if d['latency4w'] else 'lat4' if d['latency'] else 'thr')
+    expect = [(1, 'lat8'), (16384, 'lat8'), (16385, 'lat4'), (49152, 'lat4'), (49153, 'lat4w'), (65536, 'lat4w'), (65537, 'lat2'), (98304, 'lat2'),
+              (98305, 'pair'), (131072, 'pair'), (131073, 'pair3'), (1_000_000, 'pair3')]
+    for n, f in expect:
+        assert fam(P(n, 256)) == f, (n, f, P(n, 256))
+    d = P(1_000_000, 256)
+    assert d['grid'] == (1_000_000 + 127) // 128 and d['block'] == 128
+    assert P(10_000, 256)['grid'] == 157 and P(10_000, 256)['block'] == 512 and P(30_000, 256)['block'] == 256 and P(80_000, 256)['block'] == 128
+    # rk4 and the reset have no latency family; the table numerics no eight-wave / four-waves-per-SIMD builds
+    assert fam(P(1000, 256, solver=1)) == 'thr' and fam(P(1000, 256, step=False)) == 'thr'
+    assert fam(P(1000, 256, tables=True)) == 'lat4' and fam(P(60_000, 256, tables=True)) == 'lat4'
+    # a pinned variant wins over the size rule
+    assert fam(P(1000, 256, variant=_lib.KERNEL_VARIANTS['pair'])) == 'pair' and fam(P(10 ** 6, 256, variant=_lib.KERNEL_VARIANTS['throughput'])) == 'thr'
+    groups = [(8192, 1), (8193, 2), (16384, 2), (16385, 3), (26624, 3), (26625, 4), (36864, 4), (36865, 2), (53248, 2), (53249, 3), (81920, 3), (81921, 1)]
+    for n, g in groups:
+        assert P(n, 256)['planning_groups'] == g, (n, g)
+    tile32 = [(16384, 1), (26624, 1), (26625, 0), (32768, 0), (32769, 1), (43008, 1), (43009, 0), (100_000, 0)]
+    for n, t in tile32:
+        assert P(n, 256)['actor_tile32'] == t, (n, t)
+    assert P(40_000, 256)['combat_latency'] == 1 and P(40_001, 256)['combat_latency'] == 0
+    # ---- partitions: the same decision at the same rows per CU
+    for cus in (32, 128):
+        for n, f in expect:
+            if n <= 1:
+                continue
+            m = (n - 1) * cus // 256 + 1 if n % 2 else n * cus // 256   # n = k * 256 x and k * 256 x + 1 map to k * cus x (+ 1)
+            assert fam(P(m, cus)) == fam(P(n, 256)), (cus, n, m)
+        for n, g in groups:
+            m = (n - 1) * cus // 256 + 1 if n % 2 else n * cus // 256
+            assert P(m, cus)['planning_groups'] == g, (cus, n, m)
+        assert P(5000 * cus // 32, cus)['combat_latency'] == 1 and P(5000 * cus // 32 + 1, cus)['combat_latency'] == 0
+    # a 32-CU partition runs 1e6 aircraft on the three-wave pair build, like the full device, and 2 048 aircraft still on eight waves per tile
+    assert fam(P(1_000_000, 32)) == 'pair3' and fam(P(2048, 32)) == 'lat8' and fam(P(2049, 32)) == 'lat4'
+    with pytest.raises(RuntimeError):
+        P(0, 256)
+    with pytest.raises(RuntimeError):
+        P(100, 0)

@@ -138,10 +138,13 @@ def test_planning_inner_loop_row_groups_equal_the_launch_by_launch_path(golden_d
 
 @pytest.mark.parametrize('n,mode,waves,block', [(200, 'persistent', 4, 0), (200, 'persistent', 8, 0), (1, 'persistent', 4, 0), (33, 'persistent', 8, 0),
                                                 (8_192, 'persistent', 8, 0), (10_037, 'persistent', 4, 0), (10_037, 'queue', 8, 0), (10_037, 'queue', 4, 1),
-                                                (20_011, 'queue', 4, 7), (95, 'queue', 8, 1), (95, 'queue', 8, 50), (700, 'queue', 8, 3)])
+                                                (20_011, 'queue', 4, 7), (95, 'queue', 8, 1), (95, 'queue', 8, 50), (700, 'queue', 8, 3),
+                                                (10_037, 'guests', 8, 0), (9_001, 'guests', 8, 3), (12_288, 'guests', 8, 1), (16_000, 'guests', 8, 0),
+                                                (20_011, 'guests', 4, 0), (200, 'guests', 8, 0), (10_037, 'auto', 0, 0), (8_192, 'auto', 0, 0)])
 def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir, n, mode, waves, block):
     """np_planning_loop.mode = persistent / queue: all 50 iterations in ONE launch of the persistent kernel (np_planning.hip; a
-    workgroup per 32-row tile, or resident workgroups pulling (tile, block of iterations) items; eight-wave tiles run the pipelined
+    workgroup per 32-row tile, or resident workgroups pulling (tile, block of iterations) items, or the static guest schedule — every
+    resident workgroup owns a tile and hosts one block of a guest tile in between; eight-wave tiles run the pipelined
     schedule: an inner step's Overload evaluation on waves 4..7 during the next controller call) — states, observation, reward, flags, recurrent
     state, step counters and termination statistics equal the launch-by-launch path bit for bit over several macro-steps (rows that
     terminate mid-step and stay frozen included); ragged last tile; the first macro-step starts from an invalid coefficient cache."""
