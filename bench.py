@@ -511,32 +511,49 @@ def planning_mode(dev, g, npl, k7):
         penv.step(ap)
     torch.cuda.synchronize(dev)
     el7 = time.perf_counter() - t1
-    # the env kernel's share of a macro-step (HIP events attached to the 50 inner launches of one more step)
+    ms = 1e3 * el7 / k7
+    # the same macro-step through the round-3 path (2 x 50 launches, row groups on their own streams), and the env kernels' share of it
+    penv.loop_mode = 'launches'
+    for _ in range(2):
+        penv.step(ap)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(k7):
+        penv.step(ap)
+    torch.cuda.synchronize(dev)
+    ms_launches = 1e3 * (time.perf_counter() - t1) / k7
     penv._batch.set_timing(True)
     penv.step(ap)
     torch.cuda.synchronize(dev)
     env_ms = sum(penv._batch.get_timing_samples())
     penv._batch.set_timing(False)
-    ms = 1e3 * el7 / k7
+    penv.loop_mode = 'auto'
+    tiles, cus = (npl + 31) // 32, torch.cuda.get_device_properties(dev).multi_processor_count
+    auto = ('persistent kernel, eight waves per 32-row tile, one workgroup per tile' if tiles <= cus else
+            'persistent kernel, guest schedule (every CU owns a tile and hosts one block of iterations of a guest tile)' if tiles - cus <= cus // 2 else
+            'launch by launch (np_actor_forward + np_f16_step per iteration, row groups on their own streams)')
     flop_actor, flop_env = 2 * 151_000.0, ALGO_FLOP     # PPOActor.forward: 151 K multiply-adds per aircraft and call; one FDM step
     per_macro = 50 * (flop_actor + flop_env)
     ach = npl * per_macro / (ms * 1e-3) / 1e12
     out = {'value': ms, 'unit': 'ms per PlanningEnv.step (50 inner FDM steps + 50 controller calls)', 'steps': k7, 'aircraft': npl,
-           'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7, 'launches_per_macro_step': 1 + 1 + 50 * 2,
-           'env_kernels_ms_per_macro_step': env_ms, 'controller_and_gaps_ms_per_macro_step': ms - env_ms,
+           'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7, 'inner_loop': auto,
+           'launches_per_macro_step': 3 if tiles - cus <= cus // 2 else 2 + 50 * 2,
+           'launch_by_launch': {'ms': ms_launches, 'env_kernels_summed_ms': env_ms,
+                                'note': 'NP_PLANNING_MODE=launches: the round-3 path, 102 launches; env_kernels_summed_ms = sum of the 50 inner-step kernel '
+                                        'durations (kernels of different row groups overlap: a sum, not wall time)'},
            'roofline': {'bound': 'mfma+valu (fp32: the f32-input MFMA and the vector ALU share one 157.3 TFLOP/s pipe, tools/microbench/mfma_coissue.hip)',
                         'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS,
                         'algorithmic_flop_per_aircraft_macro_step': per_macro,
                         'note': '50 x (302 KFLOP controller forward + 33.8 KFLOP FDM step) = 16.8 MFLOP per aircraft and PlanningEnv.step; wall clock '
-                                'of back-to-back macro-steps, i.e. launch gaps included'},
-           'note': 'controller = np_actor_forward (K=1 fp32 MFMA chains, bit-exact to its oracle: tests/test_gpu_actor.py); the inner step writes '
-                   'the next low-level observation itself (np_f16_io.ll_obs): 102 launches per macro-step (round 2: 151), the 100 of the inner loop enqueued '
-                   'by ONE library call (np_planning_inner_loop) — as two or three row groups on their own streams for 8 192 < n <= 81 920, so that '
-                   "one group's controller call overlaps another's FDM step and every call runs on the 32-row tiles.  Up to 16 384 aircraft per call the "
-                   'controller runs on 32-row tiles (v_mfma_f32_16x16x1_4b_f32: 1 174 dependent K = 1 steps of 32 cycles = 15.7 us of matrix pipe '
-                   'per tile, ~32 us per call with the LayerNorm / gate epilogues); from 8 193 aircraft on some CUs carry two tiles (313 tiles on '
-                   '256 CUs at n = 1e4) and the call takes ~55 us: the f32 MFMA and the vector ALU share one pipe, so two tiles cost '
-                   '2 x (15.7 + ~6) us of it.  Above 16 384: 64-row tiles (v_mfma_f32_32x32x1_2b_f32), throughput-bound'}
+                                'of back-to-back macro-steps (reset + prelude launches included)'},
+           'note': 'n <= 32 x CUs: ONE launch per macro-step of the persistent kernel (np_planning.hip) — a workgroup owns a 32-row tile and loops the 50 x '
+                   '{controller call as K = 1 fp32 MFMA chains (v_mfma_f32_16x16x1_4b_f32, 1 184 dependent steps of 32 cycles per wave = 38 K of the ~76 K '
+                   "cycles of a call), inner FDM step} with the recurrent state in registers and the tile's observation / state / cached coefficients in LDS; "
+                   "eight waves per tile: an inner step's Overload evaluation, terminations and reward run on waves 4..7 during the NEXT controller call.  "
+                   'Up to 1.5 tiles per CU (n = 1e4: 313 tiles on 256 CUs) the guest schedule: every CU owns a tile and hosts one block of ~13 iterations '
+                   'of a guest tile between two stretches of its own (makespan 63 iterations instead of 100; tiles change CU through coherent sc1 '
+                   'accesses).  Larger batches: launch by launch, 32-row controller tiles up to 16 384 rows per call, 64-row tiles (v_mfma_f32_32x32x1_2b_f32) '
+                   'above, two to four row groups on their own streams.  Bit-identical between all of them (tests/test_gpu_actor.py)'}
     del penv, ctrl
     torch.cuda.empty_cache()
     return out

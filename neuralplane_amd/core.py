@@ -100,9 +100,10 @@ class F16Batch:
         # BaseEnv.__init__ leaves all three flags set so that the first reset()/step() initialises
         # every row (env_base.py:31-33)
         self.flags = torch.ones((3, n), dtype=torch.uint8, device=d)
-        # cross-step cache of the 14 force-side (alpha, beta)-only aero coefficients (np_f16_io.coef_cache).  It is
-        # valid only while nobody but the kernels wrote `s`: torch bumps `s._version` on every in-place
-        # write through a tensor (model.s[mask] = ...), raw-pointer kernel writes do not.
+        # cross-step cache of the 14 force-side (alpha, beta)-only aero coefficients (np_f16_io.coef_cache).  The cache carries the
+        # (alpha, beta) its coefficients belong to and the step kernels re-evaluate them in every wave that finds the state changed
+        # (np_nets.h, round 4): results do not depend on who wrote `s`.  The `_version` bookkeeping below is only a fast path — an edit
+        # torch can see (model.s[mask] = ...) sends the whole batch through the un-cached kernel instead of refilling wave by wave.
         self.coef_cache = torch.empty(int(self.lib.np_f16_cache_floats(n)), dtype=torch.float32, device=d)
         self._cache_valid = False
         self._no_cache = bool(os.environ.get('NPF16_NO_CACHE'))

@@ -94,7 +94,13 @@ constexpr int NUM_CACHED = 14;     // force-side alpha/beta-only nets: the first
 #define NPF16_TRIG_CACHE 0
 #endif
 constexpr int NUM_CACHED_TRIG = NPF16_TRIG_CACHE ? 10 : 0;   // sa, ca, sb, cb, st, ct, sphi, cphi, tan(theta), pow
-constexpr int NUM_CACHE_ROWS = NUM_CACHED + NUM_CACHED_TRIG;
+// Rows CACHE_KEY0, CACHE_KEY0 + 1 (round 4): the (alpha, beta) the row's 14 coefficients were evaluated at — s[7], s[8] of the state the
+// writing step reached, bit for bit.  A step that takes the coefficients from the cache compares the two with the state it was handed: any
+// difference (the caller edited the state between steps through a path no version counter sees: `tensor.data[...] = `, a raw-pointer kernel,
+// DLPack) makes the wave re-evaluate the coefficients at the state at hand before it goes on — results never depend on who wrote the state.
+constexpr int NUM_CACHE_KEYS = 2;
+constexpr int CACHE_KEY0 = NUM_CACHED + NUM_CACHED_TRIG;
+constexpr int NUM_CACHE_ROWS = CACHE_KEY0 + NUM_CACHE_KEYS;
 
 constexpr NetClass CLASSES[NUM_CLASSES] = {
     /* CL_DAMP  */ {1, 20, 10, 0, {G_A_DAMP, G_NONE, G_NONE}, 12, 4,

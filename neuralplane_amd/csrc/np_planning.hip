@@ -107,7 +107,8 @@ __device__ __forceinline__ void h_stage_to_global(float *dst, long long i0, long
 }
 
 template <int W, bool COH>
-__device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK]) {
+__device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK],
+                                            unsigned *stale_s) {
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
     const int t = (int)(tid % PLAN_TILE), r = t & (PLAN_ROWS - 1);
@@ -160,6 +161,13 @@ __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float
         float *coef = lds_fdm + t;
 #pragma unroll
         for (int k = 0; k < NUM_CACHED; k++) coef[cached_slot(k) * PLAN_TILE] = gld<COH>(cache_blk + k * CACHE_TILE);
+        // do they belong to the state at hand?  (np_nets.h: the keys are the (alpha, beta) they were evaluated at; the caller may have edited
+        // the state since.)  The workgroup re-evaluates them if not (plan_fill_cache, first iteration of a macro-step only: afterwards the
+        // cache travels with the state)
+        const unsigned ka = __float_as_uint(gld<COH>(cache_blk + CACHE_KEY0 * CACHE_TILE)), kb = __float_as_uint(gld<COH>(cache_blk + (CACHE_KEY0 + 1) * CACHE_TILE));
+        const bool stale = ka != __float_as_uint(gld<COH>(a->k.s + 7 * a->k.ld + ic)) || kb != __float_as_uint(gld<COH>(a->k.s + 8 * a->k.ld + ic));
+        const unsigned long long any = __ballot(stale);
+        if (t == 0) *stale_s = any != 0ull ? 1u : 0u;
     }
 }
 
@@ -303,6 +311,8 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
             float *cache_w = ap->k.cache + ((i >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (i & (CACHE_TILE - 1));
 #pragma unroll
             for (int k = 0; k < NUM_CACHED; k++) gst<COH>(cache_w + k * CACHE_TILE, coef[cached_slot(k) * TILE]);
+            gst<COH>(cache_w + CACHE_KEY0 * CACHE_TILE, s[7]);   // the (alpha, beta) they belong to
+            gst<COH>(cache_w + (CACHE_KEY0 + 1) * CACHE_TILE, s[8]);
         }
     }
     if (part == 0 && !last && t < PLAN_ROWS) {
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     static_assert(W == 4 || W == 8, "four or eight waves per tile");
     constexpr bool PIPE = NP_PLAN_PIPE && W == 8;   // the pipelined schedule (plan_fdm_front / plan_fdm_back) inside a tile's stay on this workgroup
     __shared__ __attribute__((aligned(16))) float lds_all[PLAN_LDS_FLOATS];
-    __shared__ unsigned item_s;
+    __shared__ unsigned item_s, stale_s;
     float *lds_act = lds_all, *lds_fdm = lds_all + npact::ACTOR32_LDS_FLOATS, *ctx = lds_fdm + PLAN_COLS * PLAN_TILE;
     PlanArgsC ap = (PlanArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             if (do_import) npact::actor32_stage_head(lds_act, ap->actor_w, tid);  // stays staged while the workgroup lives
         }
         if (do_import) {
-            plan_import<W, QUEUE>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h);
+            plan_import<W, QUEUE>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h, &stale_s);
             __syncthreads();
             if constexpr (QUEUE) {
                 if (W == 4 || wave < 4) {   // the masked recurrent state (gru.py:26) of (row, block) from the stage
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     }
                 }
             }
-            if (it == 0 && !ap->cache_valid0) plan_fill_cache<W>(ap, lds_fdm, ctx, tid);
+            if (it == 0 && (!ap->cache_valid0 || stale_s != 0u)) plan_fill_cache<W>(ap, lds_fdm, ctx, tid);
         } else if (W == 4 || wave < 4) {   // resident: h holds the previous call's new state; gru.py:26 masks it
             const float mk = ctx[CTX_ST + CTX_MK * PLAN_ROWS + (int)(tid & 31)];
 #pragma unroll

@@ -172,7 +172,7 @@ def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir,
         assert torch.equal(envs[0].termination_reasons(), envs[1].termination_reasons())
         assert torch.equal(envs[0]._batch.reward_task, envs[1]._batch.reward_task)
         assert torch.equal(envs[0].step_count, envs[1].step_count)
-        m = (n // 64) * 14 * 64   # whole 64-row tiles of the cache (the rows beyond n of a last tile are never written)
+        m = (n // 64) * 16 * 64   # whole 64-row tiles of the cache: 14 coefficients + the 2 key rows (the rows beyond n of a last tile are never written)
         assert torch.equal(envs[0]._batch.coef_cache[: m], envs[1]._batch.coef_cache[: m])
     assert envs[0].termination_counts() == envs[1].termination_counts()
     assert any(v > 0 for v in envs[0].termination_counts().values()), 'the comparison should include rows that terminated'

@@ -205,6 +205,52 @@ def test_cross_step_cache_is_invalidated_by_external_state_edits():
     assert all(used_cached[i] for i in (1, 2, 3, 5, 6, 7, 8, 10, 11))
 
 
+@pytest.mark.parametrize('variant', ['latency8', 'latency', 'latency4w', 'latency2', 'pair', 'throughput'])
+@pytest.mark.parametrize('solver', ['euler', 'rk4'])
+def test_cross_step_cache_validates_itself_against_invisible_state_edits(variant, solver):
+    """writes that bump no version counter — `env.model.s.data[...] = `, a write through an alias torch does not
+    know to be one (DLPack; what a foreign kernel holding the raw pointer does) — used to leave the next step integrating with the
+    coefficients of the OLD (alpha, beta).  The cache now carries the (alpha, beta) its coefficients belong to and the step kernel
+    re-evaluates them in the waves that find a difference: bit-identical to the oracle whoever wrote the state, with the cached kernel
+    still chosen (the version counter never moved)."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    if solver == 'rk4' and variant.startswith('latency'):
+        pytest.skip('the latency family serves the Euler solver')
+    n, seed = 1300, 5
+    env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=seed, device='cuda:0', solver=solver)
+    b = env._batch
+    b.set_kernel_variant(variant)
+    o = Oracle('heading', solver=solver)
+    st = Oracle.new_state(n)
+    rng = np.random.RandomState(17)
+    env.reset()
+    o.reset(st, seed=seed, call_idx=0)
+    alias = torch.from_dlpack(torch.utils.dlpack.to_dlpack(b.s))   # same memory, its own version counter
+    assert alias.data_ptr() == b.s.data_ptr()
+    cached = []
+    for t in range(10):
+        if t == 3:    # `.data`: no version bump
+            v0 = b.s._version
+            env.model.s.data[5::11, 7] = 0.17
+            env.model.s.data[5::11, 8] = 0.04
+            assert b.s._version == v0
+            st['s'][5::11, 7], st['s'][5::11, 8] = 0.17, 0.04
+        if t == 6:    # the raw pointer: one row in the middle of a tile, one in the ragged last tile; alpha only / beta only
+            v0 = b.s._version
+            alias[7, 700] = -0.08
+            alias[8, n - 1] = 0.11
+            assert b.s._version == v0
+            st['s'][700, 7], st['s'][n - 1, 8] = -0.08, 0.11
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        cached.append(bool(b._cache_valid and b.s._version == b._s_version))
+        obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, o_done, o_bad, _ = o.step(st, a, seed=seed, call_idx=t + 1)
+        assert _same(env.model.s.cpu().numpy(), st['s']), f'state differs at step {t}'
+        assert _same(obs.cpu().numpy(), o_obs) and _same(rew.cpu().numpy(), o_rew), f'obs/reward differ at step {t}'
+        assert np.array_equal(bad.cpu().numpy(), o_bad.astype(bool)) and np.array_equal(done.cpu().numpy(), o_done.astype(bool))
+    assert cached[3] and cached[6], 'the edits must have been invisible to the host-side check (else this test proves nothing)'
+
+
 def test_env_surface_matches_reference_contract():
     """Shapes, dtypes, attributes and getters of the ControlEnv / GPUVecEnv surface."""
     from neuralplane_amd.envs.control_env import ControlEnv
