@@ -37,7 +37,8 @@ extern "C" {
 #define NP_NUM_DERIVED 23  /* rows written by np_f16_derived()                                                    */
 #define NP_NUM_NETS 43     /* rows written by np_f16_aero_coefficients(): the aero surrogates, hifi_F16_AeroData.py    */
 #define NP_NUM_TERM_COUNTERS 7 /* per-condition termination counters (np_f16_io.term_counters)                      */
-#define NP_NUM_CACHED 14   /* values per aircraft in the cross-step coefficient cache (np_f16_io.coef_cache)      */
+#define NP_NUM_CACHED 14   /* coefficients per aircraft in the cross-step cache (np_f16_io.coef_cache); the cache also carries two key
+                            * values per aircraft since ABI 14: size it with np_f16_cache_floats()                 */
 
 enum { NP_TASK_HEADING = 0, NP_TASK_CONTROL = 1, NP_TASK_TRACKING = 2 }; /* envs/control_env.py:28-35 */
 enum { NP_SOLVER_EULER = 0, NP_SOLVER_RK4 = 1 };                          /* envs/models/F16_model.py:16,64-67 */
@@ -86,8 +87,11 @@ typedef struct np_f16_io {
      * layout private to the library (tiled per workgroup).  36 of the
      * 42 aero MLPs depend on (alpha, beta) only; their values after the integrator step are exactly what the
      * next step's integrator needs, so np_f16_step writes them here and, when cache_valid != 0, reads them
-     * back instead of re-evaluating (results are bit-identical either way).  The caller clears cache_valid
-     * whenever it modified `s` behind the library's back since the last np_f16_step on these buffers. */
+     * back instead of re-evaluating (results are bit-identical either way).  cache_valid = "the last np_f16_step / np_f16_reset on these
+     * buffers wrote the cache" (0 for a fresh or foreign buffer).  Since ABI 14 the cache also records the (alpha, beta) its
+     * coefficients belong to, and a step that finds a row's state edited since (by whatever path: the caller need not tell) re-evaluates
+     * the coefficients of that wave before it goes on: clearing cache_valid after editing `s` is an optimisation (the whole batch then
+     * runs the un-cached kernel), no longer a correctness requirement. */
     float *coef_cache;
     int32_t cache_valid;
     /* inner_step != 0 selects the semantics of ONE of the 50 low-level iterations inside PlanningEnv.step

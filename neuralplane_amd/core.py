@@ -338,6 +338,12 @@ class F16Batch:
                                                      self._stream()))
         return out
 
+    def invalidate(self):
+        """Tell the batch that `s` / `u` were written through a path torch cannot see (`.data`, DLPack, a foreign kernel): the getters'
+        cache (`derived`) is dropped.  The step kernels need no such hint — the coefficient cache validates itself (np_nets.h)."""
+        self._version += 1
+        self._derived = None
+
     def derived(self):
         """[23,n] derived quantities at the current (s,u) (np_f16_derived), cached per state version."""
         key = (self._version, self.s.data_ptr(), self.u.data_ptr(), self.s._version, self.u._version)

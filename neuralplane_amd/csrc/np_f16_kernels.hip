@@ -35,8 +35,9 @@ namespace npf16 {
 #define NPF16_BLOCK 128
 #endif
 // pair variant, de-phasing of the first generation: (blockIdx % groups) x stagger cycles; groups odd (co-resident workgroups differ
-// by powers of two in index).  Two builds of the step kernel: PW = 2 waves per SIMD (188 VGPRs, nothing in scratch) and PW = 3
-// (168 VGPRs, ~20 cold dwords per lane in scratch, stored once and reloaded once per step); launch_env picks per grid size.
+// by powers of two in index).  Two builds of the step kernel: PW = 2 waves per SIMD (an occupancy cap) and PW = 3; since round 3 both
+// Euler builds need 159 VGPRs and no scratch (rk4: 184 / 0 B and 168 / 64 B per lane) — the numbers of the library at hand are printed by
+// tools/code_object_table.py from the code object itself (DESIGN.md carries that table); launch_env picks per grid size.
 #ifndef NPF16_PAIR_STAGGER
 #define NPF16_PAIR_STAGGER 14000  // PW = 2
 #endif

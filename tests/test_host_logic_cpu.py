@@ -144,6 +144,32 @@ def test_generated_asm_is_up_to_date(tmp_path):
             assert f.read() == g.read(), f'{name} is stale: run python tools/gen_mlp_asm.py'
 
 
+def test_design_kernel_table_is_what_the_library_says():
+    """DESIGN.md's "kernels at a glance" block (registers, scratch, LDS per kernel) is generated from the metadata of the code objects inside
+    the built library (tools/code_object_table.py) and must not drift from it (the table used to be prose).  Also: every
+    generated asm statement that touches vcc declares it, and none ends with a scalar load in flight (the two contracts the parked fault of
+    round 3 was suspected of)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from neuralplane_amd import build
+    build.build_hip()
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'code_object_table.py'), '--check-design'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ('np_mlp_asm.inc', 'np_mlp_asm_dual.inc', 'np_actor_mfma16_asm.inc', 'np_actor_mfma_asm.inc', 'np_actor_asm.inc'):
+        src = open(os.path.join(root, 'neuralplane_amd', 'csrc', name)).read()
+        blocks = re.findall(r'asm volatile\((.*?)\);\n', src, flags=re.S)
+        assert blocks, name
+        for b in blocks:
+            ins = re.findall(r'"([^"\\]*)\\n\\t"', b)
+            loads = [i for i, x in enumerate(ins) if x.startswith('s_load') or x.startswith('s_buffer_load')]
+            waits = [i for i, x in enumerate(ins) if x.startswith('s_waitcnt') and 'lgkmcnt(0)' in x]
+            assert not loads or any(w > loads[-1] for w in waits), f'{name}: a statement ends with a scalar load in flight'
+            assert not any('vcc' in x for x in ins) or '"vcc"' in b.split(':')[-1], f'{name}: vcc written but not declared'
+
+
 def test_two_set_phase_statements_by_emulation():
     """The generated pair-variant statements (np_mlp_asm_dual.inc: ~20 000 lines of inline asm) executed as TEXT by
     tools/emulate_dual_asm.py — scalar control flow, weight stream, packed FMAs with op_sel / clamp, LDS traffic — on a synthetic
