@@ -531,13 +531,14 @@ def planning_mode(dev, g, npl, k7):
     tiles, cus = (npl + 31) // 32, torch.cuda.get_device_properties(dev).multi_processor_count
     auto = ('persistent kernel, eight waves per 32-row tile, one workgroup per tile' if tiles <= cus else
             'persistent kernel, guest schedule (every CU owns a tile and hosts one block of iterations of a guest tile)' if tiles - cus <= cus // 2 else
+            'persistent kernel, dual workgroups (two tiles per eight-wave workgroup, one FDM step for both)' if tiles <= 2 * cus else
             'launch by launch (np_actor_forward + np_f16_step per iteration, row groups on their own streams)')
     flop_actor, flop_env = 2 * 151_000.0, ALGO_FLOP     # PPOActor.forward: 151 K multiply-adds per aircraft and call; one FDM step
     per_macro = 50 * (flop_actor + flop_env)
     ach = npl * per_macro / (ms * 1e-3) / 1e12
     out = {'value': ms, 'unit': 'ms per PlanningEnv.step (50 inner FDM steps + 50 controller calls)', 'steps': k7, 'aircraft': npl,
            'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7, 'inner_loop': auto,
-           'launches_per_macro_step': 3 if tiles - cus <= cus // 2 else 2 + 50 * 2,
+           'launches_per_macro_step': 3 if tiles <= 2 * cus else 2 + 50 * 2,
            'launch_by_launch': {'ms': ms_launches, 'env_kernels_summed_ms': env_ms,
                                 'note': 'NP_PLANNING_MODE=launches: the round-3 path, 102 launches; env_kernels_summed_ms = sum of the 50 inner-step kernel '
                                         'durations (kernels of different row groups overlap: a sum, not wall time)'},

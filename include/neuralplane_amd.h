@@ -302,9 +302,11 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
  * to the launches they replace.  NP_PLANNING_PERSISTENT_GUESTS (ABI 14) is the static counterpart of the queue for resident < tiles <= 2 x
  * resident: every resident workgroup owns a tile, the remaining "guest" tiles are cut into blocks of iterations and each block is hosted
  * by a different workgroup between two stretches of its own tile (makespan = iterations + one block instead of 2 x iterations; `block`
- * = the slack in iterations per block index, 0 = the library chooses).  NP_PLANNING_AUTO picks by n, solver and numerics; environment
- * NP_PLANNING_MODE=launches|persistent|queue|guests (read per call) overrides it for benchmarks and the parity tests. */
-enum { NP_PLANNING_AUTO = 0, NP_PLANNING_LAUNCHES = 1, NP_PLANNING_PERSISTENT = 2, NP_PLANNING_PERSISTENT_QUEUE = 3, NP_PLANNING_PERSISTENT_GUESTS = 4 };
+ * = the slack in iterations per block index, 0 = the library chooses).  NP_PLANNING_PERSISTENT_DUAL (ABI 14) gives every eight-wave
+ * workgroup TWO tiles: their controller calls run in lock-step on waves 0..3 / 4..7 and one 64-lane FDM step serves both (a single 32-row
+ * tile fills the FDM code's 64-lane waves only half); any n, the choice above 1.5 tiles per CU.  NP_PLANNING_AUTO picks by n, solver and
+ * numerics; environment NP_PLANNING_MODE=launches|persistent|queue|guests|dual (read per call) overrides it for benchmarks and the parity tests. */
+enum { NP_PLANNING_AUTO = 0, NP_PLANNING_LAUNCHES = 1, NP_PLANNING_PERSISTENT = 2, NP_PLANNING_PERSISTENT_QUEUE = 3, NP_PLANNING_PERSISTENT_GUESTS = 4, NP_PLANNING_PERSISTENT_DUAL = 5 };
 typedef struct np_planning_loop {
     int32_t iterations;        /* planning_env.py:153: 50 */
     int32_t groups;            /* 0 = automatic */

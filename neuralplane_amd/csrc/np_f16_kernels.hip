@@ -1746,6 +1746,10 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
         ctx->flag_base += (unsigned)lp->iterations + 1u;
         ctx->queue_dirty = true;   // until the launch below is enqueued
     }
+    if (mode == NP_PLANNING_PERSISTENT_DUAL) {   // two tiles per eight-wave workgroup; any n (workgroups beyond the resident ones queue up)
+        NP_HIP(launch_planning_dual(ctx->task, pa, (unsigned)((pa.tiles + 1) / 2), st));
+        return 0;
+    }
     NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
     ctx->queue_dirty = false;
     return 0;
@@ -1761,7 +1765,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     if (lp->groups < 0 || lp->groups > 8) return fail("np_planning_loop: groups must be 0 (automatic) .. 8");
     if (lp->rnn[0] == lp->rnn[1] || lp->ll_obs[0] == lp->ll_obs[1] || lp->flags[0] == lp->flags[1])
         return fail("np_planning_loop: the two buffers of a ping-pong pair must differ");
-    if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_GUESTS) return fail("np_planning_loop: unknown mode");
+    if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_DUAL) return fail("np_planning_loop: unknown mode");
     if (lp->waves != 0 && lp->waves != 4 && lp->waves != 8) return fail("np_planning_loop: waves must be 0 (automatic), 4 or 8");
     if (lp->block < 0) return fail("np_planning_loop: block must be >= 0");
     hipStream_t st = (hipStream_t)stream;
@@ -1771,7 +1775,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         int mode = lp->mode, waves = lp->waves;
         if (const char *e = std::getenv("NP_PLANNING_MODE")) {  // read per call: benchmarks and the parity tests switch it
             mode = std::strcmp(e, "launches") == 0 ? NP_PLANNING_LAUNCHES : std::strcmp(e, "persistent") == 0 ? NP_PLANNING_PERSISTENT
-                   : std::strcmp(e, "queue") == 0 ? NP_PLANNING_PERSISTENT_QUEUE : std::strcmp(e, "guests") == 0 ? NP_PLANNING_PERSISTENT_GUESTS : mode;
+                   : std::strcmp(e, "queue") == 0 ? NP_PLANNING_PERSISTENT_QUEUE : std::strcmp(e, "guests") == 0 ? NP_PLANNING_PERSISTENT_GUESTS : std::strcmp(e, "dual") == 0 ? NP_PLANNING_PERSISTENT_DUAL : mode;
         }
         if (const char *e = std::getenv("NP_PLANNING_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
         const bool eligible = ctx->solver == 0 && !ctx->cfg.aero_1d_tables && io->coef_cache && !io->rand_u && !io->noise && io->reward;
@@ -1780,13 +1784,15 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         if (mode == NP_PLANNING_AUTO) {
             // measured per size (profiles/r04_planning_modes.log, ms per PlanningEnv.step): up to one 32-row tile per resident workgroup the
             // persistent kernel with eight waves per tile (n = 8 192: 2.49 -> 2.07); up to 1.5 tiles per workgroup its guest schedule
-            // (n = 1e4: 3.16 -> 2.6); beyond that the launches, whose 64-row controller tiles and row groups fill the chip better
+            // (n = 1e4: 3.16 -> 2.6); up to two tiles per workgroup the dual workgroups (two tiles share an eight-wave workgroup and one FDM
+            // step: n = 16 384 3.39 -> 3.21); beyond that the launches, whose 64-row controller tiles and row groups fill the chip better
             mode = NP_PLANNING_LAUNCHES;
             if (eligible && !stream_is_capturing(st)) {
                 const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, 8);
                 const int64_t resident = (int64_t)per_cu * ctx->num_cus, tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS;
                 if (per_cu > 0 && tiles <= resident) mode = NP_PLANNING_PERSISTENT, waves = 8;
                 else if (per_cu > 0 && tiles - resident <= resident / 2) mode = NP_PLANNING_PERSISTENT_GUESTS, waves = 8;
+                else if (per_cu > 0 && tiles <= 2 * resident) mode = NP_PLANNING_PERSISTENT_DUAL, waves = 8;
             }
         }
         int block = lp->block;

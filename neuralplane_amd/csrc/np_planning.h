@@ -38,6 +38,8 @@ constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_
 // (tile, iteration) items.  Returns hipSuccess or the launch error.
 hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args, unsigned grid, hipStream_t stream, hipEvent_t ev_start,
                                       hipEvent_t ev_stop);
+// dual workgroups: two 32-row tiles per eight-wave workgroup (np_planning.hip), static schedule, grid = ceil(tiles / 2)
+hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, hipStream_t stream);
 // how many workgroups of that shape fit one CU / the device (occupancy query)
 int planning_persistent_workgroups_per_cu(int task, int waves);
 

@@ -58,6 +58,16 @@ constexpr int PLAN_COLS = NUM_LDS_SLOTS + 2 * NUM_SHARED_SCALARS;  // coefficien
 // exposed on wave 0 right after a barrier)
 constexpr int CTX_OBS = 0, CTX_ACT = CTX_OBS + PLAN_ROWS * 22, CTX_ST = CTX_ACT + PLAN_ROWS * 4, CTX_ROWS = 22, CTX_SC = 16, CTX_FL = 17, CTX_MK = 18, CTX_LT = 19;
 constexpr int CTX_FLOATS = CTX_ST + CTX_ROWS * PLAN_ROWS;
+// the same layout for a context of ROWS rows (32: one tile; 64: the two tiles of a dual workgroup, tile A = rows 0..31, tile B = 32..63)
+template <int ROWS>
+struct CtxL {
+    static constexpr int OBS = 0, ACT = ROWS * 22, ST = ACT + ROWS * 4, FLOATS = ST + CTX_ROWS * ROWS;
+};
+static_assert(CtxL<PLAN_ROWS>::ST == CTX_ST && CtxL<PLAN_ROWS>::FLOATS == CTX_FLOATS, "context layout");
+// dual workgroups (round 4): TWO 32-row tiles per eight-wave workgroup — their controller calls run in lock-step on waves 0..3 / 4..7 (same
+// straight-line code, shared barriers), each with its own 36 KB of controller LDS, and ONE inner FDM step serves both: the FDM device code
+// runs 64-lane waves, which a single 32-row tile fills only half (lanes 32..63 shadow rows 0..31).  Dynamic LDS (102 KB), one workgroup per CU.
+constexpr int DUAL_LDS_FLOATS = 2 * npact::ACTOR32_LDS_FLOATS + PLAN_COLS * PLAN_TILE + CtxL<2 * PLAN_ROWS>::FLOATS;
 constexpr int PLAN_LDS_FLOATS = npact::ACTOR32_LDS_FLOATS + PLAN_COLS * PLAN_TILE + CTX_FLOATS;
 static_assert(PLAN_LDS_FLOATS * sizeof(float) <= 65536, "static LDS of the persistent kernel");
 static_assert(33 * PLAN_TILE <= npact::ACTOR32_HEAD_W && PLAN_ROWS * OBS_LD <= npact::ACTOR32_HEAD_W,
@@ -106,21 +116,24 @@ __device__ __forceinline__ void h_stage_to_global(float *dst, long long i0, long
     }
 }
 
-template <int W, bool COH>
+template <int W, bool COH, int ROWS = PLAN_ROWS>
 __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK],
                                             unsigned *stale_s) {
+    using CX = CtxL<ROWS>;
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
-    const int t = (int)(tid % PLAN_TILE), r = t & (PLAN_ROWS - 1);
+    const int t = (int)(tid % PLAN_TILE), r = t & (ROWS - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid / PLAN_TILE));
     const long long n = a->k.n;
     const long long i = i0 + r;
     const long long ic = i < n ? i : n - 1;   // rows beyond the batch shadow its last row; nothing of them is exported
     if constexpr (COH) h_global_to_stage<W>(a->rnn[it & 1], i0, n, lds_act, tid);   // the owners read the stage after the caller's barrier
-    if (!COH && wave < 4) {   // the controller's waves: this thread's 16 features of its row
-        const int blk = 2 * wave + (t >> 5);
-        const float mk = a->masks[ic];
-        const float *hp = a->rnn[it & 1] + ic * npact::HID + blk * npact::BLK;
+    if (!COH && (wave < 4 || ROWS == 2 * PLAN_ROWS)) {   // the controller's waves (dual: waves 4..7 hold tile B): this thread's 16 features of its row
+        const int blk = 2 * (wave & 3) + (t >> 5);
+        const long long ih = i0 + (ROWS == 2 * PLAN_ROWS && wave >= 4 ? PLAN_ROWS : 0) + (t & (PLAN_ROWS - 1));
+        const long long ihc = ih < n ? ih : n - 1;
+        const float mk = a->masks[ihc];
+        const float *hp = a->rnn[it & 1] + ihc * npact::HID + blk * npact::BLK;
         {
 #pragma unroll
             for (int j = 0; j < npact::BLK / 4; j++) {
@@ -132,29 +145,29 @@ __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float
             }
         }
     }
-    if (wave == 0) {  // low-level observation rows [32][22]: 704 dwords, 11 per lane
+    if (wave == 0) {  // low-level observation rows [ROWS][22]: 704 dwords, 11 per lane (dual: twice that)
         const float *src = a->ll_obs[it & 1] + i0 * 22;
         const long long avail = (n - i0) * 22;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
+        for (int k = 0; k < ROWS * 22 / 64; k++) {
             const int L = k * 64 + t;
-            ctx[CTX_OBS + L] = gld<COH>(src + (L < avail ? L : 0));
+            ctx[CX::OBS + L] = gld<COH>(src + (L < avail ? L : 0));
         }
     }
-    if (wave == PLAN_STATE_WAVE && t < PLAN_ROWS) {
-        float *st = ctx + CTX_ST + r;
+    if (wave == PLAN_STATE_WAVE && t < ROWS) {
+        float *st = ctx + CX::ST + r;
 #pragma unroll
-        for (int k = 0; k < 12; k++) st[k * PLAN_ROWS] = gld<COH>(a->k.s + k * a->k.ld + ic);
+        for (int k = 0; k < 12; k++) st[k * ROWS] = gld<COH>(a->k.s + k * a->k.ld + ic);
 #pragma unroll
-        for (int k = 0; k < 4; k++) st[(12 + k) * PLAN_ROWS] = gld<COH>(a->k.u + k * a->k.ld + ic);
-        st[CTX_SC * PLAN_ROWS] = __int_as_float((int)gld<COH>(a->k.step_count + ic));
+        for (int k = 0; k < 4; k++) st[(12 + k) * ROWS] = gld<COH>(a->k.u + k * a->k.ld + ic);
+        st[CTX_SC * ROWS] = __int_as_float((int)gld<COH>(a->k.step_count + ic));
         const uint8_t *fin = a->flags[it & 1];
         unsigned fl = (gld<COH>(fin + ic) ? 1u : 0u) | (gld<COH>(fin + n + ic) ? 2u : 0u) | (gld<COH>(fin + 2 * n + ic) ? 4u : 0u);
         if (a->k.term_reasons) fl |= (unsigned)gld<COH>(a->k.term_reasons + ic) << 8;
-        st[CTX_FL * PLAN_ROWS] = __uint_as_float(fl);
-        st[CTX_MK * PLAN_ROWS] = a->masks[ic];
+        st[CTX_FL * ROWS] = __uint_as_float(fl);
+        st[CTX_MK * ROWS] = a->masks[ic];
 #pragma unroll
-        for (int k = 0; k < 3; k++) st[(CTX_LT + k) * PLAN_ROWS] = a->k.ll_tgt[k * a->k.ld + ic];
+        for (int k = 0; k < 3; k++) st[(CTX_LT + k) * ROWS] = a->k.ll_tgt[k * a->k.ld + ic];
     }
     if (wave == PLAN_STATE_WAVE) {  // coefficient columns <- the cross-step cache (layout [row / 64][NUM_CACHE_ROWS][row % 64]); all 64 lanes
         const float *cache_blk = a->k.cache + ((ic >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (ic & (CACHE_TILE - 1));
@@ -174,35 +187,36 @@ __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float
 // One inner FDM step (np_f16_step with inner_step: f16_env_kernel<TASK, 0, true, true, 64, W, true>) of the tile in the context:
 // no auto-reset, flagged rows frozen, flags accumulate; leaves the controller's next observation in the context unless `last`, writes the
 // task observation and the reward if `last`; `do_export`: state, counters, flags, reason bits and cached coefficients -> global.
-template <int TASK, int W, bool COH>
+template <int TASK, int W, bool COH, int ROWS = PLAN_ROWS>
 __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, bool last, bool do_export,
                                               unsigned tid) {
+    using CX = CtxL<ROWS>;
     // every scalar is (re-)read from the kernel-argument segment where it is used: read through the by-value parameter the compiler
     // hoists the loads out of the iteration loop and keeps ~60 SGPRs alive across the asm phases (parked in VGPR lanes, then scratch)
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
     constexpr int TILE = PLAN_TILE;
-    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
+    const int t = (int)(tid % TILE), r = t & (ROWS - 1);
     const int part = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
     float *coef = lds_fdm + t;
     const long long n = a->k.n;
     const long long i = i0 + r;
-    const bool valid = t < PLAN_ROWS && i < n;
+    const bool valid = t < ROWS && i < n;
     const long long ic = i < n ? i : n - 1;
     const bool tables = false;  // the persistent kernel serves the MLP numerics (the launcher falls back otherwise)
     const bool want_obs = last && a->final_obs != nullptr;
     const unsigned o4 = (unsigned)ic * 4u;
 
     float s[12], u[4], tgt[3];
-    const float *st = ctx + CTX_ST + r;
+    const float *st = ctx + CX::ST + r;
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
+    for (int k = 0; k < 12; k++) s[k] = st[k * ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * ROWS];
 #pragma unroll
     for (int k = 0; k < 3; k++) tgt[k] = at_off(a->k.tgt + k * a->k.ld, o4);   // constant during the loop
-    long long sc = (long long)__float_as_int(st[CTX_SC * PLAN_ROWS]);
-    const unsigned fl_in = __float_as_uint(st[CTX_FL * PLAN_ROWS]);
+    long long sc = (long long)__float_as_int(st[CTX_SC * ROWS]);
+    const unsigned fl_in = __float_as_uint(st[CTX_FL * ROWS]);
     float *nz = lds_act + t;  // 33 noise columns, in the controller's (idle) LDS
     if (want_obs && !a->k.noise && a->k.cfg.noise_scale != 0.0f) {  // this wave's share of the observation noise (f16_env_kernel, SHARED)
         const int nb = W == 8 ? part - 4 : part;
@@ -230,7 +244,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
     float act[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        float v = ctx[CTX_ACT + r * 4 + k];
+        float v = ctx[CX::ACT + r * 4 + k];
         v = v < -1.0f ? -1.0f : v;
         v = v > 1.0f ? 1.0f : v;
         act[k] = v;
@@ -264,7 +278,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
     NP_REREAD_ARGS(ap);
     NP_PSTAMP(6);
     if (part == PLAN_STATE_WAVE) {
-        const unsigned fl0 = __float_as_uint(ctx[CTX_ST + CTX_FL * PLAN_ROWS + r]);
+        const unsigned fl0 = __float_as_uint(ctx[CX::ST + CTX_FL * ROWS + r]);
         float acc3[3];
         body_acceleration(s, tr, xd, acc3);
         const bool done_prev = (fl0 & 1u) != 0, bad_prev = (fl0 & 2u) != 0;
@@ -284,14 +298,14 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
         }
         // inner iterations: the reason bits accumulate like the flags they explain; exceed_time_limit is carried (no Timeout condition fires inside)
         const unsigned fl1 = (done ? 1u : 0u) | (bad ? 2u : 0u) | (fl0 & 4u) | (fl0 & 0x7F00u) | (reasons << 8);
-        if (t < PLAN_ROWS) {
-            float *sw = ctx + CTX_ST + r;
+        if (t < ROWS) {
+            float *sw = ctx + CX::ST + r;
 #pragma unroll
-            for (int k = 0; k < 12; k++) sw[k * PLAN_ROWS] = s[k];
+            for (int k = 0; k < 12; k++) sw[k * ROWS] = s[k];
 #pragma unroll
-            for (int k = 0; k < 4; k++) sw[(12 + k) * PLAN_ROWS] = u[k];
-            sw[CTX_SC * PLAN_ROWS] = __int_as_float((int)sc);
-            sw[CTX_FL * PLAN_ROWS] = __uint_as_float(fl1);
+            for (int k = 0; k < 4; k++) sw[(12 + k) * ROWS] = u[k];
+            sw[CTX_SC * ROWS] = __int_as_float((int)sc);
+            sw[CTX_FL * ROWS] = __uint_as_float(fl1);
         }
         if (valid && last) {   // every iteration overwrites these: the last one's survive (planning_env.py:153-176)
             ap->k.reward[i] = reward;
@@ -315,13 +329,13 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
             gst<COH>(cache_w + (CACHE_KEY0 + 1) * CACHE_TILE, s[8]);
         }
     }
-    if (part == 0 && !last && t < PLAN_ROWS) {
+    if (part == 0 && !last && t < ROWS) {
         // PlanningEnv.low_level_obs (planning_env.py:60-142) of the state just reached, for the controller's next call: straight into the context
         float o2[22], t3[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) t3[k] = ctx[CTX_ST + (CTX_LT + k) * PLAN_ROWS + r];
+        for (int k = 0; k < 3; k++) t3[k] = ctx[CX::ST + (CTX_LT + k) * ROWS + r];
         observe<1, true>(ap->k.cfg, s, u, t3, tr, o2, sc1.powv);
-        float2 *row = reinterpret_cast<float2 *>(ctx + CTX_OBS + t * 22);
+        float2 *row = reinterpret_cast<float2 *>(ctx + CX::OBS + t * 22);
 #pragma unroll
         for (int k = 0; k < 11; k++) row[k] = make_float2(o2[2 * k], o2[2 * k + 1]);
     }
@@ -344,16 +358,16 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
         }
         __syncthreads();  // wave 0 is done reading the noise columns before the tile overwrites them
         float *obs_tile = lds_act;
-        const long long rows = (n - i0) < PLAN_ROWS ? (n - i0) : PLAN_ROWS;
+        const long long rows = (n - i0) < ROWS ? (n - i0) : ROWS;
         float *dst = ap->final_obs + i0 * 22;
-        if (part == 0 && t < PLAN_ROWS) {
+        if (part == 0 && t < ROWS) {
 #pragma unroll
             for (int k = 0; k < 22; k++) obs_tile[t * OBS_LD + k] = o[k];
         }
         __syncthreads();
         const int total = (int)rows * 22;
 #pragma nounroll
-        for (int base = 0; base < 22 * PLAN_ROWS; base += TILE * W) {
+        for (int base = 0; base < 22 * ROWS; base += TILE * W) {
             const int L = base + (int)tid;
             if (L < total) {
                 const unsigned rr = ((unsigned)L * 2979u) >> 16;  // L / 22 for every L < 22 * 256
@@ -504,20 +518,21 @@ __device__ __forceinline__ void plan_fdm_back(PlanArgsC &ap, float *lds_fdm, flo
 // the cached coefficients of the tile's CURRENT state when the caller's cache is not valid for the first iteration: the force-side
 // evaluation the previous step would have left (same nets, same inputs, same statements as the Overload evaluation that fills the
 // cache in every step) -> the coefficient columns
-template <int W>
+template <int W, int ROWS = PLAN_ROWS>
 __device__ __forceinline__ void plan_fill_cache(PlanArgsC &ap, float *lds_fdm, const float *ctx, unsigned tid) {
+    using CX = CtxL<ROWS>;
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
     constexpr int TILE = PLAN_TILE;
-    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
+    const int t = (int)(tid % TILE), r = t & (ROWS - 1);
     const int part = __builtin_amdgcn_readfirstlane((int)(tid / TILE));
     float *coef = lds_fdm + t;
     float s[12], u[4];
-    const float *st = ctx + CTX_ST + r;
+    const float *st = ctx + CX::ST + r;
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
+    for (int k = 0; k < 12; k++) s[k] = st[k * ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * ROWS];
     StateScalars sc1;
     float xd[12];
     const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
@@ -525,13 +540,21 @@ __device__ __forceinline__ void plan_fill_cache(PlanArgsC &ap, float *lds_fdm, c
     NP_REREAD_ARGS(ap);
 }
 
-template <int TASK, int W, bool QUEUE>
+extern __shared__ __attribute__((aligned(16))) float np_plan_dyn_lds[];   // dual workgroups only (DUAL_LDS_FLOATS; 0 bytes otherwise)
+
+template <int TASK, int W, bool QUEUE, bool DUAL = false>
 __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const PlanArgs a) {
     static_assert(W == 4 || W == 8, "four or eight waves per tile");
-    constexpr bool PIPE = NP_PLAN_PIPE && W == 8;   // the pipelined schedule (plan_fdm_front / plan_fdm_back) inside a tile's stay on this workgroup
-    __shared__ __attribute__((aligned(16))) float lds_all[PLAN_LDS_FLOATS];
+    static_assert(!DUAL || (W == 8 && !QUEUE), "dual workgroups: eight waves = two controller calls of four, static schedule");
+    constexpr bool PIPE = NP_PLAN_PIPE && W == 8 && !DUAL;   // the pipelined schedule (plan_fdm_front / plan_fdm_back) inside a tile's stay on this workgroup
+    constexpr int ROWS = DUAL ? 2 * PLAN_ROWS : PLAN_ROWS;    // rows of the workgroup's context
+    using CX = CtxL<ROWS>;
+    constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds_static[DUAL ? 4 : PLAN_LDS_FLOATS];
     __shared__ unsigned item_s, stale_s;
-    float *lds_act = lds_all, *lds_fdm = lds_all + npact::ACTOR32_LDS_FLOATS, *ctx = lds_fdm + PLAN_COLS * PLAN_TILE;
+    float *lds_all = DUAL ? np_plan_dyn_lds : lds_static;
+    // dual: waves 4..7 run tile B's controller call in the second controller region
+    float *lds_act = lds_all, *lds_fdm = lds_all + ACT_FLOATS, *ctx = lds_fdm + PLAN_COLS * PLAN_TILE;
     PlanArgsC ap = (PlanArgsC)__builtin_amdgcn_kernarg_segment_ptr();  // `a` is the only kernel parameter
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
 #if NPACT_PRIO
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 
     // one (tile, iteration) item.  do_import: the tile is not in this workgroup's registers / LDS yet; do_export: it leaves afterwards
     auto run_item = [&](long long tile, int it, bool do_import, bool do_export) {
-        const long long i0 = tile * PLAN_ROWS;
+        const long long i0 = tile * ROWS;
         // per-thread indices and LDS addresses are recomputed from this opaque copy in every iteration: kept across the loop they
         // are ~25 registers the allocator parks in scratch
         unsigned tid = threadIdx.x;
@@ -552,17 +575,22 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         const bool last = it == ap->iterations - 1;
         NP_PSTAMP(0);
         npact::Actor32Pre pre;
-        if (W == 4 || wave < 4) {
-            npact::actor32_request_l1(ap->actor_w, tid, pre);
-            if (do_import) npact::actor32_stage_head(lds_act, ap->actor_w, tid);  // stays staged while the workgroup lives
+        // the controller's threads: waves 0..3; dual: waves 4..7 as well, on tile B (their own LDS region, thread index within the call, rows 32..63)
+        const bool ctl = W == 4 || DUAL || wave < 4;
+        const unsigned ctid = DUAL ? (tid & 255u) : tid;
+        float *lds_ctl = lds_act + (DUAL && wave >= 4 ? npact::ACTOR32_LDS_FLOATS : 0);
+        const int row0 = DUAL && wave >= 4 ? PLAN_ROWS : 0;
+        if (ctl) {
+            npact::actor32_request_l1(ap->actor_w, ctid, pre);
+            if (do_import) npact::actor32_stage_head(lds_ctl, ap->actor_w, ctid);  // stays staged while the workgroup lives
         }
         if (do_import) {
-            plan_import<W, QUEUE>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h, &stale_s);
+            plan_import<W, QUEUE, ROWS>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h, &stale_s);
             __syncthreads();
             if constexpr (QUEUE) {
                 if (W == 4 || wave < 4) {   // the masked recurrent state (gru.py:26) of (row, block) from the stage
                     const int row = (int)(tid & 31), blk = (int)(tid >> 5) & 7;
-                    const float mk = ctx[CTX_ST + CTX_MK * PLAN_ROWS + row];
+                    const float mk = ctx[CX::ST + CTX_MK * ROWS + row];
 #pragma unroll
                     for (int j = 0; j < npact::BLK / 2; j++) {
                         const float2 v = *reinterpret_cast<const float2 *>(lds_act + h_stage_off(row, 8 * blk + j));
@@ -571,23 +599,23 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     }
                 }
             }
-            if (it == 0 && (!ap->cache_valid0 || stale_s != 0u)) plan_fill_cache<W>(ap, lds_fdm, ctx, tid);
-        } else if (W == 4 || wave < 4) {   // resident: h holds the previous call's new state; gru.py:26 masks it
-            const float mk = ctx[CTX_ST + CTX_MK * PLAN_ROWS + (int)(tid & 31)];
+            if (it == 0 && (!ap->cache_valid0 || stale_s != 0u)) plan_fill_cache<W, ROWS>(ap, lds_fdm, ctx, tid);
+        } else if (ctl) {   // resident: h holds the previous call's new state; gru.py:26 masks it
+            const float mk = ctx[CX::ST + CTX_MK * ROWS + row0 + (int)(tid & 31)];
 #pragma unroll
             for (int j = 0; j < npact::BLK; j++) h[j] = h[j] * mk;
         }
         // ---- controller (ppo_actor.py:38-64): context observation, h -> context actions, h ----
         NP_PSTAMP(1);
-        if (W == 4 || wave < 4) {
+        if (ctl) {
             NP_REREAD_ARGS(ap);
-            const int row = (int)(tid & 31), hi = (int)((tid >> 5) & 1), w4 = (int)(tid >> 6);
+            const int row = row0 + (int)(tid & 31), hi = (int)((tid >> 5) & 1), w4 = (int)(ctid >> 6);
             float xr[npact::OBS];
 #pragma unroll
-            for (int j = 0; j < npact::OBS; j++) xr[j] = ctx[CTX_OBS + row * 22 + j];
+            for (int j = 0; j < npact::OBS; j++) xr[j] = ctx[CX::OBS + row * 22 + j];
             float hn[npact::BLK], action;
-            npact::actor32_body(lds_act, ap->actor_w, pre, xr, h, hn, action, tid);
-            if (hi == 0) ctx[CTX_ACT + row * 4 + w4] = action;
+            npact::actor32_body(lds_ctl, ap->actor_w, pre, xr, h, hn, action, ctid);
+            if (hi == 0) ctx[CX::ACT + row * 4 + w4] = action;
 #pragma unroll
             for (int j = 0; j < npact::BLK; j++) h[j] = hn[j];
             if (!QUEUE && do_export) {   // the recurrent state leaves: rnn[(it + 1) & 1] (the coherent variants: after the inner step, below)
@@ -620,7 +648,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         if (PIPE && !do_export) {   // the tile's next iteration runs here too: its controller call hides this step's back
             if constexpr (W == 8) plan_fdm_front<W>(ap, lds_fdm, ctx, i0, it, tid);
         } else {
-            plan_fdm_step<TASK, W, QUEUE>(ap, lds_fdm, lds_act, ctx, i0, it, last, do_export, tid);
+            plan_fdm_step<TASK, W, QUEUE, ROWS>(ap, lds_fdm, lds_act, ctx, i0, it, last, do_export, tid);
         }
         __syncthreads();  // the context holds the tile's next observation / state
         NP_PSTAMP(8);
@@ -729,6 +757,20 @@ hipError_t launch_one(const PlanArgs &args, unsigned grid, hipStream_t st, hipEv
     else hipLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), 0, st, args);
     return hipGetLastError();
 }
+template <int TASK>
+hipError_t launch_dual(const PlanArgs &args, unsigned grid, hipStream_t st) {
+    constexpr size_t bytes = sizeof(float) * DUAL_LDS_FLOATS;
+    static bool set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    if (dev < 64 && !set[dev]) {  // above the 64 KB a kernel may use without asking
+        const hipError_t e = hipFuncSetAttribute((const void *)planning_persistent_kernel<TASK, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        set[dev] = true;
+    }
+    hipLaunchKernelGGL((planning_persistent_kernel<TASK, 8, false, true>), dim3(grid), dim3(512), bytes, st, args);
+    return hipGetLastError();
+}
 template <int TASK, int W>
 int occupancy_of() {
     int blocks = 0;
@@ -743,6 +785,13 @@ int occupancy_of() {
 #ifndef NP_PLAN_TASKS
 #define NP_PLAN_TASKS 7  // bit t: build the kernels of task t
 #endif
+
+hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, hipStream_t st) {
+    if constexpr ((NP_PLAN_TASKS & 1) != 0) { if (task == 0) return launch_dual<0>(args, grid, st); }
+    if constexpr ((NP_PLAN_TASKS & 2) != 0) { if (task == 1) return launch_dual<1>(args, grid, st); }
+    if constexpr ((NP_PLAN_TASKS & 4) != 0) { if (task == 2) return launch_dual<2>(args, grid, st); }
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const bool queue = args.queue != nullptr;

@@ -131,7 +131,7 @@ class PlanningEnv(BaseEnv):
         return obs, reward, f[0], f[1], f[2], self.info()
 
     loop_groups = 0          # np_planning_loop.groups (0 = the library chooses)
-    LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3, 'guests': 4}
+    LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3, 'guests': 4, 'dual': 5}
     loop_mode = 'auto'       # np_planning_loop.mode: 'launches' = 2 x 50 launches, 'persistent' / 'queue' = ONE launch (np_planning.hip)
     loop_waves = 0           # persistent kernel: waves per 32-row tile (0 = the library chooses, 4, 8)
     loop_block = 0           # queue schedule: iterations per (tile, block) work item (0 = the library chooses)

@@ -140,7 +140,9 @@ def test_planning_inner_loop_row_groups_equal_the_launch_by_launch_path(golden_d
                                                 (8_192, 'persistent', 8, 0), (10_037, 'persistent', 4, 0), (10_037, 'queue', 8, 0), (10_037, 'queue', 4, 1),
                                                 (20_011, 'queue', 4, 7), (95, 'queue', 8, 1), (95, 'queue', 8, 50), (700, 'queue', 8, 3),
                                                 (10_037, 'guests', 8, 0), (9_001, 'guests', 8, 3), (12_288, 'guests', 8, 1), (16_000, 'guests', 8, 0),
-                                                (20_011, 'guests', 4, 0), (200, 'guests', 8, 0), (10_037, 'auto', 0, 0), (8_192, 'auto', 0, 0)])
+                                                (20_011, 'guests', 4, 0), (200, 'guests', 8, 0), (10_037, 'auto', 0, 0), (8_192, 'auto', 0, 0),
+                                                (200, 'dual', 8, 0), (33, 'dual', 8, 0), (1, 'dual', 8, 0), (95, 'dual', 8, 0), (10_037, 'dual', 8, 0),
+                                                (16_384, 'dual', 8, 0), (20_011, 'dual', 8, 0), (16_385, 'auto', 0, 0)])
 def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir, n, mode, waves, block):
     """np_planning_loop.mode = persistent / queue: all 50 iterations in ONE launch of the persistent kernel (np_planning.hip; a
     workgroup per 32-row tile, or resident workgroups pulling (tile, block of iterations) items, or the static guest schedule — every
