@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1748,6 +1749,27 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     }
     if (mode == NP_PLANNING_PERSISTENT_DUAL) {   // two tiles per eight-wave workgroup; any n (workgroups beyond the resident ones queue up)
         NP_HIP(launch_planning_dual(ctx->task, pa, (unsigned)((pa.tiles + 1) / 2), st));
+        return 0;
+    }
+    if (pa.queue) {
+        // The guest and queue schedules need every workgroup of the grid resident at once (a host spins on a progress word until the
+        // workgroup that owns the previous block raises it).  Two such kernels running side by side — two contexts stepped from two
+        // streams — could each hold the CUs the other's missing workgroups need: they are therefore chained, per device, by an event
+        // (stream order already serialises launches on one stream).  Other kernels beside them only delay them: they end.
+        static std::mutex mu;
+        static hipEvent_t last_ev[64] = {};
+        static hipStream_t last_st[64] = {};
+        std::lock_guard<std::mutex> lock(mu);
+        const int dev = ctx->device;
+        const bool chain = dev >= 0 && dev < 64 && !stream_is_capturing(st);
+        if (chain && last_ev[dev] && last_st[dev] != st) NP_HIP(hipStreamWaitEvent(st, last_ev[dev], 0));
+        NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
+        ctx->queue_dirty = false;
+        if (chain) {
+            if (!last_ev[dev]) NP_HIP(hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming));
+            NP_HIP(hipEventRecord(last_ev[dev], st));
+            last_st[dev] = st;
+        }
         return 0;
     }
     NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));

@@ -180,6 +180,33 @@ def test_planning_persistent_kernel_equals_the_launch_by_launch_path(golden_dir,
     assert any(v > 0 for v in envs[0].termination_counts().values()), 'the comparison should include rows that terminated'
 
 
+def test_two_guest_schedule_kernels_on_two_streams_do_not_wait_for_each_other_forever(golden_dir):
+    """The guest / queue schedules need all their workgroups resident at once; two such kernels side by side (two envs stepped from two
+    streams) could starve each other of CUs.  The library chains them per device by an event: both envs finish, with the results of a
+    run on one stream."""
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    w = pack_ppo_actor(_sd(np.load(f'{golden_dir}/actor_kat.npz')))
+    n = 10_037
+    ref = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=21, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+    ref.loop_mode = 'launches'
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=21, device='cuda:0', controller=FusedActor(w, 'cuda:0')) for _ in range(2)]
+    envs[0].loop_mode, envs[1].loop_mode = 'guests', 'queue'
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    a = (torch.rand((n, 3), generator=torch.Generator().manual_seed(5)) * 2 - 1).cuda()
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for k in range(4):
+        r = ref.step(a)
+        for j in (0, 1):
+            with torch.cuda.stream(streams[j]):
+                outs[j] = envs[j].step(a)
+        torch.cuda.synchronize()
+        for j in (0, 1):
+            for x, y in zip(r[:5], outs[j][:5]):
+                assert torch.equal(x, y), f'macro-step {k}, env {j}'
+
+
 def test_planning_inner_loop_rejects_bad_arguments(golden_dir):
     """np_planning_inner_loop fails loudly (no launch) on aliased ping-pong buffers and on an impossible group count."""
     from neuralplane_amd.actor import FusedActor, pack_ppo_actor
