@@ -34,6 +34,9 @@
 #ifndef NP_PLAN_PIPE
 #define NP_PLAN_PIPE 1  // 0: eight-wave tiles run the inner step sequentially like the four-wave ones (A/B)
 #endif
+#ifndef NP_PLAN_BACK_PRIO
+#define NP_PLAN_BACK_PRIO 0  // > 0: s_setprio of waves 0..3 during a controller call, waves 4..7 (the back) at 0 — A/B only (no effect measured)
+#endif
 #ifndef NP_PLAN_TRACE
 #define NP_PLAN_TRACE 0  // 1: the last workgroup stamps the shader clock at the phase boundaries of its last-but-one iteration (tools/microbench/planning_phases.py); never shipped
 #endif
@@ -608,6 +611,9 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         // ---- controller (ppo_actor.py:38-64): context observation, h -> context actions, h ----
         NP_PSTAMP(1);
         if (ctl) {
+#if NP_PLAN_BACK_PRIO
+            __builtin_amdgcn_s_setprio(NP_PLAN_BACK_PRIO);
+#endif
             NP_REREAD_ARGS(ap);
             const int row = row0 + (int)(tid & 31), hi = (int)((tid >> 5) & 1), w4 = (int)(ctid >> 6);
             float xr[npact::OBS];
@@ -633,6 +639,9 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 #pragma unroll 1
             for (int b = 0; b < ACTOR32_BARRIERS_BEFORE_GRU; b++) __builtin_amdgcn_s_barrier();
             if (back) {
+#if NP_PLAN_BACK_PRIO   // experiment (tools/microbench): the controller's waves at raised priority while the back runs beside them
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 plan_fdm_back<TASK>(ap, lds_fdm, ctx, i0, tid, wave - 4);
             } else {
                 __builtin_amdgcn_s_barrier();
