@@ -70,6 +70,7 @@ static_assert(CtxL<PLAN_ROWS>::ST == CTX_ST && CtxL<PLAN_ROWS>::FLOATS == CTX_FL
 // dual workgroups (round 4): TWO 32-row tiles per eight-wave workgroup — their controller calls run in lock-step on waves 0..3 / 4..7 (same
 // straight-line code, shared barriers), each with its own 36 KB of controller LDS, and ONE inner FDM step serves both: the FDM device code
 // runs 64-lane waves, which a single 32-row tile fills only half (lanes 32..63 shadow rows 0..31).  Dynamic LDS (102 KB), one workgroup per CU.
+constexpr int PARK_LDS_FLOATS = CtxL<PLAN_ROWS>::FLOATS + NUM_CACHED * PLAN_TILE + npact::BLK * 256;   // context + cached columns + recurrent state
 constexpr int DUAL_LDS_FLOATS = 2 * npact::ACTOR32_LDS_FLOATS + PLAN_COLS * PLAN_TILE + CtxL<2 * PLAN_ROWS>::FLOATS;
 constexpr int PLAN_LDS_FLOATS = npact::ACTOR32_LDS_FLOATS + PLAN_COLS * PLAN_TILE + CTX_FLOATS;
 static_assert(PLAN_LDS_FLOATS * sizeof(float) <= 65536, "static LDS of the persistent kernel");
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     constexpr int ROWS = DUAL ? 2 * PLAN_ROWS : PLAN_ROWS;    // rows of the workgroup's context
     using CX = CtxL<ROWS>;
     constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
+    constexpr bool PARK = QUEUE && W == 8;   // guest schedule: a host's own tile waits in (dynamic) LDS while the guest is in (PARK_LDS_FLOATS)
     __shared__ __attribute__((aligned(16))) float lds_static[DUAL ? 4 : PLAN_LDS_FLOATS];
     __shared__ unsigned item_s, stale_s;
     float *lds_all = DUAL ? np_plan_dyn_lds : lds_static;
@@ -568,7 +570,9 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     for (int j = 0; j < npact::BLK; j++) h[j] = 0.0f;
 
     // one (tile, iteration) item.  do_import: the tile is not in this workgroup's registers / LDS yet; do_export: it leaves afterwards
-    auto run_item = [&](long long tile, int it, bool do_import, bool do_export) {
+    // seq: run the inner step sequentially (nothing left pending) although the tile stays; no_back: no front ran in the previous iteration on
+    // this workgroup although the tile is resident (both: a host parking / un-parking its own tile around a guest block)
+    auto run_item = [&](long long tile, int it, bool do_import, bool do_export, bool seq, bool no_back) {
         const long long i0 = tile * ROWS;
         // per-thread indices and LDS addresses are recomputed from this opaque copy in every iteration: kept across the loop they
         // are ~25 registers the allocator parks in scratch
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             }
         } else if constexpr (W == 8) {
             // waves 4..7 match the call's 23 barriers; in the pipelined schedule they run the BACK of the previous inner step meanwhile
-            const bool back = PIPE && !do_import;   // a front ran in this workgroup's previous iteration
+            const bool back = PIPE && !do_import && !no_back;   // a front ran in this workgroup's previous iteration
 #pragma unroll 1
             for (int b = 0; b < ACTOR32_BARRIERS_BEFORE_GRU; b++) __builtin_amdgcn_s_barrier();
             if (back) {
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         __syncthreads();  // the tile's actions are in the context (and the previous step's flags, pipelined schedule)
         NP_REREAD_ARGS(ap);
         NP_PSTAMP(3);
-        if (PIPE && !do_export) {   // the tile's next iteration runs here too: its controller call hides this step's back
+        if (PIPE && !do_export && !seq) {   // the tile's next iteration runs here too: its controller call hides this step's back
             if constexpr (W == 8) plan_fdm_front<W>(ap, lds_fdm, ctx, i0, it, tid);
         } else {
             plan_fdm_step<TASK, W, QUEUE, ROWS>(ap, lds_fdm, lds_act, ctx, i0, it, last, do_export, tid);
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             NP_REREAD_ARGS(ap);
             const int iters = ap->iterations;
             if (it >= iters) break;
-            run_item(tile, it, it == 0, it == iters - 1);
+            run_item(tile, it, it == 0, it == iters - 1, false, false);
         }
     } else {
         // SEGMENTS: (tile, iterations [it0, it1)) — the tile is imported, stays resident for the segment, is exported, and
@@ -704,6 +708,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         //       which started `slack` earlier on its host, is through).  Every workgroup hosts at most one block: the makespan is
         //       iterations + the longest block instead of 2 x iterations, with four exports / imports per host instead of one per item.
         int seg = 0;
+        bool park_after = false, unpark_before = false;
 #pragma nounroll
         for (;;) {
             NP_REREAD_ARGS(ap);
@@ -738,9 +743,27 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                 tile = seg == 1 ? (long long)(C + w / B) : (long long)w;
                 it0 = seg == 0 ? 0 : seg == 1 ? b0 : p;
                 it1 = seg == 0 ? p : seg == 1 ? b1 : iters;
+                // a host's own tile stays on the CU while the guest is in: parked in LDS (eight-wave workgroups: PARK) instead of exported
+                // and imported again — context, the 14 cached coefficient columns, the recurrent state
+                park_after = PARK && seg == 0 && p < iters;
+                unpark_before = PARK && seg == 2 && p > 0;
                 seg++;
             }
-            if (it0 > 0) {
+            if (unpark_before) {
+                unsigned tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                float *park = np_plan_dyn_lds;
+                for (int L = (int)tid; L < CX::FLOATS; L += 64 * W) ctx[L] = park[L];
+                if (tid < 64) {
+#pragma unroll
+                    for (int k = 0; k < NUM_CACHED; k++) lds_fdm[cached_slot(k) * PLAN_TILE + tid] = park[CX::FLOATS + k * PLAN_TILE + tid];
+                }
+                if (tid < 256) {
+#pragma unroll
+                    for (int jj = 0; jj < npact::BLK; jj++) h[jj] = park[CX::FLOATS + NUM_CACHED * PLAN_TILE + jj * 256 + tid];
+                }
+                __syncthreads();
+            } else if (it0 > 0) {
                 if (threadIdx.x == 0) {
                     // progress words carry flag_base + iterations done; what an earlier launch left is below flag_base
                     while ((int)(__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ap->flag_base) < it0) __builtin_amdgcn_s_sleep(8);
@@ -749,7 +772,26 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             }
             asm volatile("" ::: "memory");
 #pragma nounroll
-            for (int it = it0; it < it1; it++) run_item(tile, it, it == it0, it == it1 - 1);
+            for (int it = it0; it < it1; it++) {
+                const bool last_it = it == it1 - 1;
+                run_item(tile, it, it == it0 && !unpark_before, last_it && !park_after, last_it && park_after, it == it0 && unpark_before);
+            }
+            if (park_after) {   // nothing left the CU: no progress word to raise (nobody else touches a host's own tile)
+                unsigned tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                float *park = np_plan_dyn_lds;
+                for (int L = (int)tid; L < CX::FLOATS; L += 64 * W) park[L] = ctx[L];
+                if (tid < 64) {
+#pragma unroll
+                    for (int k = 0; k < NUM_CACHED; k++) park[CX::FLOATS + k * PLAN_TILE + tid] = lds_fdm[cached_slot(k) * PLAN_TILE + tid];
+                }
+                if (tid < 256) {
+#pragma unroll
+                    for (int jj = 0; jj < npact::BLK; jj++) park[CX::FLOATS + NUM_CACHED * PLAN_TILE + jj * 256 + tid] = h[jj];
+                }
+                __syncthreads();
+                continue;
+            }
             // every wave: its exports (sc1 stores) have completed; then the flag
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -762,8 +804,19 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 namespace {
 template <int TASK, int W, bool QUEUE>
 hipError_t launch_one(const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    if (e0 && e1) hipExtLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), 0, st, e0, e1, 0, args);
-    else hipLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), 0, st, args);
+    constexpr size_t dyn = (QUEUE && W == 8) ? sizeof(float) * PARK_LDS_FLOATS : 0;   // the parking area of the guest schedule's hosts
+    if constexpr (dyn != 0) {
+        static bool set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+        if (dev < 64 && !set[dev]) {  // static + dynamic LDS above the 64 KB a kernel may use without asking
+            const hipError_t e = hipFuncSetAttribute((const void *)planning_persistent_kernel<TASK, W, QUEUE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            if (e != hipSuccess) return e;
+            set[dev] = true;
+        }
+    }
+    if (e0 && e1) hipExtLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), dyn, st, e0, e1, 0, args);
+    else hipLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), dyn, st, args);
     return hipGetLastError();
 }
 template <int TASK>
