@@ -362,7 +362,9 @@ typedef struct np_dispatch_info {
     int32_t actor_tile32;     /* np_actor_forward: 32-row tiles (1) or 64-row tiles (0) */
     int32_t combat_latency;   /* np_f16_combat_step with n aircraft: latency variant (1) or pair / throughput (0) */
     int64_t grid;             /* workgroups of the np_f16_step launch */
-    int64_t reserved_;
+    int32_t planning_mode;    /* np_planning_inner_loop, NP_PLANNING_AUTO with the fused controller (Euler, MLP numerics): the NP_PLANNING_* it resolves to,
+                               * assuming one resident eight-wave workgroup per CU */
+    int32_t reserved_;
 } np_dispatch_info;
 int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, int32_t tables, int32_t variant, np_dispatch_info *out);
 

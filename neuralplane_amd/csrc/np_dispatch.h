@@ -73,6 +73,18 @@ inline EnvChoice env_choice(int64_t n, int cus, bool step, int solver, bool tabl
     return c;
 }
 
+// np_planning_inner_loop, automatic mode (Euler, MLP numerics, cache / reward buffers present, stream not capturing): which schedule of the
+// persistent kernel — by 32-row tiles per resident eight-wave workgroup (one per CU: 248 VGPRs) — or the launches.  Numbers as
+// include/neuralplane_amd.h's NP_PLANNING_* (static_assert in np_f16_kernels.hip).  Measured on 256 CUs (profiles/r04_planning_modes*.log,
+// r04_planning_dual.log): n = 8 192 2.49 -> 2.05 ms (one tile per workgroup), 1e4 3.16 -> 2.6 (guest schedule, up to 1.5 tiles per
+// workgroup), 16 384 3.39 -> 3.2 (dual workgroups, up to two); beyond that the launches (64-row controller tiles, row groups).
+enum { PL_LAUNCHES = 1, PL_PERSISTENT = 2, PL_GUESTS = 4, PL_DUAL = 5 };
+inline int planning_mode(int64_t n, int64_t resident_workgroups) {
+    const int64_t tiles = (n + 31) / 32, r = resident_workgroups;
+    if (r <= 0) return PL_LAUNCHES;
+    return tiles <= r ? PL_PERSISTENT : tiles - r <= r / 2 ? PL_GUESTS : tiles <= 2 * r ? PL_DUAL : PL_LAUNCHES;
+}
+
 inline int planning_groups(int64_t n, int cus) {
     const Limits l = limits_for(cus);
     return n <= l.groups_n[0] ? 1 : n <= l.groups_n[1] ? 2 : n <= l.groups_n[2] ? 3 : n <= l.groups_n[3] ? 4 : n <= l.groups_n[4] ? 2 : n <= l.groups_n[5] ? 3 : 1;

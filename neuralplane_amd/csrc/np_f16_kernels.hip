@@ -1410,6 +1410,7 @@ int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, i
     out->planning_groups = npdispatch::planning_groups(n, num_cus);
     out->actor_tile32 = npdispatch::actor_tile32(n, num_cus) ? 1 : 0;
     out->combat_latency = n <= l.combat_lat_max_n ? 1 : 0;
+    out->planning_mode = npdispatch::planning_mode(n, num_cus);   // one eight-wave workgroup per CU
     out->reserved_ = 0;
     return 0;
 }
@@ -1811,10 +1812,11 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
             mode = NP_PLANNING_LAUNCHES;
             if (eligible && !stream_is_capturing(st)) {
                 const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, 8);
-                const int64_t resident = (int64_t)per_cu * ctx->num_cus, tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS;
-                if (per_cu > 0 && tiles <= resident) mode = NP_PLANNING_PERSISTENT, waves = 8;
-                else if (per_cu > 0 && tiles - resident <= resident / 2) mode = NP_PLANNING_PERSISTENT_GUESTS, waves = 8;
-                else if (per_cu > 0 && tiles <= 2 * resident) mode = NP_PLANNING_PERSISTENT_DUAL, waves = 8;
+                static_assert(NP_PLANNING_LAUNCHES == npdispatch::PL_LAUNCHES && NP_PLANNING_PERSISTENT == npdispatch::PL_PERSISTENT &&
+                                  NP_PLANNING_PERSISTENT_GUESTS == npdispatch::PL_GUESTS && NP_PLANNING_PERSISTENT_DUAL == npdispatch::PL_DUAL && PLAN_ROWS == 32,
+                              "np_dispatch.h mirrors the NP_PLANNING_* numbers");
+                mode = npdispatch::planning_mode(n, (int64_t)per_cu * ctx->num_cus);   // np_dispatch.h: by tiles per resident workgroup
+                waves = 8;
             }
         }
         int block = lp->block;

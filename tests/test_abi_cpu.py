@@ -163,6 +163,13 @@ def test_dispatch_plan_scales_with_the_cu_count(lib):
             m = (n - 1) * cus // 256 + 1 if n % 2 else n * cus // 256
             assert P(m, cus)['planning_groups'] == g, (cus, n, m)
         assert P(5000 * cus // 32, cus)['combat_latency'] == 1 and P(5000 * cus // 32 + 1, cus)['combat_latency'] == 0
+    # PlanningEnv's inner loop, automatic mode: by 32-row tiles per CU (2 = one persistent workgroup per tile, 4 = guest schedule, 5 = dual
+    # workgroups, 1 = launch by launch)
+    for cus in (32, 128, 256):
+        per = 32 * cus   # aircraft at one tile per CU
+        for n, mode in [(1, 2), (per, 2), (per + 1, 4), (per * 3 // 2, 4), (per * 3 // 2 + 32, 5), (2 * per, 5), (2 * per + 1, 1), (40 * per, 1)]:
+            assert P(n, cus)['planning_mode'] == mode, (cus, n, mode, P(n, cus))
+    assert P(10_000, 256)['planning_mode'] == 4 and P(8_192, 256)['planning_mode'] == 2 and P(16_384, 256)['planning_mode'] == 5
     # a 32-CU partition runs 1e6 aircraft on the three-wave pair build, like the full device, and 2 048 aircraft still on eight waves per tile
     assert fam(P(1_000_000, 32)) == 'pair3' and fam(P(2048, 32)) == 'lat8' and fam(P(2049, 32)) == 'lat4'
     with pytest.raises(RuntimeError):
