@@ -1074,6 +1074,9 @@ def gen_actor_mfma16(lines, LD, LDN, K=128):
             queue.append(('N',))
         if g == NGRP - 2:
             next_loads(N_G, 2 * N_G, side)
+        if os.environ.get('NPF16_GEN_ACTOR_NOSIDE') == '1':   # TIMING EXPERIMENT ONLY (wrong results): no operand traffic behind the MFMAs of groups 1.. —
+            side = [x for x in side if not (x.startswith('global_load_dword v') or x.startswith('ds_read2') or x.startswith('v_add_u32') or x.startswith('s_add'))]   # what the chain costs without side instructions
+            queue[:] = [t for t in queue if t == ('N',)]
         PER_GAP = max(3, -(-len(side) // (N_G - 1)))
         assert PER_GAP <= 5, len(side)
         for u in range(N_G):
@@ -1085,6 +1088,9 @@ def gen_actor_mfma16(lines, LD, LDN, K=128):
                 emit('s_waitcnt lgkmcnt(0)')      # group 1 came in registers
             else:
                 # loads still allowed in flight when group g + 1 starts: everything issued after the last of its own A operands
+                if os.environ.get('NPF16_GEN_ACTOR_NOSIDE') == '1':
+                    emit('s_waitcnt lgkmcnt(0)')
+                    continue
                 last = max(i for i, t in enumerate(queue) if t == ('A', g + 1))
                 emit(f's_waitcnt vmcnt({len(queue) - 1 - last}) lgkmcnt(0)')
     emit('s_waitcnt vmcnt(0)')
