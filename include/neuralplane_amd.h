@@ -347,7 +347,8 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
  * lane in scratch — and picked per grid size, environment NPF16_PAIR_WAVES=2|3 pins one) and "throughput" (two independent waves per
  * workgroup; the 1-D table mode).  This call pins the choice for a context (tests, tuning); np_f16_combat_step has latency, pair and
  * throughput. */
-enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4, NP_KERNEL_LATENCY2 = 5, NP_KERNEL_LATENCY4W = 6 };
+enum { NP_KERNEL_AUTO = 0, NP_KERNEL_LATENCY = 1, NP_KERNEL_THROUGHPUT = 2, NP_KERNEL_PAIR = 3, NP_KERNEL_LATENCY8 = 4, NP_KERNEL_LATENCY2 = 5, NP_KERNEL_LATENCY4W = 6,
+       NP_KERNEL_DUAL8 = 7, NP_KERNEL_DUAL4 = 8 /* SingleCombat contexts only: eight / four waves per 128-aircraft tile (Euler, MLP numerics; otherwise the automatic rule applies) */ };
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant);
 
 /* Which variant / tiling / row grouping a launch of n rows gets on a device with num_cus compute units (ABI 14): the selection
@@ -360,7 +361,7 @@ typedef struct np_dispatch_info {
     int32_t block;            /* threads per workgroup */
     int32_t planning_groups;  /* np_planning_inner_loop, launch-by-launch mode: row groups */
     int32_t actor_tile32;     /* np_actor_forward: 32-row tiles (1) or 64-row tiles (0) */
-    int32_t combat_latency;   /* np_f16_combat_step with n aircraft: latency variant (1) or pair / throughput (0) */
+    int32_t combat_latency;   /* np_f16_combat_step with n aircraft: 0 = pair / throughput, 1 = latency variant (four waves per 64 aircraft), 2 / 3 = dual8 / dual4 (eight / four waves per 128-aircraft tile, two-set bodies; automatic choice, Euler, MLP numerics only) */
     int64_t grid;             /* workgroups of the np_f16_step launch */
     int32_t planning_mode;    /* np_planning_inner_loop, NP_PLANNING_AUTO with the fused controller (Euler, MLP numerics): the NP_PLANNING_* it resolves to,
                                * assuming one resident eight-wave workgroup per CU */

@@ -97,7 +97,7 @@ def dispatch_plan(n, num_cus, step=True, solver=0, tables=False, variant=0):
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
            'np_f16_step', 'np_f16_derived', 'np_f16_aero_coefficients', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace', 'np_selfcheck_divc',
            'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop', 'np_planning_targets_obs', 'np_dispatch_plan')
-KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4, 'latency2': 5, 'latency4w': 6}
+KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4, 'latency2': 5, 'latency4w': 6, 'dual8': 7, 'dual4': 8}
 
 _lib = None
 

@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libneuralplane_hip.so')
-SOURCES = ['np_f16_kernels.hip', 'np_planning.hip']
+SOURCES = ['np_f16_kernels.hip', 'np_planning.hip', 'np_combat_lat.hip']
 HEADERS = ['np_f16_device.h', 'np_f16_kargs.h', 'np_planning.h', 'np_dispatch.h', 'np_f16_combat.h', 'np_actor.h', 'np_rollout.h', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc', 'np_actor_mfma16_asm.inc', 'np_math.h', 'np_nets.h', 'np_mlp_asm.inc', 'np_mlp_asm_dual.inc', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
 # -disable-machine-licm: the SingleCombat kernel's inner loop (5 FDM steps) otherwise gets ~40 loop-invariant 64-bit constants of the
 # fp64 sin / cos / pow sequences hoisted into VGPR pairs that stay live across the asm phases — 256 VGPRs plus 9 spilled dwords;

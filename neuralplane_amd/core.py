@@ -673,7 +673,9 @@ class F16CombatBatch:
         return [float(buf[i]) for i in range(cnt.value)]
 
     def set_kernel_variant(self, variant):
-        """'auto' (default: latency kernel while n <= 40000 aircraft, then 'pair'), 'latency', 'throughput', 'pair' — bit-identical results."""
+        """'auto' (default, Euler and MLP numerics, 256 CUs: 'latency' while n <= 16384 aircraft, 'dual8' while n <= 32768, 'dual4' while
+        n <= 65536, then 'pair'; rk4 / table numerics: 'latency' while n <= 40000), 'latency', 'dual8', 'dual4', 'throughput', 'pair' —
+        bit-identical results."""
         _lib.check(self.lib.np_f16_set_kernel_variant(self._ctx, _lib.KERNEL_VARIANTS[variant]))
 
     TERM_NAMES = ('overload', 'low_altitude', 'high_speed', 'low_speed', 'extreme_state', 'crash', 'timeout', 'shutdown_bad',

@@ -18,6 +18,8 @@ struct Limits {
     int64_t lat4w_max_n;       // four waves per tile built for four waves per SIMD: four tiles per CU               (65 536)
     int64_t lat_max_n;         // two waves per tile: up to six tiles per CU in one generation; the pair variant above (98 304)
     int64_t combat_lat_max_n;  // SingleCombat: latency variant up to here (aircraft)                                (40 000)
+    int64_t combat_dual8_min_n, combat_dual8_max_n;  // SingleCombat: eight waves per 128-aircraft tile, one tile per CU       (16 385 .. 32 768)
+    int64_t combat_dual4_max_n;  // four waves per 128-aircraft tile, two tiles per CU                                      (.. 65 536)
     int64_t pair3_min_grid;    // pair variant at three waves per SIMD from more than four workgroups per CU         (grid > 1 024)
     int64_t actor_tile32_a, actor_tile32_b, actor_tile32_c, actor_tile32_d;  // np_actor_forward: 32-row tiles for n <= a, <= b and c < n <= d
     int64_t groups_n[6];       // np_planning_inner_loop, launch-by-launch: upper bounds of the 1, 2, 3, 4, 2, 3 row-group ranges
@@ -31,6 +33,9 @@ inline Limits limits_for(int cus) {
     l.lat4w_max_n = 256 * c;
     l.lat_max_n = 384 * c;
     l.combat_lat_max_n = 40000 * c / REF_CUS;
+    l.combat_dual8_min_n = 64 * c + 1;   // up to one 64-aircraft tile per CU the four-wave latency kernel is as fast (r04_combat_dual_ab.log)
+    l.combat_dual8_max_n = 128 * c;
+    l.combat_dual4_max_n = 256 * c;
     l.pair3_min_grid = 4 * c;
     l.actor_tile32_a = 64 * c;   // 16 384: two 32-row tiles per CU
     l.actor_tile32_b = 104 * c;  // 26 624
@@ -39,6 +44,12 @@ inline Limits limits_for(int cus) {
     const int64_t g[6] = {32 * c, 64 * c, 104 * c, 144 * c, 208 * c, 320 * c};  // 8 192, 16 384, 26 624, 36 864, 53 248, 81 920
     for (int k = 0; k < 6; k++) l.groups_n[k] = g[k];
     return l;
+}
+
+// np_f16_combat_step, automatic choice, Euler, MLP numerics: waves per 128-aircraft tile of the dual family (0 = not the dual family)
+inline int combat_dual_waves(int64_t n, int cus) {
+    const Limits l = limits_for(cus);
+    return n < l.combat_dual8_min_n ? 0 : n <= l.combat_dual8_max_n ? 8 : n <= l.combat_dual4_max_n ? 4 : 0;
 }
 
 // np_f16_step (env kernels).  variant_pin: NP_KERNEL_* (0 = automatic); forced_latency / forced_pair / forced_off: the process-wide

@@ -220,25 +220,32 @@ __device__ __forceinline__ float distance_fn(float R) {  // utils.py:245-249
 #endif
 constexpr int COMBAT_OBS = 15;
 constexpr int COMBAT_BLOCK = 128;
+constexpr int COMBAT_DUAL_TILE = 128;  // aircraft per workgroup of the dual8 / dual4 variants (np_combat_lat.hip)
 static_assert(NUM_LIVE_NETS >= COMBAT_OBS, "the coefficient columns double as the observation transpose tile");
 
 // STEP=true: SingleCombatEnv.step; STEP=false: reset_done_envs + obs
 // TILE, WPT: as f16_env_kernel — (128, 1) throughput variant; (128, 2) pair variant: the two waves of the workgroup split the nets
 // of every evaluation and evaluate their half for both waves' aircraft (dual asm bodies, half the scalar weight traffic);
 // (64, 4) latency variant: four waves hold the same 64 aircraft (32 engagements), split the net evaluations and repeat the
-// rest.  The engagement's pair exchange stays inside each wave in every variant.
+// rest; (128, WPT_DUAL8) dual8 variant (round 4, np_combat_lat.hip; up to one tile per CU): eight waves per tile of 128 aircraft — waves
+// 0..3 hold rows 0..63, waves 4..7 rows 64..127 — and wave w evaluates slice w of the eight-wave plans for both halves with the two-set
+// bodies.  The engagement's pair exchange stays inside each wave in every variant.
 // PW: waves per SIMD the pair variant is built for (3: 168 VGPRs with ~46 dwords per lane in scratch — only worth it where six
 // workgroups per CU hold a whole grid in ONE generation, see launch_combat)
 template <int SOLVER, bool STEP, int TILE = COMBAT_BLOCK, int WPT = 1, int PW = NPF16_COMBAT_MINWAVES>
-__global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kernel(const CombatArgs a) {
+__global__ __launch_bounds__(WPT == 4 ? TILE * 4 : dual_waves(WPT) ? 64 * dual_waves(WPT) : TILE, PW) void f16_combat_kernel(const CombatArgs a) {
+    constexpr int DW = dual_waves(WPT);  // dual family: waves per 128-aircraft tile (the first DW / 2 hold rows 0..63, the others rows 64..127)
+    static_assert(DW == 0 || TILE == 128, "the dual family shares tiles of 128 aircraft");
     constexpr int B = TILE;
-    constexpr int COLS = NUM_LDS_SLOTS + (WPT == 2 ? NUM_NORM_GROUPS : 0);  // pair variant: nine more columns carry the inputs to the partner wave
+    constexpr bool SPLIT = WPT == 4 || DW != 0;  // several waves hold the same rows and split the nets
+    constexpr int THREADS = WPT == 4 ? TILE * 4 : DW ? 64 * DW : TILE;
+    constexpr int COLS = NUM_LDS_SLOTS + ((WPT == 2 || DW) ? NUM_NORM_GROUPS : 0);  // two-set bodies: nine more columns carry the inputs to the other half
     __shared__ float lds[COLS * TILE];  // > TILE * COMBAT_OBS
-    const int t = WPT != 4 ? (int)threadIdx.x : (int)(threadIdx.x % TILE);
-    // latency variant: which quarter of the nets / pair variant: which wave of the pair (wave-uniform); stores are done by part 0
-    // in the latency variant and by every wave otherwise
-    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)) % (WPT == 4 ? 4 : 2);
-    const bool storer = WPT != 4 || part == 0;
+    const int t = WPT == 4 ? (int)(threadIdx.x % TILE) : DW ? (int)((threadIdx.x & 63) + 64 * ((int)threadIdx.x / (32 * (DW ? DW : 1)))) : (int)threadIdx.x;
+    // latency variant: which quarter of the nets / dual family: which eighth or quarter / pair variant: which wave of the pair (wave-uniform);
+    // stores are done by one wave per set of rows in the latency and dual variants and by every wave otherwise
+    const int part = WPT == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)) % (WPT == 4 ? 4 : DW ? DW : 2);
+    const bool storer = WPT == 4 ? part == 0 : DW ? part % ((DW ? DW : 2) / 2) == 0 : true;
     float *coef = lds + t;
     const long long i0 = (long long)blockIdx.x * B;
     const long long i = i0 + t;
@@ -315,7 +322,9 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kern
             float xn[NUM_NORM_GROUPS];
             normalise_inputs(a.wt, s[7] * r2d, s[8] * r2d, u[1], xn);
             // pair variant: the Overload phase (the 14 nets + the force-side Cx, Cz, whose values are simply not used here)
-            if constexpr (WPT == 2) eval_nets<B, AB_FORCE, false, 2>(a.wt, xn, coef, tables, part);
+            // (the latency family too: its waves split these nets like those of every later evaluation — until round 4 each of the four
+            // waves evaluated all fourteen)
+            if constexpr (WPT == 2 || SPLIT) eval_nets<B, AB_FORCE, false, WPT>(a.wt, xn, coef, tables, part);
             else eval_ab<B, AB_FORCE>(a.wt, xn, coef, tables);
         }
         NP_REREAD_ARGS(ap);
@@ -513,7 +522,6 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kern
         }
         __syncthreads();
         const long long rows = (ap->n - i0) < B ? (ap->n - i0) : B;
-        constexpr int THREADS = TILE * (WPT == 4 ? 4 : 1);
         if (!split) {
             const int total = (int)rows * COMBAT_OBS;
             float *dst = ap->obs + i0 * COMBAT_OBS;
@@ -538,5 +546,8 @@ __global__ __launch_bounds__(TILE * (WPT == 4 ? 4 : 1), PW) void f16_combat_kern
         }
     }
 }
+
+// np_combat_lat.hip: one launch of the dual8 / dual4 variant (`waves` = 8 / 4; Euler step, MLP numerics); `start` / `stop` are attached to the dispatch when `timed`
+void launch_combat_dual(const CombatArgs &a, int waves, unsigned grid, hipStream_t st, bool timed, hipEvent_t start, hipEvent_t stop);
 
 }  // namespace npf16

@@ -272,7 +272,16 @@ struct SplitItem {
 // (mid-size batches, 32 K - 98 K aircraft: twice the waves of the pair variant for the same aircraft, so every SIMD holds two or
 // three waves where the pair variant leaves it one; the two waves split the nets by the pair plans below, single-set bodies)
 constexpr int WPT_LAT2 = 16;
-constexpr int lat_waves(int wpt) { return wpt == WPT_LAT2 ? 2 : (wpt >= 4 ? wpt : 1); }
+// WPT_DUAL8 (SingleCombat, batches up to one workgroup per CU): eight waves per tile of 128 aircraft — waves 0..3 hold rows 0..63, waves
+// 4..7 rows 64..127 — and wave w evaluates slice w of the EIGHT-wave plans for BOTH halves with the two-set class bodies (the other half's
+// normalised inputs through LDS, as in the pair variant): an eighth of the weight stream per wave where four waves per 64 aircraft stream
+// a quarter, on the same number of waves per aircraft
+constexpr int WPT_DUAL8 = 32;
+// WPT_DUAL4: the same with FOUR waves per tile of 128 aircraft (waves 0, 1 hold rows 0..63, waves 2, 3 rows 64..127; the four-wave plans):
+// two tiles per CU at two waves per SIMD, so batches of up to 256 aircraft per CU stay in one generation
+constexpr int WPT_DUAL4 = 33;
+constexpr int dual_waves(int wpt) { return wpt == WPT_DUAL8 ? 8 : wpt == WPT_DUAL4 ? 4 : 0; }  // waves per 128-aircraft tile of the dual family
+constexpr int lat_waves(int wpt) { return wpt == WPT_LAT2 ? 2 : dual_waves(wpt) ? dual_waves(wpt) / 2 : (wpt >= 4 ? wpt : 1); }
 constexpr int SPLIT_WAVES = 8, SPLIT_MAX = 4;  // rows 4..7 stay empty in the four-wave plans
 struct SplitPlan {
     SplitItem it[SPLIT_WAVES][SPLIT_MAX];
@@ -443,6 +452,19 @@ __device__ __forceinline__ void eval_pair_wave(const AeroWeights &wt, const floa
 #undef NPF16_ITEM
 }
 
+// a wave's slice of a SPLIT plan with the two-set class bodies (WPT_DUAL8)
+template <const SplitPlan &P, int W, int LD>
+__device__ __forceinline__ void eval_plan_wave_dual(const AeroWeights &wt, const float (&xa)[NUM_NORM_GROUPS], const float (&xb)[NUM_NORM_GROUPS],
+                                                    float *__restrict__ out_a, float *__restrict__ out_b) {
+#define NPF16_ITEM(K) \
+    if constexpr (P.it[W][K].cnt > 0) eval_class_dual<P.it[W][K].cl, P.it[W][K].cnt, LD, P.it[W][K].first>(wt, xa, xb, out_a, out_b)
+    NPF16_ITEM(0);
+    NPF16_ITEM(1);
+    NPF16_ITEM(2);
+    NPF16_ITEM(3);
+#undef NPF16_ITEM
+}
+
 // the same plans with ONE accumulator set (WPT_LAT2: the two waves hold the same 64 aircraft)
 template <const PairPlan &P, int W, int LD>
 __device__ __forceinline__ void eval_pairplan_single(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
@@ -526,6 +548,41 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
         else { NPF16_WAVE(1); }
 #undef NPF16_WAVE
         __syncthreads();  // all coefficient columns are complete
+        return;
+    } else if constexpr (dual_waves(WPT) != 0) {  // `part` = the wave's index in its 128-aircraft workgroup (0..7 / 0..3); no table mode (the caller's choice of variant)
+        static_assert(has_phase, "no split plan for this evaluation");
+        constexpr int HW = dual_waves(WPT) / 2;  // waves per half
+        float *out_b = out + 64 - 128 * (part / HW);  // the same lane's column in the other half of the matrix
+        if (part % HW == 0) {  // the waves of a half hold the same inputs: one of them publishes
+#pragma unroll
+            for (int g = 0; g < NUM_NORM_GROUPS; g++) out[(NUM_LIVE_NETS + g) * LD] = xn[g];
+        }
+        __syncthreads();  // inputs are visible; every wave has finished reading the coefficients of the previous evaluation
+        float xb[NUM_NORM_GROUPS];
+#pragma unroll
+        for (int g = 0; g < NUM_NORM_GROUPS; g++) xb[g] = out_b[(NUM_LIVE_NETS + g) * LD];
+#define NPF16_WAVE(W)                                                                                                       \
+    if constexpr (WPT == WPT_DUAL8) {                                                                                       \
+        if constexpr (FULL && PART == AB_ALL) eval_plan_wave_dual<PLAN8_ALL, W, LD>(wt, xn, xb, out, out_b);                \
+        else if constexpr (FULL && PART == AB_REST) eval_plan_wave_dual<PLAN8_REST, W, LD>(wt, xn, xb, out, out_b);         \
+        else eval_plan_wave_dual<PLAN8_FORCE2, W, LD>(wt, xn, xb, out, out_b);                                              \
+    } else {                                                                                                                \
+        if constexpr (FULL && PART == AB_ALL) eval_plan_wave_dual<PLAN_ALL, W, LD>(wt, xn, xb, out, out_b);                 \
+        else if constexpr (FULL && PART == AB_REST) eval_plan_wave_dual<PLAN_REST, W, LD>(wt, xn, xb, out, out_b);          \
+        else eval_plan_wave_dual<PLAN_FORCE2, W, LD>(wt, xn, xb, out, out_b);                                               \
+    }
+        if (part == 0) { NPF16_WAVE(0); }
+        else if (part == 1) { NPF16_WAVE(1); }
+        else if (part == 2) { NPF16_WAVE(2); }
+        else if (part == 3) { NPF16_WAVE(3); }
+        else if constexpr (WPT == WPT_DUAL8) {
+            if (part == 4) { NPF16_WAVE(4); }
+            else if (part == 5) { NPF16_WAVE(5); }
+            else if (part == 6) { NPF16_WAVE(6); }
+            else { NPF16_WAVE(7); }
+        }
+#undef NPF16_WAVE
+        __syncthreads();  // all coefficient columns of both halves are complete
         return;
     } else if constexpr (WPT == 4 || WPT == 8) {
         static_assert(has_phase, "no split plan for this evaluation");

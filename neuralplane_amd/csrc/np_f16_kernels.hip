@@ -1155,6 +1155,11 @@ int env_kernel_override() {  // process-wide override for experiments: NPF16_KER
     }();
     return forced;
 }
+bool combat_dual_enabled() {
+    static const bool on = [] { const char *e = std::getenv("NPF16_COMBAT_DUAL"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 int pair_waves_override() {
     static const int pw_env = [] { const char *e = std::getenv("NPF16_PAIR_WAVES"); return e ? atoi(e) : 0; }();
     return pw_env;
@@ -1365,9 +1370,16 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     if (io->obs_opp && !io->obs) return fail("obs_opp needs obs (the ego half)");
     // small batches: the latency variant (one generation of 4-wave workgroups at 2 waves per SIMD = 512 x 64 aircraft)
     const npdispatch::Limits lim = npdispatch::limits_for(ctx->num_cus);
-    const bool latency = STEP && ctx->solver == 0 &&
-                         (ctx->variant == NP_KERNEL_LATENCY || (ctx->variant == NP_KERNEL_AUTO && n <= lim.combat_lat_max_n));
-    const dim3 grid((unsigned)(latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)),
+    // more than one 64-aircraft tile per CU: the dual family (np_combat_lat.hip) — tiles of 128 aircraft, eight waves per tile up to one tile per
+    // CU, four up to two; NP_KERNEL_LATENCY pins the four-waves-per-64-aircraft kernel, NPF16_COMBAT_DUAL=0 switches the family off (A/B)
+    const bool dual_ok = STEP && ctx->solver == 0 && !ctx->ccfg.aero_1d_tables;
+    const bool dual_pin = ctx->variant == NP_KERNEL_DUAL8 || ctx->variant == NP_KERNEL_DUAL4;
+    const int dual = !dual_ok ? 0 : dual_pin ? (ctx->variant == NP_KERNEL_DUAL8 ? 8 : 4)
+                     : (ctx->variant == NP_KERNEL_AUTO && combat_dual_enabled()) ? npdispatch::combat_dual_waves(n, ctx->num_cus) : 0;
+    const bool auto_rule = ctx->variant == NP_KERNEL_AUTO || dual_pin;  // a dual pin that does not apply (reset, rk4, table numerics) leaves the size rule
+    const bool latency = !dual && STEP && ctx->solver == 0 &&
+                         (ctx->variant == NP_KERNEL_LATENCY || (auto_rule && n <= lim.combat_lat_max_n));
+    const dim3 grid((unsigned)(dual ? (n + COMBAT_DUAL_TILE - 1) / COMBAT_DUAL_TILE : latency ? (n + LAT_TILE - 1) / LAT_TILE : (n + COMBAT_BLOCK - 1) / COMBAT_BLOCK)),
         block(latency ? LAT_TILE * 4 : COMBAT_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     const bool timed = STEP && ctx->timing && !stream_is_capturing(st);
@@ -1383,7 +1395,8 @@ int launch_combat(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io *io,
     // (profiles/r03b_combat_pair_waves.log)
     const int pw_env = pair_waves_override();
     const bool pair3 = pair && (pw_env ? pw_env == 3 : (int64_t)grid.x > lim.pair3_min_grid);
-    if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
+    if (dual) launch_combat_dual(a, dual, grid.x, st, timed, ev.first, ev.second);
+    else if (latency) NP_DISPATCH(a, f16_combat_kernel<0, STEP, LAT_TILE, 4>);
     else if (pair3) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2, 3>);
     else if (pair) NP_DISPATCH(a, f16_combat_kernel<0, STEP, COMBAT_BLOCK, 2>);
     else if (STEP && ctx->solver == 1) NP_DISPATCH(a, f16_combat_kernel<1, STEP>);
@@ -1402,14 +1415,17 @@ int np_abi_version(void) { return NP_ABI_VERSION; }
 int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, int32_t tables, int32_t variant, np_dispatch_info *out) {
     if (!out) return fail("null argument");
     if (n <= 0 || num_cus <= 0) return fail("np_dispatch_plan: n and num_cus must be positive");
-    if (variant < NP_KERNEL_AUTO || variant > NP_KERNEL_LATENCY4W) return fail("np_dispatch_plan: unknown variant");
-    const npdispatch::EnvChoice c = npdispatch::env_choice(n, num_cus, step != 0, solver, tables != 0, variant, NP_KERNEL_AUTO, 0, BLOCK);
+    if (variant < NP_KERNEL_AUTO || variant > NP_KERNEL_DUAL4) return fail("np_dispatch_plan: unknown variant");
+    const bool dual_pin = variant == NP_KERNEL_DUAL8 || variant == NP_KERNEL_DUAL4;   // SingleCombat only: the env kernels keep their size rule
+    const npdispatch::EnvChoice c = npdispatch::env_choice(n, num_cus, step != 0, solver, tables != 0, dual_pin ? NP_KERNEL_AUTO : variant, NP_KERNEL_AUTO, 0, BLOCK);
     const npdispatch::Limits l = npdispatch::limits_for(num_cus);
     out->pair = c.pair; out->pair3 = c.pair3; out->latency = c.latency; out->latency8 = c.latency8; out->latency2 = c.latency2;
     out->latency4w = c.latency4w; out->block = c.block; out->grid = c.grid;
     out->planning_groups = npdispatch::planning_groups(n, num_cus);
     out->actor_tile32 = npdispatch::actor_tile32(n, num_cus) ? 1 : 0;
-    out->combat_latency = n <= l.combat_lat_max_n ? 1 : 0;
+    const int dual = !(step && solver == 0 && !tables) ? 0 : dual_pin ? (variant == NP_KERNEL_DUAL8 ? 8 : 4)
+                     : variant == NP_KERNEL_AUTO ? npdispatch::combat_dual_waves(n, num_cus) : 0;
+    out->combat_latency = dual == 8 ? 2 : dual == 4 ? 3 : n <= l.combat_lat_max_n ? 1 : 0;
     out->planning_mode = npdispatch::planning_mode(n, num_cus);   // one eight-wave workgroup per CU
     out->reserved_ = 0;
     return 0;
@@ -1922,8 +1938,10 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
 
 int np_f16_set_kernel_variant(np_f16_ctx *ctx, int variant) {
     if (!ctx) return fail("null ctx");
-    if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR &&
-        variant != NP_KERNEL_LATENCY8 && variant != NP_KERNEL_LATENCY2 && variant != NP_KERNEL_LATENCY4W)
+    if (variant == NP_KERNEL_DUAL8 || variant == NP_KERNEL_DUAL4) {
+        if (!ctx->combat) return fail("NP_KERNEL_DUAL8 / NP_KERNEL_DUAL4 are SingleCombat variants (np_f16_combat_ctx_create)");
+    } else if (variant != NP_KERNEL_AUTO && variant != NP_KERNEL_LATENCY && variant != NP_KERNEL_THROUGHPUT && variant != NP_KERNEL_PAIR &&
+               variant != NP_KERNEL_LATENCY8 && variant != NP_KERNEL_LATENCY2 && variant != NP_KERNEL_LATENCY4W)
         return fail("unknown kernel variant");
     ctx->variant = variant;
     return 0;

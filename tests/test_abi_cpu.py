@@ -151,7 +151,12 @@ def test_dispatch_plan_scales_with_the_cu_count(lib):
     tile32 = [(16384, 1), (26624, 1), (26625, 0), (32768, 0), (32769, 1), (43008, 1), (43009, 0), (100_000, 0)]
     for n, t in tile32:
         assert P(n, 256)['actor_tile32'] == t, (n, t)
-    assert P(40_000, 256)['combat_latency'] == 1 and P(40_001, 256)['combat_latency'] == 0
+    lat = _lib.KERNEL_VARIANTS['latency']   # (the automatic choice in this range is the dual family, below)
+    assert P(40_000, 256, tables=True)['combat_latency'] == 1 and P(40_001, 256, tables=True)['combat_latency'] == 0
+    # SingleCombat, up to one 128-aircraft tile per CU: the dual8 variant (automatic choice, Euler, MLP numerics only)
+    cl = lambda n, **kw: P(n, 256, **kw)['combat_latency']
+    assert cl(2) == 1 and cl(16_384) == 1 and cl(16_385) == 2 and cl(32_768) == 2 and cl(32_769) == 3 and cl(65_536) == 3 and cl(65_537) == 0
+    assert cl(25_000, tables=True) == 1 and cl(25_000, variant=_lib.KERNEL_VARIANTS['latency']) == 1 and cl(25_000, solver=1) == 1
     # ---- partitions: the same decision at the same rows per CU
     for cus in (32, 128):
         for n, f in expect:
@@ -162,7 +167,9 @@ def test_dispatch_plan_scales_with_the_cu_count(lib):
         for n, g in groups:
             m = (n - 1) * cus // 256 + 1 if n % 2 else n * cus // 256
             assert P(m, cus)['planning_groups'] == g, (cus, n, m)
-        assert P(5000 * cus // 32, cus)['combat_latency'] == 1 and P(5000 * cus // 32 + 1, cus)['combat_latency'] == 0
+        assert P(5000 * cus // 32, cus, tables=True)['combat_latency'] == 1 and P(5000 * cus // 32 + 1, cus, tables=True)['combat_latency'] == 0
+        assert P(64 * cus, cus)['combat_latency'] == 1 and P(64 * cus + 1, cus)['combat_latency'] == 2 and P(128 * cus, cus)['combat_latency'] == 2
+        assert P(128 * cus + 1, cus)['combat_latency'] == 3 and P(256 * cus, cus)['combat_latency'] == 3 and P(256 * cus + 1, cus)['combat_latency'] == 0
     # PlanningEnv's inner loop, automatic mode: by 32-row tiles per CU (2 = one persistent workgroup per tile, 4 = guest schedule, 5 = dual
     # workgroups, 1 = launch by launch)
     for cus in (32, 128, 256):

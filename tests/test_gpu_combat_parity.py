@@ -22,7 +22,7 @@ def _batch(num_envs, solver=None, seed=0, env0=0, tables=False, variant='auto'):
     from neuralplane_amd.core import F16CombatBatch
     from neuralplane_amd.envs.utils.utils import parse_config
     b = F16CombatBatch(num_envs, parse_config('selfplay'), 'cuda:0', seed=seed, solver=solver, env0=env0, aero_1d_tables=tables)
-    b.set_kernel_variant(variant)   # 'auto' picks the 4-waves-per-tile latency kernel at these sizes (Euler)
+    b.set_kernel_variant(variant)   # 'auto' picks the four-wave latency kernel at these sizes; 'dual8' / 'dual4': np_combat_lat.hip
     return b
 
 
@@ -63,11 +63,11 @@ def _fixture_state(o, d, n):
     return st
 
 
-@pytest.mark.parametrize('variant', ['latency', 'throughput', 'pair'])
+@pytest.mark.parametrize('variant', ['latency', 'throughput', 'pair', 'dual8', 'dual4'])
 @pytest.mark.parametrize('tables', [False, True], ids=['mlp', 'aero_1d_tables'])
 def test_combat_fixture_free_running_bit_exact_vs_oracle(golden_dir, tables, variant):
-    if tables and variant == 'pair':
-        pytest.skip('the pair variant evaluates the MLP numerics only (the table mode falls back to the single-set kernel)')
+    if tables and variant in ('pair', 'dual8', 'dual4'):
+        pytest.skip('the two-set variants evaluate the MLP numerics only (the table mode falls back to the single-set kernels)')
     """The 48 recorded env.steps (Crash, Timeout, both Shutdown outcomes, pairwise auto-resets with injected draws)."""
     d = np.load(f'{golden_dir}/combat_kat.npz')
     K, n = d['actions'].shape[:2]
@@ -106,7 +106,7 @@ def test_combat_fixture_vs_reference_teacher_forced(golden_dir):
                   done=d[f'flags_{k}'][0], bad=d[f'flags_{k}'][1], timeout=d[f'flags_{k}'][2])
 
 
-@pytest.mark.parametrize('solver,variant', [('euler', 'latency'), ('euler', 'throughput'), ('euler', 'pair'), ('rk4', 'auto')])
+@pytest.mark.parametrize('solver,variant', [('euler', 'latency'), ('euler', 'throughput'), ('euler', 'pair'), ('euler', 'dual8'), ('euler', 'dual4'), ('rk4', 'auto')])
 def test_combat_free_running_production_rng_bit_exact_vs_oracle(solver, variant):
     """reset + 40 env.steps (200 FDM steps) with the in-kernel Philox reset draws, hazard-rich demands, a ragged last
     workgroup and a non-zero first env (shard offset)."""
@@ -191,10 +191,14 @@ def test_singlecombat_env_surface_and_vec_wrapper():
     assert o1.shape == (4, 2, 15) and r1.shape == (4, 2, 1) and d1.shape == b1.shape == t1.shape == (4, 2, 1) and d1.dtype == np.bool_
 
 
-def test_combat_full_size_sampled_blocks_vs_oracle():
-    """BASELINE.json config 5 size (1e5 engagements = 2e5 aircraft, one GPU's worth): 3 env.steps at full size, sampled
-    workgroups compared bit for bit with the oracle, plus determinism of the whole batch."""
-    E, seed = 100_000, 11
+@pytest.mark.parametrize('E', [100_000, 25_000, 12_500], ids=['1e5_one_gpu_pair', '25000_share_of_4_gpus_dual4', '12500_share_of_8_gpus_dual8'])
+def test_combat_full_size_sampled_blocks_vs_oracle(E):
+    """BASELINE.json config 5 size (1e5 engagements = 2e5 aircraft on one GPU, and its shares of four and eight GPUs, which the automatic
+    choice gives to the dual4 / dual8 kernels): 3 env.steps at full size, sampled workgroups compared bit for bit with the oracle, plus
+    determinism of the whole batch."""
+    seed = 11
+    from neuralplane_amd import _lib
+    assert _lib.dispatch_plan(2 * E, 256)['combat_latency'] == {100_000: 0, 25_000: 3, 12_500: 2}[E]
     n = 2 * E
     g = torch.Generator(device='cpu').manual_seed(4)
     acts = [(torch.rand((n, 4), generator=g) * 2.4 - 1.2) for _ in range(3)]
@@ -209,7 +213,7 @@ def test_combat_full_size_sampled_blocks_vs_oracle():
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(f1, f2)
     assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][1]).all()
     o = CombatOracle()
-    for e0 in (0, 64 * 700 + 13, E - 96):      # first, a middle (odd offset) and the last block of engagements
+    for e0 in (0, 64 * (E // 142) + 13, E - 96):      # first, a middle (odd offset) and the last block of engagements
         cnt = 96
         st = o.new_state(cnt)
         o.combat_reset(st, seed=seed, call_idx=0, env0=e0)
@@ -219,7 +223,7 @@ def test_combat_full_size_sampled_blocks_vs_oracle():
         _check(b, outs[-1][0], outs[-1][1], outs[-1][2], st, o_obs, o_rew, f'block at env {e0}', rows=rows)
 
 
-@pytest.mark.parametrize('variant', ['latency', 'throughput', 'pair'])
+@pytest.mark.parametrize('variant', ['latency', 'throughput', 'pair', 'dual8', 'dual4'])
 def test_combat_hostile_inputs(variant):
     """NaN / inf demands and poisoned states: the per-row "non-finite target or measurement holds the previous PID output" rule,
     NaN-compares-false in Crash / Shutdown / Timeout and the pair exchange must agree with the oracle lane by lane."""
@@ -256,7 +260,7 @@ def test_combat_hostile_inputs(variant):
         _check(b, obs, rew, flags, st, o_obs, o_rew, f'hostile step {t}')
 
 
-@pytest.mark.parametrize('variant,num_envs', [('latency', 97), ('pair', 97), ('pair', 640), ('throughput', 33)])
+@pytest.mark.parametrize('variant,num_envs', [('latency', 97), ('pair', 97), ('pair', 640), ('throughput', 33), ('dual8', 97), ('dual4', 640)])
 def test_split_layout_equals_interleaved_layout(variant, num_envs):
     """np_f16_combat_io.action_opp / obs_opp: the ego / opponent halves as separate contiguous per-env arrays give exactly the
     interleaved launch's results — observations, rewards, masks, every state array — through resets, a ragged last workgroup and
