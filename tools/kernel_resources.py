@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel register / scratch / LDS / occupancy table of the HIP extension (hipcc -Rpass-analysis=kernel-resource-usage).
 
-    python tools/kernel_resources.py [extra hipcc flags ...]        # compiles csrc/np_f16_kernels.hip to a scratch .so
+    python tools/kernel_resources.py [extra hipcc flags ...]        # compiles every translation unit (neuralplane_amd/build.py::SOURCES) to a scratch .so
 
 A kernel that starts spilling shows up here (ScratchSize > 0) before it shows up in the HBM traffic counters.
 """

@@ -6,4 +6,4 @@ here=$(cd $(dirname $0)/../.. && pwd)
 mkdir -p $here/tools/microbench/libs
 cd $here/neuralplane_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -mllvm -disable-machine-licm "$@" \
-  -o $here/tools/microbench/libs/$name.so np_f16_kernels.hip && echo built $name
+  -o $here/tools/microbench/libs/$name.so np_*.hip && echo built $name   # every translation unit of neuralplane_amd/build.py::SOURCES

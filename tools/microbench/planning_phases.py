@@ -17,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'build':
     obj = os.path.join(HERE, 'libs', 'np_planning_trace.o')
     subprocess.run([nb._hipcc()] + nb.FLAGS + ['-DNP_PLAN_TRACE=1', '-DNPACT_TRACE=1'] + sys.argv[2:] + ['-c', '-o', obj, os.path.join(nb.CSRC, 'np_planning.hip')], check=True, cwd=nb.CSRC,
                    stderr=subprocess.DEVNULL)
-    subprocess.run([nb._hipcc(), '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB, os.path.join(nb.OBJ_DIR, 'np_f16_kernels.o'), obj], check=True)
+    subprocess.run([nb._hipcc(), '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB] + [os.path.join(nb.OBJ_DIR, os.path.splitext(f)[0] + '.o') for f in nb.SOURCES if f != 'np_planning.hip'] + [obj], check=True)  # every shipped unit but the planning one
     print('built', LIB)
     sys.exit(0)
 
