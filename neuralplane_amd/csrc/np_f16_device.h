@@ -237,7 +237,11 @@ __device__ __forceinline__ void eval_class(const AeroWeights &wt, const float (&
 
 // the 36 nets that depend on (alpha, beta) only -> slots 0..35.  Within every class the nets that feed
 // xdot[6..8] (force side, 14 in total) come first.
-enum AbPart : int { AB_ALL = 0, AB_FORCE = 1, AB_REST = 2 };
+// AB_EL / AB_ABALL (round 4, the persistent PlanningEnv kernel's pipelined schedule only): the integrator evaluation with ALL 36 alpha/beta-only
+// coefficients already in the columns (only the six el-dependent nets are evaluated: they are the only ones that see the step's action) and
+// the force-side evaluation extended to all 36 (what the NEXT integrator evaluation will find there) — the 22 moment-side nets move from
+// the front of an inner step, which the controller's next call waits for, to its back, which runs beside that call.
+enum AbPart : int { AB_ALL = 0, AB_FORCE = 1, AB_REST = 2, AB_EL = 3, AB_ABALL = 4, AB_GRU = 5 };
 template <int LD, int PART>
 __device__ __forceinline__ void eval_ab(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
 #define NPF16_CLS(cl)                                                                                      \
@@ -333,13 +337,63 @@ constexpr SplitPlan PLAN8_FORCE2 = {{{{CL_DAMP, 0, 3}, NO_ITEM, NO_ITEM, NO_ITEM
                                      {{CL_E_RUD, 0, 1}, {CL_YA20, 0, 1}, NO_ITEM, NO_ITEM},
                                      {{CL_YPLEF, 0, 1}, {CL_C, 1, 1}, NO_ITEM, NO_ITEM},
                                      NPF16_NO_WAVE}};
+// AB_EL (FULL, eight waves): C[0:5] + ETA, one net per wave
+constexpr SplitPlan PLAN8_EL = {{{{CL_C, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 {{CL_C, 1, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 {{CL_C, 2, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 {{CL_C, 3, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 {{CL_C, 4, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 {{CL_ETA, 0, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                 NPF16_NO_WAVE, NPF16_NO_WAVE}};
+// AB_ABALL (force-side build-up, four waves): all 36 alpha/beta-only nets + C[0:2] (an imported tile's state; the pipelined back evaluates
+// the plans below instead); balanced by VALU instructions per net as above (1 656 / 1 558 / 1 564 / 1 592)
+constexpr SplitPlan PLAN_ABALL2 = {{{{CL_DAMP, 0, 12}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    {{CL_DLEF, 0, 7}, {CL_D_RUD, 0, 2}, {CL_D_LEF, 0, 2}, NO_ITEM},
+                                    {{CL_F, 0, 3}, {CL_C, 0, 2}, {CL_YA20, 0, 1}, NO_ITEM},
+                                    {{CL_E_LEF, 0, 4}, {CL_E_RUD, 0, 4}, {CL_YPLEF, 0, 1}, NO_ITEM},
+                                    NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
+// The pipelined back spread over the controller call's barrier-free windows (np_planning.hip): the 16 force-side nets + 10 moment-side ones
+// between the GRU layers' barriers (AB_GRU: the Overload evaluation needs the force side there), and one cheap single-input net per helper
+// wave in each of the three short windows — the L2, A1 and A2 dense layers (5 K cycles each; a net is ~4 K on a wave that waits for its
+// scalar weight stream).  Together: all 36 alpha/beta-only nets + C[0:2].
+constexpr SplitPlan PLAN_ABGRU = {{{{CL_DAMP, 0, 4}, {CL_DLEF, 0, 2}, {CL_DLEF, 6, 1}, {CL_YA20, 0, 1}},
+                                   {{CL_F, 0, 3}, {CL_D_RUD, 0, 1}, NO_ITEM, NO_ITEM},
+                                   {{CL_E_LEF, 0, 4}, {CL_C, 0, 2}, {CL_D_RUD, 1, 1}, NO_ITEM},
+                                   {{CL_E_RUD, 0, 4}, {CL_YPLEF, 0, 1}, {CL_D_LEF, 0, 2}, NO_ITEM},
+                                   NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
+constexpr SplitPlan PLAN_WIN_L2 = {{{{CL_DAMP, 4, 1}, NO_ITEM, NO_ITEM, NO_ITEM}, {{CL_DAMP, 5, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    {{CL_DAMP, 6, 1}, NO_ITEM, NO_ITEM, NO_ITEM}, {{CL_DAMP, 7, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
+constexpr SplitPlan PLAN_WIN_A1 = {{{{CL_DAMP, 8, 1}, NO_ITEM, NO_ITEM, NO_ITEM}, {{CL_DAMP, 9, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    {{CL_DAMP, 10, 1}, NO_ITEM, NO_ITEM, NO_ITEM}, {{CL_DAMP, 11, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
+constexpr SplitPlan PLAN_WIN_A2 = {{{{CL_DLEF, 2, 1}, NO_ITEM, NO_ITEM, NO_ITEM}, {{CL_DLEF, 3, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    {{CL_DLEF, 4, 1}, NO_ITEM, NO_ITEM, NO_ITEM}, {{CL_DLEF, 5, 1}, NO_ITEM, NO_ITEM, NO_ITEM},
+                                    NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE, NPF16_NO_WAVE}};
+// the four together cover AB_ABALL
+constexpr bool plans_cover_aball() {
+    for (int cl = 0; cl < NUM_CLASSES; cl++) {
+        const int hi = cl < NUM_AB_CLASSES ? CLASSES[cl].count : cl == CL_C ? 2 : 0;
+        for (int net = 0; net < CLASSES[cl].count; net++) {
+            int hits = 0;
+            const SplitPlan *ps[4] = {&PLAN_ABGRU, &PLAN_WIN_L2, &PLAN_WIN_A1, &PLAN_WIN_A2};
+            for (int q = 0; q < 4; q++)
+                for (int w = 0; w < SPLIT_WAVES; w++)
+                    for (int k = 0; k < SPLIT_MAX; k++)
+                        if (ps[q]->it[w][k].cl == cl && net >= ps[q]->it[w][k].first && net < ps[q]->it[w][k].first + ps[q]->it[w][k].cnt) hits++;
+            if (hits != (net < hi ? 1 : 0)) return false;
+        }
+    }
+    return true;
+}
+static_assert(plans_cover_aball(), "the window plans of the pipelined back must cover every alpha/beta-only net and C[0:2] exactly once");
 // a plan must cover exactly the nets eval_ab<PART> + eval_el<N_C, N_ETA> evaluate, each once
 constexpr bool plan_covers(const SplitPlan &p, int part, int n_c, int n_eta) {
     for (int cl = 0; cl < NUM_CLASSES; cl++) {
         int lo = 0, hi = 0;
         if (cl < NUM_AB_CLASSES) {
             lo = part == AB_REST ? CLASSES[cl].n_force : 0;
-            hi = part == AB_FORCE ? CLASSES[cl].n_force : CLASSES[cl].count;
+            hi = part == AB_FORCE ? CLASSES[cl].n_force : part == AB_EL ? 0 : CLASSES[cl].count;
         } else {
             hi = cl == CL_C ? n_c : n_eta;
         }
@@ -357,6 +411,7 @@ static_assert(plan_covers(PLAN_REST, AB_REST, 5, 1) && plan_covers(PLAN_ALL, AB_
               "split plans must cover each net of their phase exactly once");
 static_assert(plan_covers(PLAN8_REST, AB_REST, 5, 1) && plan_covers(PLAN8_ALL, AB_ALL, 5, 1) && plan_covers(PLAN8_FORCE2, AB_FORCE, 2, 0),
               "eight-wave split plans must cover each net of their phase exactly once");
+static_assert(plan_covers(PLAN8_EL, AB_EL, 5, 1) && plan_covers(PLAN_ABALL2, AB_ABALL, 2, 0), "the pipelined schedule's plans must cover each net of their phase exactly once");
 
 template <const SplitPlan &P, int W, int LD>
 __device__ __forceinline__ void eval_plan_wave(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables) {
@@ -489,6 +544,8 @@ __device__ __forceinline__ void eval_pairplan_single(const AeroWeights &wt, cons
 template <int LD, int PART, bool FULL, int WPT = 1>
 __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&xn)[NUM_NORM_GROUPS], float *__restrict__ out, bool tables, int part = 0) {
     constexpr bool has_phase = (FULL && (PART == AB_ALL || PART == AB_REST)) || (!FULL && PART == AB_FORCE);
+    static_assert((PART != AB_EL && PART != AB_ABALL && PART != AB_GRU) || (PART == AB_EL && FULL && WPT == 8) || ((PART == AB_ABALL || PART == AB_GRU) && !FULL && WPT == 4),
+                  "AB_EL / AB_ABALL / AB_GRU exist as the eight-wave integrator plan and the four-wave force-side plans only");
     if constexpr (WPT == 2) {  // pair variant: `part` = this wave's index in its 128-aircraft workgroup
         static_assert(has_phase, "no pair plan for this evaluation");
         float *out_b = out + 64 - 128 * part;  // the same lane's column in the other wave's half of the matrix
@@ -585,10 +642,16 @@ __device__ __forceinline__ void eval_nets(const AeroWeights &wt, const float (&x
         __syncthreads();  // all coefficient columns of both halves are complete
         return;
     } else if constexpr (WPT == 4 || WPT == 8) {
-        static_assert(has_phase, "no split plan for this evaluation");
+        static_assert(has_phase || PART == AB_EL || PART == AB_ABALL || PART == AB_GRU, "no split plan for this evaluation");
         __syncthreads();  // every wave has finished reading the coefficients of the previous evaluation
 #define NPF16_WAVE(W)                                                                                                    \
-    if constexpr (WPT == 8) {                                                                                            \
+    if constexpr (PART == AB_EL) {                                                                                       \
+        eval_plan_wave<PLAN8_EL, W, LD>(wt, xn, out, tables);                                                            \
+    } else if constexpr (PART == AB_ABALL) {                                                                             \
+        eval_plan_wave<PLAN_ABALL2, W, LD>(wt, xn, out, tables);                                                         \
+    } else if constexpr (PART == AB_GRU) {                                                                               \
+        eval_plan_wave<PLAN_ABGRU, W, LD>(wt, xn, out, tables);                                                          \
+    } else if constexpr (WPT == 8) {                                                                                     \
         if constexpr (FULL && PART == AB_ALL) eval_plan_wave<PLAN8_ALL, W, LD>(wt, xn, out, tables);                     \
         else if constexpr (FULL && PART == AB_REST) eval_plan_wave<PLAN8_REST, W, LD>(wt, xn, out, tables);              \
         else eval_plan_wave<PLAN8_FORCE2, W, LD>(wt, xn, out, tables);                                                   \

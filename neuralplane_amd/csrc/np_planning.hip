@@ -31,6 +31,9 @@
 #define NPACT_NO_KERNELS 1
 #include "np_actor.h"
 
+#ifndef NP_PLAN_WIN
+#define NP_PLAN_WIN 1   // 0: the static schedule keeps the 22 moment-side nets in the front of an inner step (A/B)
+#endif
 #ifndef NP_PLAN_PIPE
 #define NP_PLAN_PIPE 1  // 0: eight-wave tiles run the inner step sequentially like the four-wave ones (A/B)
 #endif
@@ -392,7 +395,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
 constexpr int ACTOR32_BARRIERS_BEFORE_GRU = 9;   // barriers of actor32_body before "h -> LDS" (np_actor.h): obs LN 1, L1 1 + LN1 3, L2 1 + LN2 3
 static_assert(npact::ACTOR32_BARRIERS == ACTOR32_BARRIERS_BEFORE_GRU + 2 + 12, "barrier plan of the pipelined schedule");
 
-template <int W>
+template <int W, bool WIN>
 __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, float *ctx, long long i0, int it, unsigned tid) {
     static_assert(W == 8, "the pipelined schedule needs the four helper waves");
     NP_REREAD_ARGS(ap);
@@ -426,7 +429,10 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
         float k1[12];
         StateScalars sc0;
         const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
-        nlplant<true, AB_REST, TILE, W, true, 0>(wt1, s, u, sc0, coef, false, k1, part);
+        // WIN (static schedule): all 36 alpha/beta-only coefficients of this state are in the columns (the previous step's back and its
+        // window nets, or the import): only the six el-dependent nets — the ones that see this step's action — are evaluated on the
+        // critical path, one per wave; otherwise the 22 moment-side nets are evaluated here too (the cache carries the 14 force-side ones)
+        nlplant<true, WIN ? AB_EL : AB_REST, TILE, W, true, 0>(wt1, s, u, sc0, coef, false, k1, part);
         NP_REREAD_ARGS(ap);
         const float dt = ap->k.cfg.dt;
 #pragma unroll
@@ -438,7 +444,7 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
         StateScalars scx;
         float xd[12];
         const AeroWeights wt2 = {ap->k.wt.kblob, ap->k.wt.kblob_dual, ap->k.wt.pwl, ap->k.wt.pwl_unnorm};
-        nlplant<false, AB_FORCE, TILE, 4, true, 1, false, 1>(wt2, s, u, scx, coef, false, xd, part - 4);
+        nlplant<false, WIN ? AB_ABALL : AB_FORCE, TILE, 4, true, 1, false, 1>(wt2, s, u, scx, coef, false, xd, part - 4);
     }
     if (part == 4 + PLAN_STATE_WAVE && t < PLAN_ROWS) {   // the state the back (and the next front) start from
         float *sw = ctx + CTX_ST + r;
@@ -469,7 +475,7 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
 }
 
 // the BACK of an inner step on waves 4..7 (part4 = wave - 4), during the controller call that follows it: executes exactly two workgroup barriers
-template <int TASK>
+template <int TASK, bool WIN>
 __device__ __forceinline__ void plan_fdm_back(PlanArgsC &ap, float *lds_fdm, float *ctx, long long i0, unsigned tid, int part4) {
     NP_REREAD_ARGS(ap);
     const PlanArgsC a = ap;
@@ -491,7 +497,9 @@ __device__ __forceinline__ void plan_fdm_back(PlanArgsC &ap, float *lds_fdm, flo
     float xd[12];
     {
         const AeroWeights wt2 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
-        nlplant<false, AB_FORCE, TILE, 4, true, 1, false, 2>(wt2, s, u, sc1, coef, false, xd, part4);   // two barriers inside (eval_nets)
+        // force-side build-up for the Overload check; WIN: 10 of the 22 moment-side nets (what the next front finds) ride along, the other
+        // 12 are evaluated in the call's three short windows (plan_window_nets)
+        nlplant<false, WIN ? AB_GRU : AB_FORCE, TILE, 4, true, 1, false, 2>(wt2, s, u, sc1, coef, false, xd, part4);   // two barriers inside (eval_nets)
     }
     NP_REREAD_ARGS(ap);
     if (part4 == PLAN_STATE_WAVE) {
@@ -544,6 +552,55 @@ __device__ __forceinline__ void plan_fill_cache(PlanArgsC &ap, float *lds_fdm, c
     NP_REREAD_ARGS(ap);
 }
 
+// One cheap moment-side net per helper wave in a short barrier-free window of the controller call (the L2 / A1 / A2 dense layers): no barrier
+// inside — the coefficient columns it writes are read by the NEXT front, many barriers later; the state is the one the previous front left
+template <const SplitPlan &P>
+__device__ __forceinline__ void plan_window_nets(PlanArgsC &ap, float *lds_fdm, const float *ctx, unsigned tid, int part4) {
+    NP_REREAD_ARGS(ap);
+    const PlanArgsC a = ap;
+    constexpr int TILE = PLAN_TILE;
+    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
+    float *coef = lds_fdm + t;
+    const float *st = ctx + CTX_ST + r;
+    const float r2d = (float)(180.0 / 3.141592653589793);
+    const float alpha = st[7 * PLAN_ROWS] * r2d, beta = st[8 * PLAN_ROWS] * r2d, el = st[(12 + 1) * PLAN_ROWS];   // as nlplant forms them
+    const AeroWeights wt = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
+    float xn[NUM_NORM_GROUPS];
+    normalise_inputs(wt, alpha, beta, el, xn);
+    if (part4 == 0) eval_plan_wave<P, 0, TILE>(wt, xn, coef, false);
+    else if (part4 == 1) eval_plan_wave<P, 1, TILE>(wt, xn, coef, false);
+    else if (part4 == 2) eval_plan_wave<P, 2, TILE>(wt, xn, coef, false);
+    else eval_plan_wave<P, 3, TILE>(wt, xn, coef, false);
+    NP_REREAD_ARGS(ap);
+}
+
+// pipelined schedule: ALL 36 alpha/beta-only coefficients of an imported tile's state -> the coefficient columns (the global cache carries the
+// 14 force-side ones only, and a front evaluates none of them): the back's evaluation on waves 4..7, waves 0..3 pass its two barriers
+__device__ __forceinline__ void plan_fill_ab(PlanArgsC &ap, float *lds_fdm, const float *ctx, unsigned tid) {
+    const int part = __builtin_amdgcn_readfirstlane((int)(tid / PLAN_TILE));
+    if (part < 4) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    NP_REREAD_ARGS(ap);
+    const PlanArgsC a = ap;
+    constexpr int TILE = PLAN_TILE;
+    const int t = (int)(tid % TILE), r = t & (PLAN_ROWS - 1);
+    float *coef = lds_fdm + t;
+    float s[12], u[4];
+    const float *st = ctx + CTX_ST + r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = st[k * PLAN_ROWS];
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] = st[(12 + k) * PLAN_ROWS];
+    StateScalars sc1;
+    float xd[12];
+    const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
+    nlplant<false, AB_ABALL, TILE, 4, true, 1>(wt1, s, u, sc1, coef, false, xd, part - 4);
+    NP_REREAD_ARGS(ap);
+}
+
 extern __shared__ __attribute__((aligned(16))) float np_plan_dyn_lds[];   // dual workgroups only (DUAL_LDS_FLOATS; 0 bytes otherwise)
 
 template <int TASK, int W, bool QUEUE, bool DUAL = false>
@@ -551,6 +608,11 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     static_assert(W == 4 || W == 8, "four or eight waves per tile");
     static_assert(!DUAL || (W == 8 && !QUEUE), "dual workgroups: eight waves = two controller calls of four, static schedule");
     constexpr bool PIPE = NP_PLAN_PIPE && W == 8 && !DUAL;   // the pipelined schedule (plan_fdm_front / plan_fdm_back) inside a tile's stay on this workgroup
+    // WIN: the pipelined schedule with the 22 moment-side alpha/beta-only nets moved off the critical path, into the controller call's four
+    // barrier-free windows (plan_window_nets, AB_GRU) — for the static schedule, where a tile never changes workgroup: -2 % per macro-step at
+    // n <= 32 rows x CUs; a tile that moves pays an evaluation of all 36 nets per import instead of 14, which cancels the gain (guest / queue
+    // schedules: +0.2 .. +0.6 %, profiles/r04_planning_moment_nets_in_call_windows.log), so the coherent kernels keep the round-4 front
+    constexpr bool WIN = NP_PLAN_WIN && PIPE && !QUEUE;
     constexpr int ROWS = DUAL ? 2 * PLAN_ROWS : PLAN_ROWS;    // rows of the workgroup's context
     using CX = CtxL<ROWS>;
     constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
@@ -606,7 +668,8 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     }
                 }
             }
-            if (it == 0 && (!ap->cache_valid0 || stale_s != 0u)) plan_fill_cache<W, ROWS>(ap, lds_fdm, ctx, tid);
+            if constexpr (WIN) plan_fill_ab(ap, lds_fdm, ctx, tid);   // every import: the fronts rely on all 36 columns
+            else if (it == 0 && (!ap->cache_valid0 || stale_s != 0u)) plan_fill_cache<W, ROWS>(ap, lds_fdm, ctx, tid);
         } else if (ctl) {   // resident: h holds the previous call's new state; gru.py:26 masks it
             const float mk = ctx[CX::ST + CTX_MK * ROWS + row0 + (int)(tid & 31)];
 #pragma unroll
@@ -640,26 +703,51 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         } else if constexpr (W == 8) {
             // waves 4..7 match the call's 23 barriers; in the pipelined schedule they run the BACK of the previous inner step meanwhile
             const bool back = PIPE && !do_import && !no_back;   // a front ran in this workgroup's previous iteration
+            if constexpr (WIN) {
+                // the call's barriers: obs LN 1 | L1 2 | LN1 3-5 | [L2 dense] 6 | LN2 7-9 | h -> LDS 10 | [six GRU layers] 11 | 12 | LN3 13-15 | [A1 dense] 16 |
+                // LN4 17-19 | [A2 dense] 20 | LN5 21-23: the back works in the four bracketed windows
 #pragma unroll 1
-            for (int b = 0; b < ACTOR32_BARRIERS_BEFORE_GRU; b++) __builtin_amdgcn_s_barrier();
-            if (back) {
-#if NP_PLAN_BACK_PRIO   // experiment (tools/microbench): the controller's waves at raised priority while the back runs beside them
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                plan_fdm_back<TASK>(ap, lds_fdm, ctx, i0, tid, wave - 4);
+                for (int b = 0; b < 5; b++) __builtin_amdgcn_s_barrier();
+                if (back) plan_window_nets<PLAN_WIN_L2>(ap, lds_fdm, ctx, tid, wave - 4);
+#pragma unroll 1
+                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                if (back) {
+                    plan_fdm_back<TASK, true>(ap, lds_fdm, ctx, i0, tid, wave - 4);
+                } else {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+                }
+#pragma unroll 1
+                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                if (back) plan_window_nets<PLAN_WIN_A1>(ap, lds_fdm, ctx, tid, wave - 4);
+#pragma unroll 1
+                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                if (back) plan_window_nets<PLAN_WIN_A2>(ap, lds_fdm, ctx, tid, wave - 4);
+#pragma unroll 1
+                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                static_assert(npact::ACTOR32_BARRIERS == 5 + 4 + 2 + 4 + 4 + 4 && ACTOR32_BARRIERS_BEFORE_GRU == 9, "barrier plan of the spread back");
             } else {
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_s_barrier();
-            }
 #pragma unroll 1
-            for (int b = 0; b < npact::ACTOR32_BARRIERS - ACTOR32_BARRIERS_BEFORE_GRU - 2; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < ACTOR32_BARRIERS_BEFORE_GRU; b++) __builtin_amdgcn_s_barrier();
+                if (back) {
+#if NP_PLAN_BACK_PRIO   // experiment (tools/microbench): the controller's waves at raised priority while the back runs beside them
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                    plan_fdm_back<TASK, false>(ap, lds_fdm, ctx, i0, tid, wave - 4);
+                } else {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+                }
+#pragma unroll 1
+                for (int b = 0; b < npact::ACTOR32_BARRIERS - ACTOR32_BARRIERS_BEFORE_GRU - 2; b++) __builtin_amdgcn_s_barrier();
+            }
         }
         NP_PSTAMP(2);
         __syncthreads();  // the tile's actions are in the context (and the previous step's flags, pipelined schedule)
         NP_REREAD_ARGS(ap);
         NP_PSTAMP(3);
         if (PIPE && !do_export && !seq) {   // the tile's next iteration runs here too: its controller call hides this step's back
-            if constexpr (W == 8) plan_fdm_front<W>(ap, lds_fdm, ctx, i0, it, tid);
+            if constexpr (W == 8) plan_fdm_front<W, WIN>(ap, lds_fdm, ctx, i0, it, tid);
         } else {
             plan_fdm_step<TASK, W, QUEUE, ROWS>(ap, lds_fdm, lds_act, ctx, i0, it, last, do_export, tid);
         }
