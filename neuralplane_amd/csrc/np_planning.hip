@@ -34,6 +34,9 @@
 #ifndef NP_PLAN_WIN
 #define NP_PLAN_WIN 1   // 0: the static schedule keeps the 22 moment-side nets in the front of an inner step (A/B)
 #endif
+#ifndef NP_PLAN_WIN_QUEUE
+#define NP_PLAN_WIN_QUEUE 0   // 1: the coherent kernels (guest / queue schedules) too — measured level to slightly worse (A/B builds only)
+#endif
 #ifndef NP_PLAN_PIPE
 #define NP_PLAN_PIPE 1  // 0: eight-wave tiles run the inner step sequentially like the four-wave ones (A/B)
 #endif
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     // barrier-free windows (plan_window_nets, AB_GRU) — for the static schedule, where a tile never changes workgroup: -2 % per macro-step at
     // n <= 32 rows x CUs; a tile that moves pays an evaluation of all 36 nets per import instead of 14, which cancels the gain (guest / queue
     // schedules: +0.2 .. +0.6 %, profiles/r04_planning_moment_nets_in_call_windows.log), so the coherent kernels keep the round-4 front
-    constexpr bool WIN = NP_PLAN_WIN && PIPE && !QUEUE;
+    constexpr bool WIN = NP_PLAN_WIN && PIPE && (!QUEUE || NP_PLAN_WIN_QUEUE);
     constexpr int ROWS = DUAL ? 2 * PLAN_ROWS : PLAN_ROWS;    // rows of the workgroup's context
     using CX = CtxL<ROWS>;
     constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
@@ -851,6 +854,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     for (int jj = 0; jj < npact::BLK; jj++) h[jj] = park[CX::FLOATS + NUM_CACHED * PLAN_TILE + jj * 256 + tid];
                 }
                 __syncthreads();
+                if constexpr (WIN) plan_fill_ab(ap, lds_fdm, ctx, tid);   // (NP_PLAN_WIN_QUEUE builds) the parked tile left through a sequential step: its moment-side columns are one state old
             } else if (it0 > 0) {
                 if (threadIdx.x == 0) {
                     // progress words carry flag_base + iterations done; what an earlier launch left is below flag_base
