@@ -23,6 +23,15 @@
 //            waits on anything unfinished, so the schedule cannot deadlock as long as the grid is resident (the launcher sizes it by
 //            the occupancy query).  313 tiles (n = 1e4) on 512 slots of two 4-wave workgroups per CU: whichever slot is free takes
 //            the next item, and the two workgroups of a CU hide each other's barriers and load latencies.
+//   guests : (np_planning_loop.mode = guests) every workgroup owns a tile and hosts one block of a guest tile's iterations; see the
+//            schedule loop below.
+// Forward progress of the waits (the only unbounded loop of the kernel: thread 0 polling a tile's progress word): a queue item waits
+// for an item with a LOWER id, which an already running workgroup took from the counter before; a guest block j waits for block j - 1,
+// hosted by workgroup blockIdx.x - 1.  With the whole grid resident (what the launcher sizes it for) that is all there is to it.  If it is not, the
+// argument leans on the command processor dispatching workgroups in index order (what it does; not an architectural promise): whatever a workgroup waits for
+// belongs to a workgroup that was dispatched before it and is running or done — also when the grid is NOT fully resident (another
+// process or stream holds CUs): the chain of waits always ends at a workgroup that waits for nothing (block 0 / the lowest id).
+// What residency buys is speed (nobody waits long), not safety; the sizing by the occupancy query is for that.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
