@@ -207,6 +207,20 @@ def test_two_guest_schedule_kernels_on_two_streams_do_not_wait_for_each_other_fo
                 assert torch.equal(x, y), f'macro-step {k}, env {j}'
 
 
+def test_two_processes_run_the_guest_and_queue_schedules_on_one_gpu():
+    """Two processes cannot chain their launches: their persistent grids (one eight-wave workgroup per CU each, polling progress words)
+    share the GPU, neither fully resident.  Forward progress rests on a workgroup waiting only for a lower-indexed one (np_planning.hip,
+    header); each process compares its results with the launch-by-launch path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'microbench', 'planning_two_procs.py'), '9000', '20', '2'], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert 'guests: 2 processes, exit codes [0, 0]' in r.stdout and 'queue: 2 processes, exit codes [0, 0]' in r.stdout, r.stdout[-2000:]
+
+
 def test_planning_inner_loop_rejects_bad_arguments(golden_dir):
     """np_planning_inner_loop fails loudly (no launch) on aliased ping-pong buffers and on an impossible group count."""
     from neuralplane_amd.actor import FusedActor, pack_ppo_actor

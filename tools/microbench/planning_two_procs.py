@@ -36,3 +36,5 @@ for mode in ('guests', 'queue'):
     ps = [subprocess.Popen([sys.executable, __file__, 'child', str(n), str(steps), mode, str(r)]) for r in range(procs)]
     rcs = [p.wait() for p in ps]
     print(f'{mode}: {procs} processes, exit codes {rcs}', flush=True)
+    if any(rcs):
+        sys.exit(1)
