@@ -1,8 +1,9 @@
 """Would a block-fixed-point controller (DESIGN.md section 14 b) stay inside the bound the fp32 controller is held to against the reference
 recording (tests/golden/actor_kat.npz: the reference PPOActor's weights, four consecutive calls on 96 rows, its actions and recurrent
 states; tests: <= 2e-5)?  numpy prototype of the forward pass with the nine Linear(128, .) layers in (a) float64, (b) float32,
-(c) 24-bit block fixed point: row-wise exponent for the input, per-output-feature exponent for the weights, three balanced signed 8-bit
-limbs each, the six limb products of weight >= 2^16 summed exactly (int64), ONE rounding to fp32.  CPU only; no GPU, no reference code.
+(c) block fixed point (sign + 22 bits: the top balanced limb of a 24-bit value would not fit an int8, tools/microbench/i8_mlp_stack.hip):
+row-wise exponent for the input, per-output-feature exponent for the weights, three balanced signed 8-bit limbs each, the six limb products of
+weight >= 2^16, combined as two fp32 fused multiply-adds (fx6) or exactly with one rounding (fx9: all nine products).  CPU only; no GPU, no reference code.
     python tools/microbench/i8_actor_numerics.py"""
 import os, sys
 import numpy as np
@@ -19,8 +20,8 @@ def limbs(v):   # balanced signed digits: v = l2 * 65536 + l1 * 256 + l0
 def quant(x, axis):
     m = np.max(np.abs(x), axis=axis, keepdims=True).astype(np.float64)
     e = (np.floor(np.log2(np.maximum(m, 1e-300))) + 1).astype(np.int64) * (m > 0)      # max|x| < 2^e
-    q = np.rint(x.astype(np.float64) * np.exp2(23 - e)).astype(np.int64)
-    return np.clip(q, -(2 ** 23 - 1), 2 ** 23 - 1), e
+    q = np.rint(x.astype(np.float64) * np.exp2(22 - e)).astype(np.int64)      # |q| <= 2^22
+    return q, e
 
 def linear(x, W, b, mode):
     if mode == 'f64':
@@ -31,10 +32,13 @@ def linear(x, W, b, mode):
     wq, ew = quant(W.astype(np.float32), 1)                   # [out,128], [out,1]
     if mode == 'fx9':
         S = xq @ wq.T
-    else:                                                      # six of nine limb products
+        y = (S.astype(np.float64) * np.exp2((ex + ew.T - 44).astype(np.float64))).astype(np.float32)   # one rounding (the int64 -> double product is exact: |S| < 2^53)
+    else:                                                      # six of nine limb products, combined as the device would: two fp32 fused multiply-adds
         x0, x1, x2 = limbs(xq); w0, w1, w2 = limbs(wq)
-        S = ((x2 @ w2.T) << 32) + ((x2 @ w1.T + x1 @ w2.T) << 24) + ((x2 @ w0.T + x1 @ w1.T + x0 @ w2.T) << 16)
-    y = (S.astype(np.float64) * np.exp2((ex + ew.T - 46).astype(np.float64))).astype(np.float32)   # one rounding (the int64 -> double product is exact: |S| < 2^53)
+        c0 = (x2 @ w2.T).astype(np.float64); c1 = (x2 @ w1.T + x1 @ w2.T).astype(np.float64); c2 = (x2 @ w0.T + x1 @ w1.T + x0 @ w2.T).astype(np.float64)
+        u = (c0 * 256.0 + c1).astype(np.float32).astype(np.float64)          # fmaf: exact product and sum in double (|.| < 2^53), one rounding to fp32
+        v = (u * 256.0 + c2).astype(np.float32)
+        y = (v.astype(np.float64) * np.exp2((ex + ew.T - 44 + 16).astype(np.float64))).astype(np.float32)   # a power of two: exact
     return (y + b.astype(np.float32)).astype(np.float32)
 
 def ln(x, w, b, f):
