@@ -286,3 +286,65 @@ def test_planning_env_loads_a_checkpoint_into_the_fused_controller(golden_dir, t
         assert all(torch.equal(x, y) for x, y in zip(ra[:5], rb[:5]))
     with pytest.raises(RuntimeError, match='not found'):
         PlanningEnv(num_envs=4, config='tracking', model='F16', random_seed=0, device='cuda:0', controller='fused', controller_checkpoint=str(tmp_path / 'nope.pt'))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# PlanningEnv CLOSED LOOP against the reference and against the oracle, first-hand (round 5): tests/golden/planning_closed_kat.npz is the
+# reference's own PlanningEnv.step x 3 with a stored actor state_dict (tools/gen_golden.py::gen_planning_closed).
+# ---------------------------------------------------------------------------------------------------------------------------------
+CLOSED_MODES = [('launches', 0, 0), ('persistent', 8, 0), ('persistent', 4, 0), ('guests', 8, 0), ('queue', 8, 7), ('queue', 4, 0), ('dual', 8, 0), ('auto', 0, 0)]
+
+
+def _closed_env(g, mode, waves, block):
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    from tests.planning_closed import actor_state_dict
+    w = pack_ppo_actor(actor_state_dict(g))
+    n = g['hi_actions'].shape[1]
+    env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+    if mode == 'eager':
+        env.use_inner_loop = False
+    else:
+        env.loop_mode, env.loop_waves, env.loop_block = mode, waves, block
+    return env, w
+
+
+def _closed_result(env, out):
+    obs, rew, done, bad, tmo, _ = out
+    return {'s': env.model.s.cpu().numpy(), 'u': env.model.u.cpu().numpy(), 'tgt': env._batch.tgt.cpu().numpy().T.copy(),
+            'step_count': env.step_count.cpu().numpy(), 'rnn': env.ego_rnn_states.cpu().numpy()[:, 0], 'obs': obs.cpu().numpy(), 'reward': rew.cpu().numpy(),
+            'flags': np.stack([done.cpu().numpy(), bad.cpu().numpy(), tmo.cpu().numpy()]).astype(np.uint8)}
+
+
+@pytest.mark.parametrize('mode,waves,block', [('eager', 0, 0)] + CLOSED_MODES)
+def test_planning_closed_loop_vs_the_reference_recording(golden_dir, mode, waves, block):
+    """PlanningEnv(controller=FusedActor).step x 3 — 150 closed-loop inner steps, the recurrent state feeding back — against the REFERENCE's
+    own PlanningEnv.step on the same actor state_dict, high-level actions and reset draws (envs/planning_env.py:144-177,
+    algorithms/ppo/ppo_actor.py:38-64): every mask and counter equal, states <= 1e-4 (SURVEY §8(d) floors), recurrent state <= 5e-5,
+    observation <= 1e-4 — the launch-by-launch path, the 2 x 50-launch call and every schedule of the persistent kernel."""
+    from tests.planning_closed import compare_with_reference
+    g = np.load(f'{golden_dir}/planning_closed_kat.npz')
+    env, _ = _closed_env(g, mode, waves, block)
+    for k in range(g['hi_actions'].shape[0]):
+        env._batch.reset(rand_u=g[f'rand_u_{k}'], want_obs=False)     # the reference's draws: PlanningEnv.step begins with self.reset()
+        out = env.step(torch.from_numpy(g['hi_actions'][k]).cuda())
+        compare_with_reference(_closed_result(env, out), g, k)        # measured (profiles/r05_parity.json): states 3.9e-5, recurrent state 1.5e-5
+    assert int((env.step_count == 150).sum()) >= 30
+
+
+@pytest.mark.parametrize('mode,waves,block', CLOSED_MODES)
+def test_planning_macro_steps_equal_the_oracle_closed_loop_bit_for_bit(golden_dir, mode, waves, block):
+    """DIRECT: whole macro-steps of the persistent kernel (each schedule; and the 2 x 50-launch call) against Oracle.reset / lowlevel_obs /
+    step_inner + ActorOracle run closed loop on the CPU — states, controls, targets, counters, recurrent state, observation, reward and
+    masks bit for bit after every one of three macro-steps (rows that terminate mid-step and stay frozen included)."""
+    from tests.planning_closed import OracleClosedLoop
+    g = np.load(f'{golden_dir}/planning_closed_kat.npz')
+    env, w = _closed_env(g, mode, waves, block)
+    cl = OracleClosedLoop(g, w)
+    for k in range(g['hi_actions'].shape[0]):
+        env._batch.reset(rand_u=g[f'rand_u_{k}'], want_obs=False)
+        got = _closed_result(env, env.step(torch.from_numpy(g['hi_actions'][k]).cuda()))
+        want = cl.macro_step(k)
+        for q in ('flags', 'step_count', 's', 'u', 'tgt', 'rnn', 'obs', 'reward'):
+            assert _same(got[q], want[q]), f'macro-step {k}: {q} differs from the oracle (max abs {np.nanmax(np.abs(got[q].astype(np.float64) - want[q]))})'
+    assert int(want['flags'][1].sum()) > 0 and int((want['step_count'] == 150).sum()) >= 30

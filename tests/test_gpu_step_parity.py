@@ -518,7 +518,11 @@ def test_hip_parity_report_vs_reference_recordings():
     check_parity_rows(cl, cl['n'])
     assert cl['at'][-1]['t'] == 1000 and cl['at'][-1]['max'] < 2e-5
     ep = {r['t']: r for r in rep['recorded_episode']['at']}
-    assert ep[200]['max_so_far'] < 1e-5 and ep[426]['max_so_far'] < 1e-3      # the recording ends in a departure
+    # the recording ends in a departure: measured envelope 5.1e-6 @200, 8.2e-5 @400, 1.76e-4 @426 — asserted as measured; the reference's
+    # own CPU replay ends at 2.4e-5 plain and at 1.80e-4 with its MLPs in fp64 (tests/golden/recorded_episode0_ref_cpu.npz, in the report)
+    assert ep[200]['max_so_far'] < 1e-5 and ep[400]['max_so_far'] < 1e-4 and ep[426]['max_so_far'] < 2e-4
+    att = rep['recorded_episode']['attribution']
+    assert att['oracle_pin_mode_equals_reference_cpu_pin_mode_bit_for_bit'] and att['reference_cpu_vs_cuda_recording'] < 3e-5
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, 'gpurun_out')
     try:

@@ -311,22 +311,49 @@ def test_recorded_cuda_episode_replay(golden_dir):
     s[0, 2], s[0, 6] = rows[0, ix['altitude']], rows[0, ix['vt']]
     dt = np.float32(0.02)
     floors = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1], np.float32)
-    worst, worst200 = 0.0, 0.0
+    worst = {200: 0.0, 400: 0.0, 426: 0.0}
     for t in range(426):
         u = np.array([[rows[t + 1, ix['T']], rows[t + 1, ix['el']], rows[t + 1, ix['ail']], rows[t + 1, ix['rud']], 0]], np.float32)
         x = np.hstack([s, u]).astype(np.float32)
         s = (x[:, :12] + dt * o.nlplant(x)).astype(np.float32)
         ref = rows[t + 1, :9]
         e = float(np.max(np.abs(s[0, :9] - ref) / np.maximum(np.abs(ref), floors)))
-        worst = max(worst, e)
-        if t < 200:
-            worst200 = max(worst200, e)
-    # the episode ends in a departure (terminated at row 426): the CUDA-vs-CPU difference grows
-    # exponentially over the last ~150 steps (measured 5e-6 @200, 9e-5 @400, 1.9e-4 @426)
-    assert worst200 < 1e-5, worst200
-    assert worst < 1e-3, worst
+        for lim in worst:
+            if t < lim:
+                worst[lim] = max(worst[lim], e)
+    # the episode ends in a departure (terminated at row 426): the difference to the CUDA recording grows exponentially over the last
+    # ~150 steps.  Measured envelope: 5.1e-6 @200, 8.2e-5 @400, 1.76e-4 @426 — the bounds below are that envelope, not a loose 1e-3.
+    # Attribution (test_recorded_episode_pin_mode_equals_the_reference_cpu_replay_bit_for_bit, profiles/r05_parity.json): the REFERENCE's
+    # own CPU dynamics replayed the same way end at 2.4e-5 (plain ATen) and at 1.80e-4 with its MLPs evaluated in fp64 — i.e. the exact
+    # evaluation lands where this build lands; ATen-CPU and ATen-CUDA share an sgemm summation order and agree with each other 7 x
+    # better than either agrees with the correctly rounded result or with this build's fma chains.  fp32 noise floor of the reference's
+    # own arithmetic, amplified by the departure — not a restatement error.
+    assert worst[200] < 1e-5 and worst[400] < 1e-4 and worst[426] < 2e-4, worst
     G = np.sqrt((o.get_accels(s, u) ** 2).sum())
     assert abs(G - rows[426, ix['G']]) / rows[426, ix['G']] < 1e-3
+
+
+def test_recorded_episode_pin_mode_equals_the_reference_cpu_replay_bit_for_bit(golden_dir):
+    """tests/golden/recorded_episode0_ref_cpu.npz = the REFERENCE's own CPU dynamics (F16Dynamics.nlplant + Euler) replaying
+    the recorded controls for all 426 steps, as it runs and in pin mode (tools/gen_golden.py::gen_recorded_episode).  In pin mode the
+    oracle reproduces that trajectory BIT FOR BIT through the departure at the end — the restatement is the reference's arithmetic —
+    and the three end-of-episode residuals against the CUDA recording are: reference-CPU 2.4e-5, reference-CPU in pin mode 1.80e-4,
+    this build (plain) 1.76e-4."""
+    g = np.load(f'{golden_dir}/recorded_episode0.npz')
+    r = np.load(f'{golden_dir}/recorded_episode0_ref_cpu.npz')
+    rows, cols = g['rows'], list(g['columns'])
+    ix = {c: cols.index(c) for c in cols}
+    o = Oracle('heading', mode=MODE_MLP_F64 | MODE_LIBM)
+    s = np.zeros((1, 12), np.float32)
+    s[0, 2], s[0, 6] = rows[0, ix['altitude']], rows[0, ix['vt']]
+    assert same(s[0], r['states_pin'][0])
+    for t in range(426):
+        u = np.array([[rows[t + 1, ix['T']], rows[t + 1, ix['el']], rows[t + 1, ix['ail']], rows[t + 1, ix['rud']], 0]], np.float32)
+        x = np.hstack([s, u]).astype(np.float32)
+        s = (x[:, :12] + np.float32(0.02) * o.nlplant(x)).astype(np.float32)
+        assert same(s[0], r['states_pin'][t + 1]), f'step {t + 1}'
+    w_plain, w_pin = r['worst_vs_cuda_recording']
+    assert w_plain < 3e-5 and 1.5e-4 < w_pin < 2e-4      # 2.36e-5 / 1.80e-4: the exact evaluation is FURTHER from the CUDA recording
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -509,3 +536,23 @@ def test_torch_eager_formulation_matches_the_reference_fixture_and_the_oracle(go
     assert np.array_equal(d.numpy(), g[key + 'done'].astype(bool)) and np.array_equal(b.numpy(), g[key + 'bad'].astype(bool))
     o_obs, o_rew, _, _, _ = Oracle('heading').step(st, g['action'], rand_u=ru, noise=nz)
     assert relerr(e.s.numpy(), st['s'], STATE_FLOORS) < 1e-4 and relerr(obs.numpy(), o_obs, 0.1) < 1e-4
+
+
+def test_planning_env_closed_loop_vs_reference(golden_dir):
+    """The reference's PlanningEnv.step CLOSED LOOP (envs/planning_env.py:144-177: 3 x 50 x {low_level_obs -> PPOActor -> model.update ->
+    terminations}, the recurrent state feeding back; the actor's state_dict is part of the fixture, nothing is replayed) against the
+    oracle's reset / low-level observation / controller / inner step run the same way: every mask and counter equal, states <= 1e-4
+    (SURVEY §8(d) floors), recurrent state <= 5e-5 and low-level actions <= 2e-5 after 150 closed-loop inner steps.
+    Measured: states 3.9e-5, recurrent state 1.5e-5, actions 5.0e-6 (39 of 80 aircraft fly all 150 steps; 21-24 per macro-step end in
+    Overload part-way and stay frozen while their controls keep moving)."""
+    from neuralplane_amd.actor import pack_ppo_actor
+    from tests.planning_closed import OracleClosedLoop, actor_state_dict, compare_with_reference
+    g = np.load(f'{golden_dir}/planning_closed_kat.npz')
+    cl = OracleClosedLoop(g, pack_ppo_actor(actor_state_dict(g)))
+    total_bad, flown = 0, None
+    for k in range(g['hi_actions'].shape[0]):
+        res = cl.macro_step(k)
+        compare_with_reference(res, g, k)
+        total_bad += int(g[f'flags_{k}'][1].sum())
+        flown = res['step_count']
+    assert 0 < total_bad and int((flown == 150).sum()) >= 30, 'the fixture mixes rows frozen mid-step with rows that fly all 150 closed-loop steps'

@@ -495,20 +495,34 @@ def gen_recorded_episode():
     cols = ['npos', 'epos', 'altitude', 'roll', 'pitch', 'yaw', 'vt', 'alpha', 'beta', 'G', 'T', 'el', 'ail', 'rud']
     arr = np.stack([np.load(os.path.join(d, c + '.npy')).reshape(-1)[:427] for c in cols], 1).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, 'recorded_episode0.npz'), columns=np.array(cols), rows=arr)
-    # sanity: replay with the reference dynamics
+    # the same replay with the REFERENCE's own CPU dynamics: x' = x + 0.02 * nlplant(x, recorded controls),
+    # as the reference runs (plain ATen) and in pin mode (MLPs / sin / cos / pow in fp64, rounded once).  Both trajectories are stored
+    # (recorded_episode0_ref_cpu.npz) so that the attribution of the end-of-episode residual against the CUDA recording is evidence:
+    # reference-CPU vs the CUDA recording, this build vs the CUDA recording and this build vs reference-CPU on the SAME inputs.
     from envs.models.F16.F16_dynamics import F16Dynamics
     with quiet():
         dyn = F16Dynamics('cpu')
-    s = torch.zeros(1, 12)
-    s[0, 2] = float(arr[0, 2]); s[0, 6] = float(arr[0, 6])
-    worst = 0.0
-    for t in range(426):
-        u = torch.tensor([[arr[t + 1, 10], arr[t + 1, 11], arr[t + 1, 12], arr[t + 1, 13], 0.0]])
-        x = torch.hstack((s, u))
-        s = (x + torch.tensor(0.02) * dyn.nlplant(x))[:, :12]
-        ref = arr[t + 1, :9]
-        worst = max(worst, float(np.max(np.abs(s[0, :9].numpy() - ref) / np.maximum(np.abs(ref), 1e-3))))
-    print('recorded episode replay with reference dynamics: worst rel err', worst)
+    floors = np.array([100, 100, 100, .1, .1, .1, 10, .1, .1], np.float32)
+
+    def replay():
+        s = torch.zeros(1, 12)
+        s[0, 2] = float(arr[0, 2]); s[0, 6] = float(arr[0, 6])
+        traj, worst = [s[0].numpy().copy()], 0.0
+        for t in range(426):
+            u = torch.tensor([[arr[t + 1, 10], arr[t + 1, 11], arr[t + 1, 12], arr[t + 1, 13], 0.0]])
+            x = torch.hstack((s, u))
+            s = (x + torch.tensor(0.02) * dyn.nlplant(x))[:, :12]
+            ref = arr[t + 1, :9]
+            worst = max(worst, float(np.max(np.abs(s[0, :9].numpy() - ref) / np.maximum(np.abs(ref), floors))))
+            traj.append(s[0].numpy().copy())
+        return np.stack(traj).astype(np.float32), worst
+
+    plain, w_plain = replay()
+    with pin_mode(type(dyn.hifi_F16.Cx_model)):
+        pin, w_pin = replay()
+    np.savez_compressed(os.path.join(OUT, 'recorded_episode0_ref_cpu.npz'), states=plain, states_pin=pin,
+                        worst_vs_cuda_recording=np.array([w_plain, w_pin]))
+    print('recorded episode replay with the reference CPU dynamics: worst rel err vs the CUDA recording (SURVEY floors): plain', w_plain, 'pin mode', w_pin)
 
 
 def gen_planning(n=48, outer=3):
@@ -573,6 +587,79 @@ def gen_planning(n=48, outer=3):
         data[f'flags_{k}'] = np.stack([done.numpy(), bad.numpy(), tmo.numpy()]).astype(np.uint8)
         print('planning outer', k, 'done', int(done.sum()), 'bad', int(bad.sum()))
     np.savez_compressed(os.path.join(OUT, 'planning_kat.npz'), hi_actions=hi_actions, **data)
+
+
+def gen_planning_closed(n=80, outer=3, mu_scale=15.0):
+    """PlanningEnv.step CLOSED LOOP (envs/planning_env.py:144-177): the reference env constructs its own PPOActor
+    (planning_env.py:41-43) and really loads a state_dict — the one of seeded_actor(), handed over where the reference reads its
+    (unshipped) checkpoint file — then runs `outer` macro-steps = 50 x {low_level_obs -> controller -> model.update -> done / reward}
+    each, with the recurrent state feeding back.  Recorded per macro-step: the reset draws, everything `step` returns, the env state
+    (s, u, targets, step_count, flags, ego_rnn_states); per inner iteration (forward hook on the controller, outputs untouched): the
+    controller's input observation, actions and recurrent state.  The actor's state_dict is stored (`sd::*`): consumers run their own
+    controller in the loop, nothing is replayed."""
+    if not hasattr(np, 'product'):
+        np.product = np.prod  # the reference targets numpy 1.x (algorithms/utils/flatten.py:83)
+    import envs.planning_env as pe
+    actor = seeded_actor(mu_scale, 0.0)
+
+    def build(sd):
+        o_load = torch.load
+        torch.load = lambda f, *a, **k: sd if str(f).endswith('actor_latest.pt') else o_load(f, *a, **k)
+        try:
+            with quiet():
+                return pe.PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device='cpu')
+        finally:
+            torch.load = o_load
+
+    # centre the head: an un-trimmed F-16 at 1000-1200 ft/s leaves the 300 ft/s^2 Overload limit with two degrees of constant
+    # elevator, and a random-init head has a constant offset of that size; subtract the actor's mean action at the env's own
+    # first controller input (zero recurrent state) from mu_net's bias, so that what moves the aircraft is the part of the
+    # actions that depends on the observation and the recurrent state
+    probe = build({k: v.clone() for k, v in actor.state_dict().items()})
+    with quiet():
+        probe.reset()
+    z = torch.zeros(n)
+    _, pitch, yaw = probe.model.get_posture()
+    with torch.no_grad():
+        a0, _, _ = actor(probe.low_level_obs(pitch + z, yaw + z, probe.model.get_vt() + z), torch.zeros((n, 1, 128)), torch.ones((n, 1)), deterministic=True)
+        actor.act.action_out.mu_net.fc[0].bias.sub_(a0.mean(0))
+    sd = {k: v.clone() for k, v in actor.state_dict().items()}
+    env = build(sd)
+    for k, v in env.controller.state_dict().items():
+        assert torch.equal(v, sd[k]), k            # the reference's own load_state_dict took every tensor
+    log = []
+    env.controller.register_forward_hook(lambda mod, inp, out: log.append((inp[0].numpy().copy(), out[0].numpy().copy(), out[2].numpy().copy())))
+    LL_OBS_AT = (0, 1, 9, 19, 29, 39, 49)
+    rng = np.random.RandomState(77)
+    hi_actions = rng.uniform(-1.2, 1.2, (outer, n, 3)).astype(np.float32)
+    data = {}
+    for k in range(outer):
+        del log[:]
+        prev = (env.is_done | env.bad_done | env.exceed_time_limit).numpy().astype(bool)
+        with Recorder() as r, quiet():
+            obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(hi_actions[k]))
+            draws = r.take()
+        rand = [t.numpy() for kind, t in draws if kind == 'rand']
+        rand_u = np.zeros((n, 5), np.float32)
+        assert len(rand) == 5 and len(log) == 50
+        for c, x in enumerate(rand):
+            rand_u[prev, c] = x
+        data[f'rand_u_{k}'] = rand_u
+        data[f'll_obs_{k}'] = np.stack([log[i][0] for i in LL_OBS_AT])                # the controller's input at these inner iterations
+        data[f'll_act_{k}'] = np.stack([x[1] for x in log])
+        data[f'll_rnn_{k}'] = np.stack([x[2][:, 0] for x in log[9::10]])     # after inner iterations 10, 20, 30, 40, 50
+        data[f's_{k}'] = env.model.s.numpy().copy()
+        data[f'u_{k}'] = env.model.u.numpy().copy()
+        data[f'tgt_{k}'] = get_tgt(env, 'tracking')
+        data[f'step_count_{k}'] = env.step_count.numpy().copy()
+        data[f'rnn_{k}'] = env.ego_rnn_states.numpy()[:, 0].copy()
+        data[f'obs_{k}'] = obs.numpy().copy()
+        data[f'reward_{k}'] = rew.numpy().copy()
+        data[f'flags_{k}'] = np.stack([done.numpy(), bad.numpy(), tmo.numpy()]).astype(np.uint8)
+        print('planning closed loop, outer', k, 'done', int(done.sum()), 'bad', int(bad.sum()), '|ll action| max', float(np.abs(data[f'll_act_{k}']).max()),
+              'rnn std', float(data[f'rnn_{k}'].std()))
+    np.savez_compressed(os.path.join(OUT, 'planning_closed_kat.npz'), hi_actions=hi_actions, ll_obs_at=np.array(LL_OBS_AT), **data,
+                        **{'sd::' + k: v.numpy() for k, v in sd.items()})
 
 
 # ------------------------------------------------------------------------------------------------
@@ -810,10 +897,10 @@ def gen_acmi():
     print('acmi: frames', text.count('#'), 'bytes', len(text))
 
 
-def gen_actor(n=96, steps=4):
-    """PlanningEnv's low-level controller: the reference's PPOActor (algorithms/ppo/ppo_actor.py) with the argument bag of
-    envs/planning_env.py:18-29 and a seeded random initialisation whose output layers are re-scaled (the shipped gain 0.01
-    would make every action ~0): state_dict, inputs, and the actions / rnn states of `steps` consecutive deterministic calls."""
+def seeded_actor(mu_scale=60.0, mu_bias=0.1):
+    """The reference's PPOActor (algorithms/ppo/ppo_actor.py) with the argument bag of envs/planning_env.py:18-29 and a seeded random
+    initialisation whose LayerNorm affine terms / biases are perturbed and whose output layer is re-scaled INSIDE mu_net (the shipped
+    gain 0.01 would make every action ~0): a plain PPOActor, no wrapper — its state_dict is the whole controller."""
     if not hasattr(np, 'product'):
         np.product = np.prod
     import gym
@@ -838,8 +925,15 @@ def gen_actor(n=96, steps=4):
                 v.mul_(1.0 + 0.3 * torch.randn_like(v))
             if k.endswith('norm.bias') or '.fc.2.bias' in k or '.fc.5.bias' in k or k.endswith('bias_ih_l0') or k.endswith('bias_hh_l0'):
                 v.add_(0.2 * torch.randn_like(v))
-        actor.act.action_out.mu_net.fc[0].weight.mul_(60.0)
-        actor.act.action_out.mu_net.fc[0].bias.add_(0.1 * torch.randn(4))
+        actor.act.action_out.mu_net.fc[0].weight.mul_(mu_scale)
+        actor.act.action_out.mu_net.fc[0].bias.add_(mu_bias * torch.randn(4))
+    return actor
+
+
+def gen_actor(n=96, steps=4):
+    """PlanningEnv's low-level controller (seeded_actor above): state_dict, inputs, and the actions / rnn states of `steps`
+    consecutive deterministic calls."""
+    actor = seeded_actor()
     rng = np.random.RandomState(61)
     obs = (rng.normal(0, 1, (steps, n, 22)) * rng.uniform(0.1, 3, (1, 1, 22))).astype(np.float32)
     masks = np.ones((steps, n, 1), np.float32)
@@ -932,6 +1026,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'planning':
         gen_planning()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'planning_closed':
+        gen_planning_closed()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'combat':
         gen_combat_all()
         return
@@ -973,6 +1070,7 @@ def main():
     gen_combat_all()
     gen_acmi()
     gen_actor()
+    gen_planning_closed()
     gen_buffer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
