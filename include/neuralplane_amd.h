@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 14
+#define NP_ABI_VERSION 15
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -305,7 +305,24 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
  * = the slack in iterations per block index, 0 = the library chooses).  NP_PLANNING_PERSISTENT_DUAL (ABI 14) gives every eight-wave
  * workgroup TWO tiles: their controller calls run in lock-step on waves 0..3 / 4..7 and one 64-lane FDM step serves both (a single 32-row
  * tile fills the FDM code's 64-lane waves only half); any n, the choice above 1.5 tiles per CU.  NP_PLANNING_AUTO picks by n, solver and
- * numerics; environment NP_PLANNING_MODE=launches|persistent|queue|guests|dual (read per call) overrides it for benchmarks and the parity tests. */
+ * numerics; environment NP_PLANNING_MODE=launches|persistent|queue|guests|dual (read per call) overrides it for benchmarks and the parity tests.
+ * The guest and queue schedules cannot be captured into a graph (their counter / progress-word bases advance per launch on the host): the
+ * call fails on a capturing stream, and NP_PLANNING_AUTO never picks them there.
+ * Bounded waits (ABI 15).  In the guest and queue schedules a workgroup may wait for a tile's progress word, raised by another workgroup.
+ * That ends when the grid is resident, or — observed, not promised by the architecture — when workgroups are dispatched in index order.
+ * A wait that lasts longer than 2 s (environment NP_PLANNING_WAIT_MS) therefore gives up: the kernel drains and ENDS, and
+ *   check = NP_PLANNING_CHECK_SYNC (0, the default): the call waits for the launch (it is the only part of this API that synchronises
+ *     the stream; the copy of the in-place buffers it keeps meanwhile costs ~10 us per macro-step) and, had a wait expired, restores s, u,
+ *     step_count, flags[0], rnn[0], ll_obs[0], coef_cache, term_reasons and term_counters to their values before the call and returns
+ *     NP_E_PLANNING_STALLED with np_last_error() naming workgroup, tile and iteration: call again with mode = NP_PLANNING_LAUNCHES
+ *     (neuralplane_amd/envs/planning_env.py does exactly that);
+ *   check = NP_PLANNING_CHECK_DEFERRED: the call returns at once; the verdict is delivered by the context's NEXT np_planning_inner_loop call
+ *     or by np_planning_check(ctx) (both wait for that launch first) as NP_E_PLANNING_STALLED_LOST — nothing was kept, the state buffers
+ *     hold a partially advanced macro-step.
+ * The static schedule (_PERSISTENT), the dual workgroups and the launches wait for nothing and are not affected. */
+#define NP_E_PLANNING_STALLED 2
+#define NP_E_PLANNING_STALLED_LOST 3
+enum { NP_PLANNING_CHECK_SYNC = 0, NP_PLANNING_CHECK_DEFERRED = 1 };
 enum { NP_PLANNING_AUTO = 0, NP_PLANNING_LAUNCHES = 1, NP_PLANNING_PERSISTENT = 2, NP_PLANNING_PERSISTENT_QUEUE = 3, NP_PLANNING_PERSISTENT_GUESTS = 4, NP_PLANNING_PERSISTENT_DUAL = 5 };
 typedef struct np_planning_loop {
     int32_t iterations;        /* planning_env.py:153: 50 */
@@ -320,9 +337,11 @@ typedef struct np_planning_loop {
     int32_t mode;              /* NP_PLANNING_AUTO / _LAUNCHES / _PERSISTENT / _PERSISTENT_QUEUE (ABI 13) / _PERSISTENT_GUESTS (ABI 14) */
     int32_t waves;             /* persistent kernel: waves per 32-row tile, 4 or 8; 0 = the library chooses */
     int32_t block;             /* queue schedule: iterations per (tile, block) item, 1 .. iterations; 0 = the library chooses */
-    int32_t reserved_loop_;
+    int32_t check;             /* ABI 15 (was reserved, 0): NP_PLANNING_CHECK_SYNC / _DEFERRED — guest and queue schedules only, see above */
 } np_planning_loop;
 int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *loop, void *stream);
+/* check = deferred: wait for the context's last guest / queue launch and return its verdict (0 or NP_E_PLANNING_STALLED_LOST). */
+int np_planning_check(np_f16_ctx *ctx);
 
 /* Returns of one rollout for the device-resident rollout storage — replaces ReplayBuffer.compute_returns
  * (reference algorithms/utils/buffer.py:139-173; a Python loop over time with numpy array operations there): one launch, a

@@ -269,19 +269,21 @@ class F16Batch:
         self._version += 1
         return obs, reward, new_flags
 
-    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0, mode=0, waves=0, block=0):
+    def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0, mode=0, waves=0, block=0, check=0):
         """np_planning_inner_loop: the `iterations` low-level iterations of PlanningEnv.step (controller forward + inner FDM step each)
         enqueued by one library call.  ll_obs = (first input [n,22], scratch [n,22]); rnn = (state on entry [n,128], scratch [n,128]);
         flags_scratch [3,n] uint8.  Returns obs (task observation of the last iteration), reward, flags; the final recurrent state is in
         rnn[iterations & 1].  mode: np_planning_loop.mode (0 automatic, 1 launch by launch, 2 the persistent kernel — all iterations in
-        one launch, 3 the same with the (tile, iteration) work queue); waves: waves per 32-row tile of the persistent kernel (0, 4, 8)."""
+        one launch, 3 the same with the (tile, iteration) work queue); waves: waves per 32-row tile of the persistent kernel (0, 4, 8);
+        check: np_planning_loop.check (0 sync: a stalled guest / queue schedule raises _lib.PlanningStalled with every in-place buffer restored
+        and this object's bookkeeping untouched; 1 deferred)."""
         n = self.n
         obs = torch.empty((n, 22), dtype=torch.float32, device=self.device)
         reward = torch.empty(n, dtype=torch.float32, device=self.device)
         io = self._io(flags_scratch, ll_act, obs, reward, None, None, inner=True, ll_tgt=tgt3, ll_obs=ll_obs[1])
         lp = _lib.NpPlanningLoop()
         lp.iterations, lp.groups = int(iterations), int(groups)
-        lp.mode, lp.waves, lp.block = int(mode), int(waves), int(block)
+        lp.mode, lp.waves, lp.block, lp.check = int(mode), int(waves), int(block), int(check)
         lp.actor_weights = actor_weights.data_ptr()
         lp.ll_obs[0], lp.ll_obs[1] = ll_obs[0].data_ptr(), ll_obs[1].data_ptr()
         lp.rnn[0], lp.rnn[1] = rnn[0].data_ptr(), rnn[1].data_ptr()

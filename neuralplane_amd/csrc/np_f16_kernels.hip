@@ -255,6 +255,15 @@ struct np_f16_ctx {
     int64_t queue_cap;
     unsigned queue_next = 0, flag_base = 0;   // where the item counter stands / the base of the progress words for the next launch
     bool queue_dirty = true;
+    // bounded waits of the guest / queue schedules (round 5): the launch's sticky error word (device), the record the kernel leaves in pinned
+    // host memory when a wait expires, the snapshot of a macro-step's inputs (check = sync: restored before NP_E_PLANNING_STALLED is returned)
+    // and the event behind the last unchecked launch (check = deferred)
+    unsigned *d_plan_err = nullptr, *h_plan_err = nullptr, *h_plan_err_dev = nullptr;
+    char *d_snap = nullptr;
+    size_t snap_cap = 0;
+    hipEvent_t plan_done = nullptr;
+    bool plan_unchecked = false;
+    const char *plan_unchecked_mode = "";
     int num_cus;  // multiProcessorCount of the context's device
 };
 
@@ -929,6 +938,10 @@ void np_f16_ctx_destroy(np_f16_ctx *ctx) {
         (void)hipEventDestroy(e.second);
     }
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_plan_err) (void)hipFree(ctx->d_plan_err);
+    if (ctx->h_plan_err) (void)hipHostFree(ctx->h_plan_err);
+    if (ctx->d_snap) (void)hipFree(ctx->d_snap);
+    if (ctx->plan_done) (void)hipEventDestroy(ctx->plan_done);
     if (!ctx->group_streams.empty() || !ctx->group_events.empty()) {
         DeviceGuard guard;
         if (guard.enter(ctx->device) == hipSuccess) {
@@ -1064,9 +1077,97 @@ extern "C" int np_actor_trace_read(long long *out) {  // diagnostics builds only
 }
 #endif
 
+// ---- bounded waits of the guest / queue schedules: snapshot / restore of a macro-step's inputs, the stall report ---------------------------
+namespace {
+struct CopySeg { const void *src; void *dst; unsigned long long bytes; };
+constexpr int MAX_COPY_SEGS = 10;
+struct CopyArgs { CopySeg seg[MAX_COPY_SEGS]; };
+// blockIdx.y = segment; 16-byte pieces where pointers and size allow, bytes otherwise (the flag / reason arrays: n bytes each)
+__global__ void __launch_bounds__(256) plan_copy_kernel(CopyArgs a) {
+    const CopySeg sg = a.seg[blockIdx.y];
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull, i0 = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    if ((((unsigned long long)sg.src | (unsigned long long)sg.dst | sg.bytes) & 15ull) == 0ull) {
+        for (unsigned long long i = i0; i < sg.bytes / 16; i += stride) reinterpret_cast<uint4 *>(sg.dst)[i] = reinterpret_cast<const uint4 *>(sg.src)[i];
+    } else if ((((unsigned long long)sg.src | (unsigned long long)sg.dst | sg.bytes) & 3ull) == 0ull) {
+        for (unsigned long long i = i0; i < sg.bytes / 4; i += stride) reinterpret_cast<unsigned *>(sg.dst)[i] = reinterpret_cast<const unsigned *>(sg.src)[i];
+    } else {
+        for (unsigned long long i = i0; i < sg.bytes; i += stride) reinterpret_cast<unsigned char *>(sg.dst)[i] = reinterpret_cast<const unsigned char *>(sg.src)[i];
+    }
+}
+
+// everything the persistent kernel updates IN PLACE or accumulates into (np_planning.hip: plan_fdm_step's exports, the recurrent state and
+// low-level observation ping-pong whose final values land in buffer 0 again for an even number of iterations, the termination counters);
+// pure outputs (obs, reward, reward_task, ll_act, the second ping-pong buffers) are rewritten by a re-run and are not kept
+struct PlanSnapshot {
+    CopyArgs save, restore;
+    int count = 0;
+    size_t bytes = 0;
+    void add(void *p, size_t nbytes) {
+        if (!p || nbytes == 0 || count >= MAX_COPY_SEGS) return;
+        save.seg[count].src = p; save.seg[count].bytes = nbytes;
+        restore.seg[count].dst = p; restore.seg[count].bytes = nbytes;
+        save.seg[count].dst = nullptr; restore.seg[count].src = nullptr;   // the context's buffer: resolved in bind()
+        offs[count] = bytes;
+        bytes += (nbytes + 15) & ~(size_t)15;
+        count++;
+    }
+    void bind(char *base) {
+        for (int i = 0; i < count; i++) {
+            save.seg[i].dst = base + offs[i];
+            restore.seg[i].src = base + offs[i];
+        }
+    }
+    hipError_t run(bool back, hipStream_t st) const {
+        if (count == 0) return hipSuccess;
+        hipLaunchKernelGGL(plan_copy_kernel, dim3(128, (unsigned)count), dim3(256), 0, st, back ? restore : save);
+        return hipGetLastError();
+    }
+    size_t offs[MAX_COPY_SEGS] = {};
+};
+
+int plan_err_buffers(np_f16_ctx *ctx) {
+    if (ctx->d_plan_err) return 0;
+    NP_HIP(hipMalloc((void **)&ctx->d_plan_err, sizeof(unsigned) * 4));
+    NP_HIP(hipMemset(ctx->d_plan_err, 0, sizeof(unsigned) * 4));
+    NP_HIP(hipHostMalloc((void **)&ctx->h_plan_err, sizeof(unsigned) * PLAN_ERR_WORDS, hipHostMallocMapped));
+    std::memset(ctx->h_plan_err, 0, sizeof(unsigned) * PLAN_ERR_WORDS);
+    NP_HIP(hipHostGetDevicePointer((void **)&ctx->h_plan_err_dev, ctx->h_plan_err, 0));
+    NP_HIP(hipEventCreateWithFlags(&ctx->plan_done, hipEventDisableTiming));
+    return 0;
+}
+
+// the record a stalled launch left (h_plan_err[0] != 0) as a message; clears it and marks the queue words for clearing
+std::string plan_stall_message(np_f16_ctx *ctx, const char *mode, bool restored) {
+    volatile unsigned *e = ctx->h_plan_err;
+    std::string m = std::string("np_planning_inner_loop (") + mode + "): workgroup " + std::to_string(e[0] - 1u) + " waited " + std::to_string(e[4]) +
+                    " ms for tile " + std::to_string(e[1]) + " to reach iteration " + std::to_string(e[2]) + " (published: " + std::to_string(e[3]) +
+                    "): the schedule's workgroups did not make progress together (the guest / queue schedules assume a resident grid or in-order "
+                    "workgroup dispatch).  The kernel drained and ended; ";
+    m += restored ? "every buffer it updates in place (s, u, step_count, flags[0], rnn[0], ll_obs[0], coef_cache, term_reasons, term_counters) was "
+                    "restored to its value before the call: re-run the macro-step with mode = NP_PLANNING_LAUNCHES"
+                  : "check = deferred keeps no copy of the inputs: the state buffers hold a partially advanced macro-step";
+    for (int i = 0; i < PLAN_ERR_WORDS; i++) e[i] = 0u;
+    ctx->queue_dirty = true;
+    return m;
+}
+
+// check = deferred: the verdict on the previous guest / queue launch of this context, before the next one may reuse the words
+int plan_check_pending(np_f16_ctx *ctx) {
+    if (!ctx->plan_unchecked) return 0;
+    NP_HIP(hipEventSynchronize(ctx->plan_done));
+    ctx->plan_unchecked = false;
+    if (ctx->h_plan_err[0] != 0u) {
+        g_err = plan_stall_message(ctx, ctx->plan_unchecked_mode, false);
+        NP_HIP(hipMemset(ctx->d_plan_err, 0, sizeof(unsigned) * 4));
+        return NP_E_PLANNING_STALLED_LOST;
+    }
+    return 0;
+}
+}  // namespace
+
 // All iterations in one launch of the persistent kernel (np_planning.hip).  mode: NP_PLANNING_PERSISTENT (one workgroup per tile) or
 // NP_PLANNING_PERSISTENT_QUEUE (resident workgroups pull (tile, iteration) items).
-static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, hipStream_t st, int mode, int waves, int block) {
+static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *lp, hipStream_t st, int mode, int waves, int block, int check) {
     if (!io->s || !io->u || !io->tgt || !io->step_count || !io->reward || !io->coef_cache)
         return fail("np_planning_inner_loop (persistent): needs state, reward and coef_cache buffers");
     if (io->ld < n) return fail("ld < n");
@@ -1096,6 +1197,14 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     pa.queue_base = pa.flag_base = 0;
     pa.block = block > 0 ? (block < lp->iterations ? block : lp->iterations) : 1;
     pa.guest_blocks = 0;
+    pa.err = pa.err_host = nullptr;
+    pa.wait_ticks = 0;
+    pa.debug_stall = 0;
+    if ((mode == NP_PLANNING_PERSISTENT_QUEUE || mode == NP_PLANNING_PERSISTENT_GUESTS) && stream_is_capturing(st))
+        // the item counter's / progress words' bases are host state baked into the kernel arguments: a second replay of the captured launch
+        // would find the counter past its items and the words already raised — silently wrong results
+        return fail("np_planning_inner_loop: the guest and queue schedules cannot be captured into a graph (their bases advance per launch on the host); "
+                    "use NP_PLANNING_PERSISTENT, _DUAL or _LAUNCHES on a capturing stream");
     unsigned grid = (unsigned)pa.tiles;
     if (mode == NP_PLANNING_PERSISTENT_GUESTS) {
         // tiles beyond the resident workgroups are guests: cut into as many blocks as there are hosts to go round (np_planning.hip)
@@ -1146,23 +1255,69 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
         return 0;
     }
     if (pa.queue) {
+        const char *mode_name = mode == NP_PLANNING_PERSISTENT_GUESTS ? "guests" : "queue";
+        if (plan_err_buffers(ctx)) return 1;
+        pa.err = ctx->d_plan_err;
+        pa.err_host = ctx->h_plan_err_dev;
+        double wait_ms = 2000.0;   // one wait; an iteration is ~40 us, a block of a guest tile ~0.5 ms
+        if (const char *e = std::getenv("NP_PLANNING_WAIT_MS")) wait_ms = atof(e) > 0.0 ? atof(e) : wait_ms;
+        pa.wait_ticks = (unsigned long long)(wait_ms * 1e5);   // wall_clock64(): 100 MHz
+        if (const char *e = std::getenv("NP_PLANNING_DEBUG_STALL")) pa.debug_stall = atoi(e) != 0;   // fault injection (tests/test_gpu_actor.py)
+        // check = sync: keep what the kernel updates in place until its verdict is in
+        PlanSnapshot snap;
+        if (check == NP_PLANNING_CHECK_SYNC) {
+            snap.add(io->s, sizeof(float) * (size_t)(11 * io->ld + n));
+            snap.add(io->u, sizeof(float) * (size_t)(3 * io->ld + n));
+            snap.add(io->step_count, sizeof(int64_t) * (size_t)n);
+            snap.add(io->coef_cache, sizeof(float) * (size_t)np_f16_cache_floats(n));
+            snap.add(lp->flags[0], (size_t)(3 * n));
+            snap.add(lp->rnn[0], sizeof(float) * (size_t)n * npact::HID);
+            snap.add(lp->ll_obs[0], sizeof(float) * (size_t)n * npact::OBS);
+            snap.add(io->term_reasons, (size_t)n);
+            snap.add(io->term_counters, sizeof(uint32_t) * NP_NUM_TERM_COUNTERS);
+            if (ctx->snap_cap < snap.bytes) {
+                if (ctx->d_snap) NP_HIP(hipFree(ctx->d_snap));
+                ctx->d_snap = nullptr;
+                ctx->snap_cap = 0;
+                NP_HIP(hipMalloc((void **)&ctx->d_snap, snap.bytes));
+                ctx->snap_cap = snap.bytes;
+            }
+            snap.bind(ctx->d_snap);
+            NP_HIP(snap.run(false, st));
+        }
         // The guest and queue schedules need every workgroup of the grid resident at once (a host spins on a progress word until the
         // workgroup that owns the previous block raises it).  Two such kernels running side by side — two contexts stepped from two
         // streams — could each hold the CUs the other's missing workgroups need: they are therefore chained, per device, by an event
         // (stream order already serialises launches on one stream).  Other kernels beside them only delay them: they end.
-        static std::mutex mu;
-        static hipEvent_t last_ev[64] = {};
-        static hipStream_t last_st[64] = {};
-        std::lock_guard<std::mutex> lock(mu);
-        const int dev = ctx->device;
-        const bool chain = dev >= 0 && dev < 64 && !stream_is_capturing(st);
-        if (chain && last_ev[dev] && last_st[dev] != st) NP_HIP(hipStreamWaitEvent(st, last_ev[dev], 0));
-        NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
-        ctx->queue_dirty = false;
-        if (chain) {
-            if (!last_ev[dev]) NP_HIP(hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming));
-            NP_HIP(hipEventRecord(last_ev[dev], st));
-            last_st[dev] = st;
+        {
+            static std::mutex mu;
+            static hipEvent_t last_ev[64] = {};
+            static hipStream_t last_st[64] = {};
+            std::lock_guard<std::mutex> lock(mu);
+            const int dev = ctx->device;
+            const bool chain = dev >= 0 && dev < 64;
+            if (chain && last_ev[dev] && last_st[dev] != st) NP_HIP(hipStreamWaitEvent(st, last_ev[dev], 0));
+            NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
+            ctx->queue_dirty = false;
+            if (chain) {
+                if (!last_ev[dev]) NP_HIP(hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming));
+                NP_HIP(hipEventRecord(last_ev[dev], st));
+                last_st[dev] = st;
+            }
+        }
+        if (check == NP_PLANNING_CHECK_DEFERRED) {   // the verdict is read by the context's next loop call / np_planning_check
+            NP_HIP(hipEventRecord(ctx->plan_done, st));
+            ctx->plan_unchecked = true;
+            ctx->plan_unchecked_mode = mode_name;
+            return 0;
+        }
+        NP_HIP(hipStreamSynchronize(st));
+        if (ctx->h_plan_err[0] != 0u) {
+            NP_HIP(snap.run(true, st));
+            NP_HIP(hipMemsetAsync(ctx->d_plan_err, 0, sizeof(unsigned) * 4, st));
+            NP_HIP(hipStreamSynchronize(st));
+            g_err = plan_stall_message(ctx, mode_name, true);
+            return NP_E_PLANNING_STALLED;
         }
         return 0;
     }
@@ -1187,6 +1342,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard;
     NP_HIP(guard.enter(ctx->device));
+    if (const int rc = plan_check_pending(ctx)) return rc;   // check = deferred: the previous guest / queue launch's verdict comes first
     {
         int mode = lp->mode, waves = lp->waves;
         if (const char *e = std::getenv("NP_PLANNING_MODE")) {  // read per call: benchmarks and the parity tests switch it
@@ -1214,8 +1370,12 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         }
         int block = lp->block;
         if (const char *e = std::getenv("NP_PLANNING_BLOCK")) block = atoi(e) > 0 ? atoi(e) : block;
-        if (mode != NP_PLANNING_LAUNCHES)
-            return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 8, mode == NP_PLANNING_PERSISTENT_GUESTS ? (block > 0 ? block : 1) : block > 0 ? block : 5);
+        if (mode != NP_PLANNING_LAUNCHES) {
+            int check = lp->check;
+            if (const char *e = std::getenv("NP_PLANNING_CHECK")) check = std::strcmp(e, "deferred") == 0 ? NP_PLANNING_CHECK_DEFERRED : std::strcmp(e, "sync") == 0 ? NP_PLANNING_CHECK_SYNC : check;
+            if (check != NP_PLANNING_CHECK_SYNC && check != NP_PLANNING_CHECK_DEFERRED) return fail("np_planning_loop: check must be NP_PLANNING_CHECK_SYNC or NP_PLANNING_CHECK_DEFERRED");
+            return planning_persistent(ctx, n, io, lp, st, mode, waves ? waves : 8, mode == NP_PLANNING_PERSISTENT_GUESTS ? (block > 0 ? block : 1) : block > 0 ? block : 5, check);
+        }
     }
     // automatic choice, measured per size (profiles/r03g_planning_groups.log; ms per PlanningEnv.step, one group -> the choice):
     // n = 1e4 3.51 -> 3.23, 16 384 3.73 -> 3.44, 20 000 5.67 -> 4.39, 24 576 5.86 -> 4.89, 28 672 6.84 -> 5.64, 32 768 6.92 -> 6.29,
@@ -1277,6 +1437,13 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         NP_HIP(hipStreamWaitEvent(st, ctx->group_events[g], 0));
     }
     return rc;
+}
+
+int np_planning_check(np_f16_ctx *ctx) {
+    if (!ctx) return fail("null ctx");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(ctx->device));
+    return plan_check_pending(ctx);
 }
 
 int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int use_proper_time_limits,

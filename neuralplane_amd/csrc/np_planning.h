@@ -29,7 +29,15 @@ struct PlanArgs {
     unsigned queue_base, flag_base;   // the words are not cleared between launches: the launcher moves the bases past what the last launch left
     int guest_blocks;        // 0: the dynamic queue above.  B > 0: the static guest schedule (np_planning.hip) — grid = resident workgroups C,
                              // the tiles - C guest tiles are cut into B blocks each, hosted by workgroups 0 .. (tiles - C) * B - 1; `block` = slack
+    // bounded waits (round 5): a progress-word wait that lasts longer than wait_ticks gives up — the first such wait claims err[0] (device
+    // memory, sticky for the launch: every other wait sees it and gives up too, every workgroup drains without raising another word) and
+    // writes the record the launcher reads after the launch into err_host (pinned host memory)
+    unsigned *err;                  // [0] 0 = none, else 1 + the workgroup whose wait expired
+    unsigned *err_host;             // PLAN_ERR_WORDS words: code (= err[0]), tile, iteration waited for, iterations published, ms waited
+    unsigned long long wait_ticks;  // bound of ONE wait in wall_clock64() ticks (100 MHz)
+    int debug_stall;                // tests only: workgroup 0 never raises a progress word (its successors' waits expire)
 };
+constexpr int PLAN_ERR_WORDS = 8;
 
 constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_actor.h)
 

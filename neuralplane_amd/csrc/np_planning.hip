@@ -25,13 +25,17 @@
 //            the next item, and the two workgroups of a CU hide each other's barriers and load latencies.
 //   guests : (np_planning_loop.mode = guests) every workgroup owns a tile and hosts one block of a guest tile's iterations; see the
 //            schedule loop below.
-// Forward progress of the waits (the only unbounded loop of the kernel: thread 0 polling a tile's progress word): a queue item waits
-// for an item with a LOWER id, which an already running workgroup took from the counter before; a guest block j waits for block j - 1,
-// hosted by workgroup blockIdx.x - 1.  With the whole grid resident (what the launcher sizes it for) that is all there is to it.  If it is not, the
-// argument leans on the command processor dispatching workgroups in index order (what it does; not an architectural promise): whatever a workgroup waits for
+// Forward progress of the waits (thread 0 polling a tile's progress word): a queue item waits for an item with a LOWER id, which an
+// already running workgroup took from the counter before; a guest block j waits for block j - 1, hosted by workgroup blockIdx.x - 1.
+// With the whole grid resident (what the launcher sizes it for) that is all there is to it.  If it is not, the argument leans on the
+// command processor dispatching workgroups in index order (what it does; not an architectural promise): whatever a workgroup waits for
 // belongs to a workgroup that was dispatched before it and is running or done — also when the grid is NOT fully resident (another
 // process or stream holds CUs): the chain of waits always ends at a workgroup that waits for nothing (block 0 / the lowest id).
 // What residency buys is speed (nobody waits long), not safety; the sizing by the occupancy query is for that.
+// Because that order is observed behaviour and not a promise, the wait is BOUNDED (round 5): a wait that outlasts PlanArgs::wait_ticks
+// (2 s unless NP_PLANNING_WAIT_MS says otherwise) claims the launch's sticky error word, every workgroup that meets the word drains, the
+// kernel ENDS, and np_planning_inner_loop reports NP_E_PLANNING_STALLED with the buffers restored (np_f16_kernels.hip) — a violated
+// assumption is an error code and a launch-by-launch re-run, not a hung GPU.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
     constexpr bool PARK = QUEUE && W == 8;   // guest schedule: a host's own tile waits in (dynamic) LDS while the guest is in (PARK_LDS_FLOATS)
     __shared__ __attribute__((aligned(16))) float lds_static[DUAL ? 4 : PLAN_LDS_FLOATS];
-    __shared__ unsigned item_s, stale_s;
+    __shared__ unsigned item_s, stale_s, wait_ok_s;
     float *lds_all = DUAL ? np_plan_dyn_lds : lds_static;
     // dual: waves 4..7 run tile B's controller call in the second controller region
     float *lds_act = lds_all, *lds_fdm = lds_all + ACT_FLOATS, *ctx = lds_fdm + PLAN_COLS * PLAN_TILE;
@@ -866,10 +870,37 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                 if constexpr (WIN) plan_fill_ab(ap, lds_fdm, ctx, tid);   // (NP_PLAN_WIN_QUEUE builds) the parked tile left through a sequential step: its moment-side columns are one state old
             } else if (it0 > 0) {
                 if (threadIdx.x == 0) {
-                    // progress words carry flag_base + iterations done; what an earlier launch left is below flag_base
-                    while ((int)(__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ap->flag_base) < it0) __builtin_amdgcn_s_sleep(8);
+                    // progress words carry flag_base + iterations done; what an earlier launch left is below flag_base.
+                    // The wait is BOUNDED: every 64 polls thread 0 looks at the launch's error word and at the wall clock; a wait that outlasts
+                    // ap->wait_ticks claims the error word (first one wins), writes the host record and the workgroup drains — as does every
+                    // workgroup that finds the word set.  No progress word is raised after that, so all remaining waits end the same way.
+                    unsigned ok = 1u, polls = 0u;
+                    const unsigned long long t0 = wall_clock64();
+                    for (;;) {
+                        const int have = (int)(__hip_atomic_load(ap->queue + 1 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ap->flag_base);
+                        if (have >= it0) break;
+                        __builtin_amdgcn_s_sleep(8);
+                        if ((++polls & 63u) != 0u) continue;
+                        if (__hip_atomic_load(ap->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0u; break; }
+                        const unsigned long long waited = wall_clock64() - t0;
+                        if (waited > ap->wait_ticks) {
+                            unsigned expected = 0u;
+                            if (__hip_atomic_compare_exchange_strong(ap->err, &expected, 1u + blockIdx.x, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                unsigned *eh = ap->err_host;
+                                __hip_atomic_store(eh + 1, (unsigned)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(eh + 2, (unsigned)it0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(eh + 3, (unsigned)(have < 0 ? 0 : have), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(eh + 4, (unsigned)(waited / 100000ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(eh + 0, 1u + blockIdx.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                            ok = 0u;
+                            break;
+                        }
+                    }
+                    wait_ok_s = ok;
                 }
                 __syncthreads();   // what the tile's previous owner exported was complete before it raised the flag; the imports are sc1 loads
+                if (wait_ok_s == 0u) break;   // workgroup-uniform: drain (nothing of this segment was imported; nothing more is published)
             }
             asm volatile("" ::: "memory");
 #pragma nounroll
@@ -897,7 +928,8 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             NP_REREAD_ARGS(ap);
-            if (threadIdx.x == 0) __hip_atomic_store(ap->queue + 1 + tile, ap->flag_base + (unsigned)it1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0 && !(ap->debug_stall && blockIdx.x == 0))   // (debug_stall: the fault-injection hook of tests/test_gpu_actor.py)
+                __hip_atomic_store(ap->queue + 1 + tile, ap->flag_base + (unsigned)it1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -936,8 +968,17 @@ hipError_t launch_dual(const PlanArgs &args, unsigned grid, hipStream_t st) {
 }
 template <int TASK, int W>
 int occupancy_of() {
+    // the kernel the guest / queue schedules launch, with the dynamic LDS they launch it with (the hosts' parking area: ADVICE r4 — a query
+    // with 0 bytes would over-count once the registers allow two workgroups per CU; grid = resident and B = resident / guests rest on it)
+    constexpr size_t dyn = W == 8 ? sizeof(float) * PARK_LDS_FLOATS : 0;
+    if constexpr (dyn != 0) {
+        if (hipFuncSetAttribute((const void *)planning_persistent_kernel<TASK, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+    }
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, planning_persistent_kernel<TASK, W, true>, 64 * W, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, planning_persistent_kernel<TASK, W, true>, 64 * W, dyn) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
@@ -974,9 +1015,11 @@ hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args,
 
 static int workgroups_per_cu_uncached(int task, int waves);
 int planning_persistent_workgroups_per_cu(int task, int waves) {
-    static int cached[3][2] = {};   // the occupancy query costs a driver call; its answer belongs to the code object
+    static int cached[64][3][2] = {};   // the occupancy query costs a driver call; its answer belongs to the code object and the device
     if (task < 0 || task > 2) return 0;
-    int &c = cached[task][waves == 8];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return workgroups_per_cu_uncached(task, waves);
+    int &c = cached[dev][task][waves == 8];
     if (c == 0) c = workgroups_per_cu_uncached(task, waves);
     return c;
 }

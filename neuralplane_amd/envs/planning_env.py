@@ -21,6 +21,7 @@ import os
 import numpy as np
 import torch
 
+from .. import _lib
 from ..actor import FusedActor
 from .env_base import BaseEnv
 from .models.F16_model import F16Model
@@ -123,15 +124,28 @@ class PlanningEnv(BaseEnv):
         if h.data_ptr() != p['rnn'][0].data_ptr():   # somebody replaced the recurrent state (load_state_dict, the caller): take it over
             p['rnn'][0].copy_(torch.as_tensor(h, dtype=torch.float32, device=d).reshape(n, 128))
         flags_scratch = p['flags'] if p['flags'].data_ptr() != b.flags.data_ptr() else torch.empty((3, n), dtype=torch.uint8, device=d)
-        obs, reward, flags = b.planning_inner_loop(self.controller.weights, p['ll'], p['rnn'], p['masks'], p['act'], tgt3, flags_scratch,
-                                                   INNER_STEPS, groups=self.loop_groups, mode=self.LOOP_MODES[self.loop_mode],
-                                                   waves=self.loop_waves, block=self.loop_block)
+        args = (self.controller.weights, p['ll'], p['rnn'], p['masks'], p['act'], tgt3, flags_scratch, INNER_STEPS)
+        try:
+            obs, reward, flags = b.planning_inner_loop(*args, groups=self.loop_groups, mode=self.LOOP_MODES[self.loop_mode], waves=self.loop_waves,
+                                                       block=self.loop_block, check=self.LOOP_CHECKS[self.loop_check])
+        except _lib.PlanningStalled as e:
+            if not e.restored:
+                raise
+            # a bounded wait of the guest / queue schedule expired (include/neuralplane_amd.h, "Bounded waits"): the library ended the kernel
+            # and restored every buffer it updates in place, so the same macro-step runs again launch by launch — same results, bit for bit
+            import warnings
+            warnings.warn(f'{e}; re-running this macro-step launch by launch', RuntimeWarning, stacklevel=3)
+            self.loop_fallbacks += 1
+            obs, reward, flags = b.planning_inner_loop(*args, groups=self.loop_groups, mode=self.LOOP_MODES['launches'])
         self.ego_rnn_states = p['rnn'][INNER_STEPS & 1].view(n, 1, 128)
         f = flags.view(torch.bool)
         return obs, reward, f[0], f[1], f[2], self.info()
 
     loop_groups = 0          # np_planning_loop.groups (0 = the library chooses)
     LOOP_MODES = {'auto': 0, 'launches': 1, 'persistent': 2, 'queue': 3, 'guests': 4, 'dual': 5}
+    LOOP_CHECKS = {'sync': 0, 'deferred': 1}
+    loop_check = 'sync'      # np_planning_loop.check (guest / queue schedules): 'sync' = the call waits for the launch; a stalled schedule is re-run launch by launch
+    loop_fallbacks = 0       # how many macro-steps were re-run that way
     loop_mode = 'auto'       # np_planning_loop.mode: 'launches' = 2 x 50 launches, 'persistent' / 'queue' = ONE launch (np_planning.hip)
     loop_waves = 0           # persistent kernel: waves per 32-row tile (0 = the library chooses, 4, 8)
     loop_block = 0           # queue schedule: iterations per (tile, block) work item (0 = the library chooses)

@@ -348,3 +348,74 @@ def test_planning_macro_steps_equal_the_oracle_closed_loop_bit_for_bit(golden_di
         for q in ('flags', 'step_count', 's', 'u', 'tgt', 'rnn', 'obs', 'reward'):
             assert _same(got[q], want[q]), f'macro-step {k}: {q} differs from the oracle (max abs {np.nanmax(np.abs(got[q].astype(np.float64) - want[q]))})'
     assert int(want['flags'][1].sum()) > 0 and int((want['step_count'] == 150).sum()) >= 30
+
+
+@pytest.mark.parametrize('mode,n', [('guests', 10_037), ('queue', 10_037), ('queue', 700)])
+def test_a_stalled_guest_or_queue_schedule_is_an_error_and_a_clean_fallback_not_a_hang(golden_dir, monkeypatch, mode, n):
+    """Bounded waits (include/neuralplane_amd.h, ABI 15).  Fault injection: NP_PLANNING_DEBUG_STALL makes workgroup 0 never raise a progress
+    word, so its successors' waits expire (NP_PLANNING_WAIT_MS = 40 here, 2 s shipped).  The kernel must END; np_planning_inner_loop returns
+    NP_E_PLANNING_STALLED naming workgroup / tile / iteration with every in-place buffer restored; PlanningEnv re-runs the macro-step launch by
+    launch (a RuntimeWarning, env.loop_fallbacks) — and the results equal the launch-by-launch path bit for bit, this macro-step and the
+    following ones (which run the schedule again, un-stalled, on freshly cleared queue words)."""
+    from neuralplane_amd import _lib
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    w = pack_ppo_actor(_sd(np.load(f'{golden_dir}/actor_kat.npz')))
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=17, device='cuda:0', controller=FusedActor(w, 'cuda:0')) for _ in range(2)]
+    envs[0].loop_mode = 'launches'
+    envs[1].loop_mode = mode
+    for e in envs:
+        e.termination_reasons()
+    g = torch.Generator(device='cpu').manual_seed(n)
+    monkeypatch.setenv('NP_PLANNING_WAIT_MS', '40')
+    for k in range(4):
+        a = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
+        ref = envs[0].step(a)
+        if k == 1:
+            monkeypatch.setenv('NP_PLANNING_DEBUG_STALL', '1')
+            with pytest.warns(RuntimeWarning, match='re-running this macro-step launch by launch'):
+                out = envs[1].step(a)
+            monkeypatch.delenv('NP_PLANNING_DEBUG_STALL')
+            assert envs[1].loop_fallbacks == 1
+        else:
+            out = envs[1].step(a)
+        for x, y in zip(ref[:5], out[:5]):
+            assert torch.equal(x, y), f'macro-step {k}'
+        assert torch.equal(envs[0].model.s, envs[1].model.s) and torch.equal(envs[0].model.u, envs[1].model.u)
+        assert torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states) and torch.equal(envs[0].step_count, envs[1].step_count)
+        assert torch.equal(envs[0].termination_reasons(), envs[1].termination_reasons())
+    assert envs[0].termination_counts() == envs[1].termination_counts() and envs[1].loop_fallbacks == 1
+    # the raw entry point: the error names what waited for what, and check = deferred delivers the verdict with the next call
+    env = envs[1]
+    monkeypatch.setenv('NP_PLANNING_DEBUG_STALL', '1')
+    env.loop_check = 'deferred'
+    env.step(a)                                   # returns at once; nothing is kept
+    with pytest.raises(_lib.PlanningStalled, match=r'workgroup \d+ waited \d+ ms for tile \d+ to reach iteration \d+') as ei:
+        env.step(a)
+    assert not ei.value.restored
+    monkeypatch.delenv('NP_PLANNING_DEBUG_STALL')
+    assert _lib.load().np_planning_check(env._batch._ctx) == 0
+
+
+def test_guest_and_queue_schedules_refuse_a_capturing_stream(golden_dir):
+    """their counter / progress-word bases are host state baked into the launch — a replayed graph would silently compute nothing
+    (queue) or import tiles before they were exported (guests).  Explicit requests fail during capture; 'auto' picks a capturable mode."""
+    from neuralplane_amd.actor import FusedActor, pack_ppo_actor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    w = pack_ppo_actor(_sd(np.load(f'{golden_dir}/actor_kat.npz')))
+    n = 10_037
+    env = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=3, device='cuda:0', controller=FusedActor(w, 'cuda:0'))
+    a = torch.zeros((n, 3), device='cuda')
+    env.step(a)                                   # buffers exist, nothing allocates during the capture below
+    torch.cuda.synchronize()
+    for mode in ('guests', 'queue'):
+        env.loop_mode = mode
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match='cannot be captured'):
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    env.step(a)
+        torch.cuda.synchronize()
+    env.loop_mode = 'auto'
+    env.step(a)
