@@ -459,6 +459,44 @@ def run_env(args, rank, local_rank, world, dev, dist):
     modes['planning_tracking_n8192'] = planning_mode(dev, g, 8_192, 20)
     modes['planning_tracking_n1e4'] = planning_mode(dev, g, 10_000, 20)
     modes['planning_tracking_n262144'] = planning_mode(dev, g, 262_144, 4)
+    # SURVEY 8(f) N1 end to end: the reference's collect loop (policy forward -> env.step -> buffer insert -> compute_returns) at its own
+    # training sizes, device-resident / with a HIP graph / through the numpy contract (tools/collect_loop.py)
+    from tools.collect_loop import collect_loop_report
+    modes['collect_loop_n3000'] = collect_loop_report(3_000, 200, dev)
+    modes['collect_loop_n1e4'] = collect_loop_report(10_000, 200, dev)
+    # last: it wants an idle GPU
+    modes['reference_protocol'] = reference_protocol_mode(dev)
+    return out
+
+
+# the reference's published totals for 500 env.steps (envs/measure_env/time_neuralplane.npy, producer envs/measure_env.py:65-78)
+REF_PUBLISHED_S_500 = {10_000: 18.25, 100_000: 21.13, 1_000_000: 105.16}
+
+
+def reference_protocol_mode(dev):
+    """The paper's benchmark as the paper ran it (/root/reference/envs/measure_env.py:65-78,114,129): a fresh ControlEnv('heading', F16,
+    seed 0), the constant action its script builds (INIT_U's controls, which env.step clamps to (1, 0, 0, 0)), 500 env.steps, NO warm-up,
+    no clock prelude, started after two seconds of idle GPU; time.time() around the loop — plus one device synchronisation at the end,
+    which the reference's script lacks (its loop returns when the last step is enqueued; ours would too, 30 x earlier)."""
+    import torch
+    from neuralplane_amd.envs.control_env import ControlEnv
+    out = {'protocol': 'N aircraft, F-16 Heading, constant clamped action (1, 0, 0, 0), 500 steps, no warm-up, no prelude, idle GPU before; '
+                       'seconds for the 500 steps incl. a final device synchronisation', 'unit': 's per 500 env.steps'}
+    for n in (1_000_000, 100_000, 10_000):
+        env = ControlEnv(num_envs=n, config='heading', model='F16', random_seed=0, device=str(dev))
+        a = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(n, 1)
+        torch.cuda.synchronize(dev)
+        time.sleep(2.0)                       # let the clock governor fall back: the reference's run starts on an idle GPU
+        t0 = time.time()
+        for _ in range(500):
+            env.step(a)
+        torch.cuda.synchronize(dev)
+        el = time.time() - t0
+        out[f'n{n}'] = {'seconds_500_steps': el, 'reference_published_seconds_500_steps': REF_PUBLISHED_S_500[n],
+                        'aircraft_steps_per_s': n * 500 / el, 'ratio_to_published': REF_PUBLISHED_S_500[n] / el}
+        del env
+    out['note'] = ('the published column is the reference on its authors\' unnamed NVIDIA GPU (BASELINE.md section 1): other hardware, quoted for '
+                   'orientation; at N <= 1e5 this run is host-bound (one launch per step, ~16 us of Python per env.step)')
     return out
 
 
