@@ -1037,4 +1037,5 @@ int f16o_num_threads(void) {
 
 #include "f16_combat.inc"
 #include "f16_actor.inc"
+#include "f16_actor_i8.inc"
 #include "f16_rollout.inc"

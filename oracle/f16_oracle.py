@@ -42,7 +42,7 @@ class Cfg(C.Structure):
 
 def build(force=False):
     """Compile oracle/_build/libf16oracle.so with gcc (Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_actor.inc', 'f16_rollout.inc', 'f16_oracle.h', 'Makefile'))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_actor.inc', 'f16_actor_i8.inc', 'f16_rollout.inc', 'f16_oracle.h', 'Makefile'))
     if os.environ.get('F16O_SO'):      # e.g. the sanitizer build (`make -C oracle asan-test`)
         return os.environ['F16O_SO']
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
@@ -404,12 +404,22 @@ class CombatOracle(Oracle):
 # PlanningEnv's frozen low-level controller (f16_actor.inc)
 # =====================================================================================================
 class ActorOracle:
-    """PPOActor.forward(deterministic=True) for the packed weights of neuralplane_amd.actor.pack_ppo_actor."""
+    """PPOActor.forward(deterministic=True) for the packed weights of neuralplane_amd.actor.pack_ppo_actor.
+    numerics: 'fp32' (f16_actor.inc: sequential fmaf chains) or 'i8' (f16_actor_i8.inc: block fixed point, the second spec)."""
 
-    def __init__(self, weights):
+    def __init__(self, weights, numerics='fp32'):
         self.lib = C.CDLL(build())
         self.w = _f32(weights).reshape(-1)
         assert self.w.size == self.lib.f16o_actor_num_floats(), (self.w.size, self.lib.f16o_actor_num_floats())
+        assert numerics in ('fp32', 'i8'), numerics
+        self.numerics = numerics
+
+    def quantised_weights(self, layer):
+        """(wq[n_out, n_in] int32, ew[n_out] int32) of layer 0 L1, 1 L2, 2 GI, 3 GH, 4 A1, 5 A2 as the i8 restatement computes them."""
+        n_in, n_out = (22, 128, 128, 128, 128, 128)[layer], (128, 128, 384, 384, 128, 128)[layer]
+        wq, ew = np.empty((n_out, n_in), np.int32), np.empty(n_out, np.int32)
+        assert self.lib.f16o_actor_i8_weights(_p(self.w), C.c_int(layer), _p(wq, C.c_int32), _p(ew, C.c_int32)) == 0
+        return wq, ew
 
     def forward(self, obs, h, masks):
         obs, h = _f32(obs), _f32(h).reshape(-1, 128)
@@ -417,7 +427,10 @@ class ActorOracle:
         n = obs.shape[0]
         act = np.empty((n, 4), np.float32)
         h_out = np.empty((n, 128), np.float32)
-        self.lib.f16o_actor_forward(_p(self.w), C.c_int64(n), _p(obs), _p(h), _p(m), _p(act), _p(h_out))
+        if self.numerics == 'i8':
+            assert self.lib.f16o_actor_i8_forward(_p(self.w), C.c_int64(n), _p(obs), _p(h), _p(m), _p(act), _p(h_out)) == 0
+        else:
+            self.lib.f16o_actor_forward(_p(self.w), C.c_int64(n), _p(obs), _p(h), _p(m), _p(act), _p(h_out))
         return act, h_out
 
 

@@ -32,11 +32,11 @@ class OracleClosedLoop:
     """macro_step(k) -> dict of everything PlanningEnv.step leaves behind; per-inner-iteration actions / observations are kept
     for the comparison with the fixture's recording."""
 
-    def __init__(self, g, packed_weights):
+    def __init__(self, g, packed_weights, numerics='fp32'):
         self.g = g
         self.n = g['hi_actions'].shape[1]
         self.o = Oracle('tracking')
-        self.actor = ActorOracle(packed_weights)
+        self.actor = ActorOracle(packed_weights, numerics)
         self.st = Oracle.new_state(self.n)
         self.h = np.zeros((self.n, 128), np.float32)
         self.ones = np.ones(self.n, np.float32)

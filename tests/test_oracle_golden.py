@@ -556,3 +556,57 @@ def test_planning_env_closed_loop_vs_reference(golden_dir):
         total_bad += int(g[f'flags_{k}'][1].sum())
         flown = res['step_count']
     assert 0 < total_bad and int((flown == 150).sum()) >= 30, 'the fixture mixes rows frozen mid-step with rows that fly all 150 closed-loop steps'
+
+
+# ---------------------------------------------------------------------------------------------------
+# The controller's second numerics spec: block fixed point on the i8 matrix pipe (oracle/f16_actor_i8.inc)
+# ---------------------------------------------------------------------------------------------------
+def _actor_kat(golden_dir):
+    from neuralplane_amd.actor import pack_ppo_actor
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    sd = {k[4:]: d[k] for k in d.files if k.startswith('sd::')}
+    return d, sd, pack_ppo_actor(sd)
+
+
+def test_actor_i8_restatement_vs_reference_recording_and_prototype(golden_dir):
+    """f16_actor_i8.inc (integer class sums, fp32 steps spelled out) against (a) the REFERENCE PPOActor's recorded actions / recurrent states
+    of four consecutive calls (bound 2e-5 / 5e-5, the bound the fp32 spec is held to; measured 5.2e-6 / 2.5e-6) and (b) the independent numpy
+    statement of the same spec (tools/microbench/i8v2_numerics.py) bit for bit, incl. masked rows, saturating inputs and |h| > 1."""
+    import sys
+    import os
+    from oracle.f16_oracle import ActorOracle
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), '..', 'tools', 'microbench'))
+    import i8v2_numerics as proto
+    d, sd, w = _actor_kat(golden_dir)
+    o, p = ActorOracle(w, 'i8'), proto.ActorI8(sd, True)
+    h_o = h_p = np.zeros((96, 128), np.float32)
+    for t in range(d['obs'].shape[0]):
+        a_o, h_o = o.forward(d['obs'][t], h_o, d['masks'][t])
+        a_p, h_p = p.forward(d['obs'][t], h_p, d['masks'][t])
+        assert same(a_o, a_p) and same(h_o, h_p), t
+        assert np.max(np.abs(a_o - d['actions'][t])) < 2e-5 and np.max(np.abs(h_o - d['rnn'][t][:, 0])) < 5e-5, t
+    rng = np.random.RandomState(1)
+    obs = (rng.normal(0, 1, (300, 22)) * rng.uniform(0.1, 30, (1, 22))).astype(np.float32)
+    obs[0, 5] = np.float32(1e20)
+    h = rng.normal(0, 0.5, (300, 128)).astype(np.float32)
+    mk = (rng.uniform(0, 1, 300) > 0.2).astype(np.float32)
+    with np.errstate(over='ignore'):
+        a_p, h_p = p.forward(obs, h, mk)
+    a_o, h_o = o.forward(obs, h, mk)
+    assert same(a_o, a_p) and same(h_o, h_p) and np.all(np.isfinite(a_o))
+    # the two specs agree to the precision either has against the reference
+    a_f, h_f = ActorOracle(w, 'fp32').forward(obs[1:], h[1:], mk[1:])
+    assert np.max(np.abs(a_f - a_o[1:])) < 2e-5 and np.max(np.abs(h_f - h_o[1:])) < 2e-5
+
+
+def test_planning_env_closed_loop_vs_reference_with_the_i8_controller(golden_dir):
+    """test_planning_env_closed_loop_vs_reference with the controller's block-fixed-point numerics in the loop: same bounds (masks / counters
+    equal, states 1e-4, recurrent state 5e-5, actions 2e-5); measured states 4.1e-5, recurrent state 1.8e-5, actions 7.1e-6 after 150 steps."""
+    from neuralplane_amd.actor import pack_ppo_actor
+    from tests.planning_closed import OracleClosedLoop, actor_state_dict, compare_with_reference
+    g = np.load(f'{golden_dir}/planning_closed_kat.npz')
+    cl = OracleClosedLoop(g, pack_ppo_actor(actor_state_dict(g)), numerics='i8')
+    worst = 0.0
+    for k in range(g['hi_actions'].shape[0]):
+        worst = max(worst, compare_with_reference(cl.macro_step(k), g, k)['state'])
+    assert worst < 6e-5
