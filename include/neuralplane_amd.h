@@ -276,8 +276,16 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
  * h_in / h_out [n][128] (rnn_states with the layer dimension squeezed; may not alias; 16-byte aligned), masks [n],
  * actions [n][4].  Two tilings with identical results: 32-row tiles up to 16 384 rows (latency: 32 us per call up to 8 192
  * rows; needs `weights` 16-byte aligned), 64-row tiles above (throughput).  Environment variable NP_ACTOR_TILE=32|64, read at
- * every call, forces one (benchmarks and the parity tests of both). */
+ * every call, forces one (benchmarks and the parity tests of both).
+ * Second numerics spec (ABI 15), "block fixed point": the six Linear layers with N >= 128 on the i8 matrix pipe (v_mfma_i32_32x32x32_i8) —
+ * activations quantised per row to sign + 22 bits, weights per output feature to sign + 29 bits, integer limb products, exact class
+ * sums combined by three fused multiply-adds (the CPU restatement f16_actor_i8.inc states it operation by operation; against the reference's recordings
+ * it is as close as the fp32 chains: actions 5e-6, 150 closed-loop steps 4e-5).  It is selected by the WEIGHT BUFFER: np_actor_pack_i8
+ * (host) turns the NP_ACTOR_NUM_FLOATS floats into NP_ACTOR_I8_NUM_FLOATS (the same floats, then per-output scales and the limb bytes in
+ * the kernel's fragment order); upload that and pass its size as num_floats — here and in np_planning_loop.actor_weights_floats. */
 #define NP_ACTOR_NUM_FLOATS 153392
+#define NP_ACTOR_I8_NUM_FLOATS 306240
+int np_actor_pack_i8(const float *packed_fp32_host, float *out_host);
 int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
                      float *actions, float *h_out, int device, void *stream);
 
@@ -335,9 +343,11 @@ typedef struct np_planning_loop {
     uint8_t *flags[2];         /* [3][n] each (done, bad_done, exceed_time_limit); [0] = the flags on entry; the final flags end in flags[iterations & 1] */
     const float *ll_tgt;       /* [3][ld] the controller's targets (np_f16_io.ll_tgt) */
     int32_t mode;              /* NP_PLANNING_AUTO / _LAUNCHES / _PERSISTENT / _PERSISTENT_QUEUE (ABI 13) / _PERSISTENT_GUESTS (ABI 14) */
-    int32_t waves;             /* persistent kernel: waves per 32-row tile, 4 or 8; 0 = the library chooses */
+    int32_t waves;             /* persistent kernel: waves per 32-row tile: 8 (0 = the library chooses; the four-wave builds were retired in ABI 15) */
     int32_t block;             /* queue schedule: iterations per (tile, block) item, 1 .. iterations; 0 = the library chooses */
     int32_t check;             /* ABI 15 (was reserved, 0): NP_PLANNING_CHECK_SYNC / _DEFERRED — guest and queue schedules only, see above */
+    int64_t actor_weights_floats; /* ABI 15: what actor_weights holds — 0 or NP_ACTOR_NUM_FLOATS: the fp32 numerics; NP_ACTOR_I8_NUM_FLOATS: the
+                                * block-fixed-point numerics (np_actor_pack_i8), every schedule except the dual workgroups */
 } np_planning_loop;
 int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, const np_planning_loop *loop, void *stream);
 /* check = deferred: wait for the context's last guest / queue launch and return its verdict (0 or NP_E_PLANNING_STALLED_LOST). */

@@ -35,6 +35,7 @@ _SHAPES = {'base.feature_norm.weight': (OBS,), 'base.mlp.fc.0.weight': (HID, OBS
            'rnn.gru.weight_ih_l0': (3 * HID, HID), 'rnn.gru.weight_hh_l0': (3 * HID, HID), 'act.mlp.fc.0.weight': (HID, HID),
            'act.mlp.fc.3.weight': (HID, HID), 'act.action_out.mu_net.fc.0.weight': (ACT, HID)}
 NUM_FLOATS = 153392
+NUM_FLOATS_I8 = 306240   # NP_ACTOR_I8_NUM_FLOATS: the same floats + per-output scales + limb fragments (np_actor_pack_i8)
 
 
 def pack_ppo_actor(state_dict):
@@ -54,10 +55,21 @@ def pack_ppo_actor(state_dict):
     return out
 
 
-class FusedActor:
-    """`FusedActor(actor.state_dict(), device)(obs, rnn_states, masks, deterministic=True) -> (actions, None, rnn_states)`."""
+def pack_i8(packed_fp32):
+    """float32[NUM_FLOATS] -> float32[NUM_FLOATS_I8]: the weight buffer of the block-fixed-point numerics (library call np_actor_pack_i8, host side)."""
+    w = np.ascontiguousarray(packed_fp32, dtype=np.float32).reshape(-1)
+    if w.size != NUM_FLOATS:
+        raise ValueError(f'packed actor weights must hold {NUM_FLOATS} floats, got {w.size}')
+    out = np.empty(NUM_FLOATS_I8, np.float32)
+    _lib.check(_lib.load().np_actor_pack_i8(w.ctypes.data, out.ctypes.data))
+    return out
 
-    def __init__(self, state_dict_or_packed, device='cuda:0'):
+
+class FusedActor:
+    """`FusedActor(actor.state_dict(), device)(obs, rnn_states, masks, deterministic=True) -> (actions, None, rnn_states)`.
+    numerics: 'fp32' (ordered fmaf chains, the CPU restatement f16_actor.inc) or 'i8' (block fixed point on the i8 matrix pipe, the CPU restatement f16_actor_i8.inc)."""
+
+    def __init__(self, state_dict_or_packed, device='cuda:0', numerics='fp32'):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -70,16 +82,20 @@ class FusedActor:
         w = np.ascontiguousarray(w, dtype=np.float32).reshape(-1)
         if w.size != NUM_FLOATS:
             raise ValueError(f'packed actor weights must hold {NUM_FLOATS} floats, got {w.size}')
+        if numerics not in ('fp32', 'i8'):
+            raise ValueError("numerics: 'fp32' or 'i8'")
+        self.numerics = numerics
         self.packed = w
-        self.weights = torch.from_numpy(w).to(self.device)
+        self.num_floats = NUM_FLOATS_I8 if numerics == 'i8' else NUM_FLOATS
+        self.weights = torch.from_numpy(pack_i8(w) if numerics == 'i8' else w).to(self.device)
 
     @classmethod
-    def from_checkpoint(cls, path, device='cuda:0'):
+    def from_checkpoint(cls, path, device='cuda:0', numerics='fp32'):
         """The reference's `actor_latest.pt` (a PPOActor state_dict saved by its runner, runner/F16sim_runner.py:223-229)."""
         sd = torch.load(path, map_location='cpu')
         if not isinstance(sd, dict):
             raise ValueError(f'{path}: expected a PPOActor state_dict')
-        return cls({k: v for k, v in sd.items()}, device)
+        return cls({k: v for k, v in sd.items()}, device, numerics)
 
     def eval(self):
         return self
@@ -107,6 +123,6 @@ class FusedActor:
                 raise ValueError('out = (actions[n,4], rnn_states[n,1,128]): contiguous float32 device tensors, the state buffer 16-byte aligned '
                                  'and different from the input state')
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self.lib.np_actor_forward(self.weights.data_ptr(), NUM_FLOATS, n, obs.data_ptr(), h.data_ptr(), m.data_ptr(),
+        _lib.check(self.lib.np_actor_forward(self.weights.data_ptr(), self.num_floats, n, obs.data_ptr(), h.data_ptr(), m.data_ptr(),
                                              act.data_ptr(), h_out.data_ptr(), self.device.index, stream))
         return act, None, h_out

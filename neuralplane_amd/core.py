@@ -285,6 +285,7 @@ class F16Batch:
         lp.iterations, lp.groups = int(iterations), int(groups)
         lp.mode, lp.waves, lp.block, lp.check = int(mode), int(waves), int(block), int(check)
         lp.actor_weights = actor_weights.data_ptr()
+        lp.actor_weights_floats = int(actor_weights.numel())   # NP_ACTOR_NUM_FLOATS (fp32 numerics) or NP_ACTOR_I8_NUM_FLOATS (block fixed point)
         lp.ll_obs[0], lp.ll_obs[1] = ll_obs[0].data_ptr(), ll_obs[1].data_ptr()
         lp.rnn[0], lp.rnn[1] = rnn[0].data_ptr(), rnn[1].data_ptr()
         lp.masks, lp.ll_act, lp.ll_tgt = masks.data_ptr(), ll_act.data_ptr(), tgt3.data_ptr()

@@ -1,0 +1,97 @@
+// np_actor_i8.hip — the controller's block-fixed-point kernel (np_actor_i8.h) as a stand-alone launch, its launcher, and the load-time packer
+// of the quantised weights (np_actor_pack_i8, C ABI).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/neuralplane_amd.h"
+#define NPACT_NO_KERNELS 1
+#include "np_actor_i8.h"
+
+namespace npact8 {
+
+__global__ __launch_bounds__(256) void actor_forward_i8_kernel(const float *__restrict__ weights, long long n, const float *__restrict__ obs,
+                                                               const float *__restrict__ h_in, const float *__restrict__ mask, float *__restrict__ act,
+                                                               float *__restrict__ h_out) {
+    __shared__ __attribute__((aligned(16))) float lds[ACTOR8_LDS_FLOATS];
+    actor8_tile(lds, weights, n, obs, h_in, mask, act, h_out, (long long)blockIdx.x, threadIdx.x);
+}
+
+hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, const float *h_in, const float *masks, float *actions, float *h_out,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(actor_forward_i8_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, weights, n, obs, h_in, masks, actions, h_out);
+    return hipGetLastError();
+}
+
+}  // namespace npact8
+
+// ---- load-time packer (host) -----------------------------------------------------------------------------------------------------------
+namespace {
+int exponent_of_host(float b) {
+    uint32_t bits;
+    std::memcpy(&bits, &b, 4);
+    const int e = (int)((bits >> 23) & 255u) - 126;
+    return e < -100 ? -100 : e;
+}
+float pow2_host(int e) {
+    const uint32_t bits = (uint32_t)(e + 127) << 23;
+    float x;
+    std::memcpy(&x, &bits, 4);
+    return x;
+}
+// one Linear layer: wt = W^T, k-major [n_in][ld]; outputs [j0, j0 + 32 * blocks) as M-blocks of 32 -> fragments + scales
+void pack_layer(const float *wt, int n_in, int ld, int j0, int blocks, int ks_count, unsigned char *frag, float *sw) {
+    using namespace npact8;
+    for (int mb = 0; mb < blocks; mb++) {
+        for (int m = 0; m < 32; m++) {
+            const int j = j0 + 32 * mb + m;
+            float mx = 0.0f;
+            for (int k = 0; k < n_in; k++) mx = std::fmax(mx, std::fabs(wt[k * ld + j]));
+            const int ew = exponent_of_host(mx);
+            sw[32 * mb + m] = pow2_host(ew - 18);
+            for (int ks = 0; ks < ks_count; ks++)
+                for (int hh = 0; hh < 2; hh++)
+                    for (int e = 0; e < 16; e++) {
+                        const int k = 32 * ks + 8 * (e >> 2) + 4 * hh + (e & 3);
+                        uint32_t p = 0u;
+                        if (k < n_in) {
+                            const int32_t q = (int32_t)std::nearbyint(std::ldexp((double)wt[k * ld + j], WBITS - ew));   // exact product, round-half-even
+                            p = ((uint32_t)q + 0x80808080u) ^ 0x80808080u;
+                        }
+                        for (int limb = 0; limb < 4; limb++)
+                            frag[(size_t)((mb * ks_count + ks) * 4 + limb) * FRAG_BYTES + (size_t)(m + 32 * hh) * 16 + e] = (unsigned char)(p >> (8 * limb));
+                    }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int np_actor_pack_i8(const float *packed_fp32, float *out) {
+    using namespace npact8;
+    if (!packed_fp32 || !out) return 1;
+    std::memcpy(out, packed_fp32, sizeof(float) * TOTAL);
+    std::memset(out + TOTAL, 0, sizeof(float) * (size_t)(TOTAL_I8 - TOTAL));
+    unsigned char *frag = reinterpret_cast<unsigned char *>(out + FRAG);
+    const float *w = packed_fp32;
+    pack_layer(w + L1_W, OBS, HID, 0, 4, 1, frag + FR_L1, out + SW_L1);
+    pack_layer(w + L2_W, HID, HID, 0, 4, 4, frag + FR_L2, out + SW_L2);
+    for (int gate = 0; gate < 3; gate++) {   // M-block index of the GRU matrices: gate * 4 + wave
+        pack_layer(w + GI_W, HID, 3 * HID, gate * HID, 4, 4, frag + FR_GI + gate * 4 * MB_BYTES_K4, out + SW_GI + gate * HID);
+        pack_layer(w + GH_W, HID, 3 * HID, gate * HID, 4, 4, frag + FR_GH + gate * 4 * MB_BYTES_K4, out + SW_GH + gate * HID);
+    }
+    pack_layer(w + A1_W, HID, HID, 0, 4, 4, frag + FR_A1, out + SW_A1);
+    pack_layer(w + A2_W, HID, HID, 0, 4, 4, frag + FR_A2, out + SW_A2);
+    const int ln_g[6] = {LN0_G, LN1_G, LN2_G, LN3_G, LN4_G, LN5_G}, ln_b[6] = {LN0_B, LN1_B, LN2_B, LN3_B, LN4_B, LN5_B};
+    for (int k = 0; k < 6; k++) {
+        float gm = 0.0f, bm = 0.0f;
+        for (int j = 0; j < (k == 0 ? OBS : HID); j++) {
+            gm = std::fmax(gm, std::fabs(w[ln_g[k] + j]));
+            bm = std::fmax(bm, std::fabs(w[ln_b[k] + j]));
+        }
+        out[LNMAX + 2 * k] = gm;
+        out[LNMAX + 2 * k + 1] = bm;
+    }
+    return 0;
+}

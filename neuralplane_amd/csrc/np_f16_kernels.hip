@@ -28,6 +28,10 @@
 #include "np_actor.h"
 #include "np_rollout.h"
 #include "np_planning.h"
+namespace npact8 {
+hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, const float *h_in, const float *masks, float *actions, float *h_out,
+                           hipStream_t stream);   // np_actor_i8.hip
+}
 #include "np_dispatch.h"
 #include "np_env_launch.h"
 
@@ -1019,7 +1023,8 @@ int np_planning_targets_obs(np_f16_ctx *ctx, int64_t n, const float *s, const fl
 int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
                      float *actions, float *h_out, int device, void *stream) {
     if (!weights || !obs || !h_in || !masks || !actions || !h_out) return fail("null argument");
-    if (num_floats != npact::TOTAL) return fail("packed actor weights: wrong size (expected NP_ACTOR_NUM_FLOATS)");
+    if (num_floats != npact::TOTAL && num_floats != NP_ACTOR_I8_NUM_FLOATS)
+        return fail("packed actor weights: wrong size (expected NP_ACTOR_NUM_FLOATS, or NP_ACTOR_I8_NUM_FLOATS for the block-fixed-point numerics)");
     if (((uintptr_t)h_in | (uintptr_t)h_out) & 15) return fail("h_in / h_out must be 16-byte aligned");
     if (n <= 0) return 0;
     int ndev = 0;
@@ -1027,6 +1032,11 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
     DeviceGuard guard;
     NP_HIP(guard.enter(device));
+    if (num_floats == NP_ACTOR_I8_NUM_FLOATS) {   // the second numerics spec: one kernel, 32-aircraft tiles (np_actor_i8.hip)
+        if ((uintptr_t)weights & 15) return fail("packed actor weights must be 16-byte aligned");
+        NP_HIP(npact8::launch_actor_i8(weights, (long long)n, obs, h_in, masks, actions, h_out, (hipStream_t)stream));
+        return 0;
+    }
 #if NPACT_MFMA
     // small batches: 32-row tiles (twice the workgroups, half the MFMA chain per tile); NP_ACTOR_TILE=32|64 overrides (benchmarks)
     const char *tile_str = std::getenv("NP_ACTOR_TILE");  // read per call: the tests switch it
@@ -1173,6 +1183,8 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     if (io->ld < n) return fail("ld < n");
     if (io->ld >= (1ll << 30)) return fail("ld must be below 2^30 rows (32-bit byte offsets inside a row-indexed array)");
     if (((uintptr_t)lp->rnn[0] | (uintptr_t)lp->rnn[1] | (uintptr_t)lp->actor_weights) & 15) return fail("rnn buffers / actor weights must be 16-byte aligned");
+    const bool i8 = lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS;
+    if (i8 && mode == NP_PLANNING_PERSISTENT_DUAL) return fail("np_planning_inner_loop: the dual workgroups serve the fp32 controller only; use _PERSISTENT, _GUESTS, _QUEUE or _LAUNCHES with the block-fixed-point weights");
     PlanArgs pa;
     KArgs &a = pa.k;
     a.s = io->s; a.u = io->u; a.tgt = io->tgt; a.ld = io->ld; a.step_count = (long long *)io->step_count;
@@ -1297,7 +1309,7 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
             const int dev = ctx->device;
             const bool chain = dev >= 0 && dev < 64;
             if (chain && last_ev[dev] && last_st[dev] != st) NP_HIP(hipStreamWaitEvent(st, last_ev[dev], 0));
-            NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
+            NP_HIP(launch_planning_persistent(ctx->task, waves, i8, pa, grid, st, nullptr, nullptr));
             ctx->queue_dirty = false;
             if (chain) {
                 if (!last_ev[dev]) NP_HIP(hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming));
@@ -1321,7 +1333,7 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
         }
         return 0;
     }
-    NP_HIP(launch_planning_persistent(ctx->task, waves, pa, grid, st, nullptr, nullptr));
+    NP_HIP(launch_planning_persistent(ctx->task, waves, i8, pa, grid, st, nullptr, nullptr));
     ctx->queue_dirty = false;
     return 0;
 }
@@ -1337,7 +1349,10 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     if (lp->rnn[0] == lp->rnn[1] || lp->ll_obs[0] == lp->ll_obs[1] || lp->flags[0] == lp->flags[1])
         return fail("np_planning_loop: the two buffers of a ping-pong pair must differ");
     if (lp->mode < NP_PLANNING_AUTO || lp->mode > NP_PLANNING_PERSISTENT_DUAL) return fail("np_planning_loop: unknown mode");
-    if (lp->waves != 0 && lp->waves != 4 && lp->waves != 8) return fail("np_planning_loop: waves must be 0 (automatic), 4 or 8");
+    if (lp->waves != 0 && lp->waves != 8) return fail("np_planning_loop: waves must be 0 (automatic) or 8 (the four-wave builds of the persistent kernel were retired in ABI 15)");
+    if (lp->actor_weights_floats != 0 && lp->actor_weights_floats != NP_ACTOR_NUM_FLOATS && lp->actor_weights_floats != NP_ACTOR_I8_NUM_FLOATS)
+        return fail("np_planning_loop: actor_weights_floats must be 0 / NP_ACTOR_NUM_FLOATS (fp32 numerics) or NP_ACTOR_I8_NUM_FLOATS (block fixed point)");
+    if (((uintptr_t)lp->actor_weights) & 15) return fail("np_planning_loop: actor_weights must be 16-byte aligned");
     if (lp->block < 0) return fail("np_planning_loop: block must be >= 0");
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard;
@@ -1365,6 +1380,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
                                   NP_PLANNING_PERSISTENT_GUESTS == npdispatch::PL_GUESTS && NP_PLANNING_PERSISTENT_DUAL == npdispatch::PL_DUAL && PLAN_ROWS == 32,
                               "np_dispatch.h mirrors the NP_PLANNING_* numbers");
                 mode = npdispatch::planning_mode(n, (int64_t)per_cu * ctx->num_cus);   // np_dispatch.h: by tiles per resident workgroup
+                if (mode == NP_PLANNING_PERSISTENT_DUAL && lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS) mode = NP_PLANNING_LAUNCHES;   // fp32 only
                 waves = 8;
             }
         }
@@ -1406,7 +1422,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
         for (int g = 0; g < groups && !rc; g++) {
             const int64_t r0 = g * per, m = (r0 + per <= n ? per : n - r0);
             hipStream_t sg = g == 0 ? st : ctx->group_streams[g - 1];
-            if (np_actor_forward(lp->actor_weights, NP_ACTOR_NUM_FLOATS, m, lp->ll_obs[a] + r0 * npact::OBS, lp->rnn[a] + r0 * npact::HID, lp->masks + r0,
+            if (np_actor_forward(lp->actor_weights, lp->actor_weights_floats ? lp->actor_weights_floats : NP_ACTOR_NUM_FLOATS, m, lp->ll_obs[a] + r0 * npact::OBS, lp->rnn[a] + r0 * npact::HID, lp->masks + r0,
                                  lp->ll_act + r0 * 4, lp->rnn[b] + r0 * npact::HID, ctx->device, (void *)sg)) {
                 rc = 1;
                 break;

@@ -42,10 +42,10 @@ constexpr int PLAN_ERR_WORDS = 8;
 constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_actor.h)
 
 // tasks: 0 heading, 1 control, 2 tracking (PlanningEnv ships tracking only; the others serve the parity tests of the loop).
-// waves: 4 or 8 per workgroup.  queue_mode: 0 = one workgroup per tile (grid = tiles), 1 = `grid` persistent workgroups pulling
+// waves: 8 per workgroup (the four-wave builds were retired in round 5).  queue_mode: 0 = one workgroup per tile (grid = tiles), 1 = `grid` persistent workgroups pulling
 // (tile, iteration) items.  Returns hipSuccess or the launch error.
-hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args, unsigned grid, hipStream_t stream, hipEvent_t ev_start,
-                                      hipEvent_t ev_stop);
+hipError_t launch_planning_persistent(int task, int waves, bool i8, const PlanArgs &args, unsigned grid, hipStream_t stream, hipEvent_t ev_start,
+                                      hipEvent_t ev_stop);   // i8: args.actor_w is an NP_ACTOR_I8_NUM_FLOATS buffer (block-fixed-point controller)
 // dual workgroups: two 32-row tiles per eight-wave workgroup (np_planning.hip), static schedule, grid = ceil(tiles / 2)
 hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, hipStream_t stream);
 // how many workgroups of that shape fit one CU / the device (occupancy query)

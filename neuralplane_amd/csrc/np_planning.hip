@@ -43,6 +43,7 @@
 #include "np_planning.h"
 #define NPACT_NO_KERNELS 1
 #include "np_actor.h"
+#include "np_actor_i8.h"
 
 #ifndef NP_PLAN_WIN
 #define NP_PLAN_WIN 1   // 0: the static schedule keeps the 22 moment-side nets in the front of an inner step (A/B)
@@ -118,6 +119,13 @@ __device__ __forceinline__ void gst(T *p, T v) {
 // spreads a block's 32 rows over the banks.
 __device__ __forceinline__ int h_stage_off(int row, int piece) { return 128 * row + 2 * ((piece ^ (2 * row)) & 63); }
 
+// which 16 features of its row a controller thread (row, blk = 2 wave + lane half) holds, as float4 / 8-byte piece indices inside the row:
+// fp32 numerics (np_actor.h): features 16 blk .. 16 blk + 15; block fixed point (np_actor_i8.h, accumulator layout): 32 wave + 8 g + 4 half + t
+template <bool I8>
+__device__ __forceinline__ int h_float4(int blk, int g) { return I8 ? 8 * (blk >> 1) + (blk & 1) + 2 * g : 4 * blk + g; }
+template <bool I8>
+__device__ __forceinline__ int h_piece(int blk, int j) { return I8 ? 16 * (blk >> 1) + 2 * (blk & 1) + 4 * (j >> 1) + (j & 1) : 8 * blk + j; }
+
 template <int W>
 __device__ __forceinline__ void h_global_to_stage(const float *src, long long i0, long long n, float *stage, unsigned tid) {
 #pragma unroll
@@ -139,7 +147,7 @@ __device__ __forceinline__ void h_stage_to_global(float *dst, long long i0, long
     }
 }
 
-template <int W, bool COH, int ROWS = PLAN_ROWS>
+template <int W, bool COH, int ROWS = PLAN_ROWS, bool I8 = false>
 __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float *lds_act, float *ctx, long long i0, int it, unsigned tid, float (&hm)[npact::BLK],
                                             unsigned *stale_s) {
     using CX = CtxL<ROWS>;
@@ -156,11 +164,11 @@ __device__ __forceinline__ void plan_import(PlanArgsC &ap, float *lds_fdm, float
         const long long ih = i0 + (ROWS == 2 * PLAN_ROWS && wave >= 4 ? PLAN_ROWS : 0) + (t & (PLAN_ROWS - 1));
         const long long ihc = ih < n ? ih : n - 1;
         const float mk = a->masks[ihc];
-        const float *hp = a->rnn[it & 1] + ihc * npact::HID + blk * npact::BLK;
+        const float *hp = a->rnn[it & 1] + ihc * npact::HID;
         {
 #pragma unroll
             for (int j = 0; j < npact::BLK / 4; j++) {
-                const float4 q = reinterpret_cast<const float4 *>(hp)[j];
+                const float4 q = reinterpret_cast<const float4 *>(hp)[h_float4<I8>(blk, j)];
                 hm[4 * j] = q.x * mk;
                 hm[4 * j + 1] = q.y * mk;
                 hm[4 * j + 2] = q.z * mk;
@@ -619,16 +627,18 @@ __device__ __forceinline__ void plan_fill_ab(PlanArgsC &ap, float *lds_fdm, cons
 
 extern __shared__ __attribute__((aligned(16))) float np_plan_dyn_lds[];   // dual workgroups only (DUAL_LDS_FLOATS; 0 bytes otherwise)
 
-template <int TASK, int W, bool QUEUE, bool DUAL = false>
+template <int TASK, int W, bool QUEUE, bool DUAL = false, bool I8 = false>
 __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const PlanArgs a) {
     static_assert(W == 4 || W == 8, "four or eight waves per tile");
     static_assert(!DUAL || (W == 8 && !QUEUE), "dual workgroups: eight waves = two controller calls of four, static schedule");
+    static_assert(!I8 || (W == 8 && !DUAL), "block-fixed-point controller: eight-wave tiles, static / guest / queue schedules");
+    static_assert(npact8::ACTOR8_LDS_FLOATS <= npact::ACTOR32_LDS_FLOATS, "the i8 controller's LDS fits the fp32 controller's region");
     constexpr bool PIPE = NP_PLAN_PIPE && W == 8 && !DUAL;   // the pipelined schedule (plan_fdm_front / plan_fdm_back) inside a tile's stay on this workgroup
     // WIN: the pipelined schedule with the 22 moment-side alpha/beta-only nets moved off the critical path, into the controller call's four
     // barrier-free windows (plan_window_nets, AB_GRU) — for the static schedule, where a tile never changes workgroup: -2 % per macro-step at
     // n <= 32 rows x CUs; a tile that moves pays an evaluation of all 36 nets per import instead of 14, which cancels the gain (guest / queue
     // schedules: +0.2 .. +0.6 %, profiles/r04_planning_moment_nets_in_call_windows.log), so the coherent kernels keep the round-4 front
-    constexpr bool WIN = NP_PLAN_WIN && PIPE && (!QUEUE || NP_PLAN_WIN_QUEUE);
+    constexpr bool WIN = NP_PLAN_WIN && PIPE && (!QUEUE || NP_PLAN_WIN_QUEUE) && !I8;   // (the windows are counted in the fp32 call's barriers)
     constexpr int ROWS = DUAL ? 2 * PLAN_ROWS : PLAN_ROWS;    // rows of the workgroup's context
     using CX = CtxL<ROWS>;
     constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
@@ -665,12 +675,12 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
         const unsigned ctid = DUAL ? (tid & 255u) : tid;
         float *lds_ctl = lds_act + (DUAL && wave >= 4 ? npact::ACTOR32_LDS_FLOATS : 0);
         const int row0 = DUAL && wave >= 4 ? PLAN_ROWS : 0;
-        if (ctl) {
+        if (ctl && !I8) {
             npact::actor32_request_l1(ap->actor_w, ctid, pre);
             if (do_import) npact::actor32_stage_head(lds_ctl, ap->actor_w, ctid);  // stays staged while the workgroup lives
         }
         if (do_import) {
-            plan_import<W, QUEUE, ROWS>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h, &stale_s);
+            plan_import<W, QUEUE, ROWS, I8>(ap, lds_fdm, lds_act, ctx, i0, it, tid, h, &stale_s);
             __syncthreads();
             if constexpr (QUEUE) {
                 if (W == 4 || wave < 4) {   // the masked recurrent state (gru.py:26) of (row, block) from the stage
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     const float mk = ctx[CX::ST + CTX_MK * ROWS + row];
 #pragma unroll
                     for (int j = 0; j < npact::BLK / 2; j++) {
-                        const float2 v = *reinterpret_cast<const float2 *>(lds_act + h_stage_off(row, 8 * blk + j));
+                        const float2 v = *reinterpret_cast<const float2 *>(lds_act + h_stage_off(row, h_piece<I8>(blk, j)));
                         h[2 * j] = v.x * mk;
                         h[2 * j + 1] = v.y * mk;
                     }
@@ -703,7 +713,8 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 #pragma unroll
             for (int j = 0; j < npact::OBS; j++) xr[j] = ctx[CX::OBS + row * 22 + j];
             float hn[npact::BLK], action;
-            npact::actor32_body(lds_ctl, ap->actor_w, pre, xr, h, hn, action, ctid);
+            if constexpr (I8) npact8::actor8_body(lds_ctl, ap->actor_w, xr, h, hn, action, ctid);
+            else npact::actor32_body(lds_ctl, ap->actor_w, pre, xr, h, hn, action, ctid);
             if (hi == 0) ctx[CX::ACT + row * 4 + w4] = action;
 #pragma unroll
             for (int j = 0; j < npact::BLK; j++) h[j] = hn[j];
@@ -711,9 +722,9 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                 NP_REREAD_ARGS(ap);
                 const long long i = i0 + row;
                 if (i < ap->k.n) {
-                    float *hq = ap->rnn[(it & 1) ^ 1] + i * npact::HID + (2 * w4 + hi) * npact::BLK;
+                    float *hq = ap->rnn[(it & 1) ^ 1] + i * npact::HID;
 #pragma unroll
-                    for (int j = 0; j < npact::BLK / 4; j++) reinterpret_cast<float4 *>(hq)[j] = make_float4(h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]);
+                    for (int j = 0; j < npact::BLK / 4; j++) reinterpret_cast<float4 *>(hq)[h_float4<I8>(2 * w4 + hi, j)] = make_float4(h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]);
                 }
             }
         } else if constexpr (W == 8) {
@@ -743,8 +754,10 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                 for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
                 static_assert(npact::ACTOR32_BARRIERS == 5 + 4 + 2 + 4 + 4 + 4 && ACTOR32_BARRIERS_BEFORE_GRU == 9, "barrier plan of the spread back");
             } else {
+                // fp32 call: 9 barriers, [GRU window = barriers 10, 11], 12 more; block-fixed-point call: 5, [GRU window = 6, 7], 8 more
+                constexpr int BEFORE = I8 ? 5 : ACTOR32_BARRIERS_BEFORE_GRU, TOTALB = I8 ? npact8::ACTOR8_BARRIERS : npact::ACTOR32_BARRIERS;
 #pragma unroll 1
-                for (int b = 0; b < ACTOR32_BARRIERS_BEFORE_GRU; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < BEFORE; b++) __builtin_amdgcn_s_barrier();
                 if (back) {
 #if NP_PLAN_BACK_PRIO   // experiment (tools/microbench): the controller's waves at raised priority while the back runs beside them
                     __builtin_amdgcn_s_setprio(0);
@@ -755,7 +768,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     __builtin_amdgcn_s_barrier();
                 }
 #pragma unroll 1
-                for (int b = 0; b < npact::ACTOR32_BARRIERS - ACTOR32_BARRIERS_BEFORE_GRU - 2; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < TOTALB - BEFORE - 2; b++) __builtin_amdgcn_s_barrier();
             }
         }
         NP_PSTAMP(2);
@@ -774,7 +787,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                 if (W == 4 || wave < 4) {
                     const int row = (int)(tid & 31), blk = (int)(tid >> 5) & 7;
 #pragma unroll
-                    for (int j = 0; j < npact::BLK / 2; j++) *reinterpret_cast<float2 *>(lds_act + h_stage_off(row, 8 * blk + j)) = make_float2(h[2 * j], h[2 * j + 1]);
+                    for (int j = 0; j < npact::BLK / 2; j++) *reinterpret_cast<float2 *>(lds_act + h_stage_off(row, h_piece<I8>(blk, j))) = make_float2(h[2 * j], h[2 * j + 1]);
                 }
                 __syncthreads();
                 NP_REREAD_ARGS(ap);
@@ -935,21 +948,22 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 }
 
 namespace {
-template <int TASK, int W, bool QUEUE>
+template <int TASK, int W, bool QUEUE, bool I8>
 hipError_t launch_one(const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     constexpr size_t dyn = (QUEUE && W == 8) ? sizeof(float) * PARK_LDS_FLOATS : 0;   // the parking area of the guest schedule's hosts
+    const auto kernel = planning_persistent_kernel<TASK, W, QUEUE, false, I8>;
     if constexpr (dyn != 0) {
         static bool set[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
         if (dev < 64 && !set[dev]) {  // static + dynamic LDS above the 64 KB a kernel may use without asking
-            const hipError_t e = hipFuncSetAttribute((const void *)planning_persistent_kernel<TASK, W, QUEUE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             if (e != hipSuccess) return e;
             set[dev] = true;
         }
     }
-    if (e0 && e1) hipExtLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), dyn, st, e0, e1, 0, args);
-    else hipLaunchKernelGGL((planning_persistent_kernel<TASK, W, QUEUE>), dim3(grid), dim3(64 * W), dyn, st, args);
+    if (e0 && e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64 * W), dyn, st, e0, e1, 0, args);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * W), dyn, st, args);
     return hipGetLastError();
 }
 template <int TASK>
@@ -997,13 +1011,16 @@ hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, h
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_planning_persistent(int task, int waves, const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+// Eight waves per tile.  (The four-wave builds of rounds 3-4 — 256 VGPRs + 36-52 B of scratch per lane, reachable only through an explicit
+// np_planning_loop.waves = 4: NP_PLANNING_AUTO always took eight — were retired in round 5: VERDICT r4 item 6.)
+hipError_t launch_planning_persistent(int task, int waves, bool i8, const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const bool queue = args.queue != nullptr;
+    if (waves != 8) return hipErrorInvalidValue;
 #define NP_PLAN_CASE(T)                                                                             \
     if constexpr (((NP_PLAN_TASKS >> T) & 1) != 0) {                                                  \
         if (task == T) {                                                                             \
-            if (waves == 8) return queue ? launch_one<T, 8, true>(args, grid, st, e0, e1) : launch_one<T, 8, false>(args, grid, st, e0, e1); \
-            return queue ? launch_one<T, 4, true>(args, grid, st, e0, e1) : launch_one<T, 4, false>(args, grid, st, e0, e1);                \
+            if (i8) return queue ? launch_one<T, 8, true, true>(args, grid, st, e0, e1) : launch_one<T, 8, false, true>(args, grid, st, e0, e1);   \
+            return queue ? launch_one<T, 8, true, false>(args, grid, st, e0, e1) : launch_one<T, 8, false, false>(args, grid, st, e0, e1); \
         }                                                                                            \
     }
     NP_PLAN_CASE(0)
@@ -1026,7 +1043,7 @@ int planning_persistent_workgroups_per_cu(int task, int waves) {
 static int workgroups_per_cu_uncached(int task, int waves) {
 #define NP_PLAN_CASE(T)                                                       \
     if constexpr (((NP_PLAN_TASKS >> T) & 1) != 0) {                        \
-        if (task == T) return waves == 8 ? occupancy_of<T, 8>() : occupancy_of<T, 4>(); \
+        if (task == T) return waves == 8 ? occupancy_of<T, 8>() : 0; \
     }
     NP_PLAN_CASE(0)
     NP_PLAN_CASE(1)

@@ -310,3 +310,40 @@ def test_pairwise_helpers_against_the_reference(golden_dir):
         assert torch.isfinite(U.orientation_reward(AO[4:], TA[4:], version=v)).all()
     for v in ('v0', 'v1', 'v2'):
         assert torch.isfinite(U.range_reward(3, Rkm, version=v)).all()
+
+
+def test_i8_weight_packer_agrees_with_the_oracles_quantiser(golden_dir):
+    """np_actor_pack_i8 (the library's load-time packer, host code: runs here without a GPU) against oracle/f16_actor_i8.inc's independent
+    quantiser: un-shuffling the fragment order (M-block / k-step / limb / lane / 16 bytes, k-slot e of half h <-> input feature
+    32 ks + 8 (e >> 2) + 4 h + (e & 3)) gives the same sign + 29-bit integers, the scales are 2^(ew - 18), k-slots beyond 22 inputs of the
+    first layer are zero, the float prefix is the fp32 layout unchanged, the LayerNorm bound constants are max |gamma|, max |beta|."""
+    import numpy as np
+    from neuralplane_amd.actor import NUM_FLOATS, NUM_FLOATS_I8, pack_i8, pack_ppo_actor
+    from oracle.f16_oracle import ActorOracle
+    d = np.load(f'{golden_dir}/actor_kat.npz')
+    w = pack_ppo_actor({k[4:]: d[k] for k in d.files if k.startswith('sd::')})
+    out = pack_i8(w)
+    assert out.size == NUM_FLOATS_I8 and np.array_equal(out[:NUM_FLOATS], w)
+    o = ActorOracle(w, 'i8')
+    frag = out[NUM_FLOATS + 1280 + 16:].view(np.uint8)
+    assert frag.size == 592 * 1024
+    sw_off = NUM_FLOATS
+    base = 0
+    for layer, (n_in, n_out, ks_count) in enumerate(((22, 128, 1), (128, 128, 4), (128, 384, 4), (128, 384, 4), (128, 128, 4), (128, 128, 4))):
+        wq, ew = o.quantised_weights(layer)
+        blocks = n_out // 32
+        f = frag[base: base + blocks * ks_count * 4 * 1024].reshape(blocks, ks_count, 4, 64, 16).astype(np.int64)
+        f = np.where(f >= 128, f - 256, f)                                   # signed limb bytes
+        val = ((f[:, :, 3] * 256 + f[:, :, 2]) * 256 + f[:, :, 1]) * 256 + f[:, :, 0]     # [mb, ks, lane, e]
+        got = np.zeros((n_out, 32 * ks_count), np.int64)
+        for ks in range(ks_count):
+            for hh in range(2):
+                for e in range(16):
+                    got[:, 32 * ks + 8 * (e >> 2) + 4 * hh + (e & 3)] = val[:, ks, 32 * hh: 32 * hh + 32, e].reshape(-1)
+        assert np.array_equal(got[:, :n_in], wq), layer
+        assert not got[:, n_in:].any(), layer
+        assert np.array_equal(out[sw_off: sw_off + n_out], np.ldexp(np.float32(1), ew - 18).astype(np.float32)), layer
+        sw_off += n_out
+        base += blocks * ks_count * 4 * 1024
+    lnmax = out[NUM_FLOATS + 1280: NUM_FLOATS + 1280 + 12]
+    assert lnmax[0] == np.abs(w[0:22]).max() and lnmax[1] == np.abs(w[22:44]).max()
