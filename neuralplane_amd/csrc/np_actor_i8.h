@@ -49,6 +49,9 @@ constexpr int XF_FLOATS = 4 * 3 * FRAG_BYTES / 4;          // 3 072 floats = 12 
 constexpr int PART_FLOATS = 32 * 8;                        // [aircraft][lane block]
 constexpr int LDS8_XF = 0, LDS8_HF = XF_FLOATS, LDS8_PS = 2 * XF_FLOATS, LDS8_PQ = LDS8_PS + PART_FLOATS, LDS8_PM = LDS8_PQ + PART_FLOATS,
               LDS8_PH = LDS8_PM + PART_FLOATS, LDS8_HEAD = LDS8_PH + PART_FLOATS, ACTOR8_LDS_FLOATS = LDS8_HEAD + 32 * 8 * 4;
+// a second LDS region, wherever the caller has room: the masked recurrent state and the z gate wait here while the GRU's matrix phases run (the
+// registers they would hold — with 64 of weight fragments, 64 of class sums and 12 of operands in flight — are what a 256-register wave lacks)
+constexpr int ACTOR8_PARK_FLOATS = 2 * 16 * 256;   // [2][4 float4][256 threads]: 32 KB
 constexpr int ACTOR8_BARRIERS = 15;   // __syncthreads() executed by actor8_body (straight-line code)
 
 __device__ __forceinline__ int exponent_of(float b) {   // e with |b| < 2^e, clamped below
@@ -134,24 +137,37 @@ __device__ __forceinline__ int layernorm_acc(const float (&v)[16], const float *
     return exponent_of(fmaf(mm * rstd, gmax, bmax) * 1.000001f);
 }
 
+// The A-operand (weight) fragments of the M-block in flight, [k-step][limb], 64 VGPRs.  They ROTATE: as soon as the nine products of k-step ks
+// have been issued, the same registers receive k-step ks of the NEXT M-block — every fragment is requested a whole M-block (>= 1 150 cycles
+// of matrix pipe + its epilogue) before it is used, which is what the L2 round trip needs, at the register cost of one M-block.
+struct WFrags {
+    i32x4 w[4][4];
+};
+__device__ __forceinline__ void wfrag_load(WFrags &f, const unsigned char *mb_frags, int ks, int slot_ks, int lane) {
+    const i32x4 *wl = reinterpret_cast<const i32x4 *>(mb_frags) + lane;
+#pragma unroll
+    for (int l = 0; l < 4; l++) f.w[slot_ks][l] = wl[(ks * 4 + l) * 64];
+}
+
 // One M-block (32 output features x 32 aircraft) of a quantised Linear layer: KS k-steps of nine limb products into four class sums,
 // then the epilogue y = fmaf(fmaf-chain(c0..c3) * 2^(ex - 17), 2^(ew - 18), bias) per accumulator register.
-// wfrag: this M-block's A fragments [k-step][limb][lane][16 B] (global memory); xfrag: the B fragments [k-step][limb][lane][16 B] (LDS), or
-// `xreg` (KS == 1: the first layer's operand comes from registers)
-template <int KS>
-__device__ __forceinline__ void mblock(const unsigned char *wfrag, const float *xfrag, const i32x4 (&xreg)[3], const float *swp, const float *biasp, int fbase,
-                                       int ex, int lane, float (&y)[16]) {
+// wf: this M-block's A fragments (already requested); next: the NEXT M-block's fragments [k-step][limb][lane][16 B] in global memory, of
+// which k-steps [0, NEXT_KS) are requested into the registers this M-block frees (a KS = 1 block frees slot 0 only: the caller requested
+// the follower's k-steps 1..3 up front); xfrag: the B fragments [k-step][limb][lane][16 B] (LDS), or `xreg` (KS == 1: the first layer's
+// operand comes from registers)
+template <int KS, int NEXT_KS>
+__device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, const float *xfrag, const i32x4 (&xreg)[3], const float *swp, const float *biasp,
+                                       int fbase, int ex, int lane, float (&y)[16]) {
     i32x16 c0, c1, c2, c3;
 #pragma unroll
     for (int r = 0; r < 16; r++) { c0[r] = 0; c1[r] = 0; c2[r] = 0; c3[r] = 0; }
-    const i32x4 *wl = reinterpret_cast<const i32x4 *>(wfrag) + lane;
     const i32x4 *xl = reinterpret_cast<const i32x4 *>(xfrag) + lane;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-        const i32x4 w0 = wl[(ks * 4 + 0) * 64], w1 = wl[(ks * 4 + 1) * 64], w2 = wl[(ks * 4 + 2) * 64], w3 = wl[(ks * 4 + 3) * 64];
         i32x4 x0, x1, x2;
         if constexpr (KS == 1) { x0 = xreg[0]; x1 = xreg[1]; x2 = xreg[2]; }
         else { x0 = xl[(ks * 3 + 0) * 64]; x1 = xl[(ks * 3 + 1) * 64]; x2 = xl[(ks * 3 + 2) * 64]; }
+        const i32x4 w0 = wf.w[ks][0], w1 = wf.w[ks][1], w2 = wf.w[ks][2], w3 = wf.w[ks][3];
         // consecutive instructions never touch the same accumulator
         c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, x2, c3, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, x2, c2, 0, 0, 0);
@@ -162,6 +178,9 @@ __device__ __forceinline__ void mblock(const unsigned char *wfrag, const float *
         c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w3, x1, c1, 0, 0, 0);
         c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, x0, c3, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w3, x0, c2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // the refill below stays behind the products that read the registers (no renaming into fresh ones)
+        if (ks < NEXT_KS) wfrag_load(wf, next, ks, ks, lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
     const float sa = pow2f(ex - 17);
 #pragma unroll
@@ -177,6 +196,19 @@ __device__ __forceinline__ void mblock(const unsigned char *wfrag, const float *
             y[r] = fmaf(u * sa, sw[t], bi[t]);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void park_store(float *park, const float (&v)[16], unsigned tid) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) reinterpret_cast<float4 *>(park)[g * 256 + (tid & 255u)] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+__device__ __forceinline__ void park_load(const float *park, float (&v)[16], unsigned tid) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 q = reinterpret_cast<const float4 *>(park)[g * 256 + (tid & 255u)];
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
 }
 
 __device__ __forceinline__ void relu_acc(float (&v)[16]) {
@@ -187,7 +219,8 @@ __device__ __forceinline__ void relu_acc(float (&v)[16]) {
 // One 32-aircraft tile, the calling workgroup's waves 0..3 (tid < 256).  xr = the 22 raw observations of this lane's aircraft; hm = the
 // MASKED recurrent state (gru.py:26) of this lane's 16 features (accumulator layout); returns hn (same layout) and `action` = tanh(mu) of
 // (aircraft a, output w) in the lanes with h == 0.
-__device__ __forceinline__ void actor8_body(float *lds, const float *weights, const float (&xr)[OBS], const float (&hm)[16], float (&hn)[16], float &action, unsigned tid) {
+__device__ __forceinline__ void actor8_body(float *lds, float *park, const float *weights, const float (&xr)[OBS], const float (&hm)[16], float (&hn)[16], float &action,
+                                            unsigned tid) {
     const cw_ptr W = (cw_ptr)(unsigned long long)weights;   // wave-uniform reads: scalar loads
     const float *Wv = weights;
     const unsigned char *frag = reinterpret_cast<const unsigned char *>(weights + FRAG);
@@ -198,6 +231,14 @@ __device__ __forceinline__ void actor8_body(float *lds, const float *weights, co
     const i32x4 none[3] = {};
     float v[16], y[16], dummy = 0.0f;
     int ex;
+    // the weight stream starts before anything else: the first layer's single k-step and k-steps 1..3 of the second layer's M-block
+    const unsigned char *f_l1 = frag + FR_L1 + w * 4 * FRAG_BYTES, *f_l2 = frag + FR_L2 + w * MB_BYTES_K4, *f_a1 = frag + FR_A1 + w * MB_BYTES_K4,
+                        *f_a2 = frag + FR_A2 + w * MB_BYTES_K4, *f_gi = frag + FR_GI + w * MB_BYTES_K4, *f_gh = frag + FR_GH + w * MB_BYTES_K4;
+    WFrags wf;
+    wfrag_load(wf, f_l1, 0, 0, lane);
+#pragma unroll
+    for (int ks = 1; ks < 4; ks++) wfrag_load(wf, f_l2, ks, ks, lane);
+    __builtin_amdgcn_sched_barrier(0);
 
     // base.feature_norm over the 22 observations: every lane computes its aircraft's (no exchange), quantises, and picks the 16 k-slots of
     // its half: slot e <-> feature 8 (e >> 2) + 4 h + (e & 3); slots of features >= 22 are zero (as the packed weights are)
@@ -242,7 +283,7 @@ __device__ __forceinline__ void actor8_body(float *lds, const float *weights, co
     }
     NPACT_STAMP(1);
     // base.mlp: Linear(22, 128) + ReLU + LayerNorm
-    mblock<1>(frag + FR_L1 + w * 4 * FRAG_BYTES, nullptr, x1reg, Wv + SW_L1, Wv + L1_B, fbase, ex, lane, v);
+    mblock<1, 1>(wf, f_l2, nullptr, x1reg, Wv + SW_L1, Wv + L1_B, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(2);
     ex = layernorm_acc<false>(v, Wv + LN1_G, Wv + LN1_B, W[LNMAX + 2], W[LNMAX + 3], lds, blk, a, fbase, y, 0.0f, dummy);
@@ -250,7 +291,7 @@ __device__ __forceinline__ void actor8_body(float *lds, const float *weights, co
     __syncthreads();
     NPACT_STAMP(3);
     // Linear(128, 128) + ReLU + LayerNorm; the recurrent state's row maximum rides in the LayerNorm's first exchange
-    mblock<4>(frag + FR_L2 + w * MB_BYTES_K4, xf, none, Wv + SW_L2, Wv + L2_B, fbase, ex, lane, v);
+    mblock<4, 4>(wf, f_gi + 4 * MB_BYTES_K4, xf, none, Wv + SW_L2, Wv + L2_B, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(4);
     float hmax_l = 0.0f, hmax;
@@ -260,31 +301,33 @@ __device__ __forceinline__ void actor8_body(float *lds, const float *weights, co
     const int eh = exponent_of(hmax);
     quantise_store(y, ex, xf, w, lane);
     quantise_store(hm, eh, hf, w, lane);
+    park_store(park, hm, tid);   // (own data: no barrier of its own)
     __syncthreads();
     NPACT_STAMP(5);
-    // rnn: GRU cell (gate order r, z, n as in torch)
+    // rnn: GRU cell.  Gate order of the ARITHMETIC as in torch (r, z, n); evaluated z, r, n so that only one gate vector is in registers beside
+    // a matrix phase: z waits in LDS, r is folded into r * gh_n before the last M-block
     {
-        float yi[16], yh[16], rr[16], zz[16];
-        mblock<4>(frag + FR_GI + (0 * 4 + w) * MB_BYTES_K4, xf, none, Wv + SW_GI, Wv + GI_B, fbase, ex, lane, yi);
-        NPACT_STAMP(6);
-        mblock<4>(frag + FR_GH + (0 * 4 + w) * MB_BYTES_K4, hf, none, Wv + SW_GH, Wv + GH_B, fbase, eh, lane, yh);
-        NPACT_STAMP(7);
+        float yi[16], yh[16], t[16];
+        mblock<4, 4>(wf, f_gh + 4 * MB_BYTES_K4, xf, none, Wv + SW_GI + HID, Wv + GI_B + HID, fbase, ex, lane, yi);          // gi_z
+        mblock<4, 4>(wf, f_gi, hf, none, Wv + SW_GH + HID, Wv + GH_B + HID, fbase, eh, lane, yh);                           // gh_z
 #pragma unroll
-        for (int r = 0; r < 16; r++) rr[r] = act_sigmoid(yi[r] + yh[r]);
-        NPACT_STAMP(8);
-        mblock<4>(frag + FR_GI + (1 * 4 + w) * MB_BYTES_K4, xf, none, Wv + SW_GI + HID, Wv + GI_B + HID, fbase, ex, lane, yi);
-        mblock<4>(frag + FR_GH + (1 * 4 + w) * MB_BYTES_K4, hf, none, Wv + SW_GH + HID, Wv + GH_B + HID, fbase, eh, lane, yh);
-        NPACT_STAMP(9);
+        for (int r = 0; r < 16; r++) t[r] = act_sigmoid(yi[r] + yh[r]);
+        park_store(park + 16 * 256, t, tid);
+        mblock<4, 4>(wf, f_gh, xf, none, Wv + SW_GI, Wv + GI_B, fbase, ex, lane, yi);                                        // gi_r
+        mblock<4, 4>(wf, f_gh + 8 * MB_BYTES_K4, hf, none, Wv + SW_GH, Wv + GH_B, fbase, eh, lane, yh);                       // gh_r
 #pragma unroll
-        for (int r = 0; r < 16; r++) zz[r] = act_sigmoid(yi[r] + yh[r]);
-        NPACT_STAMP(10);
-        mblock<4>(frag + FR_GI + (2 * 4 + w) * MB_BYTES_K4, xf, none, Wv + SW_GI + 2 * HID, Wv + GI_B + 2 * HID, fbase, ex, lane, yi);
-        mblock<4>(frag + FR_GH + (2 * 4 + w) * MB_BYTES_K4, hf, none, Wv + SW_GH + 2 * HID, Wv + GH_B + 2 * HID, fbase, eh, lane, yh);
-        NPACT_STAMP(11);
+        for (int r = 0; r < 16; r++) t[r] = act_sigmoid(yi[r] + yh[r]);
+        mblock<4, 4>(wf, f_gi + 8 * MB_BYTES_K4, hf, none, Wv + SW_GH + 2 * HID, Wv + GH_B + 2 * HID, fbase, eh, lane, yh);   // gh_n
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = t[r] * yh[r];
+        mblock<4, 4>(wf, f_a1, xf, none, Wv + SW_GI + 2 * HID, Wv + GI_B + 2 * HID, fbase, ex, lane, yi);                    // gi_n
+        float zz[16], hq[16];
+        park_load(park + 16 * 256, zz, tid);
+        park_load(park, hq, tid);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float nn = act_tanh(yi[r] + rr[r] * yh[r]);
-            hn[r] = (hm[r] - nn) * zz[r] + nn;
+            const float nn = act_tanh(yi[r] + t[r]);
+            hn[r] = (hq[r] - nn) * zz[r] + nn;
         }
     }
     NPACT_STAMP(12);
@@ -294,14 +337,14 @@ __device__ __forceinline__ void actor8_body(float *lds, const float *weights, co
     __syncthreads();
     NPACT_STAMP(13);
     // act.mlp
-    mblock<4>(frag + FR_A1 + w * MB_BYTES_K4, xf, none, Wv + SW_A1, Wv + A1_B, fbase, ex, lane, v);
+    mblock<4, 4>(wf, f_a2, xf, none, Wv + SW_A1, Wv + A1_B, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(14);
     ex = layernorm_acc<false>(v, Wv + LN4_G, Wv + LN4_B, W[LNMAX + 8], W[LNMAX + 9], lds, blk, a, fbase, y, 0.0f, dummy);
     quantise_store(y, ex, xf, w, lane);
     __syncthreads();
     NPACT_STAMP(15);
-    mblock<4>(frag + FR_A2 + w * MB_BYTES_K4, xf, none, Wv + SW_A2, Wv + A2_B, fbase, ex, lane, v);
+    mblock<4, 0>(wf, f_a2, xf, none, Wv + SW_A2, Wv + A2_B, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(16);
     (void)layernorm_acc<false>(v, Wv + LN5_G, Wv + LN5_B, W[LNMAX + 10], W[LNMAX + 11], lds, blk, a, fbase, y, 0.0f, dummy);
@@ -349,7 +392,7 @@ __device__ __forceinline__ void actor8_tile(float *lds, const float *weights, lo
     }
 #pragma unroll
     for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
-    actor8_body(lds, weights, xr, hm, hn, action, tid);
+    actor8_body(lds, lds + ACTOR8_LDS_FLOATS, weights, xr, hm, hn, action, tid);
     if (valid && h == 0) act[i * 4 + w] = action;
     if (valid) {
 #pragma unroll

@@ -12,10 +12,10 @@
 
 namespace npact8 {
 
-__global__ __launch_bounds__(256) void actor_forward_i8_kernel(const float *__restrict__ weights, long long n, const float *__restrict__ obs,
+__global__ __launch_bounds__(256, 2) void actor_forward_i8_kernel(const float *__restrict__ weights, long long n, const float *__restrict__ obs,
                                                                const float *__restrict__ h_in, const float *__restrict__ mask, float *__restrict__ act,
                                                                float *__restrict__ h_out) {
-    __shared__ __attribute__((aligned(16))) float lds[ACTOR8_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[ACTOR8_LDS_FLOATS + ACTOR8_PARK_FLOATS];   // 64 KB: two workgroups per CU
     actor8_tile(lds, weights, n, obs, h_in, mask, act, h_out, (long long)blockIdx.x, threadIdx.x);
 }
 

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 #pragma unroll
             for (int j = 0; j < npact::OBS; j++) xr[j] = ctx[CX::OBS + row * 22 + j];
             float hn[npact::BLK], action;
-            if constexpr (I8) npact8::actor8_body(lds_ctl, ap->actor_w, xr, h, hn, action, ctid);
+            if constexpr (I8) npact8::actor8_body(lds_ctl, np_plan_dyn_lds + (PARK ? PARK_LDS_FLOATS : 0), ap->actor_w, xr, h, hn, action, ctid);   // its GRU parking area: dynamic LDS
             else npact::actor32_body(lds_ctl, ap->actor_w, pre, xr, h, hn, action, ctid);
             if (hi == 0) ctx[CX::ACT + row * 4 + w4] = action;
 #pragma unroll
@@ -950,7 +950,8 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 namespace {
 template <int TASK, int W, bool QUEUE, bool I8>
 hipError_t launch_one(const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    constexpr size_t dyn = (QUEUE && W == 8) ? sizeof(float) * PARK_LDS_FLOATS : 0;   // the parking area of the guest schedule's hosts
+    // dynamic LDS: the parking area of the guest schedule's hosts, then the block-fixed-point controller's GRU parking area
+    constexpr size_t dyn = sizeof(float) * (((QUEUE && W == 8) ? PARK_LDS_FLOATS : 0) + (I8 ? npact8::ACTOR8_PARK_FLOATS : 0));
     const auto kernel = planning_persistent_kernel<TASK, W, QUEUE, false, I8>;
     if constexpr (dyn != 0) {
         static bool set[64] = {};
