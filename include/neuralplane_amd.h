@@ -284,7 +284,7 @@ int np_f16_combat_step(np_f16_ctx *ctx, int64_t num_envs, const np_f16_combat_io
  * (host) turns the NP_ACTOR_NUM_FLOATS floats into NP_ACTOR_I8_NUM_FLOATS (the same floats, then per-output scales and the limb bytes in
  * the kernel's fragment order); upload that and pass its size as num_floats — here and in np_planning_loop.actor_weights_floats. */
 #define NP_ACTOR_NUM_FLOATS 153392
-#define NP_ACTOR_I8_NUM_FLOATS 306240
+#define NP_ACTOR_I8_NUM_FLOATS 309312
 int np_actor_pack_i8(const float *packed_fp32_host, float *out_host);
 int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const float *obs, const float *h_in, const float *masks,
                      float *actions, float *h_out, int device, void *stream);

@@ -35,7 +35,7 @@ _SHAPES = {'base.feature_norm.weight': (OBS,), 'base.mlp.fc.0.weight': (HID, OBS
            'rnn.gru.weight_ih_l0': (3 * HID, HID), 'rnn.gru.weight_hh_l0': (3 * HID, HID), 'act.mlp.fc.0.weight': (HID, HID),
            'act.mlp.fc.3.weight': (HID, HID), 'act.action_out.mu_net.fc.0.weight': (ACT, HID)}
 NUM_FLOATS = 153392
-NUM_FLOATS_I8 = 306240   # NP_ACTOR_I8_NUM_FLOATS: the same floats + per-output scales + limb fragments (np_actor_pack_i8)
+NUM_FLOATS_I8 = 309312   # NP_ACTOR_I8_NUM_FLOATS: the same floats + per-output scales + limb fragments (np_actor_pack_i8)
 
 
 def pack_ppo_actor(state_dict):

@@ -20,26 +20,38 @@
 
 #include "np_actor.h"
 
+#ifndef NPACT8_EXP
+#define NPACT8_EXP 0   // timing-only experiment switches (tools/microbench/i8_actor_phases.hip: wrong results); 0 in every shipped build
+#endif
+
 namespace npact8 {
 using namespace npact;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-// ---- the packed weight buffer (floats): [0, TOTAL) the fp32 layout of np_actor.h (LayerNorm parameters, biases and the head are read from
-// it), then per-output scales 2^(ew - 18), the LayerNorm bound constants, then the limb fragments --------------------------------------
+// ---- the packed weight buffer (floats): [0, TOTAL) the fp32 layout of np_actor.h, then a block of TABLES in the order the kernel wants
+// them (staged into LDS once per workgroup: reading them from global memory inside the call would queue behind the weight stream — every
+// s_waitcnt vmcnt for an epilogue constant drains the prefetched fragments of the NEXT M-block, measured 6 us of a 25 us call), then the limb
+// fragments -------------------------------------------------------------------------------------------------------------------------------
 enum : int {
-    L_L1 = 0, L_L2 = 1, L_GI = 2, L_GH = 3, L_A1 = 4, L_A2 = 5, NUM_QL = 6,
-    SW_L1 = TOTAL, SW_L2 = SW_L1 + 128, SW_GI = SW_L2 + 128, SW_GH = SW_GI + 384, SW_A1 = SW_GH + 384, SW_A2 = SW_A1 + 128,
-    LNMAX = SW_A2 + 128,             // [6][2]: max |gamma|, max |beta| of LayerNorm 0..5, padded to 16 floats
-    FRAG = LNMAX + 16,               // byte fragments from here (16-byte aligned: TOTAL is a multiple of 4)
+    TAB0 = TOTAL,
+    T_SW = 0,                        // per-output scales 2^(ew - 18): L1 128 | L2 128 | GI 384 | GH 384 | A1 128 | A2 128
+    T_BIAS = 1280,                   // the biases in the same order
+    T_LN = 2560,                     // LayerNorm 1..5: gamma 128 | beta 128 each
+    T_HEAD = 3840,                   // mu_net weights [feature][4], then its 4 biases
+    T_LNMAX = 4356,                  // [6][2]: max |gamma|, max |beta| of LayerNorm 0..5
+    TAB_FLOATS = 4368,
+    O_L1 = 0, O_L2 = 128, O_GI = 256, O_GH = 640, O_A1 = 1024, O_A2 = 1152,   // offsets inside T_SW / T_BIAS
+    LNMAX = TAB0 + T_LNMAX,
+    FRAG = TAB0 + TAB_FLOATS,        // byte fragments from here (16-byte aligned)
     FRAG_BYTES = 1024,               // one A-operand fragment: 64 lanes x 16 bytes
     MB_BYTES_K4 = 4 * 4 * FRAG_BYTES,   // an M-block of a K = 128 layer: [k-step][limb] fragments
     FR_L1 = 0, FR_L2 = FR_L1 + 4 * 4 * FRAG_BYTES, FR_GI = FR_L2 + 4 * MB_BYTES_K4, FR_GH = FR_GI + 12 * MB_BYTES_K4, FR_A1 = FR_GH + 12 * MB_BYTES_K4,
     FR_A2 = FR_A1 + 4 * MB_BYTES_K4, FR_END = FR_A2 + 4 * MB_BYTES_K4,
     TOTAL_I8 = FRAG + FR_END / 4
 };
-static_assert(TOTAL % 4 == 0 && FR_END == 592 * 1024 && TOTAL_I8 == 306240, "packed i8 actor layout (np_actor_pack_i8, neuralplane_amd/actor.py)");
+static_assert(TOTAL % 4 == 0 && TAB_FLOATS % 4 == 0 && FR_END == 592 * 1024 && TOTAL_I8 == 309312, "packed i8 actor layout (np_actor_pack_i8, neuralplane_amd/actor.py)");
 
 constexpr unsigned MAGIC_BITS = 0x4B400000u;   // 1.5 * 2^23
 constexpr int XBITS = 22, WBITS = 29;
@@ -144,9 +156,15 @@ struct WFrags {
     i32x4 w[4][4];
 };
 __device__ __forceinline__ void wfrag_load(WFrags &f, const unsigned char *mb_frags, int ks, int slot_ks, int lane) {
+#if NPACT8_EXP & 2   // timing only: no weight stream
+    (void)mb_frags; (void)ks; (void)lane;
+#pragma unroll
+    for (int l = 0; l < 4; l++) f.w[slot_ks][l] = i32x4{1, 2, 3, 4};
+#else
     const i32x4 *wl = reinterpret_cast<const i32x4 *>(mb_frags) + lane;
 #pragma unroll
     for (int l = 0; l < 4; l++) f.w[slot_ks][l] = wl[(ks * 4 + l) * 64];
+#endif
 }
 
 // One M-block (32 output features x 32 aircraft) of a quantised Linear layer: KS k-steps of nine limb products into four class sums,
@@ -168,6 +186,9 @@ __device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, co
         if constexpr (KS == 1) { x0 = xreg[0]; x1 = xreg[1]; x2 = xreg[2]; }
         else { x0 = xl[(ks * 3 + 0) * 64]; x1 = xl[(ks * 3 + 1) * 64]; x2 = xl[(ks * 3 + 2) * 64]; }
         const i32x4 w0 = wf.w[ks][0], w1 = wf.w[ks][1], w2 = wf.w[ks][2], w3 = wf.w[ks][3];
+#if NPACT8_EXP & 1   // timing only: no matrix instructions (the operands are kept alive)
+        asm volatile("" :: "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2));
+#else
         // consecutive instructions never touch the same accumulator
         c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, x2, c3, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, x2, c2, 0, 0, 0);
@@ -178,6 +199,7 @@ __device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, co
         c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w3, x1, c1, 0, 0, 0);
         c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, x0, c3, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w3, x0, c2, 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);   // the refill below stays behind the products that read the registers (no renaming into fresh ones)
         if (ks < NEXT_KS) wfrag_load(wf, next, ks, ks, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -190,10 +212,14 @@ __device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, co
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int r = 4 * g + t;
+#if NPACT8_EXP & 16   // timing only: one conversion instead of the epilogue
+            y[r] = (float)(c0[r] + c1[r] + c2[r] + c3[r]) * sa + sw[t] + bi[t];
+#else
             float u = fmaf((float)c0[r], 256.0f, (float)c1[r]);
             u = fmaf(u, 256.0f, (float)c2[r]);
             u = fmaf(u, 256.0f, (float)c3[r]);
             y[r] = fmaf(u * sa, sw[t], bi[t]);
+#endif
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -219,10 +245,9 @@ __device__ __forceinline__ void relu_acc(float (&v)[16]) {
 // One 32-aircraft tile, the calling workgroup's waves 0..3 (tid < 256).  xr = the 22 raw observations of this lane's aircraft; hm = the
 // MASKED recurrent state (gru.py:26) of this lane's 16 features (accumulator layout); returns hn (same layout) and `action` = tanh(mu) of
 // (aircraft a, output w) in the lanes with h == 0.
-__device__ __forceinline__ void actor8_body(float *lds, float *park, const float *weights, const float (&xr)[OBS], const float (&hm)[16], float (&hn)[16], float &action,
+__device__ __forceinline__ void actor8_body(float *lds, float *park, const float *tab, const float *weights, const float (&xr)[OBS], const float (&hm)[16], float (&hn)[16], float &action,
                                             unsigned tid) {
     const cw_ptr W = (cw_ptr)(unsigned long long)weights;   // wave-uniform reads: scalar loads
-    const float *Wv = weights;
     const unsigned char *frag = reinterpret_cast<const unsigned char *>(weights + FRAG);
     const int lane = (int)(tid & 63u), a = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -283,21 +308,21 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
     }
     NPACT_STAMP(1);
     // base.mlp: Linear(22, 128) + ReLU + LayerNorm
-    mblock<1, 1>(wf, f_l2, nullptr, x1reg, Wv + SW_L1, Wv + L1_B, fbase, ex, lane, v);
+    mblock<1, 1>(wf, f_l2, nullptr, x1reg, tab + T_SW + O_L1, tab + T_BIAS + O_L1, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(2);
-    ex = layernorm_acc<false>(v, Wv + LN1_G, Wv + LN1_B, W[LNMAX + 2], W[LNMAX + 3], lds, blk, a, fbase, y, 0.0f, dummy);
+    ex = layernorm_acc<false>(v, tab + T_LN + 0, tab + T_LN + 128, W[LNMAX + 2], W[LNMAX + 3], lds, blk, a, fbase, y, 0.0f, dummy);
     quantise_store(y, ex, xf, w, lane);
     __syncthreads();
     NPACT_STAMP(3);
     // Linear(128, 128) + ReLU + LayerNorm; the recurrent state's row maximum rides in the LayerNorm's first exchange
-    mblock<4, 4>(wf, f_gi + 4 * MB_BYTES_K4, xf, none, Wv + SW_L2, Wv + L2_B, fbase, ex, lane, v);
+    mblock<4, 4>(wf, f_gi + 4 * MB_BYTES_K4, xf, none, tab + T_SW + O_L2, tab + T_BIAS + O_L2, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(4);
     float hmax_l = 0.0f, hmax;
 #pragma unroll
     for (int r = 0; r < 16; r++) hmax_l = fmaxf(hmax_l, fabsf(hm[r]));
-    ex = layernorm_acc<true>(v, Wv + LN2_G, Wv + LN2_B, W[LNMAX + 4], W[LNMAX + 5], lds, blk, a, fbase, y, hmax_l, hmax);
+    ex = layernorm_acc<true>(v, tab + T_LN + 256, tab + T_LN + 384, W[LNMAX + 4], W[LNMAX + 5], lds, blk, a, fbase, y, hmax_l, hmax);
     const int eh = exponent_of(hmax);
     quantise_store(y, ex, xf, w, lane);
     quantise_store(hm, eh, hf, w, lane);
@@ -308,19 +333,19 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
     // a matrix phase: z waits in LDS, r is folded into r * gh_n before the last M-block
     {
         float yi[16], yh[16], t[16];
-        mblock<4, 4>(wf, f_gh + 4 * MB_BYTES_K4, xf, none, Wv + SW_GI + HID, Wv + GI_B + HID, fbase, ex, lane, yi);          // gi_z
-        mblock<4, 4>(wf, f_gi, hf, none, Wv + SW_GH + HID, Wv + GH_B + HID, fbase, eh, lane, yh);                           // gh_z
+        mblock<4, 4>(wf, f_gh + 4 * MB_BYTES_K4, xf, none, tab + T_SW + O_GI + HID, tab + T_BIAS + O_GI + HID, fbase, ex, lane, yi);          // gi_z
+        mblock<4, 4>(wf, f_gi, hf, none, tab + T_SW + O_GH + HID, tab + T_BIAS + O_GH + HID, fbase, eh, lane, yh);                           // gh_z
 #pragma unroll
         for (int r = 0; r < 16; r++) t[r] = act_sigmoid(yi[r] + yh[r]);
         park_store(park + 16 * 256, t, tid);
-        mblock<4, 4>(wf, f_gh, xf, none, Wv + SW_GI, Wv + GI_B, fbase, ex, lane, yi);                                        // gi_r
-        mblock<4, 4>(wf, f_gh + 8 * MB_BYTES_K4, hf, none, Wv + SW_GH, Wv + GH_B, fbase, eh, lane, yh);                       // gh_r
+        mblock<4, 4>(wf, f_gh, xf, none, tab + T_SW + O_GI, tab + T_BIAS + O_GI, fbase, ex, lane, yi);                                        // gi_r
+        mblock<4, 4>(wf, f_gh + 8 * MB_BYTES_K4, hf, none, tab + T_SW + O_GH, tab + T_BIAS + O_GH, fbase, eh, lane, yh);                       // gh_r
 #pragma unroll
         for (int r = 0; r < 16; r++) t[r] = act_sigmoid(yi[r] + yh[r]);
-        mblock<4, 4>(wf, f_gi + 8 * MB_BYTES_K4, hf, none, Wv + SW_GH + 2 * HID, Wv + GH_B + 2 * HID, fbase, eh, lane, yh);   // gh_n
+        mblock<4, 4>(wf, f_gi + 8 * MB_BYTES_K4, hf, none, tab + T_SW + O_GH + 2 * HID, tab + T_BIAS + O_GH + 2 * HID, fbase, eh, lane, yh);   // gh_n
 #pragma unroll
         for (int r = 0; r < 16; r++) t[r] = t[r] * yh[r];
-        mblock<4, 4>(wf, f_a1, xf, none, Wv + SW_GI + 2 * HID, Wv + GI_B + 2 * HID, fbase, ex, lane, yi);                    // gi_n
+        mblock<4, 4>(wf, f_a1, xf, none, tab + T_SW + O_GI + 2 * HID, tab + T_BIAS + O_GI + 2 * HID, fbase, ex, lane, yi);                    // gi_n
         float zz[16], hq[16];
         park_load(park + 16 * 256, zz, tid);
         park_load(park, hq, tid);
@@ -332,22 +357,22 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
     }
     NPACT_STAMP(12);
     // rnn.norm (its two barriers also separate the GRU's fragment reads from the next writes)
-    ex = layernorm_acc<false>(hn, Wv + LN3_G, Wv + LN3_B, W[LNMAX + 6], W[LNMAX + 7], lds, blk, a, fbase, y, 0.0f, dummy);
+    ex = layernorm_acc<false>(hn, tab + T_LN + 512, tab + T_LN + 640, W[LNMAX + 6], W[LNMAX + 7], lds, blk, a, fbase, y, 0.0f, dummy);
     quantise_store(y, ex, xf, w, lane);
     __syncthreads();
     NPACT_STAMP(13);
     // act.mlp
-    mblock<4, 4>(wf, f_a2, xf, none, Wv + SW_A1, Wv + A1_B, fbase, ex, lane, v);
+    mblock<4, 4>(wf, f_a2, xf, none, tab + T_SW + O_A1, tab + T_BIAS + O_A1, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(14);
-    ex = layernorm_acc<false>(v, Wv + LN4_G, Wv + LN4_B, W[LNMAX + 8], W[LNMAX + 9], lds, blk, a, fbase, y, 0.0f, dummy);
+    ex = layernorm_acc<false>(v, tab + T_LN + 768, tab + T_LN + 896, W[LNMAX + 8], W[LNMAX + 9], lds, blk, a, fbase, y, 0.0f, dummy);
     quantise_store(y, ex, xf, w, lane);
     __syncthreads();
     NPACT_STAMP(15);
-    mblock<4, 0>(wf, f_a2, xf, none, Wv + SW_A2, Wv + A2_B, fbase, ex, lane, v);
+    mblock<4, 0>(wf, f_a2, xf, none, tab + T_SW + O_A2, tab + T_BIAS + O_A2, fbase, ex, lane, v);
     relu_acc(v);
     NPACT_STAMP(16);
-    (void)layernorm_acc<false>(v, Wv + LN5_G, Wv + LN5_B, W[LNMAX + 10], W[LNMAX + 11], lds, blk, a, fbase, y, 0.0f, dummy);
+    (void)layernorm_acc<false>(v, tab + T_LN + 1024, tab + T_LN + 1152, W[LNMAX + 10], W[LNMAX + 11], lds, blk, a, fbase, y, 0.0f, dummy);
     NPACT_STAMP(17);
     // mu_net: Linear(128, 4) + tanh — per lane block a sequential chain over its 16 features for the four outputs; wave o finishes output o
     {
@@ -356,7 +381,7 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
         for (int g = 0; g < 4; g++)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const float4 hw = *reinterpret_cast<const float4 *>(Wv + HD_W + (fbase + 8 * g + t) * 4);
+                const float4 hw = *reinterpret_cast<const float4 *>(tab + T_HEAD + (fbase + 8 * g + t) * 4);
                 p4[0] = fmaf(hw.x, y[4 * g + t], p4[0]);
                 p4[1] = fmaf(hw.y, y[4 * g + t], p4[1]);
                 p4[2] = fmaf(hw.z, y[4 * g + t], p4[2]);
@@ -373,6 +398,12 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
         action = act_tanh(tot);
     }
     NPACT_STAMP(18);
+}
+
+// the tables -> LDS (TAB_FLOATS floats at `tab`): once per workgroup, by `threads` threads; the caller's barrier makes them visible
+__device__ __forceinline__ void actor8_stage_tables(float *tab, const float *weights, unsigned tid, unsigned threads) {
+    const float4 *src = reinterpret_cast<const float4 *>(weights + TAB0);
+    for (unsigned i = tid; i < TAB_FLOATS / 4; i += threads) reinterpret_cast<float4 *>(tab)[i] = src[i];
 }
 
 // tile `tile` = aircraft [32 tile, 32 tile + 32) through global memory
@@ -392,7 +423,9 @@ __device__ __forceinline__ void actor8_tile(float *lds, const float *weights, lo
     }
 #pragma unroll
     for (int j = 0; j < OBS; j++) xr[j] = obs[ic * OBS + j];
-    actor8_body(lds, lds + ACTOR8_LDS_FLOATS, weights, xr, hm, hn, action, tid);
+    actor8_stage_tables(lds + ACTOR8_LDS_FLOATS + ACTOR8_PARK_FLOATS, weights, tid, 256u);
+    __syncthreads();
+    actor8_body(lds, lds + ACTOR8_LDS_FLOATS, lds + ACTOR8_LDS_FLOATS + ACTOR8_PARK_FLOATS, weights, xr, hm, hn, action, tid);
     if (valid && h == 0) act[i * 4 + w] = action;
     if (valid) {
 #pragma unroll

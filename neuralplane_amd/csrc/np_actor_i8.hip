@@ -15,13 +15,22 @@ namespace npact8 {
 __global__ __launch_bounds__(256, 2) void actor_forward_i8_kernel(const float *__restrict__ weights, long long n, const float *__restrict__ obs,
                                                                const float *__restrict__ h_in, const float *__restrict__ mask, float *__restrict__ act,
                                                                float *__restrict__ h_out) {
-    __shared__ __attribute__((aligned(16))) float lds[ACTOR8_LDS_FLOATS + ACTOR8_PARK_FLOATS];   // 64 KB: two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // the call's LDS, its GRU parking area, the tables: 81 KB (dynamic)
     actor8_tile(lds, weights, n, obs, h_in, mask, act, h_out, (long long)blockIdx.x, threadIdx.x);
 }
 
 hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, const float *h_in, const float *masks, float *actions, float *h_out,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(actor_forward_i8_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, weights, n, obs, h_in, masks, actions, h_out);
+    constexpr size_t bytes = sizeof(float) * (ACTOR8_LDS_FLOATS + ACTOR8_PARK_FLOATS + TAB_FLOATS);
+    static bool set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    if (dev < 64 && !set[dev]) {  // above the 64 KB a kernel may use without asking
+        const hipError_t e = hipFuncSetAttribute((const void *)actor_forward_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        set[dev] = true;
+    }
+    hipLaunchKernelGGL(actor_forward_i8_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), bytes, stream, weights, n, obs, h_in, masks, actions, h_out);
     return hipGetLastError();
 }
 
@@ -75,23 +84,36 @@ extern "C" int np_actor_pack_i8(const float *packed_fp32, float *out) {
     std::memset(out + TOTAL, 0, sizeof(float) * (size_t)(TOTAL_I8 - TOTAL));
     unsigned char *frag = reinterpret_cast<unsigned char *>(out + FRAG);
     const float *w = packed_fp32;
-    pack_layer(w + L1_W, OBS, HID, 0, 4, 1, frag + FR_L1, out + SW_L1);
-    pack_layer(w + L2_W, HID, HID, 0, 4, 4, frag + FR_L2, out + SW_L2);
+    float *tab = out + TAB0;
+    pack_layer(w + L1_W, OBS, HID, 0, 4, 1, frag + FR_L1, tab + T_SW + O_L1);
+    pack_layer(w + L2_W, HID, HID, 0, 4, 4, frag + FR_L2, tab + T_SW + O_L2);
     for (int gate = 0; gate < 3; gate++) {   // M-block index of the GRU matrices: gate * 4 + wave
-        pack_layer(w + GI_W, HID, 3 * HID, gate * HID, 4, 4, frag + FR_GI + gate * 4 * MB_BYTES_K4, out + SW_GI + gate * HID);
-        pack_layer(w + GH_W, HID, 3 * HID, gate * HID, 4, 4, frag + FR_GH + gate * 4 * MB_BYTES_K4, out + SW_GH + gate * HID);
+        pack_layer(w + GI_W, HID, 3 * HID, gate * HID, 4, 4, frag + FR_GI + gate * 4 * MB_BYTES_K4, tab + T_SW + O_GI + gate * HID);
+        pack_layer(w + GH_W, HID, 3 * HID, gate * HID, 4, 4, frag + FR_GH + gate * 4 * MB_BYTES_K4, tab + T_SW + O_GH + gate * HID);
     }
-    pack_layer(w + A1_W, HID, HID, 0, 4, 4, frag + FR_A1, out + SW_A1);
-    pack_layer(w + A2_W, HID, HID, 0, 4, 4, frag + FR_A2, out + SW_A2);
+    pack_layer(w + A1_W, HID, HID, 0, 4, 4, frag + FR_A1, tab + T_SW + O_A1);
+    pack_layer(w + A2_W, HID, HID, 0, 4, 4, frag + FR_A2, tab + T_SW + O_A2);
+    std::memcpy(tab + T_BIAS + O_L1, w + L1_B, sizeof(float) * HID);
+    std::memcpy(tab + T_BIAS + O_L2, w + L2_B, sizeof(float) * HID);
+    std::memcpy(tab + T_BIAS + O_GI, w + GI_B, sizeof(float) * 3 * HID);
+    std::memcpy(tab + T_BIAS + O_GH, w + GH_B, sizeof(float) * 3 * HID);
+    std::memcpy(tab + T_BIAS + O_A1, w + A1_B, sizeof(float) * HID);
+    std::memcpy(tab + T_BIAS + O_A2, w + A2_B, sizeof(float) * HID);
     const int ln_g[6] = {LN0_G, LN1_G, LN2_G, LN3_G, LN4_G, LN5_G}, ln_b[6] = {LN0_B, LN1_B, LN2_B, LN3_B, LN4_B, LN5_B};
+    for (int k = 1; k < 6; k++) {
+        std::memcpy(tab + T_LN + 256 * (k - 1), w + ln_g[k], sizeof(float) * HID);
+        std::memcpy(tab + T_LN + 256 * (k - 1) + 128, w + ln_b[k], sizeof(float) * HID);
+    }
+    std::memcpy(tab + T_HEAD, w + HD_W, sizeof(float) * 4 * HID);
+    std::memcpy(tab + T_HEAD + 4 * HID, w + HD_B, sizeof(float) * 4);
     for (int k = 0; k < 6; k++) {
         float gm = 0.0f, bm = 0.0f;
         for (int j = 0; j < (k == 0 ? OBS : HID); j++) {
             gm = std::fmax(gm, std::fabs(w[ln_g[k] + j]));
             bm = std::fmax(bm, std::fabs(w[ln_b[k] + j]));
         }
-        out[LNMAX + 2 * k] = gm;
-        out[LNMAX + 2 * k + 1] = bm;
+        tab[T_LNMAX + 2 * k] = gm;
+        tab[T_LNMAX + 2 * k + 1] = bm;
     }
     return 0;
 }

@@ -656,6 +656,10 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     float h[npact::BLK];  // the recurrent state of (row, block of 16 features): masked on the way into a controller call, new on the way out
 #pragma unroll
     for (int j = 0; j < npact::BLK; j++) h[j] = 0.0f;
+    if constexpr (I8) {   // the block-fixed-point controller's tables (scales, biases, LayerNorm parameters, head): staged once, read by every call
+        npact8::actor8_stage_tables(np_plan_dyn_lds + (PARK ? PARK_LDS_FLOATS : 0) + npact8::ACTOR8_PARK_FLOATS, ap->actor_w, threadIdx.x, 64u * W);
+        __syncthreads();
+    }
 
     // one (tile, iteration) item.  do_import: the tile is not in this workgroup's registers / LDS yet; do_export: it leaves afterwards
     // seq: run the inner step sequentially (nothing left pending) although the tile stays; no_back: no front ran in the previous iteration on
@@ -713,7 +717,10 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
 #pragma unroll
             for (int j = 0; j < npact::OBS; j++) xr[j] = ctx[CX::OBS + row * 22 + j];
             float hn[npact::BLK], action;
-            if constexpr (I8) npact8::actor8_body(lds_ctl, np_plan_dyn_lds + (PARK ? PARK_LDS_FLOATS : 0), ap->actor_w, xr, h, hn, action, ctid);   // its GRU parking area: dynamic LDS
+            if constexpr (I8) {   // its GRU parking area and the staged tables: dynamic LDS
+                float *i8_lds = np_plan_dyn_lds + (PARK ? PARK_LDS_FLOATS : 0);
+                npact8::actor8_body(lds_ctl, i8_lds, i8_lds + npact8::ACTOR8_PARK_FLOATS, ap->actor_w, xr, h, hn, action, ctid);
+            }
             else npact::actor32_body(lds_ctl, ap->actor_w, pre, xr, h, hn, action, ctid);
             if (hi == 0) ctx[CX::ACT + row * 4 + w4] = action;
 #pragma unroll
@@ -951,7 +958,7 @@ namespace {
 template <int TASK, int W, bool QUEUE, bool I8>
 hipError_t launch_one(const PlanArgs &args, unsigned grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     // dynamic LDS: the parking area of the guest schedule's hosts, then the block-fixed-point controller's GRU parking area
-    constexpr size_t dyn = sizeof(float) * (((QUEUE && W == 8) ? PARK_LDS_FLOATS : 0) + (I8 ? npact8::ACTOR8_PARK_FLOATS : 0));
+    constexpr size_t dyn = sizeof(float) * (((QUEUE && W == 8) ? PARK_LDS_FLOATS : 0) + (I8 ? npact8::ACTOR8_PARK_FLOATS + npact8::TAB_FLOATS : 0));
     const auto kernel = planning_persistent_kernel<TASK, W, QUEUE, false, I8>;
     if constexpr (dyn != 0) {
         static bool set[64] = {};

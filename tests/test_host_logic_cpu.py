@@ -325,7 +325,7 @@ def test_i8_weight_packer_agrees_with_the_oracles_quantiser(golden_dir):
     out = pack_i8(w)
     assert out.size == NUM_FLOATS_I8 and np.array_equal(out[:NUM_FLOATS], w)
     o = ActorOracle(w, 'i8')
-    frag = out[NUM_FLOATS + 1280 + 16:].view(np.uint8)
+    frag = out[NUM_FLOATS + 4368:].view(np.uint8)      # after the fp32 prefix and the 4 368 floats of tables
     assert frag.size == 592 * 1024
     sw_off = NUM_FLOATS
     base = 0
@@ -345,5 +345,7 @@ def test_i8_weight_packer_agrees_with_the_oracles_quantiser(golden_dir):
         assert np.array_equal(out[sw_off: sw_off + n_out], np.ldexp(np.float32(1), ew - 18).astype(np.float32)), layer
         sw_off += n_out
         base += blocks * ks_count * 4 * 1024
-    lnmax = out[NUM_FLOATS + 1280: NUM_FLOATS + 1280 + 12]
+    lnmax = out[NUM_FLOATS + 4356: NUM_FLOATS + 4356 + 12]
     assert lnmax[0] == np.abs(w[0:22]).max() and lnmax[1] == np.abs(w[22:44]).max()
+    tab = out[NUM_FLOATS: NUM_FLOATS + 4368]
+    assert np.array_equal(tab[1280: 1280 + 128], w[44: 44 + 128]) and np.array_equal(tab[3840: 3840 + 512], w[NUM_FLOATS - 512:]) and np.array_equal(tab[4352: 4356], w[NUM_FLOATS - 516: NUM_FLOATS - 512])

@@ -1,7 +1,8 @@
-// Where the block-fixed-point controller call spends its cycles: the shipped body (np_actor_i8.h) with shader-clock stamps at its phase
-// boundaries, one four-wave workgroup per CU on every CU at once (the persistent PlanningEnv kernel's situation), random weights.
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -mllvm -disable-machine-licm -I../../neuralplane_amd/csrc tools/microbench/i8_actor_phases.hip -o tools/microbench/i8_actor_phases
-#define NPACT_TRACE 1
+// What the block-fixed-point controller call (np_actor_i8.h) costs and where: the shipped kernel timed with HIP events over back-to-back
+// launches, one four-wave workgroup per CU (n = 8 192: the persistent PlanningEnv kernel's situation), built several times with parts
+// REMOVED (timing-only switches, wrong results: -DNPACT8_EXP=1 no matrix instructions, 2 no weight stream, 16 a one-instruction epilogue,
+// -DNPACT_EXP=8 free gate nonlinearities) — the differences are the parts' costs under the real overlap, which clock stamps inside the
+// kernel are not (a stamp orders the memory operations around it).  tools/microbench/i8_actor_phases.sh builds and runs the set.
 #include "../../neuralplane_amd/csrc/np_actor_i8.hip"
 #include <cstdio>
 #include <random>
@@ -22,13 +23,17 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&dact, (size_t)n * 16)); CHECK(hipMalloc(&dh2, h.size() * 4));
     CHECK(hipMemcpy(dw, wi.data(), wi.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dobs, obs.data(), obs.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dh, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dm, m.data(), m.size() * 4, hipMemcpyHostToDevice));
-    for (int rep = 0; rep < 20; rep++) CHECK(npact8::launch_actor_i8(dw, n, dobs, dh, dm, dact, dh2, 0));
+    for (int rep = 0; rep < 300; rep++) CHECK(npact8::launch_actor_i8(dw, n, dobs, dh, dm, dact, dh2, 0));
     CHECK(hipDeviceSynchronize());
-    long long t[64];
-    CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(npact::npact_trace), sizeof(t)));
-    const char *names[19] = {"", "obs LayerNorm + quantise", "L1 (1 k-step) + epilogue", "LN1 + quantise + barrier", "L2 + epilogue", "LN2 + 2 x quantise + barrier", "GI r", "GH r", "sigmoid r",
-                             "GI z + GH z", "sigmoid z", "GI n + GH n", "tanh + blend", "LN3 + quantise + barrier", "A1 + epilogue", "LN4 + quantise + barrier", "A2 + epilogue", "LN5", "head"};
-    for (int k = 1; k <= 18; k++) printf("%-32s %7lld cycles\n", names[k], t[k] - t[k - 1]);
-    printf("%-32s %7lld cycles (n = %d: %d workgroups)\n", "the call", t[18] - t[0], n, (n + 31) / 32);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int K = 500;
+    CHECK(hipEventRecord(e0, 0));
+    for (int rep = 0; rep < K; rep++) CHECK(npact8::launch_actor_i8(dw, n, dobs, dh, dm, dact, dh2, 0));
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("NPACT8_EXP=%d NPACT_EXP=%d n=%d: %.2f us per launch (%d back-to-back launches)\n", NPACT8_EXP, NPACT_EXP, n, 1e3 * ms / K, K);
     return 0;
 }
