@@ -529,7 +529,7 @@ def combat_mode(dev, E, steps, warmup, prelude_s):
     return out
 
 
-def planning_mode(dev, g, npl, k7):
+def planning_mode(dev, g, npl, k7, numerics='i8'):
     """BASELINE.json configs[3] as the reference ships it (hierarchical Tracking): PlanningEnv.step = 50 x {frozen PPOActor-
     architecture controller as ONE fused MFMA kernel, fused env step that also writes the controller's next observation}, at the
     batch size of the reference's own training script (n = 1e4) and at a size that fills the GPU (262 144); random-init controller
@@ -538,7 +538,7 @@ def planning_mode(dev, g, npl, k7):
     import torch
     from neuralplane_amd.actor import FusedActor, NUM_FLOATS
     from neuralplane_amd.envs.planning_env import PlanningEnv
-    ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), str(dev))
+    ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), str(dev), numerics=numerics)
     penv = PlanningEnv(num_envs=npl, config='tracking', model='F16', random_seed=0, device=str(dev), controller=ctrl)
     ap = torch.rand((npl, 3), generator=g, device=dev) * 2 - 1
     for _ in range(3):
@@ -574,28 +574,68 @@ def planning_mode(dev, g, npl, k7):
     flop_actor, flop_env = 2 * 151_000.0, ALGO_FLOP     # PPOActor.forward: 151 K multiply-adds per aircraft and call; one FDM step
     per_macro = 50 * (flop_actor + flop_env)
     ach = npl * per_macro / (ms * 1e-3) / 1e12
+    i8 = numerics == 'i8'
+    # the integer work of the block-fixed-point controller: nine limb products per multiply-add of the six quantised layers (148 K of the 151 K)
+    i8_ops = 2 * 9 * 148_000.0 * 50
     out = {'value': ms, 'unit': 'ms per PlanningEnv.step (50 inner FDM steps + 50 controller calls)', 'steps': k7, 'aircraft': npl,
-           'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7, 'inner_loop': auto,
-           'launches_per_macro_step': 3 if tiles <= 2 * cus else 2 + 50 * 2,
+           'controller_numerics': 'block fixed point on the i8 matrix pipe (np_actor_i8.h; the CPU restatement f16_actor_i8.inc)' if i8 else 'fp32 fmaf chains (np_actor.h)',
+           'aircraft_fdm_steps_per_s': npl * 50 * k7 / el7, 'inner_loop': auto if not (i8 and 'dual' in auto) else 'launch by launch (the dual workgroups serve the fp32 controller only)',
+           'launches_per_macro_step': 3 if tiles <= 2 * cus and not (i8 and 'dual' in auto) else 2 + 50 * 2,
            'launch_by_launch': {'ms': ms_launches, 'env_kernels_summed_ms': env_ms,
                                 'note': 'NP_PLANNING_MODE=launches: the round-3 path, 102 launches; env_kernels_summed_ms = sum of the 50 inner-step kernel '
                                         'durations (kernels of different row groups overlap: a sum, not wall time)'},
-           'roofline': {'bound': 'mfma+valu (fp32: the f32-input MFMA and the vector ALU share one 157.3 TFLOP/s pipe, tools/microbench/mfma_coissue.hip)',
-                        'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS,
+           'roofline': {'bound': 'valu + latency: with the controller\'s matrix work on the i8 pipe (15 % of ITS peak) what binds is the fp32 vector work around it — '
+                                 'epilogues, LayerNorms, gates, the FDM step — and the dependent-issue latency of one wave per SIMD; the fp32 pipe is the roof quoted'
+                        if i8 else 'mfma+valu (fp32: the f32-input MFMA and the vector ALU share one 157.3 TFLOP/s pipe, tools/microbench/mfma_coissue.hip)',
+                        'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s (fp32-EQUIVALENT: the algorithmic FLOP of the fp32 formulation / time)', 'frac': ach / PEAK_FP32_TFLOPS,
                         'algorithmic_flop_per_aircraft_macro_step': per_macro,
+                        'i8_matrix_pipe': ({'achieved_tops': npl * i8_ops / (ms * 1e-3) / 1e12, 'peak_tops': 5000.0, 'frac': npl * i8_ops / (ms * 1e-3) / 1e12 / 5000.0,
+                                            'busy_fraction_pmc': planning_matrix_busy(ms) if npl == 8_192 else None,
+                                            'note': 'integer operations of the nine limb products / time against the dense i8 peak; busy_fraction_pmc = SQ_VALU_MFMA_BUSY_CYCLES '
+                                                    'per SIMD / the launch\'s shader cycles, from the committed rocprofv3 PMC pass (profiles/, n = 8 192), not measured by this run'}
+                                           if i8 else None),
                         'note': '50 x (302 KFLOP controller forward + 33.8 KFLOP FDM step) = 16.8 MFLOP per aircraft and PlanningEnv.step; wall clock '
                                 'of back-to-back macro-steps (reset + prelude launches included)'},
            'note': 'n <= 32 x CUs: ONE launch per macro-step of the persistent kernel (np_planning.hip) — a workgroup owns a 32-row tile and loops the 50 x '
-                   '{controller call as K = 1 fp32 MFMA chains (v_mfma_f32_16x16x1_4b_f32, 1 184 dependent steps of 32 cycles per wave = 38 K of the ~76 K '
-                   "cycles of a call), inner FDM step} with the recurrent state in registers and the tile's observation / state / cached coefficients in LDS; "
+                   '{controller call, inner FDM step} with the recurrent state in registers and the tile\'s observation / state / cached coefficients in LDS; '
                    "eight waves per tile: an inner step's Overload evaluation, terminations and reward run on waves 4..7 during the NEXT controller call.  "
-                   'Up to 1.5 tiles per CU (n = 1e4: 313 tiles on 256 CUs) the guest schedule: every CU owns a tile and hosts one block of ~13 iterations '
-                   'of a guest tile between two stretches of its own (makespan 63 iterations instead of 100; tiles change CU through coherent sc1 '
-                   'accesses).  Larger batches: launch by launch, 32-row controller tiles up to 16 384 rows per call, 64-row tiles (v_mfma_f32_32x32x1_2b_f32) '
-                   'above, two to four row groups on their own streams.  Bit-identical between all of them (tests/test_gpu_actor.py)'}
+                   'The controller call (round 5): the six Linear layers with N >= 128 as v_mfma_i32_32x32x32_i8 on integer limbs (activations sign + 22 bits per row, '
+                   'weights sign + 29 bits per output feature, nine limb products in four exact class sums), every activation in the accumulator layout from the '
+                   'first layer to the head, LayerNorm + quantiser fused, weight fragments prefetched one M-block ahead, 15 barriers (fp32 formulation: 1 184 dependent '
+                   'K = 1 MFMA steps, 23 barriers).  Up to 1.5 tiles per CU (n = 1e4: 313 tiles on 256 CUs) the guest schedule: every CU owns a tile and hosts one '
+                   'block of ~13 iterations of a guest tile between two stretches of its own (makespan 63 iterations instead of 100; tiles change CU through coherent sc1 '
+                   'accesses; bounded waits).  Larger batches: launch by launch, two to four row groups on their own streams.  Bit-identical between all schedules and to '
+                   'the integer CPU restatement (tests/test_gpu_actor.py)'}
+    if i8 and npl <= 16_384:   # the fp32 controller on the same schedule, for the comparison
+        del penv, ctrl
+        torch.cuda.empty_cache()
+        ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), str(dev), numerics='fp32')
+        penv = PlanningEnv(num_envs=npl, config='tracking', model='F16', random_seed=0, device=str(dev), controller=ctrl)
+        for _ in range(3):
+            penv.step(ap)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(k7):
+            penv.step(ap)
+        torch.cuda.synchronize(dev)
+        out['fp32_controller_ms'] = 1e3 * (time.perf_counter() - t1) / k7
     del penv, ctrl
     torch.cuda.empty_cache()
     return out
+
+
+def planning_matrix_busy(ms):
+    """SQ_VALU_MFMA_BUSY_CYCLES of the persistent kernel (block-fixed-point controller, n = 8 192) from the newest committed PMC summary,
+    as a fraction of the launch: summed over the chip's 1 024 SIMDs / (1 024 x the launch's shader cycles at 2.39 GHz)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_planning_pmc.csv')))
+    if not files:
+        return None
+    for r in csv.reader(open(files[-1])):
+        if len(r) >= 4 and r[0] == 'i8' and r[1] == 'SQ_VALU_MFMA_BUSY_CYCLES':
+            return {'value': float(r[3]) / 1024.0 / (ms * 1e-3 * 2.39e9), 'source': os.path.basename(files[-1])}
+    return None
 
 
 def _wall(step, batch, dev, warmup, k):

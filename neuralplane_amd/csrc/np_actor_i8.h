@@ -200,9 +200,9 @@ __device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, co
         c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, x0, c3, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w3, x0, c2, 0, 0, 0);
 #endif
-        __builtin_amdgcn_sched_barrier(0);   // the refill below stays behind the products that read the registers (no renaming into fresh ones)
+        __builtin_amdgcn_sched_barrier(0x486);   // vector ALU, scalar ALU, LDS and transcendental instructions may cross; the refill below (VMEM) stays behind the products (MFMA) that read the registers
         if (ks < NEXT_KS) wfrag_load(wf, next, ks, ks, lane);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0x486);
     }
     const float sa = pow2f(ex - 17);
 #pragma unroll
@@ -222,7 +222,7 @@ __device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, co
 #endif
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0x486);
 }
 
 __device__ __forceinline__ void park_store(float *park, const float (&v)[16], unsigned tid) {

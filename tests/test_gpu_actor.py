@@ -278,12 +278,15 @@ def test_planning_env_loads_a_checkpoint_into_the_fused_controller(golden_dir, t
     path = tmp_path / 'actor_latest.pt'
     torch.save(sd, path)
     n = 200
-    a = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=2, device='cuda:0', controller='fused', controller_checkpoint=str(path))
-    b = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=2, device='cuda:0', controller=FusedActor(sd, 'cuda:0'))
     act = torch.rand(n, 3, device='cuda') * 2 - 1
-    for _ in range(2):
-        ra, rb = a.step(act), b.step(act)
-        assert all(torch.equal(x, y) for x, y in zip(ra[:5], rb[:5]))
+    for numerics in ('i8', 'fp32'):      # 'i8' (block fixed point) is what controller='fused' takes unless controller_numerics says otherwise
+        kw = {} if numerics == 'i8' else {'controller_numerics': 'fp32'}
+        a = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=2, device='cuda:0', controller='fused', controller_checkpoint=str(path), **kw)
+        b = PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=2, device='cuda:0', controller=FusedActor(sd, 'cuda:0', numerics=numerics))
+        assert a.controller.numerics == numerics
+        for _ in range(2):
+            ra, rb = a.step(act), b.step(act)
+            assert all(torch.equal(x, y) for x, y in zip(ra[:5], rb[:5]))
     with pytest.raises(RuntimeError, match='not found'):
         PlanningEnv(num_envs=4, config='tracking', model='F16', random_seed=0, device='cuda:0', controller='fused', controller_checkpoint=str(tmp_path / 'nope.pt'))
 

@@ -19,4 +19,15 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYC
   t=$(echo $set | cut -d" " -f1)
   timeout 250 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc_$t -o p -- python bench.py --steps 3 --warmup 2 --prelude-ms 0 --headline-only > $out/pmc_$t.log 2>&1 < /dev/null
 done
+# PlanningEnv (the persistent kernel, n = 8 192 and the reference's training size 1e4), block-fixed-point controller and the fp32 one
+for nm in i8 fp32; do
+  NUMERICS=$nm timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_planning_$nm -o p -- python tools/microbench/planning_profile.py 8192 40 > $out/stats_planning_$nm.log 2>&1 < /dev/null
+done
+NUMERICS=i8 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_planning_i8_n1e4 -o p -- python tools/microbench/planning_profile.py 10000 40 > $out/stats_planning_i8_n1e4.log 2>&1 < /dev/null
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
+  t=$(echo $set | cut -d" " -f1)
+  for nm in i8 fp32; do
+    NUMERICS=$nm timeout 250 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/planning_pmc_${nm}_$t -o p -- python tools/microbench/planning_profile.py 8192 10 > $out/planning_pmc_${nm}_$t.log 2>&1 < /dev/null
+  done
+done
 ls $out

@@ -40,6 +40,39 @@ def main(tag):
     for extra in ('wg_timeline_n1e6.json', 'bench_driver_cmd.json', 'cold_start.json', 'n_sweep.json', 'bench_combat_e12500.json', 'bench_combat_e1e5.json', 'bench_tracking.json', 'bench_control.json'):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, f'{tag}_{extra}'))
+    # PlanningEnv: kernel stats per controller numerics, and the PMC passes over the persistent kernel
+    for sub in ('stats_planning_i8', 'stats_planning_fp32', 'stats_planning_i8_n1e4'):
+        ks = find(os.path.join(src, sub, '**', '*kernel_stats.csv'))
+        if ks:
+            rows = list(csv.reader(open(ks)))
+            with open(os.path.join(dst, f'{tag}_{sub[6:]}_kernel_stats.csv'), 'w', newline='') as f:
+                w = csv.writer(f)
+                for r in rows:
+                    w.writerow([c[:110] for c in r])
+        lg = os.path.join(src, sub + '.log')
+        if os.path.exists(lg):
+            shutil.copy(lg, os.path.join(dst, f'{tag}_{sub[6:]}.log'))
+    prow = []
+    for d in sorted(glob.glob(os.path.join(src, 'planning_pmc_*'))):
+        cc = find(os.path.join(d, '**', '*counter_collection.csv')) if os.path.isdir(d) else None
+        if not cc:
+            continue
+        nm = os.path.basename(d).split('_')[2]
+        acc = {}
+        for r in csv.DictReader(open(cc)):
+            if 'planning_persistent_kernel' not in r.get('Kernel_Name', ''):
+                continue
+            a = acc.setdefault(r['Counter_Name'], {})
+            a[r['Dispatch_Id']] = a.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
+        for key, a in acc.items():
+            vals = list(a.values())
+            prow.append((nm, key, len(vals), sum(vals) / len(vals)))
+    if prow:
+        with open(os.path.join(dst, f'{tag}_planning_pmc.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['controller_numerics', 'counter', 'launches', 'mean_per_launch (summed over the chip; the persistent kernel, n = 8192)'])
+            for row in sorted(prow):
+                w.writerow([row[0], row[1], row[2], f'{row[3]:.6g}'])
     # PMC passes: mean per launch / per wave for the dominant kernel
     summary, traffic = [], {}
     for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
