@@ -25,9 +25,6 @@
 #ifndef NPACT_MFMA
 #define NPACT_MFMA 1  // 1: matrix-core kernel (4 waves per tile); 0: the vector-FMA kernel with the scalar weight stream (8 waves per tile)
 #endif
-#ifndef NPACT_TILE32_MAX_N
-#define NPACT_TILE32_MAX_N 16384  // up to here the 32-row tile kernel (actor_forward_mfma32_kernel), above it the 64-row one
-#endif
 #ifndef NPACT_PRIO
 #define NPACT_PRIO 0  // > 0: wave priority outside the MFMA chains of the 32-row tile (the chains themselves run at 0)
 #endif

@@ -1044,7 +1044,7 @@ int np_actor_forward(const float *weights, int64_t num_floats, int64_t n, const 
     // which tiling: a round of the 32-row kernel is 512 tiles = 16 384 rows in ~60 us, of the 64-row kernel 32 768 rows in ~98 us; the
     // 32-row kernel wins wherever it needs fewer or shorter rounds (tools/microbench/actor_bench.py, profiles/r03h_actor_tilings.log:
     // n = 20 000 84.6 vs 98.7 us, 24 576 86.9 vs 98.3, 40 960 138.8 vs 149.2; 28 672 110.3 vs 98.5 and everything from 49 152 on the other way)
-    // (the bounds are per CU in np_dispatch.h; NPACT_TILE32_MAX_N pins the first for experiments)
+    // (the bounds are per CU in np_dispatch.h)
     static int cus_of[64] = {};
     int cus = npdispatch::REF_CUS;
     if (device < 64) {
@@ -1309,7 +1309,12 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
             const int dev = ctx->device;
             const bool chain = dev >= 0 && dev < 64;
             if (chain && last_ev[dev] && last_st[dev] != st) NP_HIP(hipStreamWaitEvent(st, last_ev[dev], 0));
-            NP_HIP(launch_planning_persistent(ctx->task, waves, i8, pa, grid, st, nullptr, nullptr));
+            const bool timed = ctx->timing;   // (these schedules are refused on a capturing stream)
+            EventLease lease(ctx);
+            if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;
+            if (timed) NP_HIP(lease.take());
+            NP_HIP(launch_planning_persistent(ctx->task, waves, i8, pa, grid, st, timed ? lease.ev.first : nullptr, timed ? lease.ev.second : nullptr));
+            if (timed) lease.commit();
             ctx->queue_dirty = false;
             if (chain) {
                 if (!last_ev[dev]) NP_HIP(hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming));
@@ -1333,7 +1338,14 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
         }
         return 0;
     }
-    NP_HIP(launch_planning_persistent(ctx->task, waves, i8, pa, grid, st, nullptr, nullptr));
+    {   // np_f16_set_timing: one sample per macro-step covers the whole persistent launch (these launches used to record nothing)
+        const bool timed = ctx->timing && !stream_is_capturing(st);
+        EventLease lease(ctx);
+        if (timed && ctx->events.size() >= MAX_PENDING_EVENTS && resolve_events(ctx)) return 1;
+        if (timed) NP_HIP(lease.take());
+        NP_HIP(launch_planning_persistent(ctx->task, waves, i8, pa, grid, st, timed ? lease.ev.first : nullptr, timed ? lease.ev.second : nullptr));
+        if (timed) lease.commit();
+    }
     ctx->queue_dirty = false;
     return 0;
 }
@@ -1380,7 +1392,13 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
                                   NP_PLANNING_PERSISTENT_GUESTS == npdispatch::PL_GUESTS && NP_PLANNING_PERSISTENT_DUAL == npdispatch::PL_DUAL && PLAN_ROWS == 32,
                               "np_dispatch.h mirrors the NP_PLANNING_* numbers");
                 mode = npdispatch::planning_mode(n, (int64_t)per_cu * ctx->num_cus);   // np_dispatch.h: by tiles per resident workgroup
-                if (mode == NP_PLANNING_PERSISTENT_DUAL && lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS) mode = NP_PLANNING_LAUNCHES;   // fp32 only
+                if (mode == NP_PLANNING_PERSISTENT_DUAL && lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS) {
+                    // the dual workgroups serve the fp32 controller only; with the block-fixed-point one the queue wins up to 1.75 tiles per resident
+                    // workgroup and the guest schedule (one 50-iteration block per host) from there to two (ms per PlanningEnv.step, queue / guests /
+                    // launches: n = 13 000 2.50 / 2.91 / 3.11, 14 000 2.70 / 2.88 / 3.20, 16 384 3.12 / 2.89 / 3.73; profiles/r05_planning_modes_i8.log)
+                    const int64_t tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS, resident = (int64_t)per_cu * ctx->num_cus;
+                    mode = 4 * tiles <= 7 * resident ? NP_PLANNING_PERSISTENT_QUEUE : NP_PLANNING_PERSISTENT_GUESTS;
+                }
                 waves = 8;
             }
         }

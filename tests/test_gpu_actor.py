@@ -20,7 +20,7 @@ def _same(a, b):
 @pytest.mark.parametrize('tile', ['32', '64'])
 @pytest.mark.parametrize('n', [1, 31, 32, 33, 63, 64, 65, 1000])
 def test_fused_actor_bit_exact_vs_oracle(golden_dir, n, tile, monkeypatch):
-    """Both tilings of the controller (32-row tiles for small batches, 64-row tiles above NPACT_TILE32_MAX_N; NP_ACTOR_TILE forces one)."""
+    """Both tilings of the controller (32-row tiles for small batches, 64-row tiles above the per-CU bound of np_dispatch.h; NP_ACTOR_TILE forces one)."""
     from neuralplane_amd.actor import FusedActor, pack_ppo_actor
     monkeypatch.setenv('NP_ACTOR_TILE', tile)
     d = np.load(f'{golden_dir}/actor_kat.npz')
