@@ -12,20 +12,23 @@
 
 namespace npact8 {
 
+// One 32-aircraft tile per four-wave workgroup, 77 KB of LDS (the call's block, its GRU parking area, the staged tables): two workgroups per CU,
+// whose phases (matrix / vector / exchange) overlap each other.
 __global__ __launch_bounds__(256, 2) void actor_forward_i8_kernel(const float *__restrict__ weights, long long n, const float *__restrict__ obs,
-                                                               const float *__restrict__ h_in, const float *__restrict__ mask, float *__restrict__ act,
-                                                               float *__restrict__ h_out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // the call's LDS, its GRU parking area, the tables: 81 KB (dynamic)
-    actor8_tile(lds, weights, n, obs, h_in, mask, act, h_out, (long long)blockIdx.x, threadIdx.x);
+                                                                  const float *__restrict__ h_in, const float *__restrict__ mask, float *__restrict__ act,
+                                                                  float *__restrict__ h_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // dynamic: above the 64 KB a kernel may use without asking
+    actor8_tiles<1>(lds, weights, n, obs, h_in, mask, act, h_out, (long long)blockIdx.x, threadIdx.x);
 }
 
 hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, const float *h_in, const float *masks, float *actions, float *h_out,
                            hipStream_t stream) {
-    constexpr size_t bytes = sizeof(float) * (ACTOR8_LDS_FLOATS + ACTOR8_PARK_FLOATS + TAB_FLOATS);
+    constexpr size_t bytes = sizeof(float) * actor8_tile_lds_floats<1>();
+    static_assert(2 * bytes <= 160 * 1024, "two workgroups per CU");
     static bool set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    if (dev < 64 && !set[dev]) {  // above the 64 KB a kernel may use without asking
+    if (dev < 64 && !set[dev]) {
         const hipError_t e = hipFuncSetAttribute((const void *)actor_forward_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         set[dev] = true;

@@ -719,7 +719,10 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             float hn[npact::BLK], action;
             if constexpr (I8) {   // its GRU parking area and the staged tables: dynamic LDS
                 float *i8_lds = np_plan_dyn_lds + (PARK ? PARK_LDS_FLOATS : 0);
-                npact8::actor8_body(lds_ctl, i8_lds, i8_lds + npact8::ACTOR8_PARK_FLOATS, ap->actor_w, xr, h, hn, action, ctid);
+                float action1[1];
+                npact8::actor8_body<1>(lds_ctl, i8_lds, i8_lds + npact8::ACTOR8_PARK_FLOATS, ap->actor_w, reinterpret_cast<const float(&)[1][npact::OBS]>(xr),
+                                       reinterpret_cast<const float(&)[1][npact::BLK]>(h), reinterpret_cast<float(&)[1][npact::BLK]>(hn), action1, ctid);
+                action = action1[0];
             }
             else npact::actor32_body(lds_ctl, ap->actor_w, pre, xr, h, hn, action, ctid);
             if (hi == 0) ctx[CX::ACT + row * 4 + w4] = action;

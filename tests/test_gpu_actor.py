@@ -429,7 +429,7 @@ def test_guest_and_queue_schedules_refuse_a_capturing_stream(golden_dir):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # The controller's second numerics spec: block fixed point on the i8 matrix pipe (csrc/np_actor_i8.h; restated in f16_actor_i8.inc)
 # ---------------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('n', [1, 31, 32, 33, 64, 65, 1000, 10_037])
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 64, 65, 97, 1000, 10_037])
 def test_i8_actor_bit_exact_vs_its_integer_restatement(golden_dir, n):
     """np_actor_forward with the NP_ACTOR_I8_NUM_FLOATS buffer == ActorOracle(numerics='i8') bit for bit over five consecutive calls: ragged
     last tile, masked rows, |h| > 1, observation scales 0.1 .. 30, a saturating input."""

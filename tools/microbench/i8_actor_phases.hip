@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <random>
 #include <vector>
+#ifndef TILES
+#define TILES 0
+#endif
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
