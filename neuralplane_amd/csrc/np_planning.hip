@@ -638,7 +638,7 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
     // barrier-free windows (plan_window_nets, AB_GRU) — for the static schedule, where a tile never changes workgroup: -2 % per macro-step at
     // n <= 32 rows x CUs; a tile that moves pays an evaluation of all 36 nets per import instead of 14, which cancels the gain (guest / queue
     // schedules: +0.2 .. +0.6 %, profiles/r04_planning_moment_nets_in_call_windows.log), so the coherent kernels keep the round-4 front
-    constexpr bool WIN = NP_PLAN_WIN && PIPE && (!QUEUE || NP_PLAN_WIN_QUEUE) && !I8;   // (the windows are counted in the fp32 call's barriers)
+    constexpr bool WIN = NP_PLAN_WIN && PIPE && (!QUEUE || NP_PLAN_WIN_QUEUE);
     constexpr int ROWS = DUAL ? 2 * PLAN_ROWS : PLAN_ROWS;    // rows of the workgroup's context
     using CX = CtxL<ROWS>;
     constexpr int ACT_FLOATS = (DUAL ? 2 : 1) * npact::ACTOR32_LDS_FLOATS;
@@ -741,13 +741,17 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
             // waves 4..7 match the call's 23 barriers; in the pipelined schedule they run the BACK of the previous inner step meanwhile
             const bool back = PIPE && !do_import && !no_back;   // a front ran in this workgroup's previous iteration
             if constexpr (WIN) {
-                // the call's barriers: obs LN 1 | L1 2 | LN1 3-5 | [L2 dense] 6 | LN2 7-9 | h -> LDS 10 | [six GRU layers] 11 | 12 | LN3 13-15 | [A1 dense] 16 |
-                // LN4 17-19 | [A2 dense] 20 | LN5 21-23: the back works in the four bracketed windows
+                // the fp32 call's barriers: obs LN 1 | L1 2 | LN1 3-5 | [L2 dense] 6 | LN2 7-9 | h -> LDS 10 | [six GRU layers] 11 | 12 | LN3 13-15 | [A1 dense] 16 |
+                // LN4 17-19 | [A2 dense] 20 | LN5 21-23; the block-fixed-point call's: LN1 1-2, fragments 3 | [L2] | LN2 4-5, fragments 6 | [GRU] | LN3 7-8,
+                // fragments 9 | [A1] | LN4 10-11, fragments 12 | [A2] | LN5 13-14, head 15.  The back works in the four bracketed windows.
+                constexpr int N0 = I8 ? 3 : 5, N1 = I8 ? 2 : 4, N2 = I8 ? 2 : 4, N3 = I8 ? 3 : 4, N4 = I8 ? 3 : 4;
+                static_assert((I8 ? npact8::ACTOR8_BARRIERS : npact::ACTOR32_BARRIERS) == N0 + N1 + 2 + N2 + N3 + N4 && (I8 || ACTOR32_BARRIERS_BEFORE_GRU == 9),
+                              "barrier plan of the spread back");
 #pragma unroll 1
-                for (int b = 0; b < 5; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < N0; b++) __builtin_amdgcn_s_barrier();
                 if (back) plan_window_nets<PLAN_WIN_L2>(ap, lds_fdm, ctx, tid, wave - 4);
 #pragma unroll 1
-                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < N1; b++) __builtin_amdgcn_s_barrier();
                 if (back) {
                     plan_fdm_back<TASK, true>(ap, lds_fdm, ctx, i0, tid, wave - 4);
                 } else {
@@ -755,14 +759,13 @@ __global__ __launch_bounds__(64 * W, 2) void planning_persistent_kernel(const Pl
                     __builtin_amdgcn_s_barrier();
                 }
 #pragma unroll 1
-                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < N2; b++) __builtin_amdgcn_s_barrier();
                 if (back) plan_window_nets<PLAN_WIN_A1>(ap, lds_fdm, ctx, tid, wave - 4);
 #pragma unroll 1
-                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
+                for (int b = 0; b < N3; b++) __builtin_amdgcn_s_barrier();
                 if (back) plan_window_nets<PLAN_WIN_A2>(ap, lds_fdm, ctx, tid, wave - 4);
 #pragma unroll 1
-                for (int b = 0; b < 4; b++) __builtin_amdgcn_s_barrier();
-                static_assert(npact::ACTOR32_BARRIERS == 5 + 4 + 2 + 4 + 4 + 4 && ACTOR32_BARRIERS_BEFORE_GRU == 9, "barrier plan of the spread back");
+                for (int b = 0; b < N4; b++) __builtin_amdgcn_s_barrier();
             } else {
                 // fp32 call: 9 barriers, [GRU window = barriers 10, 11], 12 more; block-fixed-point call: 5, [GRU window = 6, 7], 8 more
                 constexpr int BEFORE = I8 ? 5 : ACTOR32_BARRIERS_BEFORE_GRU, TOTALB = I8 ? npact8::ACTOR8_BARRIERS : npact::ACTOR32_BARRIERS;
