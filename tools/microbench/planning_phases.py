@@ -3,6 +3,9 @@ in its last-but-one iteration (waves 0, 1 and 4) plus the controller's own phase
 
     python tools/microbench/planning_phases.py build            # in the build container: tools/microbench/libs/plan_trace.so
     NPF16_LIB=tools/microbench/libs/plan_trace.so python tools/microbench/planning_phases.py 8192 [waves [mode]]     # on the GPU box
+NUMERICS=fp32|i8 selects the controller.  For the block-fixed-point controller (i8) only the OUTER phases are meaningful and even those are
+inflated: a stamp orders the memory operations around it, and the i8 call lives on its weight prefetch (a traced build ran an iteration in
+152 K cycles against 67 K untraced) — its inner breakdown comes from timing-only builds with parts removed: tools/microbench/i8_actor_phases.sh.
 """
 import ctypes as C, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
