@@ -1,8 +1,8 @@
 """Soak of the persistent PlanningEnv kernel's schedules (np_planning.hip: static / guests / queue / dual) against the launch-by-launch path:
 many macro-steps on odd sizes, every tenth compared bit for bit (a race in the coherent imports / exports, the progress words, the park or the
 window nets would show as a mismatch; a lost wake-up as a hang — run under `timeout`).
-    python tools/microbench/planning_soak_modes.py [steps] [mode:n ...]        # default: 400 steps of the list below"""
-import sys, time, torch
+    [NUMERICS=i8|fp32] python tools/microbench/planning_soak_modes.py [steps] [mode:n ...]        # default: 400 steps of the list below"""
+import os, sys, time, torch
 import numpy as np
 sys.path.insert(0, '.')
 from neuralplane_amd.envs.planning_env import PlanningEnv
@@ -14,7 +14,7 @@ cases = sys.argv[2:] or ['auto:4000', 'auto:8192', 'auto:8193', 'auto:9001', 'au
 w = np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32)
 for case in cases:
     mode, n = case.split(':'); n = int(n)
-    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=3, device='cuda:0', controller=FusedActor(w, 'cuda:0')) for _ in range(2)]
+    envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=3, device='cuda:0', controller=FusedActor(w, 'cuda:0', numerics=os.environ.get('NUMERICS', 'i8'))) for _ in range(2)]
     envs[0].loop_mode = 'launches'
     envs[1].loop_mode = mode
     if mode in ('queue', 'guests', 'persistent'):
@@ -30,6 +30,6 @@ for case in cases:
                 and torch.equal(envs[0].ego_rnn_states, envs[1].ego_rnn_states)
             bad += 0 if same else 1
     torch.cuda.synchronize()
-    print(f'{mode} n={n}: {steps} macro-steps in {time.perf_counter() - t0:.1f} s, mismatching checkpoints {bad}, '
+    print(f'{os.environ.get("NUMERICS", "i8")} {mode} n={n} (fallbacks {envs[1].loop_fallbacks}): {steps} macro-steps in {time.perf_counter() - t0:.1f} s, mismatching checkpoints {bad}, '
           f'terminations equal {envs[0].termination_counts() == envs[1].termination_counts()}', flush=True)
     del envs
