@@ -96,7 +96,7 @@ __device__ __forceinline__ void quantise_store(const float (&y)[16], int ex, flo
 }
 
 // Everything below is written for T tiles of 32 aircraft per workgroup that share ONE weight stream: a fragment in registers multiplies the
-// B operands of tile 0, then of tile 1, ... (T x the class sums, 1 / T of the L2 traffic per aircraft — the stand-alone kernel at large batches is
+// B operands of tile 0, then of tile 1, ... (T x the class sums, 1 / T of the L2 traffic per aircraft — the stand-alone kernel at large batches
 // would be bound by exactly that traffic: 592 KB per tile and call).  T = 1 is what is instantiated: T = 2 was built, is bit-identical, and was NOT
 // faster (n = 262 144: 664 us per call against 633 — a workgroup's time is the latency chain of its phases, not the weight stream; what helps is a
 // SECOND workgroup per CU, which needs the LDS block below 80 KB: profiles/r05_actor_i8_tiles.log).  Tile t's LDS block is lds + t * ACTOR8_LDS_FLOATS, its parking area park + t * ACTOR8_PARK_FLOATS.

@@ -1,7 +1,8 @@
-"""numpy prototype of the controller's block-fixed-point numerics, version 2 (round 5; DESIGN.md section 14 -> built as np_actor_i8.h):
+"""numpy prototype of the controller's block-fixed-point numerics, version 2 (round 5; built as csrc/np_actor_i8.h, restated in oracle/f16_actor_i8.inc):
 every Linear with K <= 128 except the 4-output head on the i8 matrix pipe, LayerNorm / quantiser / epilogue in the ACCUMULATOR layout
 of v_mfma_i32_32x32x32_i8 (feature f = 32 w + 8 g + 4 h + t: wave w, lane half h, register 4 g + t), the row exponent from a BOUND that
-needs no reduction of its own (max |x - mean| rides in the variance exchange), eight of the nine limb products (x0 * w0 dropped).
+needs no reduction of its own (max |x - mean| rides in the variance exchange), activations in three limbs, weights in four, the nine limb
+products of weight >= 2^16 in four class sums.
 Judged against what the REFERENCE recorded: tests/golden/actor_kat.npz (4 open-loop calls, bound 2e-5) and the closed loop of
 tests/golden/planning_closed_kat.npz driven through the oracle's FDM (bounds of tests/planning_closed.py).  CPU only.
     python tools/microbench/i8v2_numerics.py"""
