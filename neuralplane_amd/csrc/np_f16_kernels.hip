@@ -1377,9 +1377,9 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
                    : std::strcmp(e, "queue") == 0 ? NP_PLANNING_PERSISTENT_QUEUE : std::strcmp(e, "guests") == 0 ? NP_PLANNING_PERSISTENT_GUESTS : std::strcmp(e, "dual") == 0 ? NP_PLANNING_PERSISTENT_DUAL : mode;
         }
         if (const char *e = std::getenv("NP_PLANNING_WAVES")) waves = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : waves;
-        const bool eligible = ctx->solver == 0 && !ctx->cfg.aero_1d_tables && io->coef_cache && !io->rand_u && !io->noise && io->reward;
+        const bool eligible = ctx->solver == 0 && !ctx->cfg.aero_1d_tables && io->coef_cache && !io->rand_u && !io->noise && io->reward && planning_persistent_built(ctx->task);
         if (mode >= NP_PLANNING_PERSISTENT && !eligible)
-            return fail("np_planning_loop: the persistent kernel serves the Euler solver with the MLP numerics and needs coef_cache / reward buffers");
+            return fail("np_planning_loop: the persistent kernel serves tracking contexts (the reference's PlanningEnv task) with the Euler solver and the MLP numerics, and needs coef_cache / reward buffers");
         if (mode == NP_PLANNING_AUTO) {
             // measured per size (profiles/r04_planning_modes.log, ms per PlanningEnv.step): up to one 32-row tile per resident workgroup the
             // persistent kernel with eight waves per tile (n = 8 192: 2.49 -> 2.07); up to 1.5 tiles per workgroup its guest schedule

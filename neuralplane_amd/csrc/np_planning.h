@@ -41,13 +41,15 @@ constexpr int PLAN_ERR_WORDS = 8;
 
 constexpr int PLAN_ROWS = 32;  // rows per tile: one 32-row controller tile (np_actor.h)
 
-// tasks: 0 heading, 1 control, 2 tracking (PlanningEnv ships tracking only; the others serve the parity tests of the loop).
+// tasks: 0 heading, 1 control, 2 tracking (PlanningEnv is a tracking env: only task 2 is built, NP_PLAN_TASKS).
 // waves: 8 per workgroup (the four-wave builds were retired in round 5).  queue_mode: 0 = one workgroup per tile (grid = tiles), 1 = `grid` persistent workgroups pulling
 // (tile, iteration) items.  Returns hipSuccess or the launch error.
 hipError_t launch_planning_persistent(int task, int waves, bool i8, const PlanArgs &args, unsigned grid, hipStream_t stream, hipEvent_t ev_start,
                                       hipEvent_t ev_stop);   // i8: args.actor_w is an NP_ACTOR_I8_NUM_FLOATS buffer (block-fixed-point controller)
 // dual workgroups: two 32-row tiles per eight-wave workgroup (np_planning.hip), static schedule, grid = ceil(tiles / 2)
 hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, hipStream_t stream);
+// are the persistent kernels of this task (0 heading, 1 control, 2 tracking) part of the build?  (tracking: the reference's PlanningEnv task)
+bool planning_persistent_built(int task);
 // how many workgroups of that shape fit one CU / the device (occupancy query)
 int planning_persistent_workgroups_per_cu(int task, int waves);
 

@@ -1015,8 +1015,8 @@ int occupancy_of() {
 }  // namespace
 
 #ifndef NP_PLAN_TASKS
-#define NP_PLAN_TASKS 7  // bit t: build the kernels of task t
-#endif
+#define NP_PLAN_TASKS 4  // bit t: build the persistent kernels of task t.  Tracking only: the one task the reference's PlanningEnv accepts
+#endif                   // (envs/planning_env.py:57-60 raises NotImplementedError otherwise); contexts of the other tasks take the launches
 
 hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, hipStream_t st) {
     if constexpr ((NP_PLAN_TASKS & 1) != 0) { if (task == 0) return launch_dual<0>(args, grid, st); }
@@ -1043,6 +1043,8 @@ hipError_t launch_planning_persistent(int task, int waves, bool i8, const PlanAr
 #undef NP_PLAN_CASE
     return hipErrorInvalidValue;
 }
+
+bool planning_persistent_built(int task) { return task >= 0 && task <= 2 && ((NP_PLAN_TASKS >> task) & 1) != 0; }
 
 static int workgroups_per_cu_uncached(int task, int waves);
 int planning_persistent_workgroups_per_cu(int task, int waves) {
