@@ -245,7 +245,8 @@ __device__ __forceinline__ void mblock(WFrags &wf, const unsigned char *next, co
 #if NPACT8_EXP & 16   // timing only: one conversion instead of the epilogue
                 y[t][r] = (float)(c[t][0][r] + c[t][1][r] + c[t][2][r] + c[t][3][r]) * sa + sw[q] + bi[q];
 #else
-                float u = fmaf((float)c[t][0][r], 256.0f, (float)c[t][1][r]);
+                // (float)(c0 * 256 + c1) IS fmaf((float)c0, 256, (float)c1): both round the same exact integer (|c0| < 2^19, |c1| < 2^22) once, to nearest even
+                float u = (float)(c[t][0][r] * 256 + c[t][1][r]);
                 u = fmaf(u, 256.0f, (float)c[t][2][r]);
                 u = fmaf(u, 256.0f, (float)c[t][3][r]);
                 y[t][r] = fmaf(u * sa, sw[q], bi[q]);
