@@ -364,6 +364,20 @@ int np_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, in
                        const float *rewards, float *value_preds, const float *masks, const float *bad_masks, const float *next_value,
                        float *returns, int device, void *stream);
 
+/* One collect step into the device-resident rollout storage (ABI 15) — F16SimRunner.insert (reference runner/F16sim_runner.py:131-154: the
+ * recurrent states of the envs that ended are zeroed, masks = 0 where an env is done, bad_masks = 0 where it is bad_done, `any` over the env's
+ * agents) + ReplayBuffer.insert (algorithms/utils/buffer.py:76-112: obs / masks / bad_masks / recurrent states into slot step + 1, actions /
+ * rewards / log-probs / values into slot step) as ONE launch.  All pointers are device pointers; storage arrays are the buffer's, row-major
+ * [T or T + 1][num_envs * num_agents][dim]; inputs are [num_envs * num_agents][dim]; done / bad_done / exceed_time_limit are bytes (bool). */
+typedef struct np_rollout_step {
+    int64_t num_envs, num_agents, step;
+    int32_t obs_dim, act_dim, rnn_dim, reserved_;
+    float *obs, *actions, *rewards, *masks, *bad_masks, *action_log_probs, *value_preds, *rnn_states_actor, *rnn_states_critic;
+    const float *obs_in, *actions_in, *rewards_in, *action_log_probs_in, *values_in, *rnn_states_actor_in, *rnn_states_critic_in;
+    const uint8_t *done_in, *bad_done_in, *exceed_time_limit_in;
+} np_rollout_step;
+int np_rollout_insert(const np_rollout_step *step, int device, void *stream);
+
 /* np_f16_step has five bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
  * evaluations of a step, the serial fp64 chains of the state and the observation noise; chosen automatically for n <= 49152 —
  * one generation of 768 tiles at three waves per SIMD; "latency4w" = the same kernel built for four waves per SIMD, 1 024 tiles in

@@ -7,6 +7,8 @@ same field names and shapes, same methods and semantics:
 
 * `insert(obs, actions, rewards, masks, action_log_probs, value_preds, rnn_states_actor, rnn_states_critic, bad_masks=None)`
   — buffer.py:76-112 (device-to-device copies; numpy inputs are uploaded);
+* `insert_step(obs, actions, rewards, dones, bad_dones, exceed_time_limits, action_log_probs, values, rnn_states_actor, rnn_states_critic)` — the
+  runner's `insert(data)` (runner/F16sim_runner.py:131-154) and the buffer's `insert` fused into one launch (not in the reference: for device-resident loops);
 * `after_update()`, `clear()` — buffer.py:114-135;
 * `compute_returns(next_value)` — buffer.py:137-173: ONE kernel launch (`np_rollout_returns`, csrc/np_rollout.h) instead of a
   Python loop over `buffer_size` steps of numpy array operations; bit-exact to the reference's float32 arithmetic;
@@ -100,6 +102,34 @@ class DeviceReplayBuffer:
         self.rnn_states_critic[s + 1].copy_(self._dev(rnn_states_critic, self.rnn_states_critic[0]))
         if bad_masks is not None:
             self.bad_masks[s + 1].copy_(self._dev(bad_masks, self.bad_masks[0]))
+        self.step = (self.step + 1) % self.buffer_size
+
+    def insert_step(self, obs, actions, rewards, dones, bad_dones, exceed_time_limits, action_log_probs, values, rnn_states_actor, rnn_states_critic):
+        """One collect step, as the reference's runner hands it over — `F16SimRunner.insert(data)` (runner/F16sim_runner.py:131-154: the recurrent
+        states of envs that ended are zeroed, masks / bad_masks from dones / bad_dones, `any` over the agents of an env) followed by
+        `ReplayBuffer.insert` (buffer.py:76-112) — as ONE launch (np_rollout_insert) instead of ~20 small torch kernels.  Device tensors in the
+        shapes DeviceVecEnv.step and the policy return them ([E, A, ...] or flat [E * A, ...]); dones etc. bool or uint8."""
+        if self.device.type != 'cuda':
+            raise RuntimeError('DeviceReplayBuffer.insert_step runs on the GPU (np_rollout_insert); there is no CPU fallback')
+        E, A = self.n_rollout_threads, self.num_agents
+        N = E * A
+        f = lambda x, d: x.to(device=self.device, dtype=torch.float32).reshape(N, d).contiguous()                # noqa: E731
+        u8 = lambda x: (x.view(torch.uint8) if x.dtype == torch.bool else x.to(torch.uint8)).to(self.device).reshape(N).contiguous()   # noqa: E731
+        od, ad = int(np.prod(self._obs_shape)), int(np.prod(self._act_shape))
+        rd = self.recurrent_hidden_layers * self.recurrent_hidden_size
+        keep = (f(obs, od), f(actions, ad), f(rewards, 1), f(action_log_probs, 1), f(values, 1), f(rnn_states_actor, rd), f(rnn_states_critic, rd),
+                u8(dones), u8(bad_dones), u8(exceed_time_limits))
+        q = _lib.NpRolloutStep()
+        q.num_envs, q.num_agents, q.step, q.obs_dim, q.act_dim, q.rnn_dim = E, A, self.step, od, ad, rd
+        for name in ('obs', 'actions', 'rewards', 'masks', 'bad_masks', 'action_log_probs', 'value_preds', 'rnn_states_actor', 'rnn_states_critic'):
+            t = getattr(self, name)
+            assert t.is_contiguous()
+            setattr(q, name, t.data_ptr())
+        for name, t in zip(('obs_in', 'actions_in', 'rewards_in', 'action_log_probs_in', 'values_in', 'rnn_states_actor_in', 'rnn_states_critic_in', 'done_in',
+                            'bad_done_in', 'exceed_time_limit_in'), keep):
+            setattr(q, name, t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.load().np_rollout_insert(C.byref(q), self.device.index, stream))
         self.step = (self.step + 1) % self.buffer_size
 
     def after_update(self):

@@ -1473,6 +1473,33 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
     return rc;
 }
 
+int np_rollout_insert(const np_rollout_step *q, int device, void *stream) {
+    if (!q) return fail("null argument");
+    if (!q->obs || !q->actions || !q->rewards || !q->masks || !q->bad_masks || !q->action_log_probs || !q->value_preds || !q->rnn_states_actor ||
+        !q->rnn_states_critic || !q->obs_in || !q->actions_in || !q->rewards_in || !q->action_log_probs_in || !q->values_in || !q->rnn_states_actor_in ||
+        !q->rnn_states_critic_in || !q->done_in || !q->bad_done_in || !q->exceed_time_limit_in)
+        return fail("np_rollout_insert: null buffer");
+    if (q->num_envs < 0 || q->num_agents <= 0 || q->step < 0 || q->obs_dim <= 0 || q->act_dim <= 0 || q->rnn_dim <= 0) return fail("np_rollout_insert: bad sizes");
+    if (q->num_envs == 0) return 0;
+    if (q->num_envs * q->num_agents >= (1ll << 31)) return fail("np_rollout_insert: too many rows for one launch");
+    int ndev = 0;
+    NP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(device));
+    nproll::InsertArgs a;
+    a.E = q->num_envs; a.A = q->num_agents; a.step = q->step;
+    a.obs_dim = q->obs_dim; a.act_dim = q->act_dim; a.rnn_dim = q->rnn_dim;
+    a.obs = q->obs; a.actions = q->actions; a.rewards = q->rewards; a.masks = q->masks; a.bad_masks = q->bad_masks; a.logp = q->action_log_probs;
+    a.values = q->value_preds; a.rnn_a = q->rnn_states_actor; a.rnn_c = q->rnn_states_critic;
+    a.obs_in = q->obs_in; a.act_in = q->actions_in; a.rew_in = q->rewards_in; a.logp_in = q->action_log_probs_in; a.val_in = q->values_in;
+    a.rnn_a_in = q->rnn_states_actor_in; a.rnn_c_in = q->rnn_states_critic_in;
+    a.done = q->done_in; a.bad = q->bad_done_in; a.tmo = q->exceed_time_limit_in;
+    hipLaunchKernelGGL(nproll::insert_kernel, dim3((unsigned)(q->num_envs * q->num_agents)), dim3(nproll::INSERT_THREADS), 0, (hipStream_t)stream, a);
+    NP_HIP(hipGetLastError());
+    return 0;
+}
+
 int np_planning_check(np_f16_ctx *ctx) {
     if (!ctx) return fail("null ctx");
     DeviceGuard guard;

@@ -77,4 +77,40 @@ __global__ __launch_bounds__(THREADS) void returns_kernel(long long T, long long
     }
 }
 
+// ---- one collect step into the device-resident rollout storage: F16SimRunner.insert (runner/F16sim_runner.py:131-154: the recurrent states of
+// envs that ended are zeroed, masks = 0 where an env is done, bad_masks = 0 where it is bad_done — `any` over the env's agents) followed by
+// ReplayBuffer.insert (algorithms/utils/buffer.py:76-112: obs / masks / bad_masks / rnn states into slot step + 1, actions / rewards /
+// log-probs / values into slot step) as ONE launch instead of ~20 small torch kernels (9 copies + the mask arithmetic).  Pure data movement.
+struct InsertArgs {
+    long long E, A, step;            // envs (rollout threads), agents per env, slot
+    int obs_dim, act_dim, rnn_dim;   // rnn_dim = recurrent_hidden_layers * recurrent_hidden_size
+    float *obs, *actions, *rewards, *masks, *bad_masks, *logp, *values, *rnn_a, *rnn_c;              // the storage, [T(+1)][E * A][...]
+    const float *obs_in, *act_in, *rew_in, *logp_in, *val_in, *rnn_a_in, *rnn_c_in;                   // [E * A][...]
+    const unsigned char *done, *bad, *tmo;                                                           // [E * A] (bool)
+};
+constexpr int INSERT_THREADS = 64;   // per row (env, agent): one wave copies its 1.2 KB
+__global__ __launch_bounds__(INSERT_THREADS) void insert_kernel(InsertArgs a) {
+    const long long row = blockIdx.x, N = a.E * a.A, env0 = (row / a.A) * a.A;
+    const int t = threadIdx.x;
+    bool d = false, b = false, any = false;
+    for (long long k = 0; k < a.A; k++) {   // num_agents is 1 on this path (2 in the combat envs): a short loop
+        const bool dk = a.done[env0 + k] != 0, bk = a.bad[env0 + k] != 0;
+        d = d || dk; b = b || bk; any = any || dk || bk || a.tmo[env0 + k] != 0;
+    }
+    const long long s0 = a.step * N + row, s1 = (a.step + 1) * N + row;
+    for (int j = t; j < a.obs_dim; j += INSERT_THREADS) a.obs[s1 * a.obs_dim + j] = a.obs_in[row * a.obs_dim + j];
+    for (int j = t; j < a.act_dim; j += INSERT_THREADS) a.actions[s0 * a.act_dim + j] = a.act_in[row * a.act_dim + j];
+    for (int j = t; j < a.rnn_dim; j += INSERT_THREADS) {
+        a.rnn_a[s1 * a.rnn_dim + j] = any ? 0.0f : a.rnn_a_in[row * a.rnn_dim + j];
+        a.rnn_c[s1 * a.rnn_dim + j] = any ? 0.0f : a.rnn_c_in[row * a.rnn_dim + j];
+    }
+    if (t == 0) {
+        a.rewards[s0] = a.rew_in[row];
+        a.logp[s0] = a.logp_in[row];
+        a.values[s0] = a.val_in[row];
+        a.masks[s1] = d ? 0.0f : 1.0f;
+        a.bad_masks[s1] = b ? 0.0f : 1.0f;
+    }
+}
+
 }  // namespace nproll

@@ -71,3 +71,41 @@ def test_argument_checks():
     assert b'bad_masks' in lib.np_last_error()
     assert lib.np_rollout_returns(4, 8, 0.99, 0.95, 1, 0, None, p, p, None, p, p, 0, st) != 0
     assert lib.np_rollout_returns(4, 8, 0.99, 0.95, 1, 0, p, p, p, None, p, p, 99, st) != 0 and b'device' in lib.np_last_error()
+
+
+@pytest.mark.parametrize('E,A', [(1, 1), (37, 1), (3000, 1), (50, 2)])
+def test_insert_step_equals_the_runners_insert_followed_by_the_buffers(E, A):
+    """DeviceReplayBuffer.insert_step (np_rollout_insert: ONE launch) == the reference's two-stage insert done with torch operations: the runner's
+    mask arithmetic (runner/F16sim_runner.py:131-154: recurrent states of envs that ended zeroed, masks / bad_masks, `any` over an env's agents)
+    followed by ReplayBuffer.insert (buffer.py:76-112) — every field of the storage equal bit for bit over several steps incl. the wrap-around."""
+    import torch
+    from types import SimpleNamespace
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.envs.spaces import Box
+    T = 5
+    args = SimpleNamespace(buffer_size=T, n_rollout_threads=E, gamma=0.99, use_proper_time_limits=True, use_gae=True, gae_lambda=0.95,
+                           recurrent_hidden_size=128, recurrent_hidden_layers=1)
+    obs_space, act_space = Box(low=-10, high=10, shape=(22,)), Box(low=-10, high=10, shape=(4,))
+    a, b = (DeviceReplayBuffer(args, A, obs_space, act_space, device='cuda:0') for _ in range(2))
+    g = torch.Generator(device='cuda').manual_seed(E + A)
+    r = lambda *s: torch.randn(s, generator=g, device='cuda')                                   # noqa: E731
+    flag = lambda p: torch.rand((E, A, 1), generator=g, device='cuda') < p                      # noqa: E731
+    for k in range(T + 2):
+        obs, act, rew, lp, val = r(E, A, 22), r(E, A, 4), r(E, A, 1), r(E, A, 1), r(E, A, 1)
+        ha, hc = r(E, A, 1, 128), r(E, A, 1, 128)
+        d, bd, tm = flag(0.2), flag(0.2), flag(0.1)
+        # the reference's runner, on device tensors
+        reset_env = (d | bd | tm).squeeze(-1).any(-1)
+        ha2, hc2 = ha.clone(), hc.clone()
+        ha2[reset_env] = 0
+        hc2[reset_env] = 0
+        masks = torch.ones((E, A, 1), device='cuda')
+        masks[d.squeeze(-1).any(-1)] = 0
+        bad_masks = torch.ones((E, A, 1), device='cuda')
+        bad_masks[bd.squeeze(-1).any(-1)] = 0
+        a.insert(obs, act, rew, masks, lp, val, ha2, hc2, bad_masks)
+        b.insert_step(obs, act, rew, d, bd, tm, lp, val, ha, hc)
+        assert a.step == b.step
+        for name in ('obs', 'actions', 'rewards', 'masks', 'bad_masks', 'action_log_probs', 'value_preds', 'rnn_states_actor', 'rnn_states_critic'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (k, name)
+    assert float(a.masks.min()) == 0.0 and float(a.bad_masks.min()) == 0.0 or E == 1

@@ -80,8 +80,14 @@ class _Args:
         self.recurrent_hidden_size, self.recurrent_hidden_layers = 128, 1
 
 
+FUSED_INSERT = True   # DeviceReplayBuffer.insert_step (np_rollout_insert: one launch); False: the same with torch operations + buffer.insert
+
+
 def _device_insert(buf, obs, actions, rewards, dones, bad_dones, tmo, logp, values, ha, hc, n):
     """F16sim_runner.insert (:131-154) on device tensors: zero the recurrent state of envs that ended, masks / bad_masks, buffer.insert."""
+    if FUSED_INSERT:
+        buf.insert_step(obs, actions, rewards, dones, bad_dones, tmo, logp, values, ha, hc)
+        return
     reset_env = (dones | bad_dones | tmo).reshape(n, 1)
     keep = (~reset_env).to(torch.float32)
     masks = (~dones).reshape(n, 1, 1).to(torch.float32)
@@ -276,10 +282,16 @@ def run_numpy(n, T, dev, task='heading'):
 
 def collect_loop_report(n, T, dev):
     dev = torch.device(dev)
+    global FUSED_INSERT
+    FUSED_INSERT = False
+    unfused = run_device(n, T, dev)
+    FUSED_INSERT = True
     rep = {'aircraft': n, 'steps_per_rollout_timed': T, 'device': run_device(n, T, dev), 'device_graph': run_device(n, T, dev, graph=True),
+           'device_torch_insert': {'us_per_step_wall': unfused['us_per_step_wall'], 'gpu_us_insert': unfused['gpu_us_insert'],
+                                   'note': 'the same device loop with the insert as ~20 torch kernels (masks, 9 copies) instead of DeviceReplayBuffer.insert_step'},
            'numpy_contract': run_numpy(n, T, dev)}
     d = rep['device']
-    parts = {'policy (eager torch, ~110 small kernels)': d['gpu_us_policy'], 'env.step kernel': d['gpu_us_env_step'], 'insert (9 device copies + masks)': d['gpu_us_insert'],
+    parts = {'policy (eager torch, ~110 small kernels)': d['gpu_us_policy'], 'env.step kernel': d['gpu_us_env_step'], 'insert (one launch)': d['gpu_us_insert'],
              'host gaps (GPU idle)': max(0.0, d['host_gap_us'])}
     rep['dominant_part_device_loop'] = max(parts, key=parts.get)
     rep['note'] = ('reference loop shape: runner/F16sim_runner.py:52-66,123-154; buffer_size there is 3 000 (heading) / 100 (tracking): the per-step figures '
