@@ -122,7 +122,7 @@ class FusedActor:
             if not ok:
                 raise ValueError('out = (actions[n,4], rnn_states[n,1,128]): contiguous float32 device tensors, the state buffer 16-byte aligned '
                                  'and different from the input state')
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _lib.stream_ptr(self.device)
         _lib.check(self.lib.np_actor_forward(self.weights.data_ptr(), self.num_floats, n, obs.data_ptr(), h.data_ptr(), m.data_ptr(),
                                              act.data_ptr(), h_out.data_ptr(), self.device.index, stream))
         return act, None, h_out

@@ -128,7 +128,7 @@ class DeviceReplayBuffer:
         for name, t in zip(('obs_in', 'actions_in', 'rewards_in', 'action_log_probs_in', 'values_in', 'rnn_states_actor_in', 'rnn_states_critic_in', 'done_in',
                             'bad_done_in', 'exceed_time_limit_in'), keep):
             setattr(q, name, t.data_ptr())
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _lib.stream_ptr(self.device)
         _lib.check(_lib.load().np_rollout_insert(C.byref(q), self.device.index, stream))
         self.step = (self.step + 1) % self.buffer_size
 
@@ -151,7 +151,7 @@ class DeviceReplayBuffer:
         T, N = self.buffer_size, self.n_rollout_threads * self.num_agents
         for x in (self.rewards, self.value_preds, self.masks, self.bad_masks, self.returns):
             assert x.is_contiguous()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _lib.stream_ptr(self.device)
         _lib.check(lib.np_rollout_returns(T, N, float(self.gamma), float(self.gae_lambda), int(bool(self.use_gae)),
                                           int(bool(self.use_proper_time_limits)), self.rewards.data_ptr(), self.value_preds.data_ptr(),
                                           self.masks.data_ptr(), self.bad_masks.data_ptr(), nv.data_ptr(), self.returns.data_ptr(),

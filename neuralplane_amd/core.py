@@ -134,7 +134,7 @@ class F16Batch:
 
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _lib.stream_ptr(self.device)
 
     # -- graph-safe raw launches: caller-owned static buffers, no Python-side state is touched -------------
     def launch_static(self, flags_in, flags_out, call_offset, action=None, obs=None, reward=None, inner=False, cache_valid=False,
@@ -526,7 +526,7 @@ class F16CombatBatch:
             self._ctx = None
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _lib.stream_ptr(self.device)
 
     def _io(self, new_flags, action, obs, reward, rand_u, action_opp=None, obs_opp=None):
         io = _lib.NpF16CombatIo()
