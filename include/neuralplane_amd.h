@@ -408,7 +408,7 @@ typedef struct np_dispatch_info {
     int64_t grid;             /* workgroups of the np_f16_step launch */
     int32_t planning_mode;    /* np_planning_inner_loop, NP_PLANNING_AUTO with the fused controller (Euler, MLP numerics): the NP_PLANNING_* it resolves to,
                                * assuming one resident eight-wave workgroup per CU */
-    int32_t reserved_;
+    int32_t planning_mode_i8; /* ABI 15 (was reserved): the same with the block-fixed-point controller weights (no dual workgroups: queue / guests there) */
 } np_dispatch_info;
 int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, int32_t tables, int32_t variant, np_dispatch_info *out);
 

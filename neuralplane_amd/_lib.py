@@ -82,7 +82,7 @@ class NpF16CombatIo(C.Structure):
 
 class NpDispatchInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('pair', 'pair3', 'latency', 'latency8', 'latency2', 'latency4w', 'block', 'planning_groups', 'actor_tile32',
-                                          'combat_latency')] + [('grid', C.c_int64), ('planning_mode', C.c_int32), ('reserved_', C.c_int32)]
+                                          'combat_latency')] + [('grid', C.c_int64), ('planning_mode', C.c_int32), ('planning_mode_i8', C.c_int32)]
 
 
 def dispatch_plan(n, num_cus, step=True, solver=0, tables=False, variant=0):

@@ -89,11 +89,16 @@ inline EnvChoice env_choice(int64_t n, int cus, bool step, int solver, bool tabl
 // include/neuralplane_amd.h's NP_PLANNING_* (static_assert in np_f16_kernels.hip).  Measured on 256 CUs (profiles/r04_planning_modes*.log,
 // r04_planning_dual.log): n = 8 192 2.49 -> 2.05 ms (one tile per workgroup), 1e4 3.16 -> 2.6 (guest schedule, up to 1.5 tiles per
 // workgroup), 16 384 3.39 -> 3.2 (dual workgroups, up to two); beyond that the launches (64-row controller tiles, row groups).
-enum { PL_LAUNCHES = 1, PL_PERSISTENT = 2, PL_GUESTS = 4, PL_DUAL = 5 };
-inline int planning_mode(int64_t n, int64_t resident_workgroups) {
+// With the block-fixed-point controller (round 5; the dual workgroups serve the fp32 controller only) the window between 1.5 and 2 tiles per
+// workgroup goes to the queue up to 1.75 and to the guest schedule (one 50-iteration block per host) from there (ms per PlanningEnv.step, queue /
+// guests / launches: n = 13 000 2.50 / 2.91 / 3.11, 14 000 2.70 / 2.88 / 3.20, 16 384 3.12 / 2.89 / 3.73; profiles/r05_planning_modes_i8.log).
+enum { PL_LAUNCHES = 1, PL_PERSISTENT = 2, PL_QUEUE = 3, PL_GUESTS = 4, PL_DUAL = 5 };
+inline int planning_mode(int64_t n, int64_t resident_workgroups, bool i8_controller = false) {
     const int64_t tiles = (n + 31) / 32, r = resident_workgroups;
     if (r <= 0) return PL_LAUNCHES;
-    return tiles <= r ? PL_PERSISTENT : tiles - r <= r / 2 ? PL_GUESTS : tiles <= 2 * r ? PL_DUAL : PL_LAUNCHES;
+    const int m = tiles <= r ? PL_PERSISTENT : tiles - r <= r / 2 ? PL_GUESTS : tiles <= 2 * r ? PL_DUAL : PL_LAUNCHES;
+    if (m == PL_DUAL && i8_controller) return 4 * tiles <= 7 * r ? PL_QUEUE : PL_GUESTS;
+    return m;
 }
 
 inline int planning_groups(int64_t n, int cus) {

@@ -817,7 +817,7 @@ int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, i
                      : variant == NP_KERNEL_AUTO ? npdispatch::combat_dual_waves(n, num_cus) : 0;
     out->combat_latency = dual == 8 ? 2 : dual == 4 ? 3 : n <= l.combat_lat_max_n ? 1 : 0;
     out->planning_mode = npdispatch::planning_mode(n, num_cus);   // one eight-wave workgroup per CU
-    out->reserved_ = 0;
+    out->planning_mode_i8 = npdispatch::planning_mode(n, num_cus, true);
     return 0;
 }
 int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHE_ROWS; }
@@ -1389,16 +1389,9 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
             if (eligible && !stream_is_capturing(st)) {
                 const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, 8);
                 static_assert(NP_PLANNING_LAUNCHES == npdispatch::PL_LAUNCHES && NP_PLANNING_PERSISTENT == npdispatch::PL_PERSISTENT &&
-                                  NP_PLANNING_PERSISTENT_GUESTS == npdispatch::PL_GUESTS && NP_PLANNING_PERSISTENT_DUAL == npdispatch::PL_DUAL && PLAN_ROWS == 32,
+                                  NP_PLANNING_PERSISTENT_GUESTS == npdispatch::PL_GUESTS && NP_PLANNING_PERSISTENT_DUAL == npdispatch::PL_DUAL && NP_PLANNING_PERSISTENT_QUEUE == npdispatch::PL_QUEUE && PLAN_ROWS == 32,
                               "np_dispatch.h mirrors the NP_PLANNING_* numbers");
-                mode = npdispatch::planning_mode(n, (int64_t)per_cu * ctx->num_cus);   // np_dispatch.h: by tiles per resident workgroup
-                if (mode == NP_PLANNING_PERSISTENT_DUAL && lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS) {
-                    // the dual workgroups serve the fp32 controller only; with the block-fixed-point one the queue wins up to 1.75 tiles per resident
-                    // workgroup and the guest schedule (one 50-iteration block per host) from there to two (ms per PlanningEnv.step, queue / guests /
-                    // launches: n = 13 000 2.50 / 2.91 / 3.11, 14 000 2.70 / 2.88 / 3.20, 16 384 3.12 / 2.89 / 3.73; profiles/r05_planning_modes_i8.log)
-                    const int64_t tiles = (n + PLAN_ROWS - 1) / PLAN_ROWS, resident = (int64_t)per_cu * ctx->num_cus;
-                    mode = 4 * tiles <= 7 * resident ? NP_PLANNING_PERSISTENT_QUEUE : NP_PLANNING_PERSISTENT_GUESTS;
-                }
+                mode = npdispatch::planning_mode(n, (int64_t)per_cu * ctx->num_cus, lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS);   // np_dispatch.h: by tiles per resident workgroup and controller numerics
                 waves = 8;
             }
         }

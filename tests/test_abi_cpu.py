@@ -177,6 +177,8 @@ def test_dispatch_plan_scales_with_the_cu_count(lib):
         for n, mode in [(1, 2), (per, 2), (per + 1, 4), (per * 3 // 2, 4), (per * 3 // 2 + 32, 5), (2 * per, 5), (2 * per + 1, 1), (40 * per, 1)]:
             assert P(n, cus)['planning_mode'] == mode, (cus, n, mode, P(n, cus))
     assert P(10_000, 256)['planning_mode'] == 4 and P(8_192, 256)['planning_mode'] == 2 and P(16_384, 256)['planning_mode'] == 5
+    # block-fixed-point controller: the same up to 1.5 tiles per CU, then the queue (3) up to 1.75 and the guest schedule (4) up to two
+    assert [P(n, 256)['planning_mode_i8'] for n in (8_192, 10_000, 12_288, 12_320, 14_336, 14_337, 16_384, 16_385)] == [2, 4, 4, 3, 3, 4, 4, 1]
     # a 32-CU partition runs 1e6 aircraft on the three-wave pair build, like the full device, and 2 048 aircraft still on eight waves per tile
     assert fam(P(1_000_000, 32)) == 'pair3' and fam(P(2048, 32)) == 'lat8' and fam(P(2049, 32)) == 'lat4'
     with pytest.raises(RuntimeError):
