@@ -1227,7 +1227,13 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
         if (guests <= 0) mode = NP_PLANNING_PERSISTENT;
         else if (guests > resident) return fail("np_planning_inner_loop (guests): more than two tiles per resident workgroup; use the queue schedule");
         else {
-            const int64_t b = resident / guests;
+            // blocks per guest: as many as there are hosts to go round, but no more than 7 — a guest tile changes CU between blocks (an export and an
+            // import through the coherence point: ~0.85 of an iteration), so its own chain is iterations + 0.85 B while a host's is iterations +
+            // iterations / B: B = 25 for ten guests (n = 8 500) made the guests' chain the makespan (1.97 ms; the queue 1.70)
+            int64_t b = resident / guests;
+            if (const char *e = std::getenv("NP_PLANNING_GUEST_BLOCKS")) b = atoi(e) > 0 ? atoi(e) : b;   // experiments
+            else if (b > 7) b = 7;
+            if (b * guests > resident) b = resident / guests;
             pa.guest_blocks = (int)(b < lp->iterations ? b : lp->iterations);
             pa.block = block >= 0 && block <= lp->iterations ? block : 1;   // slack (iterations) per block index
         }
