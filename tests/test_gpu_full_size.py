@@ -294,3 +294,15 @@ def test_drop_in_example_runs():
     out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'drop_in_rollout.py'), '512', '24'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'numpy VecEnv loop' in out.stdout and 'device-resident loop' in out.stdout and 'device-resident collection' in out.stdout
+
+
+def test_drop_in_planning_example_runs():
+    """examples/drop_in_planning.py — `from envs.planning_env import PlanningEnv` under GPUVecEnv with `controller='fused'` and a checkpoint
+    file in the reference's format: the macro-steps run on the persistent kernel with the default numerics and never fall back."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'drop_in_planning.py'), '1000', '6'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'controller numerics i8, fallbacks 0' in out.stdout and out.stdout.rstrip().endswith('OK')
