@@ -378,6 +378,30 @@ typedef struct np_rollout_step {
 } np_rollout_step;
 int np_rollout_insert(const np_rollout_step *step, int device, void *stream);
 
+/* The rollout policy's inference step (ABI 15) — PPOPolicy.get_actions (reference algorithms/ppo/ppo_policy.py:26-32; the call of
+ * F16SimRunner.collect, runner/F16sim_runner.py:123-129): PPOActor.forward with sampled actions and their log-probabilities
+ * (ppo_actor.py:38-64, act.py:56-101, distributions.py:36-44,77-101) and PPOCritic.forward (ppo_critic.py:38-50) on the same observation,
+ * as ONE launch (the reference: ~110 small torch kernels per step).  For the networks the training scripts build (scripts/train_heading.sh:17,
+ * train_tracking.sh:17: hidden "128 128", act-hidden "128 128", GRU 128 x 1, feature normalisation, ReLU) on 22 observations with 1..4
+ * continuous actions — the frozen controller's shapes, so both networks travel in np_actor_forward's packed layout (NP_ACTOR_NUM_FLOATS
+ * floats each, 16-byte aligned; a head narrower than four columns is zero-padded; the critic's value_out is column 0 of its head block:
+ * neuralplane_amd/policy.py packs both from the state_dicts).  std = exp(log_std) and log_std [act_dim] are host values.
+ *   noise [n][act_dim]: the standard normal draws of this step (the caller's generator — the reference's sample() draws them the same
+ *   way); actions = fl(fl(noise * std) + tanh(mu)), or tanh(mu) with NP_POLICY_DETERMINISTIC (noise may be NULL then);
+ *   log_probs [n] = sum over the actions of Normal(mean, std).log_prob(action); values [n]; rnn states [n][128], in != out.
+ * flags choose the networks (get_actions = ACTOR | CRITIC; act = ACTOR [| DETERMINISTIC]; get_values = CRITIC); buffers of a network
+ * that is not evaluated may be NULL.  Results equal the CPU restatement f16_actor.inc bit for bit and the reference within 2e-5. */
+enum { NP_POLICY_ACTOR = 1, NP_POLICY_CRITIC = 2, NP_POLICY_DETERMINISTIC = 4 };
+typedef struct np_policy_step {
+    int64_t n;
+    int32_t act_dim, flags;
+    const float *actor_weights, *critic_weights;
+    float std[4], log_std[4];
+    const float *obs, *masks, *noise, *rnn_states_actor_in, *rnn_states_critic_in;
+    float *values, *actions, *action_log_probs, *rnn_states_actor_out, *rnn_states_critic_out;
+} np_policy_step;
+int np_policy_act(const np_policy_step *step, int device, void *stream);
+
 /* np_f16_step has five bit-identical kernel variants: "latency" (four waves share a tile of 64 aircraft and split the 44 net
  * evaluations of a step, the serial fp64 chains of the state and the observation noise; chosen automatically for n <= 49152 —
  * one generation of 768 tiles at three waves per SIMD; "latency4w" = the same kernel built for four waves per SIMD, 1 024 tiles in

@@ -96,7 +96,7 @@ def dispatch_plan(n, num_cus, step=True, solver=0, tables=False, variant=0):
 
 EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
            'np_f16_step', 'np_f16_derived', 'np_f16_aero_coefficients', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace', 'np_selfcheck_divc',
-           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop', 'np_planning_check', 'np_actor_pack_i8', 'np_rollout_insert', 'np_planning_targets_obs', 'np_dispatch_plan')
+           'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop', 'np_planning_check', 'np_actor_pack_i8', 'np_rollout_insert', 'np_policy_act', 'np_planning_targets_obs', 'np_dispatch_plan')
 KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4, 'latency2': 5, 'latency4w': 6, 'dual8': 7, 'dual4': 8}
 
 _lib = None
@@ -146,6 +146,7 @@ def load():
     lib.np_planning_check.argtypes = [C.c_void_p]
     lib.np_actor_pack_i8.argtypes = [C.c_void_p, C.c_void_p]
     lib.np_rollout_insert.argtypes = [C.POINTER(NpRolloutStep), C.c_int, C.c_void_p]
+    lib.np_policy_act.argtypes = [C.c_void_p, C.c_int, C.c_void_p]   # np_policy_step * (policy.py: NpPolicyStep)
     lib.np_rollout_returns.argtypes = [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.np_f16_combat_ctx_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(NpF16CombatCfg), C.c_int, C.POINTER(C.c_void_p)]

@@ -15,8 +15,8 @@ SO = os.path.join(CSRC, 'libneuralplane_hip.so')
 # one translation unit per task x solver for the env.step / env.reset kernels (np_env_tu.inc): the six compile side by side (the rk4 units
 # are the long ones: ~2 min each), beside the host side + SingleCombat / controller kernels, the persistent PlanningEnv kernel and the dual family
 SOURCES = ['np_env_t0s1.hip', 'np_env_t1s1.hip', 'np_env_t2s1.hip', 'np_env_t0s0.hip', 'np_env_t1s0.hip', 'np_env_t2s0.hip',
-           'np_f16_kernels.hip', 'np_planning.hip', 'np_combat_lat.hip', 'np_actor_i8.hip']
-HEADERS = ['np_f16_device.h', 'np_f16_kargs.h', 'np_f16_env_kernel.h', 'np_env_launch.h', 'np_env_tu.inc', 'np_planning.h', 'np_dispatch.h', 'np_f16_combat.h', 'np_actor.h', 'np_actor_i8.h', 'np_rollout.h', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc', 'np_actor_mfma16_asm.inc', 'np_math.h', 'np_nets.h', 'np_mlp_asm.inc', 'np_mlp_asm_dual.inc', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
+           'np_f16_kernels.hip', 'np_planning.hip', 'np_combat_lat.hip', 'np_actor_i8.hip', 'np_policy.hip']
+HEADERS = ['np_f16_device.h', 'np_f16_kargs.h', 'np_f16_env_kernel.h', 'np_env_launch.h', 'np_env_tu.inc', 'np_planning.h', 'np_dispatch.h', 'np_f16_combat.h', 'np_actor.h', 'np_actor_i8.h', 'np_rollout.h', 'np_policy.h', 'np_actor_asm.inc', 'np_actor_mfma_asm.inc', 'np_actor_mfma16_asm.inc', 'np_math.h', 'np_nets.h', 'np_mlp_asm.inc', 'np_mlp_asm_dual.inc', os.path.join('..', '..', 'include', 'neuralplane_amd.h')]
 # -disable-machine-licm: the SingleCombat kernel's inner loop (5 FDM steps) otherwise gets ~40 loop-invariant 64-bit constants of the
 # fp64 sin / cos / pow sequences hoisted into VGPR pairs that stay live across the asm phases — 256 VGPRs plus 9 spilled dwords;
 # re-materialised inside the loop it needs 200 and no scratch (the other kernels have no loops and compile identically)

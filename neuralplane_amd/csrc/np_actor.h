@@ -629,6 +629,7 @@ __device__ __forceinline__ void actor32_stage_head(float *lds, const float *weig
     if (tid < HID) reinterpret_cast<float4 *>(head_w)[tid] = reinterpret_cast<const float4 *>(weights + HD_W)[tid];
 }
 
+template <bool TANH = true>   // false: `action` = mu itself (np_policy.hip: the critic's value head, the sampled actor's epilogue)
 __device__ __forceinline__ void actor32_body(float *lds, const float *weights, const Actor32Pre &pre, const float (&xr)[OBS], const float (&hm)[BLK],
                                              float (&hn)[BLK], float &action, unsigned tid) {
     float *bufA = lds, *bufB = lds + HID * T32;
@@ -747,7 +748,7 @@ NPACT_STAMP(11);
         float m = W[HD_B + wave];
 #pragma unroll
         for (int k = 0; k < HID; k++) m = fmaf(head_w[k * 4 + wave], bufB[k * T32 + row], m);
-        action = act_tanh(m);
+        action = TANH ? act_tanh(m) : m;
     }
 }
 

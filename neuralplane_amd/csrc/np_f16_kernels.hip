@@ -27,6 +27,7 @@
 #include "np_f16_combat.h"
 #include "np_actor.h"
 #include "np_rollout.h"
+#include "np_policy.h"
 #include "np_planning.h"
 namespace npact8 {
 hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, const float *h_in, const float *masks, float *actions, float *h_out,
@@ -1496,6 +1497,47 @@ int np_rollout_insert(const np_rollout_step *q, int device, void *stream) {
     a.done = q->done_in; a.bad = q->bad_done_in; a.tmo = q->exceed_time_limit_in;
     hipLaunchKernelGGL(nproll::insert_kernel, dim3((unsigned)(q->num_envs * q->num_agents)), dim3(nproll::INSERT_THREADS), 0, (hipStream_t)stream, a);
     NP_HIP(hipGetLastError());
+    return 0;
+}
+
+int np_policy_act(const np_policy_step *q, int device, void *stream) {
+    if (!q) return fail("null argument");
+    const bool actor = (q->flags & NP_POLICY_ACTOR) != 0, critic = (q->flags & NP_POLICY_CRITIC) != 0, det = (q->flags & NP_POLICY_DETERMINISTIC) != 0;
+    if (!actor && !critic) return fail("np_policy_act: flags select neither network");
+    if (q->flags & ~(NP_POLICY_ACTOR | NP_POLICY_CRITIC | NP_POLICY_DETERMINISTIC)) return fail("np_policy_act: unknown flag");
+    if (q->act_dim < 1 || q->act_dim > 4) return fail("np_policy_act: 1 to 4 continuous actions");
+    if (q->n < 0) return fail("np_policy_act: bad size");
+    if (!q->obs || !q->masks) return fail("np_policy_act: null obs / masks");
+    if (actor && (!q->actor_weights || !q->rnn_states_actor_in || !q->rnn_states_actor_out || !q->actions || !q->action_log_probs || (!det && !q->noise)))
+        return fail("np_policy_act: null actor buffer");
+    if (critic && (!q->critic_weights || !q->rnn_states_critic_in || !q->rnn_states_critic_out || !q->values)) return fail("np_policy_act: null critic buffer");
+    uintptr_t al = 0;
+    if (actor) al |= (uintptr_t)q->actor_weights | (uintptr_t)q->rnn_states_actor_in | (uintptr_t)q->rnn_states_actor_out;
+    if (critic) al |= (uintptr_t)q->critic_weights | (uintptr_t)q->rnn_states_critic_in | (uintptr_t)q->rnn_states_critic_out;
+    if (al & 15) return fail("np_policy_act: packed weights and recurrent states must be 16-byte aligned");
+    if ((actor && q->rnn_states_actor_in == q->rnn_states_actor_out) || (critic && q->rnn_states_critic_in == q->rnn_states_critic_out))
+        return fail("np_policy_act: recurrent states in and out may not alias");
+    if (actor)
+        for (int j = 0; j < q->act_dim; j++)
+            if (!(q->std[j] > 0.0f)) return fail("np_policy_act: std must be positive");
+    if (q->n == 0) return 0;
+    int ndev = 0;
+    NP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");
+    DeviceGuard guard;
+    NP_HIP(guard.enter(device));
+    nppol::ActArgs a = {};
+    a.w[0] = q->actor_weights; a.w[1] = q->critic_weights;
+    a.h_in[0] = q->rnn_states_actor_in; a.h_in[1] = q->rnn_states_critic_in;
+    a.h_out[0] = q->rnn_states_actor_out; a.h_out[1] = q->rnn_states_critic_out;
+    a.obs = q->obs; a.mask = q->masks; a.noise = q->noise;
+    a.values = q->values; a.actions = q->actions; a.log_probs = q->action_log_probs;
+    a.n = (long long)q->n; a.act_dim = q->act_dim; a.flags = q->flags; a.first_net = actor ? 0 : 1;
+    for (int j = 0; j < 4; j++) {
+        a.std[j] = q->std[j];
+        a.log_std[j] = q->log_std[j];
+    }
+    NP_HIP(nppol::launch_policy_act(a, (hipStream_t)stream));
     return 0;
 }
 

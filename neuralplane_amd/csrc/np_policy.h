@@ -1,0 +1,20 @@
+// np_policy.h — arguments of the rollout policy's inference launch (np_policy.hip); the C ABI entry np_policy_act fills them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nppol {
+
+struct ActArgs {
+    const float *w[2];      // packed networks: [0] actor, [1] critic (value head in column 0 of the head block)
+    const float *h_in[2];   // recurrent states [n][128]
+    float *h_out[2];
+    const float *obs, *mask, *noise;
+    float *values, *actions, *log_probs;
+    long long n;
+    int act_dim, flags, first_net, pad_;
+    float std[4], log_std[4];
+};
+
+hipError_t launch_policy_act(const ActArgs &a, hipStream_t stream);
+
+}  // namespace nppol

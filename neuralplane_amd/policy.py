@@ -1,0 +1,212 @@
+"""FusedPolicy — the rollout policy's inference calls as ONE HIP kernel launch each ("policy-side fusion at the boundary").
+
+The reference's collect step (runner/F16sim_runner.py:123-129) is `PPOPolicy.get_actions(obs, rnn_states_actor, rnn_states_critic, masks)`
+(algorithms/ppo/ppo_policy.py:26-32): PPOActor.forward with sampled actions + log-probabilities and PPOCritic.forward, ~110 small torch
+kernels — 0.55-0.60 ms per step, nine tenths of a device-resident collect step (profiles/r05_collect_loop.json).  The training scripts
+build both networks in the frozen controller's shapes (hidden "128 128", act-hidden "128 128", GRU 128 x 1, feature LayerNorm, ReLU;
+22 observations; 4 actions for heading / control, 3 for tracking), so they run through the same matrix-core tile kernel (csrc/np_policy.hip):
+`FusedPolicy(policy)` packs `policy.actor` / `policy.critic` once and exposes the reference's three inference calls with its signatures
+
+    get_actions(obs, rnn_states_actor, rnn_states_critic, masks) -> values, actions, action_log_probs, rnn_states_actor, rnn_states_critic
+    get_values(obs, rnn_states_critic, masks)                    -> values
+    act(obs, rnn_states_actor, masks, deterministic=False)       -> actions, rnn_states_actor
+
+on device tensors.  Training (evaluate_actions, the optimiser) stays the host repository's torch code; after every update call
+`refresh()` (or construct with `auto_refresh=True`: the parameters' version counters are checked at every call) to re-pack the weights.
+The standard normal draws of a sampled step come from torch's generator on this device (`torch.randn`), as the reference's do.
+There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .actor import _LAYOUT, _SHAPES, HID, NUM_FLOATS, OBS
+
+MAX_ACT = 4
+_CRITIC_KEYS = {'act.mlp.fc.0': 'mlp.fc.0', 'act.mlp.fc.2': 'mlp.fc.2', 'act.mlp.fc.3': 'mlp.fc.3', 'act.mlp.fc.5': 'mlp.fc.5'}
+_HEAD_W, _HEAD_B = 'act.action_out.mu_net.fc.0.weight', 'act.action_out.mu_net.fc.0.bias'
+
+
+def _np(v):
+    v = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
+    return np.asarray(v, dtype=np.float32)
+
+
+def _pack(state_dict, key_of, head_w, head_b, what):
+    parts = []
+    for _, key, transpose in _LAYOUT:
+        if key == _HEAD_W:
+            v = head_w
+        elif key == _HEAD_B:
+            v = head_b
+        else:
+            k = key_of(key)
+            if k not in state_dict:
+                raise ValueError(f'not a {what} state_dict of the supported architecture: missing {k}')
+            v = _np(state_dict[k])
+            if key in _SHAPES and tuple(v.shape) != _SHAPES[key]:
+                raise ValueError(f'{k}: shape {tuple(v.shape)}, expected {_SHAPES[key]} (hidden 128 128, GRU 128 x 1, 22 observations)')
+        parts.append(np.ascontiguousarray(v.T if transpose else v).reshape(-1))
+    out = np.concatenate(parts)
+    assert out.size == NUM_FLOATS, out.size
+    return out
+
+
+def pack_policy_actor(state_dict):
+    """PPOActor.state_dict() with a DiagGaussian head of 1..4 actions -> (float32[NUM_FLOATS] in np_actor_forward's layout, the head
+    zero-padded to four columns; act_dim; log_std float32[act_dim])."""
+    for k in (_HEAD_W, _HEAD_B, 'act.action_out.log_std'):
+        if k not in state_dict:
+            raise ValueError(f'not a PPOActor state_dict with a DiagGaussian head: missing {k}')
+    w, b, log_std = _np(state_dict[_HEAD_W]), _np(state_dict[_HEAD_B]), _np(state_dict['act.action_out.log_std']).reshape(-1)
+    A = w.shape[0]
+    if not (1 <= A <= MAX_ACT) or w.shape != (A, HID) or b.shape != (A,) or log_std.shape != (A,):
+        raise ValueError(f'mu_net: {tuple(w.shape)} / {tuple(b.shape)} / log_std {tuple(log_std.shape)}; supported: 1..4 actions on 128 features')
+    wp, bp = np.zeros((MAX_ACT, HID), np.float32), np.zeros(MAX_ACT, np.float32)
+    wp[:A], bp[:A] = w, b
+    return _pack(state_dict, lambda k: k, wp, bp, 'PPOActor'), A, log_std.copy()
+
+
+def pack_policy_critic(state_dict):
+    """PPOCritic.state_dict() (ppo_critic.py:10-36: base, rnn, mlp, value_out) -> float32[NUM_FLOATS]: the actor layout with `mlp` in the
+    place of `act.mlp` and value_out in column 0 of the head block."""
+    for k in ('value_out.weight', 'value_out.bias'):
+        if k not in state_dict:
+            raise ValueError(f'not a PPOCritic state_dict: missing {k}')
+    w, b = _np(state_dict['value_out.weight']), _np(state_dict['value_out.bias'])
+    if w.shape != (1, HID) or b.shape != (1,):
+        raise ValueError(f'value_out: {tuple(w.shape)} / {tuple(b.shape)}, expected (1, 128) / (1,)')
+    wp, bp = np.zeros((MAX_ACT, HID), np.float32), np.zeros(MAX_ACT, np.float32)
+    wp[0], bp[0] = w[0], b[0]
+
+    def key_of(key):
+        for a, c in _CRITIC_KEYS.items():
+            if key.startswith(a + '.'):
+                return c + key[len(a):]
+        return key
+    return _pack(state_dict, key_of, wp, bp, 'PPOCritic')
+
+
+class NpPolicyStep(C.Structure):   # include/neuralplane_amd.h: np_policy_step
+    _fields_ = [('n', C.c_int64), ('act_dim', C.c_int32), ('flags', C.c_int32), ('actor_weights', C.c_void_p), ('critic_weights', C.c_void_p),
+                ('std', C.c_float * 4), ('log_std', C.c_float * 4), ('obs', C.c_void_p), ('masks', C.c_void_p), ('noise', C.c_void_p),
+                ('rnn_states_actor_in', C.c_void_p), ('rnn_states_critic_in', C.c_void_p), ('values', C.c_void_p), ('actions', C.c_void_p),
+                ('action_log_probs', C.c_void_p), ('rnn_states_actor_out', C.c_void_p), ('rnn_states_critic_out', C.c_void_p)]
+
+
+ACTOR, CRITIC, DETERMINISTIC = 1, 2, 4
+
+
+class FusedPolicy:
+    """`FusedPolicy(policy)` for an object with `.actor` / `.critic` torch modules of PPOActor's / PPOCritic's structure (the reference's
+    PPOPolicy), or `FusedPolicy((actor_state_dict, critic_state_dict))`.  See the module docstring."""
+
+    def __init__(self, policy, device='cuda:0', auto_refresh=False):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError(f"neuralplane_amd runs on MI355X (torch device 'cuda:N'), not on '{device}': there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self._source = policy
+        self.auto_refresh = bool(auto_refresh)
+        self.weights = torch.empty((2, NUM_FLOATS), dtype=torch.float32, device=self.device)   # [0] actor, [1] critic; rows are 16-byte aligned
+        assert NUM_FLOATS % 4 == 0 and self.weights.data_ptr() % 16 == 0
+        self._versions = None
+        self.refreshes = 0
+        self.refresh()
+
+    def _state_dicts(self):
+        p = self._source
+        if isinstance(p, (tuple, list)):
+            return p[0], p[1]
+        return p.actor.state_dict(), p.critic.state_dict()
+
+    def _watch(self):
+        p = self._source
+        if isinstance(p, (tuple, list)):
+            return None
+        return tuple(int(q._version) for net in (p.actor, p.critic) for q in net.parameters())
+
+    def refresh(self):
+        """Re-pack both networks from the source policy (after an optimiser step or load_state_dict)."""
+        sa, sc = self._state_dicts()
+        wa, self.act_dim, log_std = pack_policy_actor(sa)
+        wc = pack_policy_critic(sc)
+        self.weights.copy_(torch.from_numpy(np.stack((wa, wc))))
+        ls = torch.from_numpy(log_std)
+        v = sa['act.action_out.log_std']
+        # std as the reference computes it: exp() by torch on the parameter's own device (distributions.py:96)
+        std = v.detach().exp().reshape(-1).to(torch.float32).cpu() if hasattr(v, 'detach') else ls.exp()
+        self.log_std, self.std = [float(x) for x in ls], [float(x) for x in std]
+        self._versions = self._watch()
+        self.refreshes += 1
+
+    def _maybe_refresh(self):
+        if self.auto_refresh and self._versions is not None and self._watch() != self._versions:
+            self.refresh()
+
+    def _rows(self, x, n, width):
+        x = torch.as_tensor(x, device=self.device).to(dtype=torch.float32).reshape(n, width)
+        x = x if x.is_contiguous() else x.contiguous()
+        return x if x.data_ptr() % 16 == 0 else x.clone()
+
+    def _launch(self, flags, obs, ha, hc, masks, noise):
+        self._maybe_refresh()
+        d = self.device
+        obs = torch.as_tensor(obs, device=d)
+        n = obs.shape[0]
+        obs = self._rows(obs, n, OBS)
+        m = self._rows(masks, n, 1)
+        q = NpPolicyStep()
+        q.n, q.act_dim, q.flags = n, self.act_dim, flags
+        q.actor_weights, q.critic_weights = self.weights[0].data_ptr(), self.weights[1].data_ptr()
+        for j in range(self.act_dim):
+            q.std[j], q.log_std[j] = self.std[j], self.log_std[j]
+        q.obs, q.masks = obs.data_ptr(), m.data_ptr()
+        out = {}
+        if flags & ACTOR:
+            h = self._rows(ha, n, HID)
+            out['actions'] = torch.empty((n, self.act_dim), dtype=torch.float32, device=d)
+            out['logp'] = torch.empty((n, 1), dtype=torch.float32, device=d)
+            out['ha'] = torch.empty((n, 1, HID), dtype=torch.float32, device=d)
+            if not flags & DETERMINISTIC:
+                if noise is None:
+                    noise = torch.randn((n, self.act_dim), dtype=torch.float32, device=d)
+                noise = self._rows(noise, n, self.act_dim)
+                q.noise = noise.data_ptr()
+            q.rnn_states_actor_in, q.rnn_states_actor_out = h.data_ptr(), out['ha'].data_ptr()
+            q.actions, q.action_log_probs = out['actions'].data_ptr(), out['logp'].data_ptr()
+        if flags & CRITIC:
+            h = self._rows(hc, n, HID)
+            out['values'] = torch.empty((n, 1), dtype=torch.float32, device=d)
+            out['hc'] = torch.empty((n, 1, HID), dtype=torch.float32, device=d)
+            q.rnn_states_critic_in, q.rnn_states_critic_out, q.values = h.data_ptr(), out['hc'].data_ptr(), out['values'].data_ptr()
+        _lib.check(self.lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(d)))
+        return out
+
+    # ---- the reference's three inference calls (ppo_policy.py:26-57) ----
+    def get_actions(self, obs, rnn_states_actor, rnn_states_critic, masks, noise=None):
+        """-> values [n,1], actions [n,A], action_log_probs [n,1], rnn_states_actor [n,1,128], rnn_states_critic [n,1,128].  `noise` [n,A]: the
+        standard normal draws to use instead of torch.randn (tests; replaying a recorded step)."""
+        o = self._launch(ACTOR | CRITIC, obs, rnn_states_actor, rnn_states_critic, masks, noise)
+        return o['values'], o['actions'], o['logp'], o['ha'], o['hc']
+
+    def get_values(self, obs, rnn_states_critic, masks):
+        return self._launch(CRITIC, obs, None, rnn_states_critic, masks, None)['values']
+
+    def act(self, obs, rnn_states_actor, masks, deterministic=False, noise=None):
+        o = self._launch(ACTOR | (DETERMINISTIC if deterministic else 0), obs, rnn_states_actor, None, masks, noise)
+        return o['actions'], o['ha']
+
+    def prep_rollout(self):
+        p = self._source
+        if hasattr(p, 'prep_rollout'):
+            p.prep_rollout()
+
+    def prep_training(self):
+        p = self._source
+        if hasattr(p, 'prep_training'):
+            p.prep_training()

@@ -172,6 +172,14 @@ int f16o_actor_num_floats(void);
 void f16o_actor_forward(const float *w, int64_t n, const float *obs, const float *h_in, const float *mask, float *act,
                         float *h_out);
 
+/* The rollout policy's inference step (f16_actor.inc): PPOPolicy.get_actions (algorithms/ppo/ppo_policy.py:26-32) — actor with sampled
+ * actions + log-probabilities and critic on the same observation.  wa / wc: the two networks as f16o_actor_num_floats() packed weights
+ * (the critic's value_out in column 0 of the head block); std / log_std [act_dim]; noise [n][act_dim] the standard normal draws;
+ * flags: 1 actor, 2 critic, 4 deterministic.  values [n], actions [n][act_dim], log_probs [n], ha_out / hc_out [n][128]. */
+void f16o_policy_act(const float *wa, const float *wc, const float *std, const float *log_std, int64_t n, int act_dim, int flags,
+                     const float *obs, const float *ha_in, const float *hc_in, const float *mask, const float *noise, float *values,
+                     float *actions, float *log_probs, float *ha_out, float *hc_out);
+
 /* ReplayBuffer.compute_returns (f16_rollout.inc; reference algorithms/utils/buffer.py:139-173): rewards [T][N], value_preds / masks /
  * bad_masks / returns [T+1][N], next_value [N]; GAE modes write value_preds[T], the others returns[T] */
 void f16o_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int proper, const float *rewards,

@@ -1,0 +1,200 @@
+"""SURVEY §8 N1 — the rollout policy's inference step as one launch (np_policy_act, neuralplane_amd/policy.py FusedPolicy) against the CPU
+restatement (oracle/f16_actor.inc f16o_policy_act: bit for bit) and the reference's PPOPolicy.get_actions recording
+(tests/golden/policy_kat.npz, tools/gen_golden.py gen_policy: tolerances of tests/policy_kat.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def _t(x, dev='cuda:0'):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _setup(golden_dir, act_dim):
+    from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
+    from oracle.f16_oracle import PolicyOracle
+    from tests.policy_kat import load
+    g, sa, sc = load(golden_dir, act_dim)
+    fp = FusedPolicy((sa, sc), device='cuda:0')
+    wa, A, _ = pack_policy_actor(sa)
+    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std))
+    assert A == act_dim == fp.act_dim and same(np.float32(fp.std), g['std']) and same(np.float32(fp.log_std), g['log_std'])
+    return g, sa, sc, fp, o
+
+
+@pytest.mark.parametrize('act_dim', [4, 3])
+def test_get_actions_equals_the_restatement_bit_for_bit_and_the_reference_recording(golden_dir, act_dim):
+    """Five chained get_actions calls on the recorded inputs and normal draws (recurrent states fed back on the device): every output equals
+    the restatement's bit for bit and the REFERENCE's recording within the bounds of tests/policy_kat.py; act(deterministic=True) and
+    get_values are the same launch with one network."""
+    from tests.policy_kat import check_step
+    g, _, _, fp, o = _setup(golden_dir, act_dim)
+    n = g['obs'].shape[1]
+    ha = hc = torch.zeros((n, 1, 128), device='cuda:0')
+    ha_o = hc_o = np.zeros((n, 128), np.float32)
+    for t in range(g['obs'].shape[0]):
+        obs, m = _t(g['obs'][t]), _t(g['masks'][t])
+        mean, ha_det = fp.act(obs, ha, m, deterministic=True)
+        v_only = fp.get_values(obs, hc, m)
+        a_s, ha_s = fp.act(obs, ha, m, noise=_t(g['eps'][t]))
+        values, actions, logp, ha, hc = fp.get_actions(obs, ha, hc, m, noise=_t(g['eps'][t]))
+        assert values.shape == (n, 1) and actions.shape == (n, act_dim) and logp.shape == (n, 1) and ha.shape == hc.shape == (n, 1, 128)
+        v_o, a_o, lp_o, ha_o2, hc_o2 = o.run(g['obs'][t], ha_o, hc_o, g['masks'][t], g['eps'][t])
+        mean_o = o.run(g['obs'][t], ha_o, hc_o, g['masks'][t], flags=o.ACTOR | o.DETERMINISTIC)[1]
+        ha_o, hc_o = ha_o2, hc_o2
+        assert same(values.cpu().numpy(), v_o) and same(actions.cpu().numpy(), a_o) and same(logp.cpu().numpy(), lp_o), t
+        assert same(ha.cpu().numpy()[:, 0], ha_o) and same(hc.cpu().numpy()[:, 0], hc_o), t
+        assert same(mean.cpu().numpy(), mean_o) and same(ha_det.cpu().numpy(), ha.cpu().numpy()), t
+        assert same(v_only.cpu().numpy(), v_o) and same(a_s.cpu().numpy(), a_o) and same(ha_s.cpu().numpy(), ha.cpu().numpy()), t
+        assert np.max(np.abs(mean.cpu().numpy() - g['means'][t])) < 2e-5
+        check_step(g, t, values.cpu().numpy(), actions.cpu().numpy(), logp.cpu().numpy(), ha.cpu().numpy(), hc.cpu().numpy())
+
+
+@pytest.mark.parametrize('n', [1, 31, 33, 1000, 20001])
+def test_ragged_batches_and_wild_inputs_equal_the_restatement(golden_dir, n):
+    """Batch sizes around the 32-row tile, large observations, |h| > 1, masked rows."""
+    g, _, _, fp, o = _setup(golden_dir, 4)
+    rng = np.random.RandomState(n)
+    obs = (rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 30, (1, 22))).astype(np.float32)
+    ha, hc = rng.normal(0, 0.7, (n, 128)).astype(np.float32), rng.normal(0, 0.7, (n, 128)).astype(np.float32)
+    mk = (rng.uniform(0, 1, (n, 1)) > 0.2).astype(np.float32)
+    eps = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    out = fp.get_actions(_t(obs), _t(ha), _t(hc), _t(mk), noise=_t(eps))
+    ref = o.run(obs, ha, hc, mk, eps)
+    for k, (x, y) in enumerate(zip(out, ref)):
+        assert same(x.cpu().numpy().reshape(y.shape), y), k
+
+
+def test_sampling_draws_from_torchs_generator_like_the_reference(golden_dir):
+    """Without `noise` the draws are torch.randn's on this device: re-seeding reproduces the step, and the actions are
+    fl(fl(randn * std) + mean) of exactly those draws (what the reference's FixedNormal.sample() computes: tools/gen_golden.py asserts it)."""
+    g, _, _, fp, _ = _setup(golden_dir, 3)
+    n = g['obs'].shape[1]
+    obs, m = _t(g['obs'][0]), _t(g['masks'][0])
+    h0 = torch.zeros((n, 1, 128), device='cuda:0')
+    torch.manual_seed(11)
+    eps = torch.randn((n, 3), device='cuda:0')
+    torch.manual_seed(11)
+    v1, a1, lp1, _, _ = fp.get_actions(obs, h0, h0.clone(), m)
+    torch.manual_seed(11)
+    v2, a2, lp2, _, _ = fp.get_actions(obs, h0, h0.clone(), m)
+    mean, _ = fp.act(obs, h0, m, deterministic=True)
+    assert torch.equal(a1, a2) and torch.equal(lp1, lp2) and torch.equal(v1, v2)
+    assert torch.equal(a1, eps * torch.tensor(fp.std, device='cuda:0') + mean)
+    # log-probabilities: torch.distributions.Normal on the same device, a tolerance (its reduction order is its own)
+    ref = torch.distributions.Normal(mean, torch.tensor(fp.std, device='cuda:0')).log_prob(a1).sum(-1, keepdim=True)
+    assert float((ref - lp1).abs().max()) < 5e-6
+
+
+def test_refresh_follows_the_source_policy(golden_dir):
+    """After an in-place update of the source networks refresh() (or auto_refresh at the next call) re-packs them; a stale FusedPolicy keeps the old weights."""
+    from neuralplane_amd.policy import FusedPolicy
+    from tests.policy_kat import load
+    g, sa, sc = load(golden_dir, 4)
+
+    class Net:
+        def __init__(self, sd):
+            self.p = {k: torch.nn.Parameter(torch.from_numpy(v.copy()).to('cuda:0')) for k, v in sd.items()}
+
+        def state_dict(self):
+            return {k: v.detach() for k, v in self.p.items()}
+
+        def parameters(self):
+            return self.p.values()
+
+    class Pol:
+        pass
+    pol = Pol()
+    pol.actor, pol.critic = Net(sa), Net(sc)
+    stale, auto = FusedPolicy(pol, 'cuda:0'), FusedPolicy(pol, 'cuda:0', auto_refresh=True)
+    fixed = FusedPolicy((sa, sc), 'cuda:0')
+    obs, m = _t(g['obs'][0]), _t(g['masks'][0])
+    h = torch.zeros((96, 1, 128), device='cuda:0')
+    eps = _t(g['eps'][0])
+    base = stale.get_actions(obs, h, h.clone(), m, noise=eps)
+    assert all(torch.equal(x, y) for x, y in zip(auto.get_actions(obs, h, h.clone(), m, noise=eps), base))
+    # the state_dict source differs only in std = exp(log_std), evaluated where the parameter lives (this GPU / the host): an ulp
+    for x, y in zip(fixed.get_actions(obs, h, h.clone(), m, noise=eps), base):
+        assert float((x - y).abs().max()) < 1e-5
+    assert torch.equal(fixed.get_values(obs, h, m), base[0])
+    with torch.no_grad():
+        pol.actor.p['act.mlp.fc.0.bias'].add_(0.05)
+        pol.critic.p['value_out.bias'].add_(1.0)
+        pol.actor.p['act.action_out.log_std'].add_(0.1)
+    out_auto = auto.get_actions(obs, h, h.clone(), m, noise=eps)
+    assert auto.refreshes == 2 and not torch.equal(out_auto[1], base[1])
+    assert torch.allclose(out_auto[0], base[0] + 1.0, atol=1e-5)
+    assert all(torch.equal(x, y) for x, y in zip(stale.get_actions(obs, h, h.clone(), m, noise=eps), base)) and stale.refreshes == 1
+    stale.refresh()
+    assert all(torch.equal(x, y) for x, y in zip(stale.get_actions(obs, h, h.clone(), m, noise=eps), out_auto))
+    assert abs(auto.log_std[0] - (float(g['log_std'][0]) + 0.1)) < 1e-6
+
+
+def test_policy_act_argument_errors(golden_dir):
+    from neuralplane_amd import _lib
+    from neuralplane_amd.policy import ACTOR, CRITIC, NpPolicyStep
+    _, _, _, fp, _ = _setup(golden_dir, 4)
+    lib = _lib.load()
+    n = 40
+    bufs = {k: torch.zeros(s, device='cuda:0') for k, s in (('obs', (n, 22)), ('m', (n,)), ('eps', (n, 4)), ('ha', (n, 128)), ('hc', (n, 128)), ('ha2', (n, 128)),
+                                                           ('hc2', (n, 128)), ('v', (n,)), ('a', (n, 4)), ('lp', (n,)))}
+
+    def step(**kw):
+        q = NpPolicyStep()
+        q.n, q.act_dim, q.flags = n, 4, ACTOR | CRITIC
+        q.actor_weights, q.critic_weights = fp.weights[0].data_ptr(), fp.weights[1].data_ptr()
+        for j in range(4):
+            q.std[j], q.log_std[j] = 0.5, -0.7
+        q.obs, q.masks, q.noise = bufs['obs'].data_ptr(), bufs['m'].data_ptr(), bufs['eps'].data_ptr()
+        q.rnn_states_actor_in, q.rnn_states_critic_in = bufs['ha'].data_ptr(), bufs['hc'].data_ptr()
+        q.rnn_states_actor_out, q.rnn_states_critic_out = bufs['ha2'].data_ptr(), bufs['hc2'].data_ptr()
+        q.values, q.actions, q.action_log_probs = bufs['v'].data_ptr(), bufs['a'].data_ptr(), bufs['lp'].data_ptr()
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return lib.np_policy_act(C.byref(q), 0, _lib.stream_ptr(torch.device('cuda:0')))
+
+    assert step() == 0
+    for bad in (dict(flags=0), dict(flags=8 | ACTOR), dict(act_dim=5), dict(act_dim=0), dict(noise=None), dict(values=None), dict(n=-1),
+                dict(rnn_states_actor_out=bufs['ha'].data_ptr()), dict(rnn_states_critic_in=bufs['hc'].data_ptr() + 4)):
+        assert step(**bad) != 0, bad
+        assert lib.np_last_error()
+    assert step(flags=ACTOR, values=None, critic_weights=None, rnn_states_critic_in=None, rnn_states_critic_out=None) == 0   # one network: the other's buffers may be NULL
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        from neuralplane_amd.policy import FusedPolicy
+        FusedPolicy(fp._source, device='cpu')
+
+
+def test_fused_policy_against_a_torch_module_of_the_same_weights_on_the_gpu():
+    """tools/collect_loop.py's torch policy (the PPO actor-critic shape, eager torch on this GPU) and FusedPolicy of its parameters agree on
+    the same draws to rounding: actions 2e-5, values 1e-4, log-probabilities 5e-5 (rocBLAS GEMMs / ATen kernels vs the ordered chains)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from neuralplane_amd.policy import FusedPolicy
+    from tools.collect_loop import TorchPolicy
+    torch.manual_seed(5)
+    tp = TorchPolicy().to('cuda:0').eval()
+    with torch.no_grad():
+        tp.logstd.add_(-0.5)
+        tp.actor.head.weight.mul_(3.0)
+    fp = FusedPolicy(tp.state_dicts(), 'cuda:0')
+    n = 3000
+    obs = torch.randn((n, 22), device='cuda:0') * 2
+    ha, hc = torch.randn((n, 128), device='cuda:0') * 0.5, torch.randn((n, 128), device='cuda:0') * 0.5
+    m = (torch.rand((n, 1), device='cuda:0') > 0.1).float()
+    torch.manual_seed(9)
+    v_t, a_t, lp_t, ha_t, hc_t = tp.get_actions(obs, ha, hc, m)
+    torch.manual_seed(9)
+    v_f, a_f, lp_f, ha_f, hc_f = fp.get_actions(obs, ha, hc, m)
+    assert float((a_t - a_f).abs().max()) < 2e-5 and float((v_t - v_f).abs().max()) < 1e-4 and float((lp_t - lp_f).abs().max()) < 5e-5
+    assert float((ha_t - ha_f.reshape(n, 128)).abs().max()) < 5e-5 and float((hc_t - hc_f.reshape(n, 128)).abs().max()) < 5e-5

@@ -610,3 +610,52 @@ def test_planning_env_closed_loop_vs_reference_with_the_i8_controller(golden_dir
     for k in range(g['hi_actions'].shape[0]):
         worst = max(worst, compare_with_reference(cl.macro_step(k), g, k)['state'])
     assert worst < 6e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# The rollout policy's inference step: PPOPolicy.get_actions restated (oracle/f16_actor.inc, f16o_policy_act)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('act_dim', [4, 3])
+def test_policy_get_actions_restatement_vs_reference_recording(golden_dir, act_dim):
+    """f16o_policy_act against the REFERENCE's PPOPolicy.get_actions (algorithms/ppo/ppo_policy.py:26-32) recorded over five chained calls
+    (recurrent states fed back — here the oracle's own, so errors accumulate as they would in a rollout; rows with masks = 0 in two of them)
+    for the heading (4 actions) and tracking (3 actions) policies: sampled actions from the recorded normal draws <= 2e-5, values <= 1e-4
+    (|value| up to 9), log-probabilities <= 5e-5, recurrent states <= 5e-5; plus act(deterministic=True) = the means and get_values."""
+    from neuralplane_amd.policy import pack_policy_actor, pack_policy_critic
+    from oracle.f16_oracle import PolicyOracle
+    from tests.policy_kat import TOL, check_step, load
+    g, sa, sc = load(golden_dir, act_dim)
+    wa, A, log_std = pack_policy_actor(sa)
+    assert A == act_dim and same(log_std, g['log_std'])
+    o = PolicyOracle(wa, pack_policy_critic(sc), g['std'], g['log_std'])
+    n = g['obs'].shape[1]
+    ha = hc = np.zeros((n, 128), np.float32)
+    worst = {}
+    for t in range(g['obs'].shape[0]):
+        _, mean, lp0, _, _ = o.run(g['obs'][t], ha, hc, g['masks'][t], flags=o.ACTOR | o.DETERMINISTIC)
+        assert np.max(np.abs(mean - g['means'][t])) < TOL['means']
+        assert same(lp0, np.full((n, 1), lp0[0, 0])), 'at the mean every row has the same log-probability'
+        v_only = o.run(g['obs'][t], ha, hc, g['masks'][t], flags=o.CRITIC)[0]
+        values, actions, logp, ha, hc = o.run(g['obs'][t], ha, hc, g['masks'][t], g['eps'][t])
+        assert same(values, v_only)
+        for k, v in check_step(g, t, values, actions, logp, ha, hc).items():
+            worst[k] = max(worst.get(k, 0.0), float(v))
+    print('policy restatement vs reference', act_dim, worst)
+
+
+def test_policy_packers_reject_other_architectures(golden_dir):
+    from neuralplane_amd.policy import pack_policy_actor, pack_policy_critic
+    from tests.policy_kat import load
+    _, sa, sc = load(golden_dir, 3)
+    wa, A, _ = pack_policy_actor(sa)
+    assert A == 3 and wa.size == 153392 and np.all(wa[-512:].reshape(128, 4)[:, 3] == 0.0) and wa[-516 + 3] == 0.0   # the padded head column / bias
+    wc = pack_policy_critic(sc)
+    assert np.all(wc[-512:].reshape(128, 4)[:, 1:] == 0.0) and same(wc[-512:].reshape(128, 4)[:, 0], sc['value_out.weight'][0])
+    with pytest.raises(ValueError):
+        pack_policy_critic(sa)            # an actor is not a critic
+    with pytest.raises(ValueError):
+        pack_policy_actor(sc)
+    bad = dict(sa)
+    bad['base.mlp.fc.0.weight'] = np.zeros((64, 22), np.float32)
+    with pytest.raises(ValueError):
+        pack_policy_actor(bad)

@@ -53,6 +53,17 @@ class _Tower(nn.Module):
         x = self.n5(torch.relu(self.a2(x)))
         return self.head(x), h
 
+    def reference_state_dict(self, critic):
+        """The same parameters under the key names of the reference's PPOActor / PPOCritic state_dict (what FusedPolicy packs)."""
+        mlp = 'mlp' if critic else 'act.mlp'
+        names = {'ln0': 'base.feature_norm', 'l1': 'base.mlp.fc.0', 'n1': 'base.mlp.fc.2', 'l2': 'base.mlp.fc.3', 'n2': 'base.mlp.fc.5', 'n3': 'rnn.norm',
+                 'a1': mlp + '.fc.0', 'n4': mlp + '.fc.2', 'a2': mlp + '.fc.3', 'n5': mlp + '.fc.5', 'head': 'value_out' if critic else 'act.action_out.mu_net.fc.0'}
+        sd = {}
+        for k, v in self.state_dict().items():
+            mod, par = k.split('.')
+            sd[f'rnn.gru.{par}_l0' if mod == 'gru' else f'{names[mod]}.{par}'] = v
+        return sd
+
 
 class TorchPolicy(nn.Module):
     """get_actions(obs[n,22], h_actor[n,128], h_critic[n,128], masks[n,1]) -> values, actions, action_log_probs, h_actor, h_critic
@@ -66,11 +77,21 @@ class TorchPolicy(nn.Module):
     @torch.no_grad()
     def get_actions(self, obs, ha, hc, masks):
         mu, ha = self.actor(obs, ha, masks)
+        mu = torch.tanh(mu)                                      # MuNet: Linear + Tanh (distributions.py:77-87)
         std = self.logstd.exp()
-        actions = mu + std * torch.randn_like(mu)
+        actions = torch.randn_like(mu) * std + mu
         logp = (-0.5 * ((actions - mu) / std) ** 2 - self.logstd - 0.9189385332046727).sum(-1, keepdim=True)
         values, hc = self.critic(obs, hc, masks)
         return values, actions, logp, ha, hc
+
+    def state_dicts(self):
+        sa = self.actor.reference_state_dict(False)
+        sa['act.action_out.log_std'] = self.logstd.detach()
+        return sa, self.critic.reference_state_dict(True)
+
+    @torch.no_grad()
+    def get_values(self, obs, hc, masks):
+        return self.critic(obs, hc, masks)[0]
 
 
 class _Args:
@@ -119,12 +140,15 @@ class _Phases:
         self.ev = []
 
 
-def run_device(n, T, dev, graph=False, task='heading'):
+def run_device(n, T, dev, graph=False, task='heading', fused_policy=False):
     from neuralplane_amd.buffer import DeviceReplayBuffer
     from neuralplane_amd.envs.control_env import ControlEnv
     from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
     torch.manual_seed(0)
     policy = TorchPolicy().to(dev).eval()
+    if fused_policy:   # the same networks through neuralplane_amd.policy.FusedPolicy: one launch per get_actions (np_policy_act)
+        from neuralplane_amd.policy import FusedPolicy
+        policy = FusedPolicy(policy.state_dicts(), device=dev)
     envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config=task, model='F16', random_seed=0, device=str(dev))])
     env = envs.env
     buf = DeviceReplayBuffer(_Args(n, T), 1, env.observation_space, env.action_space, device=dev)
@@ -191,7 +215,7 @@ def run_device(n, T, dev, graph=False, task='heading'):
     ph = _Phases(True)
     loop(ph)
     t0 = time.perf_counter()
-    nv = policy.critic(buf.obs[-1].reshape(n, 22), buf.rnn_states_critic[-1].reshape(n, 128), buf.masks[-1].reshape(n, 1))[0]
+    nv = policy.get_values(buf.obs[-1].reshape(n, 22), buf.rnn_states_critic[-1].reshape(n, 128), buf.masks[-1].reshape(n, 1))
     buf.compute_returns(nv.reshape(n, 1, 1))
     torch.cuda.synchronize(dev)
     ret_ms = 1e3 * (time.perf_counter() - t0)
@@ -290,6 +314,10 @@ def collect_loop_report(n, T, dev):
            'device_torch_insert': {'us_per_step_wall': unfused['us_per_step_wall'], 'gpu_us_insert': unfused['gpu_us_insert'],
                                    'note': 'the same device loop with the insert as ~20 torch kernels (masks, 9 copies) instead of DeviceReplayBuffer.insert_step'},
            'numpy_contract': run_numpy(n, T, dev)}
+    # the same loop with the policy's inference step as ONE launch (neuralplane_amd.policy.FusedPolicy, np_policy_act)
+    rep['device_fused_policy'] = run_device(n, T, dev, fused_policy=True)
+    rep['device_fused_policy_graph'] = run_device(n, T, dev, graph=True, fused_policy=True)
+    rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
     d = rep['device']
     parts = {'policy (eager torch, ~110 small kernels)': d['gpu_us_policy'], 'env.step kernel': d['gpu_us_env_step'], 'insert (one launch)': d['gpu_us_insert'],
              'host gaps (GPU idle)': max(0.0, d['host_gap_us'])}

@@ -951,6 +951,78 @@ def gen_actor(n=96, steps=4):
     print('actor: |action| max', float(np.abs(np.stack(acts)).max()), 'rnn std', float(np.stack(hs).std()))
 
 
+def seeded_policy(act_dim):
+    """The reference's PPOPolicy (algorithms/ppo/ppo_policy.py: PPOActor + PPOCritic) in the configuration the training scripts build
+    (scripts/train_heading.sh:17 / train_tracking.sh:17: hidden "128 128", act-hidden "128 128", GRU 128 x 1; config.py defaults for the
+    rest) with a seeded initialisation whose LayerNorm terms, biases, output layers and log_std are moved off their trivial start values."""
+    if not hasattr(np, 'product'):
+        np.product = np.prod
+    import gym
+    from algorithms.ppo.ppo_policy import PPOPolicy
+
+    class A:
+        pass
+    args = A()
+    args.gain, args.hidden_size, args.act_hidden_size, args.activation_id = 0.01, '128 128', '128 128', 1
+    args.use_feature_normalization, args.use_recurrent_policy = True, True
+    args.recurrent_hidden_size, args.recurrent_hidden_layers, args.use_prior, args.lr = 128, 1, False, 3e-4
+    torch.manual_seed(900 + act_dim)
+    pol = PPOPolicy(args, gym.spaces.Box(low=-10, high=10, shape=(22,)), gym.spaces.Box(low=-10, high=10, shape=(act_dim,)), device=torch.device('cpu'))
+    pol.prep_rollout()
+    with torch.no_grad():
+        for net in (pol.actor, pol.critic):
+            for k, v in net.state_dict().items():
+                if k.endswith('norm.weight') or '.fc.2.weight' in k or '.fc.5.weight' in k:
+                    v.mul_(1.0 + 0.3 * torch.randn_like(v))
+                if k.endswith('norm.bias') or '.fc.2.bias' in k or '.fc.5.bias' in k or k.endswith('bias_ih_l0') or k.endswith('bias_hh_l0'):
+                    v.add_(0.2 * torch.randn_like(v))
+        pol.actor.act.action_out.mu_net.fc[0].weight.mul_(40.0)
+        pol.actor.act.action_out.mu_net.fc[0].bias.add_(0.1 * torch.randn(act_dim))
+        pol.actor.act.action_out.log_std.add_(-0.7 + 0.4 * torch.randn(act_dim))
+        pol.critic.value_out.weight.mul_(6.0)
+        pol.critic.value_out.bias.add_(0.3)
+    return pol
+
+
+def gen_policy(n=96, steps=5):
+    """The rollout policy's inference step, PPOPolicy.get_actions (ppo_policy.py:26-32), for the heading (4 actions) and tracking (3 actions)
+    policies: `steps` chained calls (recurrent states fed back, a few masks zeroed) with sampled actions.  The standard normal draws behind
+    every sample are stored too — drawn here from the same generator state with normal_(), and checked to reproduce the reference's actions
+    exactly as fl(fl(eps * std) + mean) — together with the means (act(..., deterministic=True)) and get_values."""
+    out = {}
+    for act_dim in (4, 3):
+        pol = seeded_policy(act_dim)
+        rng = np.random.RandomState(70 + act_dim)
+        obs = (rng.normal(0, 1, (steps, n, 22)) * rng.uniform(0.1, 3, (1, 1, 22))).astype(np.float32)
+        masks = np.ones((steps, n, 1), np.float32)
+        masks[2, ::5] = 0.0
+        masks[4, 1::9] = 0.0
+        ha, hc = torch.zeros((n, 1, 128)), torch.zeros((n, 1, 128))
+        std = pol.actor.act.action_out.log_std.detach().exp()
+        rec = {k: [] for k in ('eps', 'values', 'actions', 'logp', 'ha', 'hc', 'means', 'values_only')}
+        with torch.no_grad():
+            for t in range(steps):
+                o, m = torch.from_numpy(obs[t]), torch.from_numpy(masks[t])
+                mean, _ = pol.act(o, ha, m, deterministic=True)
+                vonly = pol.get_values(o, hc, m)
+                torch.manual_seed(5000 + 10 * act_dim + t)
+                eps = torch.empty(n, act_dim).normal_()
+                torch.manual_seed(5000 + 10 * act_dim + t)
+                values, actions, logp, ha, hc = pol.get_actions(o, ha, hc, m)
+                assert torch.equal(actions, eps * std + mean), 'the sample is not fl(fl(eps * std) + mean)'
+                assert torch.equal(values, vonly)
+                for k, v in (('eps', eps), ('values', values), ('actions', actions), ('logp', logp), ('ha', ha), ('hc', hc), ('means', mean), ('values_only', vonly)):
+                    rec[k].append(v.numpy().copy())
+        pre = f'a{act_dim}::'
+        out.update({pre + 'obs': obs, pre + 'masks': masks, pre + 'std': std.numpy(), pre + 'log_std': pol.actor.act.action_out.log_std.detach().numpy().copy()})
+        out.update({pre + k: np.stack(v) for k, v in rec.items()})
+        out.update({pre + 'actor::' + k: v.numpy() for k, v in pol.actor.state_dict().items()})
+        out.update({pre + 'critic::' + k: v.numpy() for k, v in pol.critic.state_dict().items()})
+        print(f'policy a{act_dim}: |mean| max', float(np.abs(np.stack(rec['means'])).max()), 'values', float(np.stack(rec['values']).min()),
+              float(np.stack(rec['values']).max()), 'logp', float(np.stack(rec['logp']).min()), float(np.stack(rec['logp']).max()), 'std', std.numpy())
+    np.savez_compressed(os.path.join(OUT, 'policy_kat.npz'), **out)
+
+
 def gen_combat_all():
     gen_geodesy()
     gen_pairwise()
@@ -1034,6 +1106,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'acmi':
         gen_acmi()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'policy':
+        gen_policy()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'actor':
         gen_actor()
