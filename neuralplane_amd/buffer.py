@@ -65,6 +65,7 @@ class DeviceReplayBuffer:
         self.step = 0
 
     def _alloc(self):
+        self._q_insert = None   # insert_step's argument struct holds the storage addresses
         T, N, A = self.buffer_size, self.n_rollout_threads, self.num_agents
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
         o = lambda *s: torch.ones(s, dtype=torch.float32, device=self.device)
@@ -104,6 +105,8 @@ class DeviceReplayBuffer:
             self.bad_masks[s + 1].copy_(self._dev(bad_masks, self.bad_masks[0]))
         self.step = (self.step + 1) % self.buffer_size
 
+    _STORAGE = ('obs', 'actions', 'rewards', 'masks', 'bad_masks', 'action_log_probs', 'value_preds', 'rnn_states_actor', 'rnn_states_critic')
+
     def insert_step(self, obs, actions, rewards, dones, bad_dones, exceed_time_limits, action_log_probs, values, rnn_states_actor, rnn_states_critic):
         """One collect step, as the reference's runner hands it over — `F16SimRunner.insert(data)` (runner/F16sim_runner.py:131-154: the recurrent
         states of envs that ended are zeroed, masks / bad_masks from dones / bad_dones, `any` over the agents of an env) followed by
@@ -113,21 +116,32 @@ class DeviceReplayBuffer:
             raise RuntimeError('DeviceReplayBuffer.insert_step runs on the GPU (np_rollout_insert); there is no CPU fallback')
         E, A = self.n_rollout_threads, self.num_agents
         N = E * A
-        f = lambda x, d: x.to(device=self.device, dtype=torch.float32).reshape(N, d).contiguous()                # noqa: E731
-        u8 = lambda x: (x.view(torch.uint8) if x.dtype == torch.bool else x.to(torch.uint8)).to(self.device).reshape(N).contiguous()   # noqa: E731
+        dev = self.device
+
+        def f(x, d):   # device-resident float32 rows are used where they are (only the address is needed)
+            if type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == dev and x.is_contiguous() and x.numel() == N * d:
+                return x
+            return x.to(device=dev, dtype=torch.float32).reshape(N, d).contiguous()
+
+        def u8(x):
+            if type(x) is torch.Tensor and x.device == dev and x.is_contiguous() and x.numel() == N and x.dtype in (torch.bool, torch.uint8):
+                return x   # bool and uint8 are both one byte, 0 / 1
+            return (x.view(torch.uint8) if x.dtype == torch.bool else x.to(torch.uint8)).to(dev).reshape(N).contiguous()
         od, ad = int(np.prod(self._obs_shape)), int(np.prod(self._act_shape))
         rd = self.recurrent_hidden_layers * self.recurrent_hidden_size
         keep = (f(obs, od), f(actions, ad), f(rewards, 1), f(action_log_probs, 1), f(values, 1), f(rnn_states_actor, rd), f(rnn_states_critic, rd),
                 u8(dones), u8(bad_dones), u8(exceed_time_limits))
-        q = _lib.NpRolloutStep()
-        q.num_envs, q.num_agents, q.step, q.obs_dim, q.act_dim, q.rnn_dim = E, A, self.step, od, ad, rd
-        for name in ('obs', 'actions', 'rewards', 'masks', 'bad_masks', 'action_log_probs', 'value_preds', 'rnn_states_actor', 'rnn_states_critic'):
-            t = getattr(self, name)
-            assert t.is_contiguous()
-            setattr(q, name, t.data_ptr())
-        for name, t in zip(('obs_in', 'actions_in', 'rewards_in', 'action_log_probs_in', 'values_in', 'rnn_states_actor_in', 'rnn_states_critic_in', 'done_in',
-                            'bad_done_in', 'exceed_time_limit_in'), keep):
-            setattr(q, name, t.data_ptr())
+        q = self._q_insert
+        if q is None or any(getattr(q, name) != getattr(self, name).data_ptr() for name in self._STORAGE):   # somebody replaced a storage tensor
+            q = self._q_insert = _lib.NpRolloutStep()
+            q.num_envs, q.num_agents, q.obs_dim, q.act_dim, q.rnn_dim = E, A, od, ad, rd
+            for name in self._STORAGE:
+                t = getattr(self, name)
+                assert t.is_contiguous()
+                setattr(q, name, t.data_ptr())
+        q.step = self.step
+        (q.obs_in, q.actions_in, q.rewards_in, q.action_log_probs_in, q.values_in, q.rnn_states_actor_in, q.rnn_states_critic_in, q.done_in, q.bad_done_in,
+         q.exceed_time_limit_in) = [t.data_ptr() for t in keep]
         stream = _lib.stream_ptr(self.device)
         _lib.check(_lib.load().np_rollout_insert(C.byref(q), self.device.index, stream))
         self.step = (self.step + 1) % self.buffer_size

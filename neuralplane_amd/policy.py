@@ -141,6 +141,11 @@ class FusedPolicy:
         # std as the reference computes it: exp() by torch on the parameter's own device (distributions.py:96)
         std = v.detach().exp().reshape(-1).to(torch.float32).cpu() if hasattr(v, 'detach') else ls.exp()
         self.log_std, self.std = [float(x) for x in ls], [float(x) for x in std]
+        q = self._q = NpPolicyStep()
+        q.act_dim = self.act_dim
+        q.actor_weights, q.critic_weights = self.weights[0].data_ptr(), self.weights[1].data_ptr()
+        for j in range(self.act_dim):
+            q.std[j], q.log_std[j] = self.std[j], self.log_std[j]
         self._versions = self._watch()
         self.refreshes += 1
 
@@ -149,6 +154,8 @@ class FusedPolicy:
             self.refresh()
 
     def _rows(self, x, n, width):
+        if type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == self.device and x.is_contiguous() and x.numel() == n * width and x.data_ptr() % 16 == 0:
+            return x   # the common case (a device-resident loop): only the address is used
         x = torch.as_tensor(x, device=self.device).to(dtype=torch.float32).reshape(n, width)
         x = x if x.is_contiguous() else x.contiguous()
         return x if x.data_ptr() % 16 == 0 else x.clone()
@@ -156,15 +163,13 @@ class FusedPolicy:
     def _launch(self, flags, obs, ha, hc, masks, noise):
         self._maybe_refresh()
         d = self.device
-        obs = torch.as_tensor(obs, device=d)
+        if type(obs) is not torch.Tensor:
+            obs = torch.as_tensor(obs, device=d)
         n = obs.shape[0]
         obs = self._rows(obs, n, OBS)
         m = self._rows(masks, n, 1)
-        q = NpPolicyStep()
-        q.n, q.act_dim, q.flags = n, self.act_dim, flags
-        q.actor_weights, q.critic_weights = self.weights[0].data_ptr(), self.weights[1].data_ptr()
-        for j in range(self.act_dim):
-            q.std[j], q.log_std[j] = self.std[j], self.log_std[j]
+        q = self._q   # weights, act_dim, std / log_std: filled by refresh(); the library reads the struct during the call only
+        q.n, q.flags = n, flags
         q.obs, q.masks = obs.data_ptr(), m.data_ptr()
         out = {}
         if flags & ACTOR:

@@ -69,10 +69,10 @@ class TorchPolicy(nn.Module):
     """get_actions(obs[n,22], h_actor[n,128], h_critic[n,128], masks[n,1]) -> values, actions, action_log_probs, h_actor, h_critic
     (PPOPolicy.get_actions, algorithms/ppo/ppo_policy.py:26-32, stochastic actions)."""
 
-    def __init__(self):
+    def __init__(self, act_dim=4):
         super().__init__()
-        self.actor, self.critic = _Tower(out=4), _Tower(out=1)
-        self.logstd = nn.Parameter(torch.zeros(4))
+        self.actor, self.critic = _Tower(out=act_dim), _Tower(out=1)
+        self.logstd = nn.Parameter(torch.zeros(act_dim))
 
     @torch.no_grad()
     def get_actions(self, obs, ha, hc, masks):
@@ -113,7 +113,7 @@ def _device_insert(buf, obs, actions, rewards, dones, bad_dones, tmo, logp, valu
     keep = (~reset_env).to(torch.float32)
     masks = (~dones).reshape(n, 1, 1).to(torch.float32)
     bad_masks = (~bad_dones).reshape(n, 1, 1).to(torch.float32)
-    buf.insert(obs, actions.reshape(n, 1, 4), rewards, masks, logp.reshape(n, 1, 1), values.reshape(n, 1, 1), (ha * keep).reshape(n, 1, 1, 128),
+    buf.insert(obs, actions.reshape(n, 1, -1), rewards, masks, logp.reshape(n, 1, 1), values.reshape(n, 1, 1), (ha * keep).reshape(n, 1, 1, 128),
                (hc * keep).reshape(n, 1, 1, 128), bad_masks)
 
 
@@ -145,11 +145,20 @@ def run_device(n, T, dev, graph=False, task='heading', fused_policy=False):
     from neuralplane_amd.envs.control_env import ControlEnv
     from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
     torch.manual_seed(0)
-    policy = TorchPolicy().to(dev).eval()
+    policy = TorchPolicy(act_dim=3 if task == 'tracking' else 4).to(dev).eval()
     if fused_policy:   # the same networks through neuralplane_amd.policy.FusedPolicy: one launch per get_actions (np_policy_act)
         from neuralplane_amd.policy import FusedPolicy
         policy = FusedPolicy(policy.state_dicts(), device=dev)
-    envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config=task, model='F16', random_seed=0, device=str(dev))])
+    if task == 'tracking':
+        # scripts/train_tracking.sh: PlanningEnv (one high-level action = 50 x {frozen controller, FDM step}); the controller's checkpoint is
+        # not part of the reference snapshot: random weights of its architecture, run by the persistent kernel
+        from neuralplane_amd.actor import NUM_FLOATS, FusedActor
+        from neuralplane_amd.envs.planning_env import PlanningEnv
+        assert not graph
+        ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), str(dev), numerics='i8')
+        envs = DeviceVecEnv([lambda: PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=0, device=str(dev), controller=ctrl)])
+    else:
+        envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config=task, model='F16', random_seed=0, device=str(dev))])
     env = envs.env
     buf = DeviceReplayBuffer(_Args(n, T), 1, env.observation_space, env.action_space, device=dev)
     buf.obs[0].copy_(envs.reset())
@@ -318,6 +327,12 @@ def collect_loop_report(n, T, dev):
     rep['device_fused_policy'] = run_device(n, T, dev, fused_policy=True)
     rep['device_fused_policy_graph'] = run_device(n, T, dev, graph=True, fused_policy=True)
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
+    if n == 10000:
+        # the configuration the reference runs 10 000 rollout threads on (scripts/train_tracking.sh): PlanningEnv macro-steps, a 3-action policy
+        Tt = max(10, T // 10)
+        rep['tracking_torch_policy'] = run_device(n, Tt, dev, task='tracking')
+        rep['tracking_fused_policy'] = run_device(n, Tt, dev, task='tracking', fused_policy=True)
+        rep['tracking_fused_policy']['speedup_vs_torch_policy'] = rep['tracking_torch_policy']['us_per_step_wall'] / rep['tracking_fused_policy']['us_per_step_wall']
     d = rep['device']
     parts = {'policy (eager torch, ~110 small kernels)': d['gpu_us_policy'], 'env.step kernel': d['gpu_us_env_step'], 'insert (one launch)': d['gpu_us_insert'],
              'host gaps (GPU idle)': max(0.0, d['host_gap_us'])}
@@ -332,8 +347,13 @@ if __name__ == '__main__':
     ap.add_argument('--n', type=int, nargs='*', default=[3000, 10000])
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--only', default=None, choices=['fused', 'torch'], help='profiling: run just the device loop with the fused / the eager torch policy')
     args = ap.parse_args()
-    rep = {f'collect_loop_n{n}': collect_loop_report(n, args.steps, 'cuda:0') for n in args.n}
+    if args.only:
+        rep = {f'collect_loop_n{n}': {'device_fused_policy' if args.only == 'fused' else 'device': run_device(n, args.steps, 'cuda:0', fused_policy=args.only == 'fused')}
+               for n in args.n}
+    else:
+        rep = {f'collect_loop_n{n}': collect_loop_report(n, args.steps, 'cuda:0') for n in args.n}
     txt = json.dumps(rep, indent=1)
     if args.out:
         with open(args.out, 'w') as f:

@@ -30,4 +30,6 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
     NUMERICS=$nm timeout 250 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/planning_pmc_${nm}_$t -o p -- python tools/microbench/planning_profile.py 8192 10 > $out/planning_pmc_${nm}_$t.log 2>&1 < /dev/null
   done
 done
+# the collect loop with the policy's inference step as one launch (N1): which kernels a collect step is made of
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_collect -o p -- python tools/collect_loop.py --only fused --n 3000 --steps 300 > $out/stats_collect.log 2>&1 < /dev/null
 ls $out

@@ -29,7 +29,7 @@ def main(tag):
         json.dump(json.loads(line), open(os.path.join(dst, f'{tag}_bench.json'), 'w'), indent=1)
     # kernel stats (names truncated so that the csv stays readable)
     for sub, out in (('stats', f'{tag}_kernel_stats.csv'), ('stats_combat', f'{tag}_combat_kernel_stats.csv'),
-                     ('stats_actor', f'{tag}_actor_kernel_stats.csv')):
+                     ('stats_actor', f'{tag}_actor_kernel_stats.csv'), ('stats_collect', f'{tag}_collect_loop_kernel_stats.csv')):
         ks = find(os.path.join(src, sub, '**', '*kernel_stats.csv'))
         if ks:
             rows = list(csv.reader(open(ks)))
