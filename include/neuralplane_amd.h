@@ -390,7 +390,8 @@ int np_rollout_insert(const np_rollout_step *step, int device, void *stream);
  *   way); actions = fl(fl(noise * std) + tanh(mu)), or tanh(mu) with NP_POLICY_DETERMINISTIC (noise may be NULL then);
  *   log_probs [n] = sum over the actions of Normal(mean, std).log_prob(action); values [n]; rnn states [n][128], in != out.
  * flags choose the networks (get_actions = ACTOR | CRITIC; act = ACTOR [| DETERMINISTIC]; get_values = CRITIC); buffers of a network
- * that is not evaluated may be NULL.  Results equal the CPU restatement f16_actor.inc bit for bit and the reference within 2e-5. */
+ * that is not evaluated may be NULL.  Results equal the CPU restatement (f16_actor.inc; f16_actor_i8.inc for the second numerics) bit for
+ * bit and the reference's recording within 2e-5 (measured: actions 1.1e-6 / 3.4e-6, values 1.4e-5 / 2.6e-5, log-probabilities 2e-6). */
 enum { NP_POLICY_ACTOR = 1, NP_POLICY_CRITIC = 2, NP_POLICY_DETERMINISTIC = 4 };
 typedef struct np_policy_step {
     int64_t n;
@@ -399,6 +400,8 @@ typedef struct np_policy_step {
     float std[4], log_std[4];
     const float *obs, *masks, *noise, *rnn_states_actor_in, *rnn_states_critic_in;
     float *values, *actions, *action_log_probs, *rnn_states_actor_out, *rnn_states_critic_out;
+    int64_t weights_floats;   /* what actor_weights / critic_weights hold, each: 0 or NP_ACTOR_NUM_FLOATS = the fp32 chains; NP_ACTOR_I8_NUM_FLOATS =
+                               * np_actor_pack_i8's output: both networks in the block-fixed-point numerics (as np_actor_forward) */
 } np_policy_step;
 int np_policy_act(const np_policy_step *step, int device, void *stream);
 

@@ -280,7 +280,7 @@ __device__ __forceinline__ void relu_acc(float (&v)[T][16]) {
 // T tiles of 32 aircraft, the calling workgroup's waves 0..3 (tid < 256).  xr[t] = the 22 raw observations of this lane's aircraft of tile t;
 // hm[t] = the MASKED recurrent state (gru.py:26) of this lane's 16 features (accumulator layout); returns hn (same layout) and action[t] =
 // tanh(mu) of (aircraft a, output w) in the lanes with h == 0.  tab: the staged tables (actor8_stage_tables).
-template <int T>
+template <int T, bool TANH = true>   // TANH = false: action = mu itself (the policy step's sampled act layer / value head: policy_act_i8_kernel)
 __device__ __forceinline__ void actor8_body(float *lds, float *park, const float *tab, const float *weights, const float (&xr)[T][OBS], const float (&hm)[T][16],
                                             float (&hn)[T][16], float (&action)[T], unsigned tid) {
     const cw_ptr W = (cw_ptr)(unsigned long long)weights;   // wave-uniform reads: scalar loads
@@ -450,7 +450,7 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
         float tot = W[HD_B + w];
         tot = tot + q0.x; tot = tot + q0.y; tot = tot + q0.z; tot = tot + q0.w;
         tot = tot + q1.x; tot = tot + q1.y; tot = tot + q1.z; tot = tot + q1.w;
-        action[t] = act_tanh(tot);
+        action[t] = TANH ? act_tanh(tot) : tot;
     }
 }
 

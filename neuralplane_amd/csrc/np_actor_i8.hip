@@ -9,6 +9,7 @@
 #include "../../include/neuralplane_amd.h"
 #define NPACT_NO_KERNELS 1
 #include "np_actor_i8.h"
+#include "np_policy.h"
 
 namespace npact8 {
 
@@ -34,6 +35,86 @@ hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, 
         set[dev] = true;
     }
     hipLaunchKernelGGL(actor_forward_i8_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), bytes, stream, weights, n, obs, h_in, masks, actions, h_out);
+    return hipGetLastError();
+}
+
+// The rollout policy's inference step (np_policy.hip states the act layer / value head) with both networks in these numerics: one workgroup per
+// (32-row tile, network), grid.y 0 = actor, 1 = critic.
+__global__ __launch_bounds__(256, 2) void policy_act_i8_kernel(const nppol::ActArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned tid = threadIdx.x;
+    const int net = __builtin_amdgcn_readfirstlane(a.first_net + (int)blockIdx.y);
+    const float *weights = a.w[net];
+    const float *h_in = a.h_in[net];
+    float *h_out = a.h_out[net];
+    const long long n = a.n;
+    const int lane = (int)(tid & 63u), row = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const long long i = (long long)blockIdx.x * 32 + row;
+    const bool valid = i < n;
+    const long long ic = valid ? i : n - 1;
+    float hm[1][16], xr[1][OBS], hn[1][16], mu[1];
+    {
+        const float mk = a.mask[ic];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 q = *reinterpret_cast<const float4 *>(h_in + ic * HID + 32 * w + 4 * h + 8 * g);
+            hm[0][4 * g] = q.x * mk; hm[0][4 * g + 1] = q.y * mk; hm[0][4 * g + 2] = q.z * mk; hm[0][4 * g + 3] = q.w * mk;
+        }
+#pragma unroll
+        for (int j = 0; j < OBS; j++) xr[0][j] = a.obs[ic * OBS + j];
+    }
+    float *park = lds + ACTOR8_LDS_FLOATS, *tab = park + ACTOR8_PARK_FLOATS;
+    actor8_stage_tables(tab, weights, tid, 256u);
+    __syncthreads();
+    actor8_body<1, false>(lds, park, tab, weights, xr, hm, hn, mu, tid);   // mu of (row, head column = wave) in the lanes with h == 0
+    if (net == 0) {
+        float *lp = lds + LDS8_PS;   // the LayerNorm exchange: every wave is past its last read (the head's barrier)
+        const int A = a.act_dim;
+        if (h == 0 && w < A) {
+            const float mean = act_tanh(mu[0]);
+            float act = mean;
+            if (!(a.flags & NP_POLICY_DETERMINISTIC)) {
+                const float e = a.noise[ic * A + w] * a.std[w];
+                act = e + mean;
+            }
+            const float d = act - mean;
+            const float q = -(d * d);
+            const float var = a.std[w] * a.std[w];
+            float t = q / (2.0f * var);
+            t = t - a.log_std[w];
+            t = t - 0.9189385f;
+            lp[w * 32 + row] = t;
+            if (valid) a.actions[i * A + w] = act;
+        }
+        __syncthreads();
+        if (w == 0 && h == 0 && valid) {
+            float s = lp[row];
+            for (int j = 1; j < A; j++) s = s + lp[j * 32 + row];
+            a.log_probs[i] = s;
+        }
+    } else if (w == 0 && h == 0 && valid) {
+        a.values[i] = mu[0];
+    }
+    if (valid) {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<float4 *>(h_out + i * HID + 32 * w + 4 * h + 8 * g) = make_float4(hn[0][4 * g], hn[0][4 * g + 1], hn[0][4 * g + 2], hn[0][4 * g + 3]);
+    }
+}
+
+hipError_t launch_policy_act_i8(const nppol::ActArgs &a, hipStream_t stream) {
+    constexpr size_t bytes = sizeof(float) * actor8_tile_lds_floats<1>();
+    static bool set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    if (dev < 64 && !set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void *)policy_act_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        set[dev] = true;
+    }
+    const int nets = ((a.flags & NP_POLICY_ACTOR) ? 1 : 0) + ((a.flags & NP_POLICY_CRITIC) ? 1 : 0);
+    hipLaunchKernelGGL(policy_act_i8_kernel, dim3((unsigned)((a.n + 31) / 32), (unsigned)nets), dim3(256), bytes, stream, a);
     return hipGetLastError();
 }
 

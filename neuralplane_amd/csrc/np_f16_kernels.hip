@@ -1507,6 +1507,8 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
     if (q->flags & ~(NP_POLICY_ACTOR | NP_POLICY_CRITIC | NP_POLICY_DETERMINISTIC)) return fail("np_policy_act: unknown flag");
     if (q->act_dim < 1 || q->act_dim > 4) return fail("np_policy_act: 1 to 4 continuous actions");
     if (q->n < 0) return fail("np_policy_act: bad size");
+    if (q->weights_floats != 0 && q->weights_floats != NP_ACTOR_NUM_FLOATS && q->weights_floats != NP_ACTOR_I8_NUM_FLOATS)
+        return fail("np_policy_act: weights_floats must be 0 / NP_ACTOR_NUM_FLOATS (fp32 chains) or NP_ACTOR_I8_NUM_FLOATS (block fixed point)");
     if (!q->obs || !q->masks) return fail("np_policy_act: null obs / masks");
     if (actor && (!q->actor_weights || !q->rnn_states_actor_in || !q->rnn_states_actor_out || !q->actions || !q->action_log_probs || (!det && !q->noise)))
         return fail("np_policy_act: null actor buffer");
@@ -1537,7 +1539,10 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
         a.std[j] = q->std[j];
         a.log_std[j] = q->log_std[j];
     }
-    NP_HIP(nppol::launch_policy_act(a, (hipStream_t)stream));
+    if (q->weights_floats == NP_ACTOR_I8_NUM_FLOATS)
+        NP_HIP(npact8::launch_policy_act_i8(a, (hipStream_t)stream));
+    else
+        NP_HIP(nppol::launch_policy_act(a, (hipStream_t)stream));
     return 0;
 }
 

@@ -18,3 +18,7 @@ struct ActArgs {
 hipError_t launch_policy_act(const ActArgs &a, hipStream_t stream);
 
 }  // namespace nppol
+
+namespace npact8 {
+hipError_t launch_policy_act_i8(const nppol::ActArgs &a, hipStream_t stream);   // np_actor_i8.hip: both networks in the block-fixed-point numerics
+}

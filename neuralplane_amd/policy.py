@@ -4,7 +4,8 @@ The reference's collect step (runner/F16sim_runner.py:123-129) is `PPOPolicy.get
 (algorithms/ppo/ppo_policy.py:26-32): PPOActor.forward with sampled actions + log-probabilities and PPOCritic.forward, ~110 small torch
 kernels — 0.55-0.60 ms per step, nine tenths of a device-resident collect step (profiles/r05_collect_loop.json).  The training scripts
 build both networks in the frozen controller's shapes (hidden "128 128", act-hidden "128 128", GRU 128 x 1, feature LayerNorm, ReLU;
-22 observations; 4 actions for heading / control, 3 for tracking), so they run through the same matrix-core tile kernel (csrc/np_policy.hip):
+22 observations; 4 actions for heading / control, 3 for tracking), so they run through the controller's matrix-core tile bodies
+(csrc/np_policy.hip: fp32 chains; csrc/np_actor_i8.hip policy_act_i8_kernel: block fixed point on the i8 pipe, the default):
 `FusedPolicy(policy)` packs `policy.actor` / `policy.critic` once and exposes the reference's three inference calls with its signatures
 
     get_actions(obs, rnn_states_actor, rnn_states_critic, masks) -> values, actions, action_log_probs, rnn_states_actor, rnn_states_critic
@@ -22,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .actor import _LAYOUT, _SHAPES, HID, NUM_FLOATS, OBS
+from .actor import _LAYOUT, _SHAPES, HID, NUM_FLOATS, NUM_FLOATS_I8, OBS, pack_i8
 
 MAX_ACT = 4
 _CRITIC_KEYS = {'act.mlp.fc.0': 'mlp.fc.0', 'act.mlp.fc.2': 'mlp.fc.2', 'act.mlp.fc.3': 'mlp.fc.3', 'act.mlp.fc.5': 'mlp.fc.5'}
@@ -93,7 +94,7 @@ class NpPolicyStep(C.Structure):   # include/neuralplane_amd.h: np_policy_step
     _fields_ = [('n', C.c_int64), ('act_dim', C.c_int32), ('flags', C.c_int32), ('actor_weights', C.c_void_p), ('critic_weights', C.c_void_p),
                 ('std', C.c_float * 4), ('log_std', C.c_float * 4), ('obs', C.c_void_p), ('masks', C.c_void_p), ('noise', C.c_void_p),
                 ('rnn_states_actor_in', C.c_void_p), ('rnn_states_critic_in', C.c_void_p), ('values', C.c_void_p), ('actions', C.c_void_p),
-                ('action_log_probs', C.c_void_p), ('rnn_states_actor_out', C.c_void_p), ('rnn_states_critic_out', C.c_void_p)]
+                ('action_log_probs', C.c_void_p), ('rnn_states_actor_out', C.c_void_p), ('rnn_states_critic_out', C.c_void_p), ('weights_floats', C.c_int64)]
 
 
 ACTOR, CRITIC, DETERMINISTIC = 1, 2, 4
@@ -103,7 +104,13 @@ class FusedPolicy:
     """`FusedPolicy(policy)` for an object with `.actor` / `.critic` torch modules of PPOActor's / PPOCritic's structure (the reference's
     PPOPolicy), or `FusedPolicy((actor_state_dict, critic_state_dict))`.  See the module docstring."""
 
-    def __init__(self, policy, device='cuda:0', auto_refresh=False):
+    def __init__(self, policy, device='cuda:0', auto_refresh=False, numerics='i8'):
+        """numerics: 'i8' (default, as PlanningEnv's controller) = block fixed point on the i8 matrix pipe — against the reference's recording actions
+        3.4e-6, values 2.6e-5, log-probabilities 1.9e-6; 22 / 49 / 360 us per get_actions at 3 000 / 10 000 / 100 000 rows; 'fp32' = ordered fmaf chains on the
+        fp32 matrix pipe (actions 1.1e-6, values 1.4e-5; 34 / 83 / 642 us)."""
+        if numerics not in ('fp32', 'i8'):
+            raise ValueError("numerics: 'fp32' or 'i8'")
+        self.numerics = numerics
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -112,8 +119,9 @@ class FusedPolicy:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self._source = policy
         self.auto_refresh = bool(auto_refresh)
-        self.weights = torch.empty((2, NUM_FLOATS), dtype=torch.float32, device=self.device)   # [0] actor, [1] critic; rows are 16-byte aligned
-        assert NUM_FLOATS % 4 == 0 and self.weights.data_ptr() % 16 == 0
+        self.num_floats = NUM_FLOATS_I8 if numerics == 'i8' else NUM_FLOATS
+        self.weights = torch.empty((2, self.num_floats), dtype=torch.float32, device=self.device)   # [0] actor, [1] critic; rows are 16-byte aligned
+        assert self.num_floats % 4 == 0 and self.weights.data_ptr() % 16 == 0
         self._versions = None
         self.refreshes = 0
         self.refresh()
@@ -135,6 +143,8 @@ class FusedPolicy:
         sa, sc = self._state_dicts()
         wa, self.act_dim, log_std = pack_policy_actor(sa)
         wc = pack_policy_critic(sc)
+        if self.numerics == 'i8':   # per-output scales + limb fragments behind the same floats (np_actor_pack_i8, host side)
+            wa, wc = pack_i8(wa), pack_i8(wc)
         self.weights.copy_(torch.from_numpy(np.stack((wa, wc))))
         ls = torch.from_numpy(log_std)
         v = sa['act.action_out.log_std']
@@ -142,7 +152,7 @@ class FusedPolicy:
         std = v.detach().exp().reshape(-1).to(torch.float32).cpu() if hasattr(v, 'detach') else ls.exp()
         self.log_std, self.std = [float(x) for x in ls], [float(x) for x in std]
         q = self._q = NpPolicyStep()
-        q.act_dim = self.act_dim
+        q.act_dim, q.weights_floats = self.act_dim, self.num_floats
         q.actor_weights, q.critic_weights = self.weights[0].data_ptr(), self.weights[1].data_ptr()
         for j in range(self.act_dim):
             q.std[j], q.log_std[j] = self.std[j], self.log_std[j]

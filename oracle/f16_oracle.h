@@ -180,6 +180,11 @@ void f16o_policy_act(const float *wa, const float *wc, const float *std, const f
                      const float *obs, const float *ha_in, const float *hc_in, const float *mask, const float *noise, float *values,
                      float *actions, float *log_probs, float *ha_out, float *hc_out);
 
+/* the same with both networks in the controller's block-fixed-point numerics (f16_actor_i8.inc); returns non-zero when out of memory */
+int f16o_policy_act_i8(const float *wa, const float *wc, const float *std, const float *log_std, int64_t n, int act_dim, int flags,
+                       const float *obs, const float *ha_in, const float *hc_in, const float *mask, const float *noise, float *values,
+                       float *actions, float *log_probs, float *ha_out, float *hc_out);
+
 /* ReplayBuffer.compute_returns (f16_rollout.inc; reference algorithms/utils/buffer.py:139-173): rewards [T][N], value_preds / masks /
  * bad_masks / returns [T+1][N], next_value [N]; GAE modes write value_preds[T], the others returns[T] */
 void f16o_rollout_returns(int64_t T, int64_t N, double gamma, double gae_lambda, int use_gae, int proper, const float *rewards,

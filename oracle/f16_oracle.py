@@ -436,11 +436,14 @@ class ActorOracle:
 
 class PolicyOracle:
     """PPOPolicy.get_actions / get_values / act (algorithms/ppo/ppo_policy.py:26-57) for two packed networks (f16_actor.inc,
-    f16o_policy_act): `actor_w`, `critic_w` as neuralplane_amd.policy packs them, std / log_std [act_dim] float32."""
+    f16o_policy_act; numerics='i8': f16_actor_i8.inc, f16o_policy_act_i8): `actor_w`, `critic_w` as neuralplane_amd.policy packs them,
+    std / log_std [act_dim] float32."""
     ACTOR, CRITIC, DETERMINISTIC = 1, 2, 4
 
-    def __init__(self, actor_w, critic_w, std, log_std):
+    def __init__(self, actor_w, critic_w, std, log_std, numerics='fp32'):
         self.lib = C.CDLL(build())
+        assert numerics in ('fp32', 'i8'), numerics
+        self.numerics = numerics
         self.wa, self.wc = _f32(actor_w).reshape(-1), _f32(critic_w).reshape(-1)
         assert self.wa.size == self.wc.size == self.lib.f16o_actor_num_floats()
         self.std, self.log_std = _f32(std).reshape(-1), _f32(log_std).reshape(-1)
@@ -454,8 +457,10 @@ class PolicyOracle:
         noise = np.zeros((n, A), np.float32) if noise is None else _f32(noise).reshape(n, A)
         values, actions, logp = np.zeros((n, 1), np.float32), np.zeros((n, A), np.float32), np.zeros((n, 1), np.float32)
         ha_out, hc_out = ha.copy(), hc.copy()
-        self.lib.f16o_policy_act(_p(self.wa), _p(self.wc), _p(self.std), _p(self.log_std), C.c_int64(n), C.c_int(A), C.c_int(flags), _p(obs), _p(ha),
-                                 _p(hc), _p(m), _p(noise), _p(values), _p(actions), _p(logp), _p(ha_out), _p(hc_out))
+        fn = self.lib.f16o_policy_act_i8 if self.numerics == 'i8' else self.lib.f16o_policy_act
+        rc = fn(_p(self.wa), _p(self.wc), _p(self.std), _p(self.log_std), C.c_int64(n), C.c_int(A), C.c_int(flags), _p(obs), _p(ha),
+                _p(hc), _p(m), _p(noise), _p(values), _p(actions), _p(logp), _p(ha_out), _p(hc_out))
+        assert self.numerics == 'fp32' or rc == 0
         return values, actions, logp, ha_out, hc_out
 
 

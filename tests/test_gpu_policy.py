@@ -19,25 +19,26 @@ def _t(x, dev='cuda:0'):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
-def _setup(golden_dir, act_dim):
+def _setup(golden_dir, act_dim, numerics='fp32'):
     from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
     from oracle.f16_oracle import PolicyOracle
     from tests.policy_kat import load
     g, sa, sc = load(golden_dir, act_dim)
-    fp = FusedPolicy((sa, sc), device='cuda:0')
+    fp = FusedPolicy((sa, sc), device='cuda:0', numerics=numerics)
     wa, A, _ = pack_policy_actor(sa)
-    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std))
+    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std), numerics)
     assert A == act_dim == fp.act_dim and same(np.float32(fp.std), g['std']) and same(np.float32(fp.log_std), g['log_std'])
     return g, sa, sc, fp, o
 
 
+@pytest.mark.parametrize('numerics', ['fp32', 'i8'])
 @pytest.mark.parametrize('act_dim', [4, 3])
-def test_get_actions_equals_the_restatement_bit_for_bit_and_the_reference_recording(golden_dir, act_dim):
+def test_get_actions_equals_the_restatement_bit_for_bit_and_the_reference_recording(golden_dir, act_dim, numerics):
     """Five chained get_actions calls on the recorded inputs and normal draws (recurrent states fed back on the device): every output equals
-    the restatement's bit for bit and the REFERENCE's recording within the bounds of tests/policy_kat.py; act(deterministic=True) and
-    get_values are the same launch with one network."""
+    the restatement's bit for bit (both numerics: the fp32 chains, f16_actor.inc, and the block fixed point, f16_actor_i8.inc) and the
+    REFERENCE's recording within the bounds of tests/policy_kat.py; act(deterministic=True) and get_values are the same launch with one network."""
     from tests.policy_kat import check_step
-    g, _, _, fp, o = _setup(golden_dir, act_dim)
+    g, _, _, fp, o = _setup(golden_dir, act_dim, numerics)
     n = g['obs'].shape[1]
     ha = hc = torch.zeros((n, 1, 128), device='cuda:0')
     ha_o = hc_o = np.zeros((n, 128), np.float32)
@@ -59,10 +60,11 @@ def test_get_actions_equals_the_restatement_bit_for_bit_and_the_reference_record
         check_step(g, t, values.cpu().numpy(), actions.cpu().numpy(), logp.cpu().numpy(), ha.cpu().numpy(), hc.cpu().numpy())
 
 
+@pytest.mark.parametrize('numerics', ['fp32', 'i8'])
 @pytest.mark.parametrize('n', [1, 31, 33, 1000, 20001])
-def test_ragged_batches_and_wild_inputs_equal_the_restatement(golden_dir, n):
+def test_ragged_batches_and_wild_inputs_equal_the_restatement(golden_dir, n, numerics):
     """Batch sizes around the 32-row tile, large observations, |h| > 1, masked rows."""
-    g, _, _, fp, o = _setup(golden_dir, 4)
+    g, _, _, fp, o = _setup(golden_dir, 4, numerics)
     rng = np.random.RandomState(n)
     obs = (rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 30, (1, 22))).astype(np.float32)
     ha, hc = rng.normal(0, 0.7, (n, 128)).astype(np.float32), rng.normal(0, 0.7, (n, 128)).astype(np.float32)
@@ -174,7 +176,8 @@ def test_policy_act_argument_errors(golden_dir):
         FusedPolicy(fp._source, device='cpu')
 
 
-def test_fused_policy_against_a_torch_module_of_the_same_weights_on_the_gpu():
+@pytest.mark.parametrize('numerics', ['fp32', 'i8'])
+def test_fused_policy_against_a_torch_module_of_the_same_weights_on_the_gpu(numerics):
     """tools/collect_loop.py's torch policy (the PPO actor-critic shape, eager torch on this GPU) and FusedPolicy of its parameters agree on
     the same draws to rounding: actions 2e-5, values 1e-4, log-probabilities 5e-5 (rocBLAS GEMMs / ATen kernels vs the ordered chains)."""
     import os
@@ -187,7 +190,7 @@ def test_fused_policy_against_a_torch_module_of_the_same_weights_on_the_gpu():
     with torch.no_grad():
         tp.logstd.add_(-0.5)
         tp.actor.head.weight.mul_(3.0)
-    fp = FusedPolicy(tp.state_dicts(), 'cuda:0')
+    fp = FusedPolicy(tp.state_dicts(), 'cuda:0', numerics=numerics)
     n = 3000
     obs = torch.randn((n, 22), device='cuda:0') * 2
     ha, hc = torch.randn((n, 128), device='cuda:0') * 0.5, torch.randn((n, 128), device='cuda:0') * 0.5

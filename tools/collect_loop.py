@@ -140,7 +140,7 @@ class _Phases:
         self.ev = []
 
 
-def run_device(n, T, dev, graph=False, task='heading', fused_policy=False):
+def run_device(n, T, dev, graph=False, task='heading', fused_policy=False, policy_numerics='fp32'):
     from neuralplane_amd.buffer import DeviceReplayBuffer
     from neuralplane_amd.envs.control_env import ControlEnv
     from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
@@ -148,7 +148,7 @@ def run_device(n, T, dev, graph=False, task='heading', fused_policy=False):
     policy = TorchPolicy(act_dim=3 if task == 'tracking' else 4).to(dev).eval()
     if fused_policy:   # the same networks through neuralplane_amd.policy.FusedPolicy: one launch per get_actions (np_policy_act)
         from neuralplane_amd.policy import FusedPolicy
-        policy = FusedPolicy(policy.state_dicts(), device=dev)
+        policy = FusedPolicy(policy.state_dicts(), device=dev, numerics=policy_numerics)
     if task == 'tracking':
         # scripts/train_tracking.sh: PlanningEnv (one high-level action = 50 x {frozen controller, FDM step}); the controller's checkpoint is
         # not part of the reference snapshot: random weights of its architecture, run by the persistent kernel
@@ -327,6 +327,8 @@ def collect_loop_report(n, T, dev):
     rep['device_fused_policy'] = run_device(n, T, dev, fused_policy=True)
     rep['device_fused_policy_graph'] = run_device(n, T, dev, graph=True, fused_policy=True)
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
+    rep['device_fused_policy_i8'] = run_device(n, T, dev, fused_policy=True, policy_numerics='i8')   # both networks in the block-fixed-point numerics
+    rep['device_fused_policy_i8']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy_i8']['us_per_step_wall']
     if n == 10000:
         # the configuration the reference runs 10 000 rollout threads on (scripts/train_tracking.sh): PlanningEnv macro-steps, a 3-action policy
         Tt = max(10, T // 10)

@@ -33,7 +33,8 @@ def main():
     sizes = [int(x) for x in sys.argv[1:]] or [1000, 3000, 8192, 10000, 16384, 32768, 100000]
     torch.manual_seed(0)
     tp = TorchPolicy().to(dev).eval()
-    fp = FusedPolicy(tp.state_dicts(), dev)
+    fp = FusedPolicy(tp.state_dicts(), dev, numerics='fp32')
+    f8 = FusedPolicy(tp.state_dicts(), dev, numerics='i8')
     for n in sizes:
         obs = torch.randn((n, 22), device=dev)
         ha, hc = torch.randn((n, 128), device=dev) * 0.3, torch.randn((n, 128), device=dev) * 0.3
@@ -42,8 +43,10 @@ def main():
         g_f, h_f = timed(lambda: fp.get_actions(obs, ha, hc, m), 200)
         g_n, h_n = timed(lambda: fp.get_actions(obs, ha, hc, m, noise=eps), 200)
         g_v, _ = timed(lambda: fp.get_values(obs, hc, m), 200)
+        g_8, _ = timed(lambda: f8.get_actions(obs, ha, hc, m, noise=eps), 200)
+        g_v8, _ = timed(lambda: f8.get_values(obs, hc, m), 200)
         g_t, h_t = timed(lambda: tp.get_actions(obs, ha, hc, m), 50)
-        print(f'n = {n:7d}: get_actions {g_f:7.1f} us GPU / {h_f:5.1f} us host enqueue (given noise: {g_n:7.1f} / {h_n:5.1f}); get_values {g_v:6.1f} us; '
+        print(f'n = {n:7d}: get_actions {g_f:7.1f} us GPU / {h_f:5.1f} us host enqueue fp32 chains (given noise: {g_n:7.1f} / {h_n:5.1f}; i8 numerics {g_8:7.1f}); get_values {g_v:6.1f} us (i8 {g_v8:6.1f}); '
               f'eager torch {g_t:7.1f} us GPU / {h_t:6.1f} us host   -> {g_t / g_f:4.1f} x', flush=True)
 
 
