@@ -201,3 +201,20 @@ def test_fused_policy_against_a_torch_module_of_the_same_weights_on_the_gpu(nume
     v_f, a_f, lp_f, ha_f, hc_f = fp.get_actions(obs, ha, hc, m)
     assert float((a_t - a_f).abs().max()) < 2e-5 and float((v_t - v_f).abs().max()) < 1e-4 and float((lp_t - lp_f).abs().max()) < 5e-5
     assert float((ha_t - ha_f.reshape(n, 128)).abs().max()) < 5e-5 and float((hc_t - hc_f.reshape(n, 128)).abs().max()) < 5e-5
+
+
+def test_numpy_inputs_as_the_reference_runner_passes_them(golden_dir):
+    """F16SimRunner.collect hands PPOPolicy.get_actions numpy arrays (np.concatenate of the buffer's slices, runner/F16sim_runner.py:125-128) and
+    converts the returned tensors with _t2n: FusedPolicy takes the same arrays ([n, 1, 128] recurrent states, [n, 1] masks) and returns tensors."""
+    g, _, _, fp, _ = _setup(golden_dir, 4, 'i8')
+    n = g['obs'].shape[1]
+    ha, hc = np.zeros((n, 1, 128), np.float32), np.zeros((n, 1, 128), np.float32)
+    eps = _t(g['eps'][0])
+    out_np = fp.get_actions(g['obs'][0], ha, hc, g['masks'][0], noise=eps)
+    out_t = fp.get_actions(_t(g['obs'][0]), _t(ha), _t(hc), _t(g['masks'][0]), noise=eps)
+    assert all(isinstance(x, torch.Tensor) and x.is_cuda for x in out_np)
+    assert all(torch.equal(x, y) for x, y in zip(out_np, out_t))
+    v = fp.get_values(g['obs'][0].astype(np.float64), hc, g['masks'][0])      # other dtypes are converted
+    assert torch.equal(v, out_t[0])
+    a, h = fp.act(g['obs'][0], ha, g['masks'][0], deterministic=True)
+    assert a.shape == (n, 4) and h.shape == (n, 1, 128)

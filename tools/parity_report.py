@@ -305,6 +305,44 @@ def planning_closed_report(engine):
             'bounds': 'masks / counters equal; states 1e-4 (SURVEY floors), recurrent state 5e-5 (absolute), low-level actions 2e-5', 'at': rows}
 
 
+def policy_report(engine):
+    """The rollout policy's inference step: the reference's PPOPolicy.get_actions recorded over five chained calls
+    (tests/golden/policy_kat.npz, tools/gen_golden.py::gen_policy; 4- and 3-action policies, the normal draws stored) against the engine
+    fed the same inputs and draws, recurrent states chained on the engine's side; both numerics."""
+    from neuralplane_amd.policy import pack_policy_actor, pack_policy_critic
+    from tests.policy_kat import load
+    rows = []
+    for act_dim in (4, 3):
+        g, sa, sc = load(GOLDEN, act_dim)
+        for numerics in ('fp32', 'i8'):
+            n = g['obs'].shape[1]
+            if engine == 'hip':
+                import torch
+                from neuralplane_amd.policy import FusedPolicy
+                fp = FusedPolicy((sa, sc), 'cuda:0', numerics=numerics)
+                ha = hc = torch.zeros((n, 1, 128), device='cuda:0')
+            else:
+                from oracle.f16_oracle import PolicyOracle
+                o = PolicyOracle(pack_policy_actor(sa)[0], pack_policy_critic(sc), g['std'], g['log_std'], numerics)
+                ha = hc = np.zeros((n, 128), np.float32)
+            worst = {'actions': 0.0, 'values': 0.0, 'log_probs': 0.0, 'rnn_states': 0.0}
+            for t in range(g['obs'].shape[0]):
+                if engine == 'hip':
+                    v, a, lp, ha, hc = fp.get_actions(torch.from_numpy(g['obs'][t]).cuda(), ha, hc, torch.from_numpy(g['masks'][t]).cuda(),
+                                                      noise=torch.from_numpy(g['eps'][t]).cuda())
+                    vn, an, lpn, han, hcn = (x.cpu().numpy() for x in (v, a, lp, ha, hc))
+                else:
+                    vn, an, lpn, ha, hc = o.run(g['obs'][t], ha, hc, g['masks'][t], g['eps'][t])
+                    han, hcn = ha, hc
+                e = {'actions': np.abs(an - g['actions'][t]).max(), 'values': np.abs(vn.reshape(-1) - g['values'][t].reshape(-1)).max(),
+                     'log_probs': np.abs(lpn.reshape(-1) - g['logp'][t].reshape(-1)).max(),
+                     'rnn_states': max(np.abs(han.reshape(n, 128) - g['ha'][t][:, 0]).max(), np.abs(hcn.reshape(n, 128) - g['hc'][t][:, 0]).max())}
+                worst = {k: max(worst[k], float(x)) for k, x in e.items()}
+            rows.append(dict({'act_dim': act_dim, 'numerics': numerics, 'chained_calls': int(g['obs'].shape[0]), 'rows': int(n)}, **{'max_abs_err_' + k: x for k, x in worst.items()}))
+    return {'fixture': 'tests/golden/policy_kat.npz (reference PPOPolicy.get_actions, five chained calls, sampled actions from stored normal draws)',
+            'bounds': {'actions': 2e-5, 'values': 1e-4, 'log_probs': 5e-5, 'rnn_states': 5e-5}, 'cases': rows}
+
+
 def combat_report(engine):
     """SingleCombat 1v1: the recorded env.steps of tests/golden/combat_kat.npz (the reference's components driven in
     the order of the stale singlecombat_env.step, plain ATen arithmetic), teacher-forced per env.step (5 FDM steps behind the
@@ -383,7 +421,8 @@ def build(engine):
                                              'reset draws injected, observation noise off',
             'metric': 'per aircraft max_k |x_k - ref_k| / max(|ref_k|, floor_k); aircraft that left the reference episode schedule excluded',
             'trajectories': [trajectory_report(cls, *t) for t in TRAJ], 'closed_loop': closed_loop_report(cls), 'recorded_episode': recorded_episode_report(cls),
-            'planning_env': planning_report(engine), 'planning_env_closed_loop': planning_closed_report(engine), 'single_combat': combat_report(engine)}
+            'planning_env': planning_report(engine), 'planning_env_closed_loop': planning_closed_report(engine), 'single_combat': combat_report(engine),
+            'rollout_policy': policy_report(engine)}
 
 
 def main():
