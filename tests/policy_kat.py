@@ -23,3 +23,23 @@ def check_step(g, t, values, actions, logp, ha, hc):
     for k, v in err.items():
         assert v < TOL[k], (t, k, float(v))
     return err
+
+
+def random_state_dicts(act_dim, seed, scale=1.0):
+    """(actor, critic) numpy state_dicts with PPOActor's / PPOCritic's keys and shapes, every parameter random (LayerNorm terms included)."""
+    rng = np.random.RandomState(seed)
+
+    def trunk(mlp):
+        sd = {'base.feature_norm.weight': 1 + 0.3 * rng.normal(size=22), 'base.feature_norm.bias': 0.2 * rng.normal(size=22)}
+        for name, (o, i) in (('base.mlp.fc.0', (128, 22)), ('base.mlp.fc.3', (128, 128)), (mlp + '.fc.0', (128, 128)), (mlp + '.fc.3', (128, 128))):
+            sd[name + '.weight'], sd[name + '.bias'] = scale * rng.normal(size=(o, i)) / np.sqrt(i), 0.1 * rng.normal(size=o)
+        for name in ('base.mlp.fc.2', 'base.mlp.fc.5', 'rnn.norm', mlp + '.fc.2', mlp + '.fc.5'):
+            sd[name + '.weight'], sd[name + '.bias'] = 1 + 0.3 * rng.normal(size=128), 0.2 * rng.normal(size=128)
+        for k in ('ih', 'hh'):
+            sd[f'rnn.gru.weight_{k}_l0'], sd[f'rnn.gru.bias_{k}_l0'] = scale * rng.normal(size=(384, 128)) / np.sqrt(128), 0.1 * rng.normal(size=384)
+        return sd
+    actor, critic = trunk('act.mlp'), trunk('mlp')
+    actor['act.action_out.mu_net.fc.0.weight'], actor['act.action_out.mu_net.fc.0.bias'] = 0.2 * rng.normal(size=(act_dim, 128)), 0.1 * rng.normal(size=act_dim)
+    actor['act.action_out.log_std'] = rng.uniform(-2.0, 0.5, act_dim)
+    critic['value_out.weight'], critic['value_out.bias'] = 0.5 * rng.normal(size=(1, 128)), 0.3 * rng.normal(size=1)
+    return ({k: np.asarray(v, np.float32) for k, v in actor.items()}, {k: np.asarray(v, np.float32) for k, v in critic.items()})

@@ -218,3 +218,31 @@ def test_numpy_inputs_as_the_reference_runner_passes_them(golden_dir):
     assert torch.equal(v, out_t[0])
     a, h = fp.act(g['obs'][0], ha, g['masks'][0], deterministic=True)
     assert a.shape == (n, 4) and h.shape == (n, 1, 128)
+
+
+@pytest.mark.parametrize('numerics', ['fp32', 'i8'])
+@pytest.mark.parametrize('act_dim,scale', [(1, 1.0), (2, 0.05), (3, 8.0), (4, 1.0)])
+def test_one_to_four_actions_and_weight_scales_equal_the_restatement(act_dim, scale, numerics):
+    """Random networks (every parameter random; weight scales 0.05 … 8, so the i8 path sees small and large exponents), 1 … 4 actions, three chained
+    steps at a ragged size: every output equals the restatement bit for bit."""
+    from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
+    from oracle.f16_oracle import PolicyOracle
+    from tests.policy_kat import random_state_dicts
+    sa, sc = random_state_dicts(act_dim, 100 * act_dim + (numerics == 'i8'), scale)
+    fp = FusedPolicy((sa, sc), 'cuda:0', numerics=numerics)
+    wa, A, _ = pack_policy_actor(sa)
+    assert A == act_dim
+    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std), numerics)
+    n = 777
+    rng = np.random.RandomState(act_dim)
+    ha = hc = np.zeros((n, 128), np.float32)
+    dha = dhc = torch.zeros((n, 1, 128), device='cuda:0')
+    for t in range(3):
+        obs = (rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 5, (1, 22))).astype(np.float32)
+        mk = (rng.uniform(0, 1, (n, 1)) > 0.1).astype(np.float32)
+        eps = rng.normal(0, 1, (n, act_dim)).astype(np.float32)
+        v, a, lp, dha, dhc = fp.get_actions(_t(obs), dha, dhc, _t(mk), noise=_t(eps))
+        v_o, a_o, lp_o, ha, hc = o.run(obs, ha, hc, mk, eps)
+        assert same(v.cpu().numpy(), v_o) and same(a.cpu().numpy(), a_o) and same(lp.cpu().numpy(), lp_o), t
+        assert same(dha.cpu().numpy()[:, 0], ha) and same(dhc.cpu().numpy()[:, 0], hc), t
+        assert np.all(np.isfinite(lp_o)) and np.all(np.isfinite(v_o))
