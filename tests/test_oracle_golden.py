@@ -663,3 +663,52 @@ def test_policy_packers_reject_other_architectures(golden_dir):
     bad['base.mlp.fc.0.weight'] = np.zeros((64, 22), np.float32)
     with pytest.raises(ValueError):
         pack_policy_actor(bad)
+
+
+def test_policy_numerics_against_a_float64_evaluation_of_the_same_networks():
+    """Both numerics specs of the policy step against numpy float64 (random networks, every parameter random — rows ~1.6 times the norm of the
+    reference's initialisation, |value| up to ~20): the fp32 chains sit at fp32 rounding (means 4.8e-6, values 1.3e-5, recurrent state 1.1e-6), the
+    block fixed point at four times that (1.9e-5, 5.7e-5, 4.8e-6: 22-bit activations) — independent of the reference, so it also says what to
+    expect for networks no fixture covers.  With weight rows eight times larger: fp32 2.3e-5 / 6.2e-5 / 1.0e-5, i8 2.8e-5 / 1.0e-4 / 4.0e-5."""
+    from neuralplane_amd.policy import pack_policy_actor, pack_policy_critic
+    from oracle.f16_oracle import PolicyOracle
+    from tests.policy_kat import random_state_dicts
+
+    def ln(x, g, b):
+        m = x.mean(-1, keepdims=True)
+        return (x - m) / np.sqrt(((x - m) ** 2).mean(-1, keepdims=True) + 1e-5) * g + b
+
+    def fwd64(sd, mlp, obs, h, head):
+        f = lambda k: sd[k].astype(np.float64)                                                                        # noqa: E731
+        lin = lambda x, k: x @ f(k + '.weight').T + f(k + '.bias')                                                   # noqa: E731
+        x = ln(obs.astype(np.float64), f('base.feature_norm.weight'), f('base.feature_norm.bias'))
+        x = ln(np.maximum(lin(x, 'base.mlp.fc.0'), 0), f('base.mlp.fc.2.weight'), f('base.mlp.fc.2.bias'))
+        x = ln(np.maximum(lin(x, 'base.mlp.fc.3'), 0), f('base.mlp.fc.5.weight'), f('base.mlp.fc.5.bias'))
+        hm = h.astype(np.float64)
+        gi = x @ f('rnn.gru.weight_ih_l0').T + f('rnn.gru.bias_ih_l0')
+        gh = hm @ f('rnn.gru.weight_hh_l0').T + f('rnn.gru.bias_hh_l0')
+        sig = lambda z: 1 / (1 + np.exp(-z))                                                                         # noqa: E731
+        r, z = sig(gi[:, :128] + gh[:, :128]), sig(gi[:, 128:256] + gh[:, 128:256])
+        nn = np.tanh(gi[:, 256:] + r * gh[:, 256:])
+        hn = (hm - nn) * z + nn
+        x = ln(hn, f('rnn.norm.weight'), f('rnn.norm.bias'))
+        x = ln(np.maximum(lin(x, mlp + '.fc.0'), 0), f(mlp + '.fc.2.weight'), f(mlp + '.fc.2.bias'))
+        x = ln(np.maximum(lin(x, mlp + '.fc.3'), 0), f(mlp + '.fc.5.weight'), f(mlp + '.fc.5.bias'))
+        return lin(x, head), hn
+
+    for scale, bound in ((1.0, {'fp32': (1.2e-5, 3e-5, 3e-6), 'i8': (5e-5, 1.4e-4, 1.2e-5)}), (8.0, {'fp32': (6e-5, 1.5e-4, 3e-5), 'i8': (8e-5, 3e-4, 1e-4)})):
+        sa, sc = random_state_dicts(4, 11, scale)
+        wa, _, ls = pack_policy_actor(sa)
+        std = np.exp(ls).astype(np.float32)
+        rng = np.random.RandomState(5)
+        n = 400
+        obs = (rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 5, (1, 22))).astype(np.float32)
+        h0 = rng.normal(0, 0.5, (n, 128)).astype(np.float32)
+        mu, hn = fwd64(sa, 'act.mlp', obs, h0, 'act.action_out.mu_net.fc.0')
+        v64, _ = fwd64(sc, 'mlp', obs, h0, 'value_out')
+        for numerics, (b_mean, b_val, b_rnn) in bound.items():
+            o = PolicyOracle(wa, pack_policy_critic(sc), std, ls, numerics)
+            v, a, _, ha, _ = o.run(obs, h0, h0, np.ones(n, np.float32), flags=o.ACTOR | o.CRITIC | o.DETERMINISTIC)
+            e = (np.abs(a - np.tanh(mu)).max(), np.abs(v - v64).max(), np.abs(ha - hn).max())
+            print('policy vs float64', scale, numerics, [float(x) for x in e])
+            assert e[0] < b_mean and e[1] < b_val and e[2] < b_rnn, (scale, numerics, e)
