@@ -382,7 +382,8 @@ int np_rollout_insert(const np_rollout_step *step, int device, void *stream);
  * F16SimRunner.collect, runner/F16sim_runner.py:123-129): PPOActor.forward with sampled actions and their log-probabilities
  * (ppo_actor.py:38-64, act.py:56-101, distributions.py:36-44,77-101) and PPOCritic.forward (ppo_critic.py:38-50) on the same observation,
  * as ONE launch (the reference: ~110 small torch kernels per step).  For the networks the training scripts build (scripts/train_heading.sh:17,
- * train_tracking.sh:17: hidden "128 128", act-hidden "128 128", GRU 128 x 1, feature normalisation, ReLU) on 22 observations with 1..4
+ * train_tracking.sh:17: hidden "128 128", act-hidden "128 128", GRU 128 x 1, feature normalisation, ReLU — config.py's defaults) on 22
+ * observations (15 for the 1v1 combat env's policies, runner/selfplay_F16sim_runner.py:76-100: np_policy_step.obs_dim) with 1..4
  * continuous actions — the frozen controller's shapes, so both networks travel in np_actor_forward's packed layout (NP_ACTOR_NUM_FLOATS
  * floats each, 16-byte aligned; a head narrower than four columns is zero-padded; the critic's value_out is column 0 of its head block:
  * neuralplane_amd/policy.py packs both from the state_dicts).  std = exp(log_std) and log_std [act_dim] are host values.
@@ -402,6 +403,9 @@ typedef struct np_policy_step {
     float *values, *actions, *action_log_probs, *rnn_states_actor_out, *rnn_states_critic_out;
     int64_t weights_floats;   /* what actor_weights / critic_weights hold, each: 0 or NP_ACTOR_NUM_FLOATS = the fp32 chains; NP_ACTOR_I8_NUM_FLOATS =
                                * np_actor_pack_i8's output: both networks in the block-fixed-point numerics (as np_actor_forward) */
+    int32_t obs_dim;          /* observations per row: 0 or 22 (control / heading / tracking: envs/configs/*.yaml num_observation), or 15 (the 1v1 combat
+                               * env, selfplay.yaml) — obs is [n][obs_dim]; the packed layout is the same, the first layer's rows >= obs_dim are zero */
+    int32_t reserved_;
 } np_policy_step;
 int np_policy_act(const np_policy_step *step, int device, void *stream);
 

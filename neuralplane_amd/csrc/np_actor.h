@@ -629,7 +629,9 @@ __device__ __forceinline__ void actor32_stage_head(float *lds, const float *weig
     if (tid < HID) reinterpret_cast<float4 *>(head_w)[tid] = reinterpret_cast<const float4 *>(weights + HD_W)[tid];
 }
 
-template <bool TANH = true>   // false: `action` = mu itself (np_policy.hip: the critic's value head, the sampled actor's epilogue)
+// TANH = false: `action` = mu itself (np_policy.hip: the critic's value head, the sampled actor's epilogue); NOBS < 22: a network on fewer
+// observations (the 1v1 combat policy's 15) in the same packed layout — xr[j >= NOBS] and the first layer's rows k >= NOBS are not read
+template <bool TANH = true, int NOBS = OBS>
 __device__ __forceinline__ void actor32_body(float *lds, const float *weights, const Actor32Pre &pre, const float (&xr)[OBS], const float (&hm)[BLK],
                                              float (&hn)[BLK], float &action, unsigned tid) {
     float *bufA = lds, *bufB = lds + HID * T32;
@@ -644,27 +646,28 @@ __device__ __forceinline__ void actor32_body(float *lds, const float *weights, c
     const int blk = 2 * wave + hi;       // row role: features [16 blk, 16 blk + 16) of row `row`
     // base.feature_norm (two blocks: 16 + 6) -> bufB rows 0..21; every thread computes its row's, block 0 stores it
     {
+        constexpr int N0 = NOBS < 16 ? NOBS : 16;   // the first block of 16 (or fewer) features
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 16; j++) s0 = s0 + xr[j];
+        for (int j = 0; j < N0; j++) s0 = s0 + xr[j];
 #pragma unroll
-        for (int j = 16; j < OBS; j++) s1 = s1 + xr[j];
-        const float mean = ((0.0f + s0) + s1) / (float)OBS;
+        for (int j = 16; j < NOBS; j++) s1 = s1 + xr[j];
+        const float mean = ((0.0f + s0) + s1) / (float)NOBS;
         float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < N0; j++) {
             const float d = xr[j] - mean;
             q0 = fmaf(d, d, q0);
         }
 #pragma unroll
-        for (int j = 16; j < OBS; j++) {
+        for (int j = 16; j < NOBS; j++) {
             const float d = xr[j] - mean;
             q1 = fmaf(d, d, q1);
         }
-        const float rstd = 1.0f / sqrtf(((0.0f + q0) + q1) / (float)OBS + 1e-5f);
+        const float rstd = 1.0f / sqrtf(((0.0f + q0) + q1) / (float)NOBS + 1e-5f);
         if (blk == 0) {
 #pragma unroll
-            for (int j = 0; j < OBS; j++) bufB[j * T32 + row] = fmaf((xr[j] - mean) * rstd, W[LN0_G + j], W[LN0_B + j]);
+            for (int j = 0; j < NOBS; j++) bufB[j * T32 + row] = fmaf((xr[j] - mean) * rstd, W[LN0_G + j], W[LN0_B + j]);
         }
     }
     float pa[33];
@@ -679,7 +682,7 @@ __device__ __forceinline__ void actor32_body(float *lds, const float *weights, c
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
     acc = __builtin_amdgcn_mfma_f32_16x16x1f32(pre.b1, 1.0f, acc, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < OBS; k++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(pre.a1[k], bufB[k * T32 + row], acc, 0, 0, 0);
+    for (int k = 0; k < NOBS; k++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(pre.a1[k], bufB[k * T32 + row], acc, 0, 0, 0);
     store_transposed16<true>(acc, bufA, f0, l16, g4);
     __syncthreads();
     NPACT_STAMP(2);

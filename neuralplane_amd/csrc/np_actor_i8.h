@@ -280,7 +280,9 @@ __device__ __forceinline__ void relu_acc(float (&v)[T][16]) {
 // T tiles of 32 aircraft, the calling workgroup's waves 0..3 (tid < 256).  xr[t] = the 22 raw observations of this lane's aircraft of tile t;
 // hm[t] = the MASKED recurrent state (gru.py:26) of this lane's 16 features (accumulator layout); returns hn (same layout) and action[t] =
 // tanh(mu) of (aircraft a, output w) in the lanes with h == 0.  tab: the staged tables (actor8_stage_tables).
-template <int T, bool TANH = true>   // TANH = false: action = mu itself (the policy step's sampled act layer / value head: policy_act_i8_kernel)
+// TANH = false: action = mu itself (the policy step's sampled act layer / value head: policy_act_i8_kernel); NOBS < 22: a network on fewer observations
+// in the same packed layout (xr[.][j >= NOBS] is not read; the first layer's k-slots of features >= NOBS are zero on both sides)
+template <int T, bool TANH = true, int NOBS = OBS>
 __device__ __forceinline__ void actor8_body(float *lds, float *park, const float *tab, const float *weights, const float (&xr)[T][OBS], const float (&hm)[T][16],
                                             float (&hn)[T][16], float (&action)[T], unsigned tid) {
     const cw_ptr W = (cw_ptr)(unsigned long long)weights;   // wave-uniform reads: scalar loads
@@ -313,22 +315,22 @@ __device__ __forceinline__ void actor8_body(float *lds, float *park, const float
     for (int t = 0; t < T; t++) {
         float total = 0.0f;
 #pragma unroll
-        for (int j = 0; j < OBS; j++) total = total + xr[t][j];
-        const float mean = total * (1.0f / (float)OBS);
-        float d[OBS], q = 0.0f, m = 0.0f;
+        for (int j = 0; j < NOBS; j++) total = total + xr[t][j];
+        const float mean = total * (1.0f / (float)NOBS);
+        float d[NOBS], q = 0.0f, m = 0.0f;
 #pragma unroll
-        for (int j = 0; j < OBS; j++) {
+        for (int j = 0; j < NOBS; j++) {
             d[j] = xr[t][j] - mean;
             q = fmaf(d[j], d[j], q);
             m = fmaxf(m, fabsf(d[j]));
         }
-        const float rstd = 1.0f / sqrtf(q * (1.0f / (float)OBS) + 1e-5f);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / (float)NOBS) + 1e-5f);
         ex[t] = exponent_of(fmaf(m * rstd, W[LNMAX + 0], W[LNMAX + 1]) * 1.000001f);
         const float scale = pow2f(XBITS - ex[t]), magic = __uint_as_float(MAGIC_BITS);
         unsigned p[32];
 #pragma unroll
         for (int j = 0; j < 32; j++) {
-            if (j < OBS) {
+            if (j < NOBS) {
                 const float yy = fmaf(d[j] * rstd, W[LN0_G + j], W[LN0_B + j]);
                 p[j] = (__float_as_uint(fmaf(yy, scale, magic)) + (0x808080u - MAGIC_BITS)) ^ 0x808080u;
             } else {

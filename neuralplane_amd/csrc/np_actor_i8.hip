@@ -40,6 +40,7 @@ hipError_t launch_actor_i8(const float *weights, long long n, const float *obs, 
 
 // The rollout policy's inference step (np_policy.hip states the act layer / value head) with both networks in these numerics: one workgroup per
 // (32-row tile, network), grid.y 0 = actor, 1 = critic.
+template <int NOBS>
 __global__ __launch_bounds__(256, 2) void policy_act_i8_kernel(const nppol::ActArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned tid = threadIdx.x;
@@ -62,12 +63,12 @@ __global__ __launch_bounds__(256, 2) void policy_act_i8_kernel(const nppol::ActA
             hm[0][4 * g] = q.x * mk; hm[0][4 * g + 1] = q.y * mk; hm[0][4 * g + 2] = q.z * mk; hm[0][4 * g + 3] = q.w * mk;
         }
 #pragma unroll
-        for (int j = 0; j < OBS; j++) xr[0][j] = a.obs[ic * OBS + j];
+        for (int j = 0; j < NOBS; j++) xr[0][j] = a.obs[ic * NOBS + j];
     }
     float *park = lds + ACTOR8_LDS_FLOATS, *tab = park + ACTOR8_PARK_FLOATS;
     actor8_stage_tables(tab, weights, tid, 256u);
     __syncthreads();
-    actor8_body<1, false>(lds, park, tab, weights, xr, hm, hn, mu, tid);   // mu of (row, head column = wave) in the lanes with h == 0
+    actor8_body<1, false, NOBS>(lds, park, tab, weights, xr, hm, hn, mu, tid);   // mu of (row, head column = wave) in the lanes with h == 0
     if (net == 0) {
         float *lp = lds + LDS8_PS;   // the LayerNorm exchange: every wave is past its last read (the head's barrier)
         const int A = a.act_dim;
@@ -109,12 +110,17 @@ hipError_t launch_policy_act_i8(const nppol::ActArgs &a, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
     if (dev < 64 && !set[dev]) {
-        const hipError_t e = hipFuncSetAttribute((const void *)policy_act_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)policy_act_i8_kernel<OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)policy_act_i8_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         set[dev] = true;
     }
     const int nets = ((a.flags & NP_POLICY_ACTOR) ? 1 : 0) + ((a.flags & NP_POLICY_CRITIC) ? 1 : 0);
-    hipLaunchKernelGGL(policy_act_i8_kernel, dim3((unsigned)((a.n + 31) / 32), (unsigned)nets), dim3(256), bytes, stream, a);
+    const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)nets);
+    if (a.obs_dim == 15)
+        hipLaunchKernelGGL(policy_act_i8_kernel<15>, grid, dim3(256), bytes, stream, a);
+    else
+        hipLaunchKernelGGL(policy_act_i8_kernel<OBS>, grid, dim3(256), bytes, stream, a);
     return hipGetLastError();
 }
 

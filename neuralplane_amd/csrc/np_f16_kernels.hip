@@ -1507,6 +1507,8 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
     if (q->flags & ~(NP_POLICY_ACTOR | NP_POLICY_CRITIC | NP_POLICY_DETERMINISTIC)) return fail("np_policy_act: unknown flag");
     if (q->act_dim < 1 || q->act_dim > 4) return fail("np_policy_act: 1 to 4 continuous actions");
     if (q->n < 0) return fail("np_policy_act: bad size");
+    if (q->obs_dim != 0 && q->obs_dim != 22 && q->obs_dim != 15) return fail("np_policy_act: obs_dim must be 22 (0) or 15");
+    if (q->reserved_ != 0) return fail("np_policy_act: reserved_ must be 0");
     if (q->weights_floats != 0 && q->weights_floats != NP_ACTOR_NUM_FLOATS && q->weights_floats != NP_ACTOR_I8_NUM_FLOATS)
         return fail("np_policy_act: weights_floats must be 0 / NP_ACTOR_NUM_FLOATS (fp32 chains) or NP_ACTOR_I8_NUM_FLOATS (block fixed point)");
     if (!q->obs || !q->masks) return fail("np_policy_act: null obs / masks");
@@ -1535,6 +1537,7 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
     a.obs = q->obs; a.mask = q->masks; a.noise = q->noise;
     a.values = q->values; a.actions = q->actions; a.log_probs = q->action_log_probs;
     a.n = (long long)q->n; a.act_dim = q->act_dim; a.flags = q->flags; a.first_net = actor ? 0 : 1;
+    a.obs_dim = q->obs_dim ? q->obs_dim : 22;
     for (int j = 0; j < 4; j++) {
         a.std[j] = q->std[j];
         a.log_std[j] = q->log_std[j];

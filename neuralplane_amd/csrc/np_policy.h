@@ -11,7 +11,7 @@ struct ActArgs {
     const float *obs, *mask, *noise;
     float *values, *actions, *log_probs;
     long long n;
-    int act_dim, flags, first_net, pad_;
+    int act_dim, flags, first_net, obs_dim;   // obs_dim: 22 or 15
     float std[4], log_std[4];
 };
 

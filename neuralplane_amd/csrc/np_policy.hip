@@ -20,6 +20,7 @@ namespace nppol {
 
 using namespace npact;
 
+template <int NOBS>   // observations per row: 22 (control / heading / tracking) or 15 (the 1v1 combat env)
 __global__ __launch_bounds__(MTHREADS, 2) void policy_act_kernel(const ActArgs a) {
     __shared__ float lds[ACTOR32_LDS_FLOATS];
     const unsigned tid = threadIdx.x;
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(MTHREADS, 2) void policy_act_kernel(const ActArgs a
     actor32_stage_head(lds, weights, tid);
     float xr[OBS];
 #pragma unroll
-    for (int j = 0; j < OBS; j++) xr[j] = a.obs[ic * OBS + j];
+    for (int j = 0; j < NOBS; j++) xr[j] = a.obs[ic * NOBS + j];
     float hn[BLK], mu;
-    actor32_body<false>(lds, weights, pre, xr, hm, hn, mu, tid);   // mu of (row, head column = wave); lanes with hi == 0 hold it
+    actor32_body<false, NOBS>(lds, weights, pre, xr, hm, hn, mu, tid);   // mu of (row, head column = wave); lanes with hi == 0 hold it
     if (net == 0) {
         float *lp = lds;   // bufA: nobody reads it after the last layer's barrier
         const int A = a.act_dim;
@@ -92,7 +93,11 @@ __global__ __launch_bounds__(MTHREADS, 2) void policy_act_kernel(const ActArgs a
 
 hipError_t launch_policy_act(const ActArgs &a, hipStream_t stream) {
     const int nets = ((a.flags & NP_POLICY_ACTOR) ? 1 : 0) + ((a.flags & NP_POLICY_CRITIC) ? 1 : 0);
-    hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((a.n + T32 - 1) / T32), (unsigned)nets), dim3(MTHREADS), 0, stream, a);
+    const dim3 grid((unsigned)((a.n + T32 - 1) / T32), (unsigned)nets);
+    if (a.obs_dim == 15)
+        hipLaunchKernelGGL(policy_act_kernel<15>, grid, dim3(MTHREADS), 0, stream, a);
+    else
+        hipLaunchKernelGGL(policy_act_kernel<OBS>, grid, dim3(MTHREADS), 0, stream, a);
     return hipGetLastError();
 }
 

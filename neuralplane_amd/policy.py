@@ -4,7 +4,7 @@ The reference's collect step (runner/F16sim_runner.py:123-129) is `PPOPolicy.get
 (algorithms/ppo/ppo_policy.py:26-32): PPOActor.forward with sampled actions + log-probabilities and PPOCritic.forward, ~110 small torch
 kernels — 0.55-0.60 ms per step, nine tenths of a device-resident collect step (profiles/r05_collect_loop.json).  The training scripts
 build both networks in the frozen controller's shapes (hidden "128 128", act-hidden "128 128", GRU 128 x 1, feature LayerNorm, ReLU;
-22 observations; 4 actions for heading / control, 3 for tracking), so they run through the controller's matrix-core tile bodies
+22 observations — 15 for the 1v1 combat env's policies, runner/selfplay_F16sim_runner.py —; 4 actions for heading / control, 3 for tracking), so they run through the controller's matrix-core tile bodies
 (csrc/np_policy.hip: fp32 chains; csrc/np_actor_i8.hip policy_act_i8_kernel: block fixed point on the i8 pipe, the default):
 `FusedPolicy(policy)` packs `policy.actor` / `policy.critic` once and exposes the reference's three inference calls with its signatures
 
@@ -35,8 +35,19 @@ def _np(v):
     return np.asarray(v, dtype=np.float32)
 
 
+OBS_DIMS = (22, 15)   # envs/configs/*.yaml num_observation: control / heading / tracking 22, the 1v1 combat env (selfplay.yaml) 15
+
+
 def _pack(state_dict, key_of, head_w, head_b, what):
+    """-> (float32[NUM_FLOATS], obs_dim).  A network on fewer than 22 observations keeps the layout: its feature LayerNorm terms and the first
+    layer's columns are zero-padded to 22 (the kernels read the first obs_dim of them)."""
     parts = []
+    k0 = key_of('base.feature_norm.weight')
+    if k0 not in state_dict:
+        raise ValueError(f'not a {what} state_dict of the supported architecture: missing {k0}')
+    obs_dim = int(_np(state_dict[k0]).shape[0])
+    if obs_dim not in OBS_DIMS:
+        raise ValueError(f'{k0}: {obs_dim} observations; supported: {OBS_DIMS}')
     for _, key, transpose in _LAYOUT:
         if key == _HEAD_W:
             v = head_w
@@ -47,12 +58,17 @@ def _pack(state_dict, key_of, head_w, head_b, what):
             if k not in state_dict:
                 raise ValueError(f'not a {what} state_dict of the supported architecture: missing {k}')
             v = _np(state_dict[k])
-            if key in _SHAPES and tuple(v.shape) != _SHAPES[key]:
-                raise ValueError(f'{k}: shape {tuple(v.shape)}, expected {_SHAPES[key]} (hidden 128 128, GRU 128 x 1, 22 observations)')
+            want = {'base.feature_norm.weight': (obs_dim,), 'base.feature_norm.bias': (obs_dim,), 'base.mlp.fc.0.weight': (HID, obs_dim)}.get(key, _SHAPES.get(key))
+            if want is not None and tuple(v.shape) != want:
+                raise ValueError(f'{k}: shape {tuple(v.shape)}, expected {want} (hidden 128 128, GRU 128 x 1, {obs_dim} observations)')
+            if obs_dim != OBS and key in ('base.feature_norm.weight', 'base.feature_norm.bias', 'base.mlp.fc.0.weight'):
+                pad = np.zeros(v.shape[:-1] + (OBS,), np.float32)
+                pad[..., :obs_dim] = v
+                v = pad
         parts.append(np.ascontiguousarray(v.T if transpose else v).reshape(-1))
     out = np.concatenate(parts)
     assert out.size == NUM_FLOATS, out.size
-    return out
+    return out, obs_dim
 
 
 def pack_policy_actor(state_dict):
@@ -67,7 +83,8 @@ def pack_policy_actor(state_dict):
         raise ValueError(f'mu_net: {tuple(w.shape)} / {tuple(b.shape)} / log_std {tuple(log_std.shape)}; supported: 1..4 actions on 128 features')
     wp, bp = np.zeros((MAX_ACT, HID), np.float32), np.zeros(MAX_ACT, np.float32)
     wp[:A], bp[:A] = w, b
-    return _pack(state_dict, lambda k: k, wp, bp, 'PPOActor'), A, log_std.copy()
+    w, _ = _pack(state_dict, lambda k: k, wp, bp, 'PPOActor')
+    return w, A, log_std.copy()
 
 
 def pack_policy_critic(state_dict):
@@ -87,14 +104,20 @@ def pack_policy_critic(state_dict):
             if key.startswith(a + '.'):
                 return c + key[len(a):]
         return key
-    return _pack(state_dict, key_of, wp, bp, 'PPOCritic')
+    return _pack(state_dict, key_of, wp, bp, 'PPOCritic')[0]
+
+
+def obs_dim_of(state_dict):
+    """Observations per row of a PPOActor / PPOCritic state_dict (22 or 15)."""
+    return int(_np(state_dict['base.feature_norm.weight']).shape[0])
 
 
 class NpPolicyStep(C.Structure):   # include/neuralplane_amd.h: np_policy_step
     _fields_ = [('n', C.c_int64), ('act_dim', C.c_int32), ('flags', C.c_int32), ('actor_weights', C.c_void_p), ('critic_weights', C.c_void_p),
                 ('std', C.c_float * 4), ('log_std', C.c_float * 4), ('obs', C.c_void_p), ('masks', C.c_void_p), ('noise', C.c_void_p),
                 ('rnn_states_actor_in', C.c_void_p), ('rnn_states_critic_in', C.c_void_p), ('values', C.c_void_p), ('actions', C.c_void_p),
-                ('action_log_probs', C.c_void_p), ('rnn_states_actor_out', C.c_void_p), ('rnn_states_critic_out', C.c_void_p), ('weights_floats', C.c_int64)]
+                ('action_log_probs', C.c_void_p), ('rnn_states_actor_out', C.c_void_p), ('rnn_states_critic_out', C.c_void_p), ('weights_floats', C.c_int64),
+                ('obs_dim', C.c_int32), ('reserved_', C.c_int32)]
 
 
 ACTOR, CRITIC, DETERMINISTIC = 1, 2, 4
@@ -143,6 +166,9 @@ class FusedPolicy:
         sa, sc = self._state_dicts()
         wa, self.act_dim, log_std = pack_policy_actor(sa)
         wc = pack_policy_critic(sc)
+        self.obs_dim = obs_dim_of(sa)
+        if obs_dim_of(sc) != self.obs_dim:
+            raise ValueError(f'actor on {self.obs_dim} observations, critic on {obs_dim_of(sc)}')
         if self.numerics == 'i8':   # per-output scales + limb fragments behind the same floats (np_actor_pack_i8, host side)
             wa, wc = pack_i8(wa), pack_i8(wc)
         self.weights.copy_(torch.from_numpy(np.stack((wa, wc))))
@@ -152,7 +178,7 @@ class FusedPolicy:
         std = v.detach().exp().reshape(-1).to(torch.float32).cpu() if hasattr(v, 'detach') else ls.exp()
         self.log_std, self.std = [float(x) for x in ls], [float(x) for x in std]
         q = self._q = NpPolicyStep()
-        q.act_dim, q.weights_floats = self.act_dim, self.num_floats
+        q.act_dim, q.weights_floats, q.obs_dim = self.act_dim, self.num_floats, self.obs_dim
         q.actor_weights, q.critic_weights = self.weights[0].data_ptr(), self.weights[1].data_ptr()
         for j in range(self.act_dim):
             q.std[j], q.log_std[j] = self.std[j], self.log_std[j]
@@ -176,7 +202,7 @@ class FusedPolicy:
         if type(obs) is not torch.Tensor:
             obs = torch.as_tensor(obs, device=d)
         n = obs.shape[0]
-        obs = self._rows(obs, n, OBS)
+        obs = self._rows(obs, n, self.obs_dim)
         m = self._rows(masks, n, 1)
         q = self._q   # weights, act_dim, std / log_std: filled by refresh(); the library reads the struct during the call only
         q.n, q.flags = n, flags

@@ -174,14 +174,15 @@ void f16o_actor_forward(const float *w, int64_t n, const float *obs, const float
 
 /* The rollout policy's inference step (f16_actor.inc): PPOPolicy.get_actions (algorithms/ppo/ppo_policy.py:26-32) — actor with sampled
  * actions + log-probabilities and critic on the same observation.  wa / wc: the two networks as f16o_actor_num_floats() packed weights
- * (the critic's value_out in column 0 of the head block); std / log_std [act_dim]; noise [n][act_dim] the standard normal draws;
+ * (the critic's value_out in column 0 of the head block); obs [n][obs_dim], obs_dim = 22 or fewer (15: the 1v1 combat env); std / log_std
+ * [act_dim]; noise [n][act_dim] the standard normal draws;
  * flags: 1 actor, 2 critic, 4 deterministic.  values [n], actions [n][act_dim], log_probs [n], ha_out / hc_out [n][128]. */
-void f16o_policy_act(const float *wa, const float *wc, const float *std, const float *log_std, int64_t n, int act_dim, int flags,
+void f16o_policy_act(const float *wa, const float *wc, const float *std, const float *log_std, int64_t n, int obs_dim, int act_dim, int flags,
                      const float *obs, const float *ha_in, const float *hc_in, const float *mask, const float *noise, float *values,
                      float *actions, float *log_probs, float *ha_out, float *hc_out);
 
 /* the same with both networks in the controller's block-fixed-point numerics (f16_actor_i8.inc); returns non-zero when out of memory */
-int f16o_policy_act_i8(const float *wa, const float *wc, const float *std, const float *log_std, int64_t n, int act_dim, int flags,
+int f16o_policy_act_i8(const float *wa, const float *wc, const float *std, const float *log_std, int64_t n, int obs_dim, int act_dim, int flags,
                        const float *obs, const float *ha_in, const float *hc_in, const float *mask, const float *noise, float *values,
                        float *actions, float *log_probs, float *ha_out, float *hc_out);
 

@@ -440,10 +440,10 @@ class PolicyOracle:
     std / log_std [act_dim] float32."""
     ACTOR, CRITIC, DETERMINISTIC = 1, 2, 4
 
-    def __init__(self, actor_w, critic_w, std, log_std, numerics='fp32'):
+    def __init__(self, actor_w, critic_w, std, log_std, numerics='fp32', obs_dim=22):
         self.lib = C.CDLL(build())
         assert numerics in ('fp32', 'i8'), numerics
-        self.numerics = numerics
+        self.numerics, self.obs_dim = numerics, int(obs_dim)
         self.wa, self.wc = _f32(actor_w).reshape(-1), _f32(critic_w).reshape(-1)
         assert self.wa.size == self.wc.size == self.lib.f16o_actor_num_floats()
         self.std, self.log_std = _f32(std).reshape(-1), _f32(log_std).reshape(-1)
@@ -451,14 +451,14 @@ class PolicyOracle:
         assert 1 <= self.act_dim <= 4 and self.log_std.size == self.act_dim
 
     def run(self, obs, ha, hc, masks, noise=None, flags=3):
-        obs, ha, hc = _f32(obs).reshape(-1, 22), _f32(ha).reshape(-1, 128), _f32(hc).reshape(-1, 128)
+        obs, ha, hc = _f32(obs).reshape(-1, self.obs_dim), _f32(ha).reshape(-1, 128), _f32(hc).reshape(-1, 128)
         m = _f32(masks).reshape(-1)
         n, A = obs.shape[0], self.act_dim
         noise = np.zeros((n, A), np.float32) if noise is None else _f32(noise).reshape(n, A)
         values, actions, logp = np.zeros((n, 1), np.float32), np.zeros((n, A), np.float32), np.zeros((n, 1), np.float32)
         ha_out, hc_out = ha.copy(), hc.copy()
         fn = self.lib.f16o_policy_act_i8 if self.numerics == 'i8' else self.lib.f16o_policy_act
-        rc = fn(_p(self.wa), _p(self.wc), _p(self.std), _p(self.log_std), C.c_int64(n), C.c_int(A), C.c_int(flags), _p(obs), _p(ha),
+        rc = fn(_p(self.wa), _p(self.wc), _p(self.std), _p(self.log_std), C.c_int64(n), C.c_int(self.obs_dim), C.c_int(A), C.c_int(flags), _p(obs), _p(ha),
                 _p(hc), _p(m), _p(noise), _p(values), _p(actions), _p(logp), _p(ha_out), _p(hc_out))
         assert self.numerics == 'fp32' or rc == 0
         return values, actions, logp, ha_out, hc_out

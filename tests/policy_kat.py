@@ -6,9 +6,9 @@ import numpy as np
 TOL = {'actions': 2e-5, 'means': 2e-5, 'values': 1e-4, 'logp': 5e-5, 'rnn': 5e-5}
 
 
-def load(golden_dir, act_dim):
+def load(golden_dir, act_dim, obs_dim=22):
     d = np.load(f'{golden_dir}/policy_kat.npz')
-    pre = f'a{act_dim}::'
+    pre = f'a{act_dim}::' if obs_dim == 22 else f'a{act_dim}o{obs_dim}::'
     g = {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
     sa = {k[len('actor::'):]: v for k, v in g.items() if k.startswith('actor::')}
     sc = {k[len('critic::'):]: v for k, v in g.items() if k.startswith('critic::')}
@@ -25,13 +25,13 @@ def check_step(g, t, values, actions, logp, ha, hc):
     return err
 
 
-def random_state_dicts(act_dim, seed, scale=1.0):
+def random_state_dicts(act_dim, seed, scale=1.0, obs_dim=22):
     """(actor, critic) numpy state_dicts with PPOActor's / PPOCritic's keys and shapes, every parameter random (LayerNorm terms included)."""
     rng = np.random.RandomState(seed)
 
     def trunk(mlp):
-        sd = {'base.feature_norm.weight': 1 + 0.3 * rng.normal(size=22), 'base.feature_norm.bias': 0.2 * rng.normal(size=22)}
-        for name, (o, i) in (('base.mlp.fc.0', (128, 22)), ('base.mlp.fc.3', (128, 128)), (mlp + '.fc.0', (128, 128)), (mlp + '.fc.3', (128, 128))):
+        sd = {'base.feature_norm.weight': 1 + 0.3 * rng.normal(size=obs_dim), 'base.feature_norm.bias': 0.2 * rng.normal(size=obs_dim)}
+        for name, (o, i) in (('base.mlp.fc.0', (128, obs_dim)), ('base.mlp.fc.3', (128, 128)), (mlp + '.fc.0', (128, 128)), (mlp + '.fc.3', (128, 128))):
             sd[name + '.weight'], sd[name + '.bias'] = scale * rng.normal(size=(o, i)) / np.sqrt(i), 0.1 * rng.normal(size=o)
         for name in ('base.mlp.fc.2', 'base.mlp.fc.5', 'rnn.norm', mlp + '.fc.2', mlp + '.fc.5'):
             sd[name + '.weight'], sd[name + '.bias'] = 1 + 0.3 * rng.normal(size=128), 0.2 * rng.normal(size=128)

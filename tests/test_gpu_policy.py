@@ -19,26 +19,27 @@ def _t(x, dev='cuda:0'):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
-def _setup(golden_dir, act_dim, numerics='fp32'):
+def _setup(golden_dir, act_dim, numerics='fp32', obs_dim=22):
     from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
     from oracle.f16_oracle import PolicyOracle
     from tests.policy_kat import load
-    g, sa, sc = load(golden_dir, act_dim)
+    g, sa, sc = load(golden_dir, act_dim, obs_dim)
     fp = FusedPolicy((sa, sc), device='cuda:0', numerics=numerics)
     wa, A, _ = pack_policy_actor(sa)
-    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std), numerics)
+    assert fp.obs_dim == obs_dim
+    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std), numerics, obs_dim)
     assert A == act_dim == fp.act_dim and same(np.float32(fp.std), g['std']) and same(np.float32(fp.log_std), g['log_std'])
     return g, sa, sc, fp, o
 
 
 @pytest.mark.parametrize('numerics', ['fp32', 'i8'])
-@pytest.mark.parametrize('act_dim', [4, 3])
-def test_get_actions_equals_the_restatement_bit_for_bit_and_the_reference_recording(golden_dir, act_dim, numerics):
+@pytest.mark.parametrize('act_dim,obs_dim', [(4, 22), (3, 22), (4, 15)])
+def test_get_actions_equals_the_restatement_bit_for_bit_and_the_reference_recording(golden_dir, act_dim, obs_dim, numerics):
     """Five chained get_actions calls on the recorded inputs and normal draws (recurrent states fed back on the device): every output equals
     the restatement's bit for bit (both numerics: the fp32 chains, f16_actor.inc, and the block fixed point, f16_actor_i8.inc) and the
     REFERENCE's recording within the bounds of tests/policy_kat.py; act(deterministic=True) and get_values are the same launch with one network."""
     from tests.policy_kat import check_step
-    g, _, _, fp, o = _setup(golden_dir, act_dim, numerics)
+    g, _, _, fp, o = _setup(golden_dir, act_dim, numerics, obs_dim)
     n = g['obs'].shape[1]
     ha = hc = torch.zeros((n, 1, 128), device='cuda:0')
     ha_o = hc_o = np.zeros((n, 128), np.float32)
@@ -221,24 +222,24 @@ def test_numpy_inputs_as_the_reference_runner_passes_them(golden_dir):
 
 
 @pytest.mark.parametrize('numerics', ['fp32', 'i8'])
-@pytest.mark.parametrize('act_dim,scale', [(1, 1.0), (2, 0.05), (3, 8.0), (4, 1.0)])
-def test_one_to_four_actions_and_weight_scales_equal_the_restatement(act_dim, scale, numerics):
+@pytest.mark.parametrize('act_dim,scale,obs_dim', [(1, 1.0, 22), (2, 0.05, 15), (3, 8.0, 22), (4, 1.0, 15)])
+def test_one_to_four_actions_and_weight_scales_equal_the_restatement(act_dim, scale, obs_dim, numerics):
     """Random networks (every parameter random; weight scales 0.05 … 8, so the i8 path sees small and large exponents), 1 … 4 actions, three chained
     steps at a ragged size: every output equals the restatement bit for bit."""
     from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
     from oracle.f16_oracle import PolicyOracle
     from tests.policy_kat import random_state_dicts
-    sa, sc = random_state_dicts(act_dim, 100 * act_dim + (numerics == 'i8'), scale)
+    sa, sc = random_state_dicts(act_dim, 100 * act_dim + (numerics == 'i8'), scale, obs_dim)
     fp = FusedPolicy((sa, sc), 'cuda:0', numerics=numerics)
     wa, A, _ = pack_policy_actor(sa)
     assert A == act_dim
-    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std), numerics)
+    o = PolicyOracle(wa, pack_policy_critic(sc), np.float32(fp.std), np.float32(fp.log_std), numerics, obs_dim)
     n = 777
     rng = np.random.RandomState(act_dim)
     ha = hc = np.zeros((n, 128), np.float32)
     dha = dhc = torch.zeros((n, 1, 128), device='cuda:0')
     for t in range(3):
-        obs = (rng.normal(0, 1, (n, 22)) * rng.uniform(0.1, 5, (1, 22))).astype(np.float32)
+        obs = (rng.normal(0, 1, (n, obs_dim)) * rng.uniform(0.1, 5, (1, obs_dim))).astype(np.float32)
         mk = (rng.uniform(0, 1, (n, 1)) > 0.1).astype(np.float32)
         eps = rng.normal(0, 1, (n, act_dim)).astype(np.float32)
         v, a, lp, dha, dhc = fp.get_actions(_t(obs), dha, dhc, _t(mk), noise=_t(eps))

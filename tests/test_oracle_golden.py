@@ -616,21 +616,21 @@ def test_planning_env_closed_loop_vs_reference_with_the_i8_controller(golden_dir
 # The rollout policy's inference step: PPOPolicy.get_actions restated (oracle/f16_actor.inc, f16o_policy_act)
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('numerics', ['fp32', 'i8'])
-@pytest.mark.parametrize('act_dim', [4, 3])
-def test_policy_get_actions_restatement_vs_reference_recording(golden_dir, act_dim, numerics):
+@pytest.mark.parametrize('act_dim,obs_dim', [(4, 22), (3, 22), (4, 15)])
+def test_policy_get_actions_restatement_vs_reference_recording(golden_dir, act_dim, obs_dim, numerics):
     """f16o_policy_act against the REFERENCE's PPOPolicy.get_actions (algorithms/ppo/ppo_policy.py:26-32) recorded over five chained calls
     (recurrent states fed back — here the oracle's own, so errors accumulate as they would in a rollout; rows with masks = 0 in two of them)
-    for the heading (4 actions) and tracking (3 actions) policies: sampled actions from the recorded normal draws <= 2e-5, values <= 1e-4
+    for the heading (4 actions), tracking (3 actions) and 1v1-combat (15 observations, 4 actions) policies: sampled actions from the recorded normal draws <= 2e-5, values <= 1e-4
     (|value| up to 9), log-probabilities <= 5e-5, recurrent states <= 5e-5; plus act(deterministic=True) = the means and get_values.
     Measured: fp32 chains actions 1.1e-6, values 1.4e-5, log-probabilities 1.9e-6, recurrent states 7.5e-7; block fixed point (f16o_policy_act_i8)
     3.4e-6, 2.6e-5, 1.9e-6, 2.5e-6."""
     from neuralplane_amd.policy import pack_policy_actor, pack_policy_critic
     from oracle.f16_oracle import PolicyOracle
     from tests.policy_kat import TOL, check_step, load
-    g, sa, sc = load(golden_dir, act_dim)
+    g, sa, sc = load(golden_dir, act_dim, obs_dim)
     wa, A, log_std = pack_policy_actor(sa)
-    assert A == act_dim and same(log_std, g['log_std'])
-    o = PolicyOracle(wa, pack_policy_critic(sc), g['std'], g['log_std'], numerics)
+    assert A == act_dim and same(log_std, g['log_std']) and g['obs'].shape[-1] == obs_dim
+    o = PolicyOracle(wa, pack_policy_critic(sc), g['std'], g['log_std'], numerics, obs_dim)
     n = g['obs'].shape[1]
     ha = hc = np.zeros((n, 128), np.float32)
     worst = {}
@@ -643,7 +643,7 @@ def test_policy_get_actions_restatement_vs_reference_recording(golden_dir, act_d
         assert same(values, v_only)
         for k, v in check_step(g, t, values, actions, logp, ha, hc).items():
             worst[k] = max(worst.get(k, 0.0), float(v))
-    print('policy restatement vs reference', act_dim, numerics, worst)
+    print('policy restatement vs reference', act_dim, obs_dim, numerics, worst)
     assert worst['actions'] < (2e-6 if numerics == 'fp32' else 6e-6)
 
 

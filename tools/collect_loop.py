@@ -69,9 +69,9 @@ class TorchPolicy(nn.Module):
     """get_actions(obs[n,22], h_actor[n,128], h_critic[n,128], masks[n,1]) -> values, actions, action_log_probs, h_actor, h_critic
     (PPOPolicy.get_actions, algorithms/ppo/ppo_policy.py:26-32, stochastic actions)."""
 
-    def __init__(self, act_dim=4):
+    def __init__(self, act_dim=4, obs_dim=22):
         super().__init__()
-        self.actor, self.critic = _Tower(out=act_dim), _Tower(out=1)
+        self.actor, self.critic = _Tower(obs_dim=obs_dim, out=act_dim), _Tower(obs_dim=obs_dim, out=1)
         self.logstd = nn.Parameter(torch.zeros(act_dim))
 
     @torch.no_grad()
@@ -92,6 +92,12 @@ class TorchPolicy(nn.Module):
     @torch.no_grad()
     def get_values(self, obs, hc, masks):
         return self.critic(obs, hc, masks)[0]
+
+    @torch.no_grad()
+    def act(self, obs, ha, masks):                               # PPOPolicy.act, sampled (ppo_policy.py:51-57)
+        mu, ha = self.actor(obs, ha, masks)
+        mu = torch.tanh(mu)
+        return torch.randn_like(mu) * self.logstd.exp() + mu, ha
 
 
 class _Args:
@@ -236,6 +242,54 @@ def run_device(n, T, dev, graph=False, task='heading', fused_policy=False, polic
     return out
 
 
+def run_selfplay(E, T, dev, fused_policy=False, policy_numerics='i8'):
+    """The self-play runner's collect step (runner/selfplay_F16sim_runner.py:76-100 `collect`, :102-128 `insert`) on the device for the 1v1 combat
+    env: ego policy `get_actions` on obs[:, :A//2], opponent policy `act` (sampled) on obs[:, A//2:], env.step on both actions, the ego half into
+    the rollout storage.  15 observations, 4 actions (envs/configs/selfplay.yaml), the network shapes of config.py's defaults."""
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+    from neuralplane_amd.envs.spaces import Box
+    torch.manual_seed(0)
+    ego, opp = TorchPolicy(act_dim=4, obs_dim=15).to(dev).eval(), TorchPolicy(act_dim=4, obs_dim=15).to(dev).eval()
+    if fused_policy:
+        from neuralplane_amd.policy import FusedPolicy
+        ego, opp = FusedPolicy(ego.state_dicts(), device=dev, numerics=policy_numerics), FusedPolicy(opp.state_dicts(), device=dev, numerics=policy_numerics)
+    env = SingleCombatEnv(num_envs=E, config='selfplay', random_seed=0, device=str(dev))
+    buf = DeviceReplayBuffer(_Args(E, T), 1, Box(low=-np.inf, high=np.inf, shape=(15,)), Box(low=-np.inf, high=np.inf, shape=(4,)), device=dev)
+    oe, oo = env.reset_split()
+    buf.obs[0].copy_(oe.reshape(E, 1, 15))
+    st = {'opp_obs': oo, 'opp_h': torch.zeros((E, 128), device=dev), 'opp_m': torch.ones((E, 1), device=dev)}
+
+    def loop(ph):
+        for s in range(T):
+            ph.mark()
+            v, a, lp, ha, hc = ego.get_actions(buf.obs[s].reshape(E, 15), buf.rnn_states_actor[s].reshape(E, 128), buf.rnn_states_critic[s].reshape(E, 128),
+                                               buf.masks[s].reshape(E, 1))
+            oa, oh = opp.act(st['opp_obs'], st['opp_h'], st['opp_m'])
+            ph.mark()
+            oe, oo, rew, d, bd, tm, _ = env.step_split(a, oa)
+            ph.mark()
+            # rows 2k / 2k + 1 = ego / enemy: the ego half of rewards and flags
+            rew_e, d_e, bd_e, tm_e = rew.reshape(E, 2)[:, 0], d.reshape(E, 2).any(1), bd.reshape(E, 2).any(1), tm.reshape(E, 2).any(1)
+            _device_insert(buf, oe.reshape(E, 1, 15), a, rew_e.reshape(E, 1, 1), d_e.reshape(E, 1, 1), bd_e.reshape(E, 1, 1), tm_e.reshape(E, 1, 1), lp, v, ha, hc, E)
+            ended = (d_e | bd_e | tm_e).reshape(E, 1)
+            st['opp_obs'], st['opp_h'], st['opp_m'] = oo, oh.reshape(E, 128) * (~ended), (~d_e).reshape(E, 1).float()
+            ph.mark()
+        ph.close()
+
+    loop(_Phases(False))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    loop(_Phases(False))
+    torch.cuda.synchronize(dev)
+    wall_us = 1e6 * (time.perf_counter() - t0) / T
+    ph = _Phases(True)
+    loop(ph)
+    gpu = {k: v / T for k, v in ph.t.items()}
+    return {'us_per_step_wall': wall_us, 'gpu_us_both_policies': gpu['policy'], 'gpu_us_env_step': gpu['env'], 'gpu_us_insert_and_opponent_bookkeeping': gpu['insert'],
+            'engagements': E, 'steps': T, 'engagement_steps_per_s': E * 1e6 / wall_us}
+
+
 class _NumpyBuffer:
     """The fields and the insert of the reference's ReplayBuffer (algorithms/utils/buffer.py:37-112), numpy, for the timing of the numpy contract."""
 
@@ -329,6 +383,13 @@ def collect_loop_report(n, T, dev):
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
     rep['device_fused_policy_i8'] = run_device(n, T, dev, fused_policy=True, policy_numerics='i8')   # both networks in the block-fixed-point numerics
     rep['device_fused_policy_i8']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy_i8']['us_per_step_wall']
+    if n == 3000:
+        # the 1v1 combat env with the self-play runner's two policies (15 observations): BASELINE config 5's share of one GPU of eight
+        E, Ts = 12500, max(20, T // 4)
+        rep['selfplay_e12500_torch_policies'] = run_selfplay(E, Ts, dev)
+        rep['selfplay_e12500_fused_policies'] = run_selfplay(E, Ts, dev, fused_policy=True)
+        rep['selfplay_e12500_fused_policies']['speedup_vs_torch_policies'] = (rep['selfplay_e12500_torch_policies']['us_per_step_wall'] /
+                                                                               rep['selfplay_e12500_fused_policies']['us_per_step_wall'])
     if n == 10000:
         # the configuration the reference runs 10 000 rollout threads on (scripts/train_tracking.sh): PlanningEnv macro-steps, a 3-action policy
         Tt = max(10, T // 10)
@@ -349,9 +410,11 @@ if __name__ == '__main__':
     ap.add_argument('--n', type=int, nargs='*', default=[3000, 10000])
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--out', default=None)
-    ap.add_argument('--only', default=None, choices=['fused', 'torch'], help='profiling: run just the device loop with the fused / the eager torch policy')
+    ap.add_argument('--only', default=None, choices=['fused', 'torch', 'selfplay'], help='profiling: run just the device loop with the fused / the eager torch policy')
     args = ap.parse_args()
-    if args.only:
+    if args.only == 'selfplay':
+        rep = {'selfplay_e12500': {'torch_policies': run_selfplay(12500, args.steps, 'cuda:0'), 'fused_policies': run_selfplay(12500, args.steps, 'cuda:0', fused_policy=True)}}
+    elif args.only:
         rep = {f'collect_loop_n{n}': {'device_fused_policy' if args.only == 'fused' else 'device': run_device(n, args.steps, 'cuda:0', fused_policy=args.only == 'fused')}
                for n in args.n}
     else:

@@ -951,7 +951,7 @@ def gen_actor(n=96, steps=4):
     print('actor: |action| max', float(np.abs(np.stack(acts)).max()), 'rnn std', float(np.stack(hs).std()))
 
 
-def seeded_policy(act_dim):
+def seeded_policy(act_dim, obs_dim=22):
     """The reference's PPOPolicy (algorithms/ppo/ppo_policy.py: PPOActor + PPOCritic) in the configuration the training scripts build
     (scripts/train_heading.sh:17 / train_tracking.sh:17: hidden "128 128", act-hidden "128 128", GRU 128 x 1; config.py defaults for the
     rest) with a seeded initialisation whose LayerNorm terms, biases, output layers and log_std are moved off their trivial start values."""
@@ -966,8 +966,8 @@ def seeded_policy(act_dim):
     args.gain, args.hidden_size, args.act_hidden_size, args.activation_id = 0.01, '128 128', '128 128', 1
     args.use_feature_normalization, args.use_recurrent_policy = True, True
     args.recurrent_hidden_size, args.recurrent_hidden_layers, args.use_prior, args.lr = 128, 1, False, 3e-4
-    torch.manual_seed(900 + act_dim)
-    pol = PPOPolicy(args, gym.spaces.Box(low=-10, high=10, shape=(22,)), gym.spaces.Box(low=-10, high=10, shape=(act_dim,)), device=torch.device('cpu'))
+    torch.manual_seed(900 + act_dim + (0 if obs_dim == 22 else 100 * obs_dim))
+    pol = PPOPolicy(args, gym.spaces.Box(low=-10, high=10, shape=(obs_dim,)), gym.spaces.Box(low=-10, high=10, shape=(act_dim,)), device=torch.device('cpu'))
     pol.prep_rollout()
     with torch.no_grad():
         for net in (pol.actor, pol.critic):
@@ -990,10 +990,11 @@ def gen_policy(n=96, steps=5):
     every sample are stored too — drawn here from the same generator state with normal_(), and checked to reproduce the reference's actions
     exactly as fl(fl(eps * std) + mean) — together with the means (act(..., deterministic=True)) and get_values."""
     out = {}
-    for act_dim in (4, 3):
-        pol = seeded_policy(act_dim)
-        rng = np.random.RandomState(70 + act_dim)
-        obs = (rng.normal(0, 1, (steps, n, 22)) * rng.uniform(0.1, 3, (1, 1, 22))).astype(np.float32)
+    # (actions, observations): heading / control 4 x 22, tracking 3 x 22, the 1v1 combat env's policies 4 x 15 (envs/configs/selfplay.yaml)
+    for act_dim, obs_dim in ((4, 22), (3, 22), (4, 15)):
+        pol = seeded_policy(act_dim, obs_dim)
+        rng = np.random.RandomState(70 + act_dim + (0 if obs_dim == 22 else obs_dim))
+        obs = (rng.normal(0, 1, (steps, n, obs_dim)) * rng.uniform(0.1, 3, (1, 1, obs_dim))).astype(np.float32)
         masks = np.ones((steps, n, 1), np.float32)
         masks[2, ::5] = 0.0
         masks[4, 1::9] = 0.0
@@ -1013,12 +1014,12 @@ def gen_policy(n=96, steps=5):
                 assert torch.equal(values, vonly)
                 for k, v in (('eps', eps), ('values', values), ('actions', actions), ('logp', logp), ('ha', ha), ('hc', hc), ('means', mean), ('values_only', vonly)):
                     rec[k].append(v.numpy().copy())
-        pre = f'a{act_dim}::'
+        pre = f'a{act_dim}::' if obs_dim == 22 else f'a{act_dim}o{obs_dim}::'
         out.update({pre + 'obs': obs, pre + 'masks': masks, pre + 'std': std.numpy(), pre + 'log_std': pol.actor.act.action_out.log_std.detach().numpy().copy()})
         out.update({pre + k: np.stack(v) for k, v in rec.items()})
         out.update({pre + 'actor::' + k: v.numpy() for k, v in pol.actor.state_dict().items()})
         out.update({pre + 'critic::' + k: v.numpy() for k, v in pol.critic.state_dict().items()})
-        print(f'policy a{act_dim}: |mean| max', float(np.abs(np.stack(rec['means'])).max()), 'values', float(np.stack(rec['values']).min()),
+        print(f'policy {pre} |mean| max', float(np.abs(np.stack(rec['means'])).max()), 'values', float(np.stack(rec['values']).min()),
               float(np.stack(rec['values']).max()), 'logp', float(np.stack(rec['logp']).min()), float(np.stack(rec['logp']).max()), 'std', std.numpy())
     np.savez_compressed(os.path.join(OUT, 'policy_kat.npz'), **out)
 
