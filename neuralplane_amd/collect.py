@@ -1,0 +1,103 @@
+"""DeviceCollector — the runner's collect step with everything pre-bound.
+
+`F16SimRunner.run` (reference runner/F16sim_runner.py:52-66) does, per step: `collect` (:123-129: policy.get_actions on the buffer's slot
+`step`), `envs.step(actions)`, `insert` (:131-154: masks, zeroed recurrent states, ReplayBuffer.insert).  With `FusedPolicy`, `DeviceVecEnv`
+and `DeviceReplayBuffer` those are three launches (+ the normal draws) — 47 us of kernels at 3 000 envs — behind ~55 us of Python (tensor
+views of the buffer's slots, five output allocations, argument checks): at the sizes the reference trains at the host sets the rate.
+`DeviceCollector(policy, envs, buffer).step()` is the same step with the addresses computed instead of sliced: the policy reads the buffer's
+slot `step` in place and writes actions / log-probabilities / values straight into it, the env steps on that slot's actions, the insert
+launch finishes the slot (rewards, next observation, masks, recurrent states zeroed where an env ended).  Same kernels, same results as the
+three calls (tests/test_gpu_policy.py); nothing here computes.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .buffer import DeviceReplayBuffer
+from .envs.env_base import BaseEnv
+from .policy import ACTOR, CRITIC, FusedPolicy
+
+HID = 128
+
+
+class DeviceCollector:
+    """collector = DeviceCollector(policy, envs, buffer); `collector.step()` = one collect step at `buffer.step` (which it advances);
+    `collector.compute_returns()` = the runner's `compute` (:112-121).  Single-agent envs (ControlEnv, PlanningEnv under DeviceVecEnv)."""
+
+    def __init__(self, policy, envs, buffer):
+        if not isinstance(policy, FusedPolicy) or not isinstance(buffer, DeviceReplayBuffer):
+            raise TypeError('DeviceCollector(policy: FusedPolicy, envs: DeviceVecEnv, buffer: DeviceReplayBuffer)')
+        env = getattr(envs, 'env', envs)
+        self.policy, self.env, self.buffer = policy, env, buffer
+        self.device = policy.device
+        n, A = int(env.n), int(getattr(env, 'num_agents', 1))
+        if A != 1 or buffer.num_agents != 1 or buffer.n_rollout_threads != n:
+            raise ValueError(f'single-agent envs only: env rows {n} x {A} agents, buffer {buffer.n_rollout_threads} x {buffer.num_agents}')
+        if buffer.device != self.device or torch.device(env.device) != self.device:
+            raise ValueError('policy, envs and buffer must live on the same device')
+        if (buffer.obs.shape[-1], buffer.actions.shape[-1]) != (policy.obs_dim, policy.act_dim):
+            raise ValueError(f'buffer holds {buffer.obs.shape[-1]} observations / {buffer.actions.shape[-1]} actions, the policy {policy.obs_dim} / {policy.act_dim}')
+        if buffer.recurrent_hidden_layers != 1 or buffer.recurrent_hidden_size != HID:
+            raise ValueError('recurrent state: one layer of 128')
+        self.n = n
+        d = self.device
+        self.noise = torch.empty((n, policy.act_dim), dtype=torch.float32, device=d)
+        self.ha, self.hc = torch.empty((n, HID), dtype=torch.float32, device=d), torch.empty((n, HID), dtype=torch.float32, device=d)
+        self._plain = type(env).step is BaseEnv.step       # ControlEnv: the batch's own step (obs, reward, flags[3, n]) without the per-flag views
+        self._lib = _lib.load()
+        self._bound = None
+
+    def _bind(self):
+        """Base addresses of the storage (re-read when the buffer re-allocated or somebody replaced a tensor)."""
+        b = self.buffer
+        key = tuple(getattr(b, k).data_ptr() for k in b._STORAGE)
+        if self._bound is None or self._bound[0] != key:
+            assert all(getattr(b, k).is_contiguous() for k in b._STORAGE)
+            q = _lib.NpRolloutStep()
+            q.num_envs, q.num_agents, q.obs_dim, q.act_dim, q.rnn_dim = self.n, 1, self.policy.obs_dim, self.policy.act_dim, HID
+            for k in b._STORAGE:
+                setattr(q, k, getattr(b, k).data_ptr())
+            q.rnn_states_actor_in, q.rnn_states_critic_in = self.ha.data_ptr(), self.hc.data_ptr()
+            self._bound = (key, dict(zip(b._STORAGE, key)), q)
+        return self._bound[1], self._bound[2]
+
+    def step(self):
+        """One collect step at buffer.step: returns the env's (obs, reward, flags[3, n] uint8 = done / bad_done / exceed_time_limit)."""
+        p, b, n = self.policy, self.buffer, self.n
+        p._maybe_refresh()
+        base, qi = self._bind()
+        s, od, ad = b.step, p.obs_dim, p.act_dim
+        f4 = 4 * n
+        a_ptr, lp_ptr, v_ptr = base['actions'] + s * f4 * ad, base['action_log_probs'] + s * f4, base['value_preds'] + s * f4
+        self.noise.normal_()                                # the step's normal draws: torch's generator on this device, as the reference's sample()
+        q = p._q
+        q.n, q.flags = n, ACTOR | CRITIC
+        q.obs, q.masks, q.noise = base['obs'] + s * f4 * od, base['masks'] + s * f4, self.noise.data_ptr()
+        q.rnn_states_actor_in, q.rnn_states_critic_in = base['rnn_states_actor'] + s * f4 * HID, base['rnn_states_critic'] + s * f4 * HID
+        q.values, q.actions, q.action_log_probs = v_ptr, a_ptr, lp_ptr
+        q.rnn_states_actor_out, q.rnn_states_critic_out = self.ha.data_ptr(), self.hc.data_ptr()
+        stream = _lib.stream_ptr(self.device)
+        _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, stream))
+        actions = b.actions[s].view(n, ad)
+        if self._plain:
+            obs, reward, flags = self.env._batch.step(actions)
+        else:
+            obs, reward, done, bad, tmo, _ = self.env.step(actions)
+            flags = torch.stack((done, bad, tmo)).view(torch.uint8) if done.dtype == torch.bool else torch.stack((done, bad, tmo)).to(torch.uint8)
+        if not (obs.is_contiguous() and reward.is_contiguous() and flags.is_contiguous() and flags.dtype == torch.uint8):
+            obs, reward, flags = obs.contiguous(), reward.contiguous(), flags.contiguous().view(torch.uint8)
+        qi.step = s
+        qi.obs_in, qi.rewards_in = obs.data_ptr(), reward.data_ptr()
+        qi.actions_in, qi.action_log_probs_in, qi.values_in = a_ptr, lp_ptr, v_ptr          # already in their slot: the launch rewrites them in place
+        fp = flags.data_ptr()
+        qi.done_in, qi.bad_done_in, qi.exceed_time_limit_in = fp, fp + n, fp + 2 * n
+        _lib.check(self._lib.np_rollout_insert(C.byref(qi), self.device.index, stream))
+        b.step = (s + 1) % b.buffer_size
+        return obs, reward, flags
+
+    def compute_returns(self):
+        """F16SimRunner.compute (:112-121): next values from the critic on the last slot, then ReplayBuffer.compute_returns."""
+        b, n = self.buffer, self.n
+        nv = self.policy.get_values(b.obs[-1].reshape(n, -1), b.rnn_states_critic[-1].reshape(n, HID), b.masks[-1].reshape(n, 1))
+        b.compute_returns(nv.reshape(n, 1, 1))

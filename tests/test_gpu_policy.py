@@ -247,3 +247,58 @@ def test_one_to_four_actions_and_weight_scales_equal_the_restatement(act_dim, sc
         assert same(v.cpu().numpy(), v_o) and same(a.cpu().numpy(), a_o) and same(lp.cpu().numpy(), lp_o), t
         assert same(dha.cpu().numpy()[:, 0], ha) and same(dhc.cpu().numpy()[:, 0], hc), t
         assert np.all(np.isfinite(lp_o)) and np.all(np.isfinite(v_o))
+
+
+@pytest.mark.parametrize('task', ['heading', 'tracking'])
+def test_device_collector_equals_the_three_calls(task):
+    """neuralplane_amd.collect.DeviceCollector (addresses computed, the policy writing into the buffer's slot in place) against the same collect
+    steps spelled as FusedPolicy.get_actions -> DeviceVecEnv.step -> DeviceReplayBuffer.insert_step: every storage array bit-identical after a
+    rollout that wraps the buffer, same torch seed, same env seed; then compute_returns."""
+    from neuralplane_amd.actor import NUM_FLOATS, FusedActor
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.collect import DeviceCollector
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    from neuralplane_amd.policy import FusedPolicy
+    from tests.policy_kat import random_state_dicts
+    n, T, act_dim = (700, 6, 4) if task == 'heading' else (300, 3, 3)
+
+    class Args:
+        buffer_size, n_rollout_threads = T, n
+        gamma, use_proper_time_limits, use_gae, gae_lambda = 0.99, True, True, 0.95
+        recurrent_hidden_size, recurrent_hidden_layers = 128, 1
+    sds = random_state_dicts(act_dim, 3)
+
+    def make():
+        if task == 'heading':
+            envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=5, device='cuda:0')])
+        else:
+            ctrl = FusedActor(np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32), 'cuda:0', numerics='i8')
+            envs = DeviceVecEnv([lambda: PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=5, device='cuda:0', controller=ctrl)])
+        buf = DeviceReplayBuffer(Args, 1, envs.observation_space, envs.action_space, device='cuda:0')
+        buf.obs[0].copy_(envs.reset())
+        return FusedPolicy(sds, 'cuda:0'), envs, buf
+
+    pol, envs, buf = make()
+    torch.manual_seed(21)
+    for _ in range(T + 2):                                   # wraps: steps T, T + 1 overwrite slots 0, 1 as the reference's buffer does
+        s = buf.step
+        v, a, lp, ha, hc = pol.get_actions(buf.obs[s].reshape(n, -1), buf.rnn_states_actor[s].reshape(n, 128), buf.rnn_states_critic[s].reshape(n, 128),
+                                           buf.masks[s].reshape(n, 1))
+        obs, rew, d, bd, tm, _ = envs.step(a)
+        buf.insert_step(obs, a, rew, d, bd, tm, lp, v, ha, hc)
+    pol2, envs2, buf2 = make()
+    col = DeviceCollector(pol2, envs2, buf2)
+    torch.manual_seed(21)
+    for _ in range(T + 2):
+        col.step()
+    assert buf2.step == buf.step == 2
+    for k in buf._STORAGE:
+        assert torch.equal(getattr(buf, k), getattr(buf2, k)), k
+    assert torch.equal(envs.env.model.s, envs2.env.model.s)
+    col.compute_returns()
+    buf.compute_returns(pol.get_values(buf.obs[-1].reshape(n, -1), buf.rnn_states_critic[-1].reshape(n, 128), buf.masks[-1].reshape(n, 1)).reshape(n, 1, 1))
+    assert torch.equal(buf.returns, buf2.returns) and float(buf.actions.abs().sum()) > 0
+    with pytest.raises(ValueError):
+        DeviceCollector(FusedPolicy(random_state_dicts(2, 1), 'cuda:0'), envs2, buf2)       # a 2-action policy on a 4-action buffer

@@ -242,6 +242,39 @@ def run_device(n, T, dev, graph=False, task='heading', fused_policy=False, polic
     return out
 
 
+def run_collector(n, T, dev, task='heading', policy_numerics='i8'):
+    """The device loop through neuralplane_amd.collect.DeviceCollector: FusedPolicy writing into the buffer's slot in place, env.step, insert."""
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.collect import DeviceCollector
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+    from neuralplane_amd.policy import FusedPolicy
+    torch.manual_seed(0)
+    policy = FusedPolicy(TorchPolicy().to(dev).eval().state_dicts(), device=dev, numerics=policy_numerics)
+    envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config=task, model='F16', random_seed=0, device=str(dev))])
+    buf = DeviceReplayBuffer(_Args(n, T), 1, envs.observation_space, envs.action_space, device=dev)
+    buf.obs[0].copy_(envs.reset())
+    col = DeviceCollector(policy, envs, buf)
+    for _ in range(T):
+        col.step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(T):
+        col.step()
+    torch.cuda.synchronize(dev)
+    wall_us = 1e6 * (time.perf_counter() - t0) / T
+    t0 = time.perf_counter()
+    for _ in range(T):
+        col.step()
+    host_us = 1e6 * (time.perf_counter() - t0) / T        # enqueue only (the GPU may lag behind)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    col.compute_returns()
+    torch.cuda.synchronize(dev)
+    return {'us_per_step_wall': wall_us, 'host_enqueue_us_per_step': host_us, 'compute_returns_ms': 1e3 * (time.perf_counter() - t0), 'steps': T,
+            'env_steps_per_s': n * 1e6 / wall_us}
+
+
 def run_selfplay(E, T, dev, fused_policy=False, policy_numerics='i8'):
     """The self-play runner's collect step (runner/selfplay_F16sim_runner.py:76-100 `collect`, :102-128 `insert`) on the device for the 1v1 combat
     env: ego policy `get_actions` on obs[:, :A//2], opponent policy `act` (sampled) on obs[:, A//2:], env.step on both actions, the ego half into
@@ -381,6 +414,7 @@ def collect_loop_report(n, T, dev):
     rep['device_fused_policy'] = run_device(n, T, dev, fused_policy=True)
     rep['device_fused_policy_graph'] = run_device(n, T, dev, graph=True, fused_policy=True)
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
+    rep['device_collector_i8'] = run_collector(n, T, dev)   # the same three launches behind neuralplane_amd.collect.DeviceCollector (addresses pre-bound)
     rep['device_fused_policy_i8'] = run_device(n, T, dev, fused_policy=True, policy_numerics='i8')   # both networks in the block-fixed-point numerics
     rep['device_fused_policy_i8']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy_i8']['us_per_step_wall']
     if n == 3000:
@@ -410,10 +444,12 @@ if __name__ == '__main__':
     ap.add_argument('--n', type=int, nargs='*', default=[3000, 10000])
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--out', default=None)
-    ap.add_argument('--only', default=None, choices=['fused', 'torch', 'selfplay'], help='profiling: run just the device loop with the fused / the eager torch policy')
+    ap.add_argument('--only', default=None, choices=['fused', 'torch', 'selfplay', 'collector'], help='profiling: run just the device loop with the fused / the eager torch policy')
     args = ap.parse_args()
     if args.only == 'selfplay':
         rep = {'selfplay_e12500': {'torch_policies': run_selfplay(12500, args.steps, 'cuda:0'), 'fused_policies': run_selfplay(12500, args.steps, 'cuda:0', fused_policy=True)}}
+    elif args.only == 'collector':
+        rep = {f'collect_loop_n{n}': {'device_collector_i8': run_collector(n, args.steps, 'cuda:0'), 'device_fused_policy_i8': run_device(n, args.steps, 'cuda:0', fused_policy=True, policy_numerics='i8')} for n in args.n}
     elif args.only:
         rep = {f'collect_loop_n{n}': {'device_fused_policy' if args.only == 'fused' else 'device': run_device(n, args.steps, 'cuda:0', fused_policy=args.only == 'fused')}
                for n in args.n}
