@@ -112,6 +112,18 @@ def main():
     print(f'device-resident collect loop: {steps} x (FusedPolicy.get_actions + PlanningEnv macro-step + insert) + returns in {dt * 1e3:.1f} ms = '
           f'{dt / steps * 1e3:.3f} ms per collect step, mean |action| {float(buf.actions.abs().mean()):.3f}, mean value {float(buf.value_preds[:-1].mean()):.3f}, '
           f'fallbacks {denvs.env.loop_fallbacks}')
+    # ---- the same step with the buffer's addresses pre-bound: the policy writes into the slot in place (neuralplane_amd.collect) ----
+    from neuralplane_amd.collect import DeviceCollector
+    col = DeviceCollector(policy, denvs, buf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        col.step()
+    col.compute_returns()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(buf.returns).all()
+    print(f'DeviceCollector: {dt / steps * 1e3:.3f} ms per collect step')
     print('OK')
 
 
