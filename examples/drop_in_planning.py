@@ -115,6 +115,8 @@ def main():
     # ---- the same step with the buffer's addresses pre-bound: the policy writes into the slot in place (neuralplane_amd.collect) ----
     from neuralplane_amd.collect import DeviceCollector
     col = DeviceCollector(policy, denvs, buf)
+    for _ in range(3):
+        col.step()                                                # first use: allocations
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
