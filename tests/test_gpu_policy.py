@@ -302,3 +302,61 @@ def test_device_collector_equals_the_three_calls(task):
     assert torch.equal(buf.returns, buf2.returns) and float(buf.actions.abs().sum()) > 0
     with pytest.raises(ValueError):
         DeviceCollector(FusedPolicy(random_state_dicts(2, 1), 'cuda:0'), envs2, buf2)       # a 2-action policy on a 4-action buffer
+
+
+@pytest.mark.parametrize('numerics', ['fp32', 'i8'])
+def test_a_rollout_equals_the_oracle_chain_bit_for_bit(numerics):
+    """End to end: 40 collect steps of DeviceCollector — policy step, fused env.step, insert, the policy's outputs feeding the env and
+    the env's observations / end-of-episode masks feeding the policy back through the rollout storage — against the same chain on the CPU: the
+    policy restatement (f16o_policy_act / _i8) on the same normal draws, the env oracle with the same seed, and the reference's insert rule in
+    numpy (runner/F16sim_runner.py:131-154: recurrent states of ended envs zeroed, masks / bad_masks).  Every storage array and the flight state
+    equal bit for bit; episodes end and re-start inside the window."""
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.collect import DeviceCollector
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+    from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
+    from oracle.f16_oracle import Oracle, PolicyOracle
+    from tests.policy_kat import random_state_dicts
+    n, T, seed = 333, 40, 9
+
+    class Args:
+        buffer_size, n_rollout_threads = T, n
+        gamma, use_proper_time_limits, use_gae, gae_lambda = 0.99, True, True, 0.95
+        recurrent_hidden_size, recurrent_hidden_layers = 128, 1
+    sa, sc = random_state_dicts(4, 17)
+    sa['act.action_out.mu_net.fc.0.weight'] *= np.float32(4.0)          # lively commands: some aircraft leave the envelope within the window
+    pol = FusedPolicy((sa, sc), 'cuda:0', numerics=numerics)
+    envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=seed, device='cuda:0')])
+    buf = DeviceReplayBuffer(Args, 1, envs.observation_space, envs.action_space, device='cuda:0')
+    buf.obs[0].copy_(envs.reset())
+    col = DeviceCollector(pol, envs, buf)
+    torch.manual_seed(77)
+    eps = [torch.randn((n, 4), device='cuda:0').cpu().numpy() for _ in range(T)]     # the draws the collector is about to make
+    torch.manual_seed(77)
+    for _ in range(T):
+        col.step()
+    # ---- the same rollout on the CPU
+    o, st = Oracle('heading'), Oracle.new_state(n)
+    po = PolicyOracle(pack_policy_actor(sa)[0], pack_policy_critic(sc), np.float32(pol.std), np.float32(pol.log_std), numerics)
+    r = {'obs': np.zeros((T + 1, n, 22), np.float32), 'actions': np.zeros((T, n, 4), np.float32), 'rewards': np.zeros((T, n), np.float32),
+         'masks': np.ones((T + 1, n), np.float32), 'bad_masks': np.ones((T + 1, n), np.float32), 'action_log_probs': np.zeros((T, n), np.float32),
+         'value_preds': np.zeros((T + 1, n), np.float32), 'rnn_states_actor': np.zeros((T + 1, n, 128), np.float32),
+         'rnn_states_critic': np.zeros((T + 1, n, 128), np.float32)}
+    r['obs'][0] = o.reset(st, seed=seed, call_idx=0)
+    ended = 0
+    for t in range(T):
+        v, a, lp, ha, hc = po.run(r['obs'][t], r['rnn_states_actor'][t], r['rnn_states_critic'][t], r['masks'][t], eps[t])
+        obs, rew, done, bad, tmo = o.step(st, a, seed=seed, call_idx=t + 1)
+        done, bad, tmo = done.astype(bool), bad.astype(bool), tmo.astype(bool)
+        reset_env = done | bad | tmo
+        ended += int(reset_env.sum())
+        ha[reset_env], hc[reset_env] = 0.0, 0.0
+        r['obs'][t + 1], r['actions'][t], r['rewards'][t], r['action_log_probs'][t], r['value_preds'][t] = obs, a, rew.reshape(n), lp.reshape(n), v.reshape(n)
+        r['masks'][t + 1], r['bad_masks'][t + 1] = (~done).astype(np.float32), (~bad).astype(np.float32)
+        r['rnn_states_actor'][t + 1], r['rnn_states_critic'][t + 1] = ha, hc
+    assert ended > 0, 'no episode ended inside the window: the masks / zeroed recurrent states were not exercised'
+    for k, ref in r.items():
+        got = getattr(buf, k).cpu().numpy().reshape(ref.shape)
+        assert same(got, ref), (k, int(np.argmax((got != ref).reshape(ref.shape[0], -1).any(1))))
+    assert same(envs.env.model.s.cpu().numpy(), st['s'])
