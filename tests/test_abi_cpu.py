@@ -51,7 +51,7 @@ def test_struct_layout_matches_ctypes(tmp_path):
     from neuralplane_amd import _lib
     pairs = [('np_f16_cfg', _lib.NpF16Cfg), ('np_f16_io', _lib.NpF16Io), ('np_pid_gains', _lib.NpPidGains),
              ('np_f16_combat_cfg', _lib.NpF16CombatCfg), ('np_f16_combat_io', _lib.NpF16CombatIo), ('np_planning_loop', _lib.NpPlanningLoop),
-             ('np_dispatch_info', _lib.NpDispatchInfo), ('np_rollout_step', _lib.NpRolloutStep)]
+             ('np_dispatch_info', _lib.NpDispatchInfo), ('np_rollout_step', _lib.NpRolloutStep), ('np_policy_step', __import__('neuralplane_amd.policy', fromlist=['x']).NpPolicyStep)]
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     exp = []
     for cname, st in pairs:
