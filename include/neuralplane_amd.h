@@ -406,6 +406,13 @@ typedef struct np_policy_step {
     int32_t obs_dim;          /* observations per row: 0 or 22 (control / heading / tracking: envs/configs/*.yaml num_observation), or 15 (the 1v1 combat
                                * env, selfplay.yaml) — obs is [n][obs_dim]; the packed layout is the same, the first layer's rows >= obs_dim are zero */
     int32_t reserved_;
+    /* optional (NULL: off) — the runner's insert rule applied by this launch instead of a separate one (F16SimRunner.insert, reference
+     * runner/F16sim_runner.py:131-154): prev_flags [3][n] = done, bad_done, exceed_time_limit of the env step that produced `obs`.  Then `masks`
+     * is not read: masks_out[n] = !done and bad_masks_out[n] = !bad_done are WRITTEN (the rollout storage's slot), the recurrent state of
+     * every env with any flag set is taken as zero and zeroed IN PLACE in rnn_states_*_in (which therefore must be writable: the slot the
+     * previous launch wrote as its rnn_states_*_out).  Results equal np_rollout_insert followed by this call without prev_flags, bit for bit. */
+    const uint8_t *prev_flags;
+    float *masks_out, *bad_masks_out;
 } np_policy_step;
 int np_policy_act(const np_policy_step *step, int device, void *stream);
 

@@ -6,8 +6,10 @@ and `DeviceReplayBuffer` those are three launches (+ the normal draws) — 47 us
 views of the buffer's slots, five output allocations, argument checks): at the sizes the reference trains at the host sets the rate.
 `DeviceCollector(policy, envs, buffer).step()` is the same step with the addresses computed instead of sliced: the policy reads the buffer's
 slot `step` in place and writes actions / log-probabilities / values straight into it, the env steps on that slot's actions, the insert
-launch finishes the slot (rewards, next observation, masks, recurrent states zeroed where an env ended).  Same kernels, same results as the
-three calls (tests/test_gpu_policy.py); nothing here computes.
+launch finishes the slot (rewards, next observation, masks, recurrent states zeroed where an env ended).  For ControlEnv the insert launch
+disappears as well (`in_place`): the env writes observation and reward into the slots themselves, the policy its recurrent states, and the
+NEXT policy launch applies the runner's insert rule from the env's flags (np_policy_step.prev_flags) — two launches + the normal draws per
+step, 41 us at 3 000 envs.  Same results as the three calls, bit for bit (tests/test_gpu_policy.py); nothing here computes.
 """
 import ctypes as C
 
@@ -25,7 +27,8 @@ class DeviceCollector:
     """collector = DeviceCollector(policy, envs, buffer); `collector.step()` = one collect step at `buffer.step` (which it advances);
     `collector.compute_returns()` = the runner's `compute` (:112-121).  Single-agent envs (ControlEnv, PlanningEnv under DeviceVecEnv)."""
 
-    def __init__(self, policy, envs, buffer):
+    def __init__(self, policy, envs, buffer, in_place=True):
+        """in_place: for ControlEnv, skip the insert launch (see below); False keeps the three launches per step."""
         if not isinstance(policy, FusedPolicy) or not isinstance(buffer, DeviceReplayBuffer):
             raise TypeError('DeviceCollector(policy: FusedPolicy, envs: DeviceVecEnv, buffer: DeviceReplayBuffer)')
         env = getattr(envs, 'env', envs)
@@ -47,6 +50,13 @@ class DeviceCollector:
         self._plain = type(env).step is BaseEnv.step       # ControlEnv: the batch's own step (obs, reward, flags[3, n]) without the per-flag views
         self._lib = _lib.load()
         self._bound = None
+        # ControlEnv: no insert launch at all.  The env writes observation / reward straight into the storage's slots, the policy writes its
+        # recurrent states straight into slot step + 1, and the NEXT policy launch applies the runner's insert rule from the env's flags
+        # (np_policy_step.prev_flags: masks / bad_masks of its slot, recurrent states of ended envs zeroed in place).  The last slot of a
+        # rollout is finished by one in-place insert launch (`finish`, called when the buffer wraps and by compute_returns).
+        self.in_place = bool(in_place) and self._plain and policy.obs_dim == 22
+        self._flag_bufs = [torch.zeros((3, n), dtype=torch.uint8, device=d) for _ in range(2)]
+        self._pending = None       # (flags tensor, slot) of the env step whose insert rule has not been applied yet
 
     def _bind(self):
         """Base addresses of the storage (re-read when the buffer re-allocated or somebody replaced a tensor)."""
@@ -62,8 +72,60 @@ class DeviceCollector:
             self._bound = (key, dict(zip(b._STORAGE, key)), q)
         return self._bound[1], self._bound[2]
 
+    def finish(self):
+        """Apply the insert rule that is still pending for the newest slot (in_place mode): masks, bad_masks, zeroed recurrent states of the envs
+        that ended in the last env step — one np_rollout_insert launch working in place."""
+        if self._pending is None:
+            return
+        flags, slot = self._pending              # slot = step index of that env step: its results live in slot (actions …) and slot + 1 (obs …)
+        base, qi = self._bind()
+        n, f4, od, ad = self.n, 4 * self.n, self.policy.obs_dim, self.policy.act_dim
+        qi.step = slot
+        qi.obs_in, qi.rewards_in = base['obs'] + (slot + 1) * f4 * od, base['rewards'] + slot * f4
+        qi.actions_in, qi.action_log_probs_in, qi.values_in = base['actions'] + slot * f4 * ad, base['action_log_probs'] + slot * f4, base['value_preds'] + slot * f4
+        ra, rc = base['rnn_states_actor'] + (slot + 1) * f4 * HID, base['rnn_states_critic'] + (slot + 1) * f4 * HID
+        qi.rnn_states_actor_in, qi.rnn_states_critic_in = ra, rc
+        fp = flags.data_ptr()
+        qi.done_in, qi.bad_done_in, qi.exceed_time_limit_in = fp, fp + n, fp + 2 * n
+        _lib.check(self._lib.np_rollout_insert(C.byref(qi), self.device.index, _lib.stream_ptr(self.device)))
+        qi.rnn_states_actor_in, qi.rnn_states_critic_in = self.ha.data_ptr(), self.hc.data_ptr()
+        self._pending = None
+
+    def _step_in_place(self):
+        p, b, n = self.policy, self.buffer, self.n
+        p._maybe_refresh()
+        base, _ = self._bind()
+        s, od, ad = b.step, p.obs_dim, p.act_dim
+        f4 = 4 * n
+        if self._pending is not None and self._pending[1] + 1 != s:      # somebody moved buffer.step: settle the old slot first
+            self.finish()
+        self.noise.normal_()
+        q = p._q
+        q.n, q.flags = n, ACTOR | CRITIC
+        q.obs, q.noise = base['obs'] + s * f4 * od, self.noise.data_ptr()
+        m_ptr, bm_ptr = base['masks'] + s * f4, base['bad_masks'] + s * f4
+        if self._pending is not None:
+            q.prev_flags, q.masks, q.masks_out, q.bad_masks_out = self._pending[0].data_ptr(), None, m_ptr, bm_ptr
+        else:
+            q.prev_flags, q.masks = None, m_ptr
+        q.rnn_states_actor_in, q.rnn_states_critic_in = base['rnn_states_actor'] + s * f4 * HID, base['rnn_states_critic'] + s * f4 * HID
+        q.rnn_states_actor_out, q.rnn_states_critic_out = base['rnn_states_actor'] + (s + 1) * f4 * HID, base['rnn_states_critic'] + (s + 1) * f4 * HID
+        q.values, q.actions, q.action_log_probs = base['value_preds'] + s * f4, base['actions'] + s * f4 * ad, base['action_log_probs'] + s * f4
+        _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(self.device)))
+        q.prev_flags = None
+        flags = self._flag_bufs[0] if self.env._batch.flags.data_ptr() != self._flag_bufs[0].data_ptr() else self._flag_bufs[1]
+        out = (b.obs[s + 1].view(n, od), b.rewards[s].view(n), flags)
+        self.env._batch.step(b.actions[s].view(n, ad), out=out)
+        self._pending = (flags, s)
+        b.step = (s + 1) % b.buffer_size
+        if b.step == 0:
+            self.finish()                        # the rollout is complete: its last slot settled before anybody reads or copies it
+        return out
+
     def step(self):
         """One collect step at buffer.step: returns the env's (obs, reward, flags[3, n] uint8 = done / bad_done / exceed_time_limit)."""
+        if self.in_place:
+            return self._step_in_place()
         p, b, n = self.policy, self.buffer, self.n
         p._maybe_refresh()
         base, qi = self._bind()
@@ -98,6 +160,7 @@ class DeviceCollector:
 
     def compute_returns(self):
         """F16SimRunner.compute (:112-121): next values from the critic on the last slot, then ReplayBuffer.compute_returns."""
+        self.finish()
         b, n = self.buffer, self.n
         nv = self.policy.get_values(b.obs[-1].reshape(n, -1), b.rnn_states_critic[-1].reshape(n, HID), b.masks[-1].reshape(n, 1))
         b.compute_returns(nv.reshape(n, 1, 1))

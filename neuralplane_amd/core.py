@@ -242,8 +242,9 @@ class F16Batch:
         self.call_idx += 1
         return obs
 
-    def step(self, action, rand_u=None, noise=None, inner=False, ll_tgt=None, ll_obs=None, want_obs=True):
+    def step(self, action, rand_u=None, noise=None, inner=False, ll_tgt=None, ll_obs=None, want_obs=True, out=None):
         """BaseEnv.step(action): ONE kernel launch.  Returns obs, reward, flags[3,n] (uint8).
+        out = (obs[n,22], reward[n], flags[3,n] uint8): caller-owned contiguous device buffers to write into (a rollout storage's slots).
         inner=True: one low-level iteration of PlanningEnv.step (np_f16_io.inner_step); with ll_tgt[3,n] and ll_obs[n,22] the
         launch also writes the low-level controller's NEXT observation into ll_obs (np_f16_io.ll_obs), and want_obs=False then skips
         the task observation (returned as None)."""
@@ -257,9 +258,16 @@ class F16Batch:
             raise ValueError('ll_tgt and ll_obs come together, with inner=True')
         if not want_obs and ll_obs is None:
             raise ValueError('want_obs=False needs ll_obs (an inner step that writes the low-level observation instead)')
-        obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device) if want_obs else None
-        reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
-        new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        if out is not None:
+            obs, reward, new_flags = out
+            if not (obs.is_contiguous() and reward.is_contiguous() and new_flags.is_contiguous() and obs.numel() == 22 * self.n and reward.numel() == self.n and
+                    new_flags.numel() == 3 * self.n and obs.dtype == reward.dtype == torch.float32 and new_flags.dtype == torch.uint8 and
+                    obs.device == reward.device == new_flags.device == self.device and new_flags.data_ptr() != self.flags.data_ptr()):
+                raise ValueError('out = (obs[n,22] float32, reward[n] float32, flags[3,n] uint8): contiguous device buffers, flags distinct from the current flags')
+        else:
+            obs = torch.empty((self.n, 22), dtype=torch.float32, device=self.device) if want_obs else None
+            reward = torch.empty(self.n, dtype=torch.float32, device=self.device)
+            new_flags = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
         rand_u, noise = self._inject(rand_u, 5), self._inject(noise, 22)
         io = self._io(new_flags, action, obs, reward, rand_u, noise, inner=inner, ll_tgt=ll_tgt, ll_obs=ll_obs)
         _lib.check(self.lib.np_f16_step(self._ctx, self.n, C.byref(io), self._stream()))

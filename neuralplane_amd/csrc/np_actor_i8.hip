@@ -56,11 +56,26 @@ __global__ __launch_bounds__(256, 2) void policy_act_i8_kernel(const nppol::ActA
     const long long ic = valid ? i : n - 1;
     float hm[1][16], xr[1][OBS], hn[1][16], mu[1];
     {
-        const float mk = a.mask[ic];
+        float mk;   // masks[i], or the previous env step's flags turned into the runner's insert rule (np_policy.hip)
+        bool ended = false;
+        if (a.prev) {
+            const bool d = a.prev[ic] != 0, b = a.prev[n + ic] != 0;
+            ended = d || b || a.prev[2 * n + ic] != 0;
+            mk = 1.0f;
+            if (valid && net == a.first_net && w == 0 && h == 0) {
+                a.masks_out[i] = d ? 0.0f : 1.0f;
+                a.bad_masks_out[i] = b ? 0.0f : 1.0f;
+            }
+        } else {
+            mk = a.mask[ic];
+        }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const float4 q = *reinterpret_cast<const float4 *>(h_in + ic * HID + 32 * w + 4 * h + 8 * g);
-            hm[0][4 * g] = q.x * mk; hm[0][4 * g + 1] = q.y * mk; hm[0][4 * g + 2] = q.z * mk; hm[0][4 * g + 3] = q.w * mk;
+            const float4 *hp = reinterpret_cast<const float4 *>(h_in + ic * HID + 32 * w + 4 * h + 8 * g);
+            const float4 q = *hp;
+            hm[0][4 * g] = ended ? 0.0f : q.x * mk; hm[0][4 * g + 1] = ended ? 0.0f : q.y * mk;
+            hm[0][4 * g + 2] = ended ? 0.0f : q.z * mk; hm[0][4 * g + 3] = ended ? 0.0f : q.w * mk;
+            if (ended && valid) *const_cast<float4 *>(hp) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
         for (int j = 0; j < NOBS; j++) xr[0][j] = a.obs[ic * NOBS + j];

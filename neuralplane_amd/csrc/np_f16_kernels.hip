@@ -1511,7 +1511,8 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
     if (q->reserved_ != 0) return fail("np_policy_act: reserved_ must be 0");
     if (q->weights_floats != 0 && q->weights_floats != NP_ACTOR_NUM_FLOATS && q->weights_floats != NP_ACTOR_I8_NUM_FLOATS)
         return fail("np_policy_act: weights_floats must be 0 / NP_ACTOR_NUM_FLOATS (fp32 chains) or NP_ACTOR_I8_NUM_FLOATS (block fixed point)");
-    if (!q->obs || !q->masks) return fail("np_policy_act: null obs / masks");
+    if (!q->obs || (!q->masks && !q->prev_flags)) return fail("np_policy_act: null obs / masks");
+    if (q->prev_flags && (!q->masks_out || !q->bad_masks_out)) return fail("np_policy_act: prev_flags needs masks_out and bad_masks_out");
     if (actor && (!q->actor_weights || !q->rnn_states_actor_in || !q->rnn_states_actor_out || !q->actions || !q->action_log_probs || (!det && !q->noise)))
         return fail("np_policy_act: null actor buffer");
     if (critic && (!q->critic_weights || !q->rnn_states_critic_in || !q->rnn_states_critic_out || !q->values)) return fail("np_policy_act: null critic buffer");
@@ -1538,6 +1539,7 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
     a.values = q->values; a.actions = q->actions; a.log_probs = q->action_log_probs;
     a.n = (long long)q->n; a.act_dim = q->act_dim; a.flags = q->flags; a.first_net = actor ? 0 : 1;
     a.obs_dim = q->obs_dim ? q->obs_dim : 22;
+    a.prev = q->prev_flags; a.masks_out = q->masks_out; a.bad_masks_out = q->bad_masks_out;
     for (int j = 0; j < 4; j++) {
         a.std[j] = q->std[j];
         a.log_std[j] = q->log_std[j];

@@ -13,6 +13,9 @@ struct ActArgs {
     long long n;
     int act_dim, flags, first_net, obs_dim;   // obs_dim: 22 or 15
     float std[4], log_std[4];
+    // optional: the flags [3][n] of the env step that produced `obs` — the runner's insert rule applied on the fly (see np_policy_step.prev_flags)
+    const unsigned char *prev;
+    float *masks_out, *bad_masks_out;
 };
 
 hipError_t launch_policy_act(const ActArgs &a, hipStream_t stream);

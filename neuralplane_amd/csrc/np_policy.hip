@@ -37,17 +37,35 @@ __global__ __launch_bounds__(MTHREADS, 2) void policy_act_kernel(const ActArgs a
     const long long ic = valid ? i : n - 1;
     Actor32Pre pre;
     actor32_request_l1(weights, tid, pre);
-    const float mk = a.mask[ic];
+    // the recurrent state's mask: masks[i], or — with the previous env step's flags — the runner's insert rule applied here
+    float mk;
+    bool ended = false;
+    if (a.prev) {
+        const bool d = a.prev[ic] != 0, b = a.prev[n + ic] != 0;
+        ended = d || b || a.prev[2 * n + ic] != 0;
+        mk = 1.0f;   // done implies ended: the state is zero there anyway
+        if (valid && net == a.first_net && wave == 0 && hi == 0) {
+            a.masks_out[i] = d ? 0.0f : 1.0f;
+            a.bad_masks_out[i] = b ? 0.0f : 1.0f;
+        }
+    } else {
+        mk = a.mask[ic];
+    }
     float hm[BLK];
     {
         const float4 *hp = reinterpret_cast<const float4 *>(h_in + ic * HID + blk * BLK);
 #pragma unroll
         for (int j = 0; j < BLK / 4; j++) {
             const float4 q = hp[j];
-            hm[4 * j] = q.x * mk;
-            hm[4 * j + 1] = q.y * mk;
-            hm[4 * j + 2] = q.z * mk;
-            hm[4 * j + 3] = q.w * mk;
+            hm[4 * j] = ended ? 0.0f : q.x * mk;
+            hm[4 * j + 1] = ended ? 0.0f : q.y * mk;
+            hm[4 * j + 2] = ended ? 0.0f : q.z * mk;
+            hm[4 * j + 3] = ended ? 0.0f : q.w * mk;
+        }
+        if (ended && valid) {   // the stored state of an env that ended is zero (F16SimRunner.insert): written back in place
+            float4 *hz = const_cast<float4 *>(hp);
+#pragma unroll
+            for (int j = 0; j < BLK / 4; j++) hz[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     actor32_stage_head(lds, weights, tid);

@@ -117,7 +117,7 @@ class NpPolicyStep(C.Structure):   # include/neuralplane_amd.h: np_policy_step
                 ('std', C.c_float * 4), ('log_std', C.c_float * 4), ('obs', C.c_void_p), ('masks', C.c_void_p), ('noise', C.c_void_p),
                 ('rnn_states_actor_in', C.c_void_p), ('rnn_states_critic_in', C.c_void_p), ('values', C.c_void_p), ('actions', C.c_void_p),
                 ('action_log_probs', C.c_void_p), ('rnn_states_actor_out', C.c_void_p), ('rnn_states_critic_out', C.c_void_p), ('weights_floats', C.c_int64),
-                ('obs_dim', C.c_int32), ('reserved_', C.c_int32)]
+                ('obs_dim', C.c_int32), ('reserved_', C.c_int32), ('prev_flags', C.c_void_p), ('masks_out', C.c_void_p), ('bad_masks_out', C.c_void_p)]
 
 
 ACTOR, CRITIC, DETERMINISTIC = 1, 2, 4
@@ -206,7 +206,7 @@ class FusedPolicy:
         m = self._rows(masks, n, 1)
         q = self._q   # weights, act_dim, std / log_std: filled by refresh(); the library reads the struct during the call only
         q.n, q.flags = n, flags
-        q.obs, q.masks = obs.data_ptr(), m.data_ptr()
+        q.obs, q.masks, q.prev_flags = obs.data_ptr(), m.data_ptr(), None   # (prev_flags: the collector's mode, collect.py)
         out = {}
         if flags & ACTOR:
             h = self._rows(ha, n, HID)

@@ -249,10 +249,10 @@ def test_one_to_four_actions_and_weight_scales_equal_the_restatement(act_dim, sc
         assert np.all(np.isfinite(lp_o)) and np.all(np.isfinite(v_o))
 
 
-@pytest.mark.parametrize('task', ['heading', 'tracking'])
-def test_device_collector_equals_the_three_calls(task):
-    """neuralplane_amd.collect.DeviceCollector (addresses computed, the policy writing into the buffer's slot in place) against the same collect
-    steps spelled as FusedPolicy.get_actions -> DeviceVecEnv.step -> DeviceReplayBuffer.insert_step: every storage array bit-identical after a
+@pytest.mark.parametrize('task,in_place', [('heading', True), ('heading', False), ('tracking', True)])
+def test_device_collector_equals_the_three_calls(task, in_place):
+    """neuralplane_amd.collect.DeviceCollector (addresses computed, the policy writing into the buffer's slot in place; in_place: no insert launch,
+    the next policy launch applies the insert rule from the env's flags) against the same collect steps spelled as FusedPolicy.get_actions -> DeviceVecEnv.step -> DeviceReplayBuffer.insert_step: every storage array bit-identical after a
     rollout that wraps the buffer, same torch seed, same env seed; then compute_returns."""
     from neuralplane_amd.actor import NUM_FLOATS, FusedActor
     from neuralplane_amd.buffer import DeviceReplayBuffer
@@ -289,10 +289,14 @@ def test_device_collector_equals_the_three_calls(task):
         obs, rew, d, bd, tm, _ = envs.step(a)
         buf.insert_step(obs, a, rew, d, bd, tm, lp, v, ha, hc)
     pol2, envs2, buf2 = make()
-    col = DeviceCollector(pol2, envs2, buf2)
+    col = DeviceCollector(pol2, envs2, buf2, in_place=in_place)
+    assert col.in_place == (in_place and task == 'heading')      # PlanningEnv steps through its own path: the insert launch stays
     torch.manual_seed(21)
-    for _ in range(T + 2):
+    for k in range(T + 2):
         col.step()
+        if k == 2:
+            col.finish()                                     # settling a slot early changes nothing
+    col.finish()
     assert buf2.step == buf.step == 2
     for k in buf._STORAGE:
         assert torch.equal(getattr(buf, k), getattr(buf2, k)), k
@@ -304,8 +308,9 @@ def test_device_collector_equals_the_three_calls(task):
         DeviceCollector(FusedPolicy(random_state_dicts(2, 1), 'cuda:0'), envs2, buf2)       # a 2-action policy on a 4-action buffer
 
 
+@pytest.mark.parametrize('in_place', [True, False])
 @pytest.mark.parametrize('numerics', ['fp32', 'i8'])
-def test_a_rollout_equals_the_oracle_chain_bit_for_bit(numerics):
+def test_a_rollout_equals_the_oracle_chain_bit_for_bit(numerics, in_place):
     """End to end: 40 collect steps of DeviceCollector — policy step, fused env.step, insert, the policy's outputs feeding the env and
     the env's observations / end-of-episode masks feeding the policy back through the rollout storage — against the same chain on the CPU: the
     policy restatement (f16o_policy_act / _i8) on the same normal draws, the env oracle with the same seed, and the reference's insert rule in
@@ -330,7 +335,7 @@ def test_a_rollout_equals_the_oracle_chain_bit_for_bit(numerics):
     envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=seed, device='cuda:0')])
     buf = DeviceReplayBuffer(Args, 1, envs.observation_space, envs.action_space, device='cuda:0')
     buf.obs[0].copy_(envs.reset())
-    col = DeviceCollector(pol, envs, buf)
+    col = DeviceCollector(pol, envs, buf, in_place=in_place)
     torch.manual_seed(77)
     eps = [torch.randn((n, 4), device='cuda:0').cpu().numpy() for _ in range(T)]     # the draws the collector is about to make
     torch.manual_seed(77)
