@@ -27,8 +27,10 @@ class DeviceCollector:
     """collector = DeviceCollector(policy, envs, buffer); `collector.step()` = one collect step at `buffer.step` (which it advances);
     `collector.compute_returns()` = the runner's `compute` (:112-121).  Single-agent envs (ControlEnv, PlanningEnv under DeviceVecEnv)."""
 
-    def __init__(self, policy, envs, buffer, in_place=True):
-        """in_place: for ControlEnv, skip the insert launch (see below); False keeps the three launches per step."""
+    def __init__(self, policy, envs, buffer, in_place=True, noise_block=1):
+        """in_place: for ControlEnv, skip the insert launch (see below); False keeps the three launches per step.
+        noise_block = K > 1: the normal draws of K consecutive steps come from ONE torch.randn((K, n, A)) (the same generator, one launch per K
+        steps instead of one per step; the draws are then not the ones K separate calls would have produced)."""
         if not isinstance(policy, FusedPolicy) or not isinstance(buffer, DeviceReplayBuffer):
             raise TypeError('DeviceCollector(policy: FusedPolicy, envs: DeviceVecEnv, buffer: DeviceReplayBuffer)')
         env = getattr(envs, 'env', envs)
@@ -45,7 +47,10 @@ class DeviceCollector:
             raise ValueError('recurrent state: one layer of 128')
         self.n = n
         d = self.device
-        self.noise = torch.empty((n, policy.act_dim), dtype=torch.float32, device=d)
+        self.noise_block = max(1, int(noise_block))
+        self._block = torch.empty((self.noise_block, n, policy.act_dim), dtype=torch.float32, device=d)
+        self.noise = self._block[0]
+        self._drawn = 0            # steps of the current block already used
         self.ha, self.hc = torch.empty((n, HID), dtype=torch.float32, device=d), torch.empty((n, HID), dtype=torch.float32, device=d)
         self._plain = type(env).step is BaseEnv.step       # ControlEnv: the batch's own step (obs, reward, flags[3, n]) without the per-flag views
         self._lib = _lib.load()
@@ -71,6 +76,17 @@ class DeviceCollector:
             q.rnn_states_actor_in, q.rnn_states_critic_in = self.ha.data_ptr(), self.hc.data_ptr()
             self._bound = (key, dict(zip(b._STORAGE, key)), q)
         return self._bound[1], self._bound[2]
+
+    def _noise_ptr(self):
+        """The address of this step's normal draws (drawn now, or K steps at a time)."""
+        if self.noise_block == 1:
+            self.noise.normal_()                            # torch's generator on this device, as the reference's sample()
+            return self.noise.data_ptr()
+        k = self._drawn % self.noise_block
+        if k == 0:
+            self._block.normal_()
+        self._drawn += 1
+        return self._block.data_ptr() + 4 * k * self.n * self.policy.act_dim
 
     def finish(self):
         """Apply the insert rule that is still pending for the newest slot (in_place mode): masks, bad_masks, zeroed recurrent states of the envs
@@ -99,10 +115,10 @@ class DeviceCollector:
         f4 = 4 * n
         if self._pending is not None and self._pending[1] + 1 != s:      # somebody moved buffer.step: settle the old slot first
             self.finish()
-        self.noise.normal_()
+        noise_ptr = self._noise_ptr()
         q = p._q
         q.n, q.flags = n, ACTOR | CRITIC
-        q.obs, q.noise = base['obs'] + s * f4 * od, self.noise.data_ptr()
+        q.obs, q.noise = base['obs'] + s * f4 * od, noise_ptr
         m_ptr, bm_ptr = base['masks'] + s * f4, base['bad_masks'] + s * f4
         if self._pending is not None:
             q.prev_flags, q.masks, q.masks_out, q.bad_masks_out = self._pending[0].data_ptr(), None, m_ptr, bm_ptr
@@ -132,10 +148,10 @@ class DeviceCollector:
         s, od, ad = b.step, p.obs_dim, p.act_dim
         f4 = 4 * n
         a_ptr, lp_ptr, v_ptr = base['actions'] + s * f4 * ad, base['action_log_probs'] + s * f4, base['value_preds'] + s * f4
-        self.noise.normal_()                                # the step's normal draws: torch's generator on this device, as the reference's sample()
+        noise_ptr = self._noise_ptr()
         q = p._q
         q.n, q.flags = n, ACTOR | CRITIC
-        q.obs, q.masks, q.noise = base['obs'] + s * f4 * od, base['masks'] + s * f4, self.noise.data_ptr()
+        q.obs, q.masks, q.noise = base['obs'] + s * f4 * od, base['masks'] + s * f4, noise_ptr
         q.rnn_states_actor_in, q.rnn_states_critic_in = base['rnn_states_actor'] + s * f4 * HID, base['rnn_states_critic'] + s * f4 * HID
         q.values, q.actions, q.action_log_probs = v_ptr, a_ptr, lp_ptr
         q.rnn_states_actor_out, q.rnn_states_critic_out = self.ha.data_ptr(), self.hc.data_ptr()

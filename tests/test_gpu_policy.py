@@ -365,3 +365,43 @@ def test_a_rollout_equals_the_oracle_chain_bit_for_bit(numerics, in_place):
         got = getattr(buf, k).cpu().numpy().reshape(ref.shape)
         assert same(got, ref), (k, int(np.argmax((got != ref).reshape(ref.shape[0], -1).any(1))))
     assert same(envs.env.model.s.cpu().numpy(), st['s'])
+
+
+def test_collector_noise_blocks_use_the_draws_of_one_randn():
+    """noise_block = K: step k of a block uses rows [k] of ONE torch.randn((K, n, A)) — the same rollout as K-step blocks handed to get_actions."""
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.collect import DeviceCollector
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+    from neuralplane_amd.policy import FusedPolicy
+    from tests.policy_kat import random_state_dicts
+    n, T, K = 500, 7, 3
+
+    class Args:
+        buffer_size, n_rollout_threads = T, n
+        gamma, use_proper_time_limits, use_gae, gae_lambda = 0.99, True, True, 0.95
+        recurrent_hidden_size, recurrent_hidden_layers = 128, 1
+    sds = random_state_dicts(4, 8)
+
+    def make():
+        envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=2, device='cuda:0')])
+        buf = DeviceReplayBuffer(Args, 1, envs.observation_space, envs.action_space, device='cuda:0')
+        buf.obs[0].copy_(envs.reset())
+        return FusedPolicy(sds, 'cuda:0'), envs, buf
+    pol, envs, buf = make()
+    torch.manual_seed(4)
+    for t in range(T):
+        if t % K == 0:
+            block = torch.randn((K, n, 4), device='cuda:0')
+        s = buf.step
+        v, a, lp, ha, hc = pol.get_actions(buf.obs[s].reshape(n, -1), buf.rnn_states_actor[s].reshape(n, 128), buf.rnn_states_critic[s].reshape(n, 128),
+                                           buf.masks[s].reshape(n, 1), noise=block[t % K])
+        obs, rew, d, bd, tm, _ = envs.step(a)
+        buf.insert_step(obs, a, rew, d, bd, tm, lp, v, ha, hc)
+    pol2, envs2, buf2 = make()
+    col = DeviceCollector(pol2, envs2, buf2, noise_block=K)
+    torch.manual_seed(4)
+    for _ in range(T):
+        col.step()
+    for k in buf._STORAGE:
+        assert torch.equal(getattr(buf, k), getattr(buf2, k)), k

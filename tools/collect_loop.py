@@ -242,7 +242,7 @@ def run_device(n, T, dev, graph=False, task='heading', fused_policy=False, polic
     return out
 
 
-def run_collector(n, T, dev, task='heading', policy_numerics='i8'):
+def run_collector(n, T, dev, task='heading', policy_numerics='i8', noise_block=1):
     """The device loop through neuralplane_amd.collect.DeviceCollector: FusedPolicy writing into the buffer's slot in place, env.step, insert."""
     from neuralplane_amd.buffer import DeviceReplayBuffer
     from neuralplane_amd.collect import DeviceCollector
@@ -254,7 +254,7 @@ def run_collector(n, T, dev, task='heading', policy_numerics='i8'):
     envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config=task, model='F16', random_seed=0, device=str(dev))])
     buf = DeviceReplayBuffer(_Args(n, T), 1, envs.observation_space, envs.action_space, device=dev)
     buf.obs[0].copy_(envs.reset())
-    col = DeviceCollector(policy, envs, buf)
+    col = DeviceCollector(policy, envs, buf, noise_block=noise_block)
     for _ in range(T):
         col.step()
     torch.cuda.synchronize(dev)
@@ -414,6 +414,7 @@ def collect_loop_report(n, T, dev):
     rep['device_fused_policy'] = run_device(n, T, dev, fused_policy=True)
     rep['device_fused_policy_graph'] = run_device(n, T, dev, graph=True, fused_policy=True)
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
+    rep['device_collector_i8_noise_block16'] = run_collector(n, T, dev, noise_block=16)   # the normal draws of 16 steps from one randn
     rep['device_collector_i8'] = run_collector(n, T, dev)   # the same three launches behind neuralplane_amd.collect.DeviceCollector (addresses pre-bound)
     rep['device_fused_policy_i8'] = run_device(n, T, dev, fused_policy=True, policy_numerics='i8')   # both networks in the block-fixed-point numerics
     rep['device_fused_policy_i8']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy_i8']['us_per_step_wall']
@@ -449,7 +450,7 @@ if __name__ == '__main__':
     if args.only == 'selfplay':
         rep = {'selfplay_e12500': {'torch_policies': run_selfplay(12500, args.steps, 'cuda:0'), 'fused_policies': run_selfplay(12500, args.steps, 'cuda:0', fused_policy=True)}}
     elif args.only == 'collector':
-        rep = {f'collect_loop_n{n}': {'device_collector_i8': run_collector(n, args.steps, 'cuda:0'), 'device_fused_policy_i8': run_device(n, args.steps, 'cuda:0', fused_policy=True, policy_numerics='i8')} for n in args.n}
+        rep = {f'collect_loop_n{n}': {'device_collector_i8': run_collector(n, args.steps, 'cuda:0'), 'device_collector_i8_noise_block16': run_collector(n, args.steps, 'cuda:0', noise_block=16), 'device_fused_policy_i8': run_device(n, args.steps, 'cuda:0', fused_policy=True, policy_numerics='i8')} for n in args.n}
     elif args.only:
         rep = {f'collect_loop_n{n}': {'device_fused_policy' if args.only == 'fused' else 'device': run_device(n, args.steps, 'cuda:0', fused_policy=args.only == 'fused')}
                for n in args.n}
