@@ -405,3 +405,44 @@ def test_collector_noise_blocks_use_the_draws_of_one_randn():
         col.step()
     for k in buf._STORAGE:
         assert torch.equal(getattr(buf, k), getattr(buf2, k)), k
+
+
+@pytest.mark.parametrize('numerics', ['fp32', 'i8'])
+def test_prev_flags_equal_insert_then_policy(numerics):
+    """np_policy_step.prev_flags on synthetic flags (done, bad_done and exceed_time_limit each set on a random fifth of the rows, in every
+    combination): one launch that applies the runner's insert rule itself == np_rollout_insert followed by the plain launch — every policy output,
+    the masks / bad_masks it writes and the recurrent states it zeroes in place, bit for bit."""
+    from neuralplane_amd import _lib
+    from neuralplane_amd.policy import ACTOR, CRITIC, FusedPolicy, NpPolicyStep
+    from tests.policy_kat import random_state_dicts
+    fp = FusedPolicy(random_state_dicts(3, 44), 'cuda:0', numerics=numerics)
+    n, dev = 1234, 'cuda:0'
+    g = torch.Generator(device='cpu').manual_seed(6)
+    obs = torch.randn((n, 22), generator=g).to(dev)
+    ha0, hc0 = (torch.randn((n, 128), generator=g) * 0.5).to(dev), (torch.randn((n, 128), generator=g) * 0.5).to(dev)
+    eps = torch.randn((n, 3), generator=g).to(dev)
+    flags = (torch.rand((3, n), generator=g) < 0.2).to(torch.uint8).to(dev)
+    assert int(flags[0].sum()) > 50 and int((flags[0] & flags[1]).sum()) > 5
+    # reference: the insert rule in torch, then the plain launch
+    ended = (flags != 0).any(0)                    # (uint8.any() stays uint8: compare first)
+    ha_ref, hc_ref = ha0 * (~ended).float().unsqueeze(1), hc0 * (~ended).float().unsqueeze(1)
+    masks_ref, bad_ref = (flags[0] == 0).float(), (flags[1] == 0).float()
+    ref = fp.get_actions(obs, ha_ref, hc_ref, masks_ref.reshape(n, 1), noise=eps)
+    # one launch with prev_flags
+    ha, hc = ha0.clone(), hc0.clone()
+    out = {k: torch.empty(s, device=dev) for k, s in (('v', (n, 1)), ('a', (n, 3)), ('lp', (n, 1)), ('ha', (n, 1, 128)), ('hc', (n, 1, 128)), ('m', (n,)), ('bm', (n,)))}
+    q = NpPolicyStep()
+    C.memmove(C.byref(q), C.byref(fp._q), C.sizeof(q))
+    q.n, q.flags = n, ACTOR | CRITIC
+    q.obs, q.masks, q.noise = obs.data_ptr(), None, eps.data_ptr()
+    q.prev_flags, q.masks_out, q.bad_masks_out = flags.data_ptr(), out['m'].data_ptr(), out['bm'].data_ptr()
+    q.rnn_states_actor_in, q.rnn_states_critic_in = ha.data_ptr(), hc.data_ptr()
+    q.rnn_states_actor_out, q.rnn_states_critic_out = out['ha'].data_ptr(), out['hc'].data_ptr()
+    q.values, q.actions, q.action_log_probs = out['v'].data_ptr(), out['a'].data_ptr(), out['lp'].data_ptr()
+    _lib.check(_lib.load().np_policy_act(C.byref(q), 0, _lib.stream_ptr(torch.device(dev))))
+    for k, (x, y) in enumerate(zip((out['v'], out['a'], out['lp'], out['ha'], out['hc']), ref)):
+        assert torch.equal(x, y), (k, float((x - y).abs().max()), int((x != y).sum()))
+    assert torch.equal(out['m'], masks_ref) and torch.equal(out['bm'], bad_ref)
+    assert torch.equal(ha, ha_ref) and torch.equal(hc, hc_ref)                 # zeroed in place where an env ended, untouched elsewhere
+    q.masks_out = None
+    assert _lib.load().np_policy_act(C.byref(q), 0, _lib.stream_ptr(torch.device(dev))) != 0      # prev_flags without somewhere to put the masks
