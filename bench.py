@@ -20,7 +20,8 @@ Protocol (the reference's own benchmark is envs/measure_env.py:65-78: back-to-ba
      the in-kernel counters, tools/microbench/cold_start.py), so an 8 ms window right after start-up measures the ramp.
   2. `prelude`: untimed env.steps for --prelude-ms (default 300 ms) of GPU load, count reported.
   3. W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides, MAX over ranks -> `value`.
-Prints ONE JSON line on rank 0 (DESIGN.md §6 has the roofline arithmetic).
+Rank 0 prints `BENCH_DETAILS {...}` (everything measured) and then, LAST, the one contract JSON line (< 4 KB: metric, value,
+ms_per_step, config, roofline, cpu_baseline).  `--full` adds the side modes to the details (DESIGN.md §6 has the roofline arithmetic).
 """
 import argparse
 import json
@@ -73,7 +74,7 @@ def usable_cpus():
     return cpus
 
 
-def cpu_baseline(task, budget_s=15.0):
+def cpu_baseline(task, budget_s=10.0, eager_budget_s=5.0):
     """The CPU oracle (oracle/, the C restatement of the reference path) timed on this box's host cores on a bounded sample of
     the same workload.  A reported baseline, never the thing shipped."""
     import numpy as np
@@ -100,7 +101,7 @@ def cpu_baseline(task, budget_s=15.0):
         # bench infrastructure, checked against the reference's fixtures; the reference's own files cannot travel to this box)
         try:
             from oracle.torch_eager import timed_rate
-            eager = timed_rate(n=100_000, budget_s=8.0, threads=cpus)
+            eager = timed_rate(n=100_000, budget_s=eager_budget_s, threads=cpus)
         except Exception as e:   # the baseline is context, never a reason to lose the bench line
             eager = {'error': repr(e)}
     return {'value': n * steps / el, 'unit': 'aircraft-steps/s', 'cores': int(o.threads), 'kind': 'port',
@@ -389,7 +390,7 @@ def run_env(args, rank, local_rank, world, dev, dist):
         # the reference publishes 245.5 MB allocated after its N = 1e6 run (envs/measure_env/gpu_memory_neuralplane.npy)
         'device_memory_mb': mem_mb,
     }
-    if world > 1 or args.headline_only:
+    if world > 1 or args.headline_only or not args.full:
         return out
     del env, tm
     torch.cuda.empty_cache()
@@ -709,7 +710,7 @@ def run_combat(args, rank, local_rank, world, dev, dist):
     # all-gathers of a step.  Strong scaling: the work per GPU shrinks 8x, the per-step floor (kernel latency at a small grid,
     # policy launches, exchange) does not.
     expected = None
-    if world == 1 and not args.headline_only:
+    if world == 1 and not args.headline_only and args.full:
         share = max(64, e_total // 8)
         senv = SingleCombatEnv(num_envs=share, config='selfplay', random_seed=0, device=str(dev), env0=0)
         sex = OpponentExchange(share, 0, share, None, dev, opponent_policy=opp_policy, lag=args.opponent_lag)
@@ -764,6 +765,57 @@ def run_combat(args, rank, local_rank, world, dev, dist):
     }
 
 
+DETAILS_PREFIX = 'BENCH_DETAILS '
+CONTRACT_MAX_BYTES = 4000
+
+
+def contract_line(out, details_path=None):
+    """The ONE line the driver parses: the contract fields and nothing else (< 4 KB).  Everything else this run measured (per-rank
+    times, cold start, prelude, expected scaling, optional modes, the long notes) is on the BENCH_DETAILS line printed before it
+    and in gpurun_out/bench_details.json."""
+    r = out['roofline']
+    keep_r = ('bound', 'achieved', 'peak', 'unit', 'frac', 'executed_frac', 'kernel', 'kernel_avg_ms', 'kernel_median_ms', 'launches_timed',
+              'traffic', 'traffic_source', 'algorithmic_bytes_per_launch', 'algorithmic_flop_per_aircraft_step', 'executed_flop_per_aircraft_step',
+              'algorithmic_flop_per_engagement_step', 'effective_shader_mhz')
+    line = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                'vs_baseline', 'dtype', 'data')}
+    line['config'] = {k: v for k, v in out['config'].items() if k in ('workload', 'aircraft_per_gpu', 'engagements_total', 'sharding')}
+    line['roofline'] = {k: r[k] for k in keep_r if k in r}
+    if 'roofline_hbm' in out:
+        line['roofline']['hbm_achieved_gbs'] = out['roofline_hbm']['achieved']
+        line['roofline']['hbm_frac'] = out['roofline_hbm']['frac']
+    line['roofline']['kernel_avg_source'] = 'HIP events on the launch stream over the K timed launches'
+    c = out.get('cpu_baseline')
+    if c:
+        te = c.get('torch_eager') or {}
+        line['cpu_baseline'] = {'value': c['value'], 'unit': c['unit'], 'cores': c['cores'], 'kind': c['kind'], 'sample': c['sample'],
+                                'torch_eager': te.get('value', te.get('aircraft_steps_per_s')) if isinstance(te, dict) else te}
+    for k in ('world_size', 'backend', 'rccl_ranks', 'state_finite'):
+        if k in out:
+            line[k] = out[k]
+    line['details'] = details_path
+    txt = json.dumps(line)
+    if len(txt) > CONTRACT_MAX_BYTES:   # never let the contract line grow again (round 5: 28.8 KB, unparsed)
+        raise SystemExit(f'bench.py: contract line is {len(txt)} bytes (> {CONTRACT_MAX_BYTES})')
+    return txt
+
+
+def emit(out):
+    """BENCH_DETAILS <everything> on an earlier stdout line + gpurun_out/bench_details.json; the contract line LAST."""
+    path = None
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'bench_details.json')
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1)
+        path = os.path.relpath(path, ROOT)
+    except OSError:
+        path = None
+    print(DETAILS_PREFIX + json.dumps(out), flush=True)
+    print(contract_line(out, path), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -781,6 +833,9 @@ def main():
     ap.add_argument('--prelude-ms', type=float, default=300.0, help='untimed GPU load before the timed window (clock-governor ramp); 0 disables')
     ap.add_argument('--headline-only', '--no-cpu-baseline', dest='headline_only', action='store_true',
                     help='skip cpu_baseline and the optional modes reported beside the headline')
+    ap.add_argument('--full', action='store_true',
+                    help='also run the modes reported beside the headline (rk4, 1-D tables, N = 1e7, N = 256 latency, SingleCombat, PlanningEnv, the collect '
+                         'loop, the reference protocol): minutes, reported on the BENCH_DETAILS line / gpurun_out/bench_details.json, never on the contract line')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend: 'nccl' = RCCL (default); 'gloo' lets the multi-rank path be exercised on a box with "
                          'fewer GPUs than ranks (ranks then share GPUs: a functional check, not a benchmark)')
@@ -812,7 +867,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.headline_only:
             out['cpu_baseline'] = cpu_baseline('heading' if args.task == 'combat' else args.task)
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

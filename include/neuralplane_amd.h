@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 15
+#define NP_ABI_VERSION 16
 
 #define NP_NUM_STATES 12   /* npos epos alt | roll pitch yaw | vt alpha beta | P Q R   (F16_dynamics.py:39-51) */
 #define NP_NUM_CONTROLS 5  /* T el ail rud lef                                         (F16_dynamics.py:53-58) */
@@ -42,6 +42,7 @@ extern "C" {
 
 enum { NP_TASK_HEADING = 0, NP_TASK_CONTROL = 1, NP_TASK_TRACKING = 2 }; /* envs/control_env.py:28-35 */
 enum { NP_SOLVER_EULER = 0, NP_SOLVER_RK4 = 1 };                          /* envs/models/F16_model.py:16,64-67 */
+#define NP_INNER_UPDATE_ONLY 2 /* np_f16_io.inner_step: F16Model.update(action) on its own (envs/models/F16_model.py:51-67) */
 
 /* Scenario constants = the keys of envs/configs/{heading,control,tracking}.yaml, with the
  * defaults of the reference's getattr(config, key, default) calls.  Values are passed as Python
@@ -97,7 +98,11 @@ typedef struct np_f16_io {
     /* inner_step != 0 selects the semantics of ONE of the 50 low-level iterations inside PlanningEnv.step
      * (envs/planning_env.py:153-176): no auto-reset, rows whose *_in flags are already set keep their state
      * (`s[reset] = recent_s[reset]`, controls still advance), step_count += 1 for every row, and the *_out
-     * flags ACCUMULATE (out = in | new), as BaseEnv.done does between two reset() calls (env_base.py:70-75). */
+     * flags ACCUMULATE (out = in | new), as BaseEnv.done does between two reset() calls (env_base.py:70-75).
+     * inner_step == NP_INNER_UPDATE_ONLY (ABI 16): F16Model.update(action) on its own (envs/models/F16_model.py:51-67, called directly by
+     * envs/planning_env.py:160 and example/quick_start.ipynb): clamp, control lag and the integrator for EVERY row — no auto-reset, no hold,
+     * step_count untouched, *_out = *_in, no termination condition or reward reported (obs, reward, term_* may be NULL; obs, when given,
+     * receives task.get_obs of the new state).  The cross-step coefficient cache is refreshed for the state reached, as by any step. */
     int32_t inner_step;
     uint64_t seed;         /* RNG key */
     uint64_t call_idx;     /* RNG counter word: the caller increments it once per reset()/step() call */

@@ -13,7 +13,8 @@ from . import build as _build
 
 TASKS = {'heading': 0, 'control': 1, 'tracking': 2}
 SOLVERS = {'euler': 0, 'rk4': 1}
-ABI_VERSION = 15
+ABI_VERSION = 16
+INNER_UPDATE_ONLY = 2   # np_f16_io.inner_step: F16Model.update(action) on its own (NP_INNER_UPDATE_ONLY)
 
 
 class NpF16Cfg(C.Structure):

@@ -38,8 +38,20 @@ NUM_FLOATS = 153392
 NUM_FLOATS_I8 = 309312   # NP_ACTOR_I8_NUM_FLOATS: the same floats + per-output scales + limb fragments (np_actor_pack_i8)
 
 
+SUPPORTED = 'hidden-size "128 128", act-hidden-size "128 128", recurrent-hidden-size 128 x 1 layer, feature LayerNorm, ReLU'
+
+
+def reject_deeper_networks(state_dict, key_of=lambda k: k):
+    """The reference builds its networks from --hidden-size / --act-hidden-size / --recurrent-hidden-size / --recurrent-hidden-layers
+    (/root/reference/config.py:48-285): a third MLP layer or a second GRU layer shows up as extra state_dict keys, not as a shape."""
+    for k in ('base.mlp.fc.6.weight', 'act.mlp.fc.6.weight', 'rnn.gru.weight_ih_l1'):
+        if key_of(k) in state_dict:
+            raise ValueError(f'{key_of(k)} present: a deeper network than the fused kernels are built for (supported: {SUPPORTED})')
+
+
 def pack_ppo_actor(state_dict):
     """PPOActor.state_dict() (tensors or arrays) -> float32[153392] in kernel order.  Raises on any other architecture."""
+    reject_deeper_networks(state_dict)
     parts = []
     for _, key, transpose in _LAYOUT:
         if key not in state_dict:

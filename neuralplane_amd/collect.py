@@ -20,6 +20,19 @@ from .buffer import DeviceReplayBuffer
 from .envs.env_base import BaseEnv
 from .policy import ACTOR, CRITIC, FusedPolicy
 
+
+def fuse_or_torch(policy, device='cuda:0', **kw):
+    """FusedPolicy(policy) when its networks have the shape the fused kernels are built for (hidden "128 128", act-hidden "128 128", one GRU layer
+    of 128 — the reference's training scripts; its command line also takes --hidden-size / --act-hidden-size / --recurrent-hidden-size,
+    /root/reference/config.py:48-285); any other shape: a warning naming the supported one, and the policy itself — DeviceCollector then runs
+    its torch get_actions on the device loop."""
+    import warnings
+    try:
+        return FusedPolicy(policy, device, **kw)
+    except ValueError as e:
+        warnings.warn(f'FusedPolicy: {e}; collecting with the policy\'s own torch modules on the device loop', RuntimeWarning, stacklevel=2)
+        return policy
+
 HID = 128
 
 
@@ -31,16 +44,26 @@ class DeviceCollector:
         """in_place: for ControlEnv, skip the insert launch (see below); False keeps the three launches per step.
         noise_block = K > 1: the normal draws of K consecutive steps come from ONE torch.randn((K, n, A)) (the same generator, one launch per K
         steps instead of one per step; the draws are then not the ones K separate calls would have produced)."""
-        if not isinstance(policy, FusedPolicy) or not isinstance(buffer, DeviceReplayBuffer):
-            raise TypeError('DeviceCollector(policy: FusedPolicy, envs: DeviceVecEnv, buffer: DeviceReplayBuffer)')
+        if not isinstance(buffer, DeviceReplayBuffer):
+            raise TypeError('DeviceCollector(policy, envs: DeviceVecEnv, buffer: DeviceReplayBuffer)')
         env = getattr(envs, 'env', envs)
         self.policy, self.env, self.buffer = policy, env, buffer
-        self.device = policy.device
+        # a policy of another shape than the fused kernels' (FusedPolicy raises ValueError for it, see fuse_or_torch): the same loop with the
+        # policy's own torch get_actions / get_values on the device — env.step and the insert launch stay this library's
+        self.fused = isinstance(policy, FusedPolicy)
+        if not self.fused and not (hasattr(policy, 'get_actions') and hasattr(policy, 'get_values')):
+            raise TypeError('policy: a FusedPolicy, or an object with the reference PPOPolicy\'s get_actions / get_values on device tensors')
+        self.device = policy.device if self.fused else buffer.device
         n, A = int(env.n), int(getattr(env, 'num_agents', 1))
         if A != 1 or buffer.num_agents != 1 or buffer.n_rollout_threads != n:
             raise ValueError(f'single-agent envs only: env rows {n} x {A} agents, buffer {buffer.n_rollout_threads} x {buffer.num_agents}')
         if buffer.device != self.device or torch.device(env.device) != self.device:
             raise ValueError('policy, envs and buffer must live on the same device')
+        self._plain = type(env).step is BaseEnv.step       # ControlEnv: the batch's own step (obs, reward, flags[3, n]) without the per-flag views
+        self.n = n
+        if not self.fused:
+            self.in_place, self._pending, self.noise_block = False, None, 1
+            return
         if (buffer.obs.shape[-1], buffer.actions.shape[-1]) != (policy.obs_dim, policy.act_dim):
             raise ValueError(f'buffer holds {buffer.obs.shape[-1]} observations / {buffer.actions.shape[-1]} actions, the policy {policy.obs_dim} / {policy.act_dim}')
         if buffer.recurrent_hidden_layers != 1 or buffer.recurrent_hidden_size != HID:
@@ -52,7 +75,6 @@ class DeviceCollector:
         self.noise = self._block[0]
         self._drawn = 0            # steps of the current block already used
         self.ha, self.hc = torch.empty((n, HID), dtype=torch.float32, device=d), torch.empty((n, HID), dtype=torch.float32, device=d)
-        self._plain = type(env).step is BaseEnv.step       # ControlEnv: the batch's own step (obs, reward, flags[3, n]) without the per-flag views
         self._lib = _lib.load()
         self._bound = None
         # ControlEnv: no insert launch at all.  The env writes observation / reward straight into the storage's slots, the policy writes its
@@ -90,7 +112,11 @@ class DeviceCollector:
 
     def finish(self):
         """Apply the insert rule that is still pending for the newest slot (in_place mode): masks, bad_masks, zeroed recurrent states of the envs
-        that ended in the last env step — one np_rollout_insert launch working in place."""
+        that ended in the last env step — one np_rollout_insert launch working in place.
+
+        Between two in_place steps slot step + 1 is UNFINISHED (stale masks / bad_masks, recurrent states of ended envs not yet zeroed): call
+        finish() before reading the storage directly mid-rollout (a checkpoint, buffer.compute_returns, policy.get_values on the newest slot).
+        compute_returns() here and the wrap of the buffer call it themselves."""
         if self._pending is None:
             return
         flags, slot = self._pending              # slot = step index of that env step: its results live in slot (actions …) and slot + 1 (obs …)
@@ -127,8 +153,10 @@ class DeviceCollector:
         q.rnn_states_actor_in, q.rnn_states_critic_in = base['rnn_states_actor'] + s * f4 * HID, base['rnn_states_critic'] + s * f4 * HID
         q.rnn_states_actor_out, q.rnn_states_critic_out = base['rnn_states_actor'] + (s + 1) * f4 * HID, base['rnn_states_critic'] + (s + 1) * f4 * HID
         q.values, q.actions, q.action_log_probs = base['value_preds'] + s * f4, base['actions'] + s * f4 * ad, base['action_log_probs'] + s * f4
-        _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(self.device)))
-        q.prev_flags = None
+        try:
+            _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(self.device)))
+        finally:
+            q.prev_flags = None    # the struct is the policy's own: a failed launch must not leave the collector's mode set in it
         flags = self._flag_bufs[0] if self.env._batch.flags.data_ptr() != self._flag_bufs[0].data_ptr() else self._flag_bufs[1]
         out = (b.obs[s + 1].view(n, od), b.rewards[s].view(n), flags)
         self.env._batch.step(b.actions[s].view(n, ad), out=out)
@@ -142,6 +170,8 @@ class DeviceCollector:
         """One collect step at buffer.step: returns the env's (obs, reward, flags[3, n] uint8 = done / bad_done / exceed_time_limit)."""
         if self.in_place:
             return self._step_in_place()
+        if not self.fused:
+            return self._step_torch_policy()
         p, b, n = self.policy, self.buffer, self.n
         p._maybe_refresh()
         base, qi = self._bind()
@@ -151,7 +181,7 @@ class DeviceCollector:
         noise_ptr = self._noise_ptr()
         q = p._q
         q.n, q.flags = n, ACTOR | CRITIC
-        q.obs, q.masks, q.noise = base['obs'] + s * f4 * od, base['masks'] + s * f4, noise_ptr
+        q.obs, q.masks, q.noise, q.prev_flags = base['obs'] + s * f4 * od, base['masks'] + s * f4, noise_ptr, None
         q.rnn_states_actor_in, q.rnn_states_critic_in = base['rnn_states_actor'] + s * f4 * HID, base['rnn_states_critic'] + s * f4 * HID
         q.values, q.actions, q.action_log_probs = v_ptr, a_ptr, lp_ptr
         q.rnn_states_actor_out, q.rnn_states_critic_out = self.ha.data_ptr(), self.hc.data_ptr()
@@ -174,9 +204,35 @@ class DeviceCollector:
         b.step = (s + 1) % b.buffer_size
         return obs, reward, flags
 
+    def _step_torch_policy(self):
+        """The collect step with a policy this library has no fused kernel for: `policy.get_actions` as the reference's runner calls it
+        (runner/F16sim_runner.py:123-129: rows = envs x agents, recurrent states [rows, layers, hidden], masks [rows, 1]) on views of the
+        buffer's slot, env.step on its actions, the runner's insert as one np_rollout_insert launch."""
+        p, b, n = self.policy, self.buffer, self.n
+        s = b.step
+        L, H = b.recurrent_hidden_layers, b.recurrent_hidden_size
+        with torch.no_grad():
+            values, actions, logp, ha, hc = p.get_actions(b.obs[s].reshape(n, -1), b.rnn_states_actor[s].reshape(n, L, H),
+                                                          b.rnn_states_critic[s].reshape(n, L, H), b.masks[s].reshape(n, 1))
+        actions = torch.as_tensor(actions, device=self.device).to(torch.float32).reshape(n, -1).contiguous()
+        if self._plain:
+            obs, reward, flags = self.env._batch.step(actions)
+            done, bad, tmo = flags[0], flags[1], flags[2]
+        else:
+            obs, reward, done, bad, tmo, _ = self.env.step(actions)
+            flags = torch.stack((done, bad, tmo)).view(torch.uint8) if done.dtype == torch.bool else torch.stack((done, bad, tmo)).to(torch.uint8)
+        as_t = lambda x: torch.as_tensor(x, device=self.device)   # noqa: E731
+        b.insert_step(obs, actions, reward, done, bad, tmo, as_t(logp), as_t(values), as_t(ha), as_t(hc))
+        return obs, reward, flags
+
     def compute_returns(self):
         """F16SimRunner.compute (:112-121): next values from the critic on the last slot, then ReplayBuffer.compute_returns."""
         self.finish()
         b, n = self.buffer, self.n
-        nv = self.policy.get_values(b.obs[-1].reshape(n, -1), b.rnn_states_critic[-1].reshape(n, HID), b.masks[-1].reshape(n, 1))
+        if self.fused:
+            nv = self.policy.get_values(b.obs[-1].reshape(n, -1), b.rnn_states_critic[-1].reshape(n, HID), b.masks[-1].reshape(n, 1))
+        else:
+            with torch.no_grad():
+                nv = torch.as_tensor(self.policy.get_values(b.obs[-1].reshape(n, -1), b.rnn_states_critic[-1].reshape(n, b.recurrent_hidden_layers, b.recurrent_hidden_size),
+                                                            b.masks[-1].reshape(n, 1)), device=self.device).to(torch.float32)
         b.compute_returns(nv.reshape(n, 1, 1))

@@ -277,6 +277,43 @@ class F16Batch:
         self._version += 1
         return obs, reward, new_flags
 
+    def update(self, action):
+        """F16Model.update(action) on its own (reference envs/models/F16_model.py:51-67; called directly by envs/planning_env.py:160 and
+        example/quick_start.ipynb): clamp, control lag and the integrator for every row as ONE launch (np_f16_io.inner_step =
+        NP_INNER_UPDATE_ONLY) — no auto-reset, step_count / flags / targets untouched, no observation, no reward.  The cross-step
+        coefficient cache is refreshed for the state reached, so update() and step() can be mixed freely."""
+        if action.device != self.device or action.dtype != torch.float32:
+            action = action.to(device=self.device, dtype=torch.float32)
+        if action.dim() != 2 or action.shape[0] != self.n or action.shape[1] < 4:
+            raise ValueError(f'action must be [n={self.n}, >=4], got {tuple(action.shape)}')
+        if action.stride(1) != 1:
+            action = action.contiguous()
+        scratch = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)   # *_out = *_in: the env's flags stay where they are
+        io = self._io(scratch, action, None, None, None, None)
+        io.inner_step = _lib.INNER_UPDATE_ONLY
+        io.term_reasons = io.reward_task = None
+        try:
+            _lib.check(self.lib.np_f16_step(self._ctx, self.n, C.byref(io), self._stream()))
+        finally:
+            io.inner_step = 0
+        self._cache_valid = True
+        self.call_idx += 1
+        self._version += 1
+
+    def model_reset(self, rand_u=None):
+        """F16Model.reset(env) on its own (F16_model.py:33-45): state and controls of the rows the env has flagged are re-initialised
+        (altitude and vt drawn) — the reset kernel on the env's flags; what BaseEnv.reset does beyond that (task.reset's targets, the step
+        counters, clearing the flags: env_base.py:83-97) is undone around the launch, so flags, targets and counters are as before."""
+        keep_tgt, keep_sc = self.tgt.clone(), self.step_count.clone()
+        scratch = torch.empty((3, self.n), dtype=torch.uint8, device=self.device)
+        io = self._io(scratch, None, None, None, self._inject(rand_u, 5), None)
+        io.term_reasons = io.reward_task = None
+        _lib.check(self.lib.np_f16_reset(self._ctx, self.n, C.byref(io), self._stream()))
+        self.tgt.copy_(keep_tgt)
+        self.step_count.copy_(keep_sc)
+        self.call_idx += 1
+        self._version += 1
+
     def planning_inner_loop(self, actor_weights, ll_obs, rnn, masks, ll_act, tgt3, flags_scratch, iterations, groups=0, mode=0, waves=0, block=0, check=0):
         """np_planning_inner_loop: the `iterations` low-level iterations of PlanningEnv.step (controller forward + inner FDM step each)
         enqueued by one library call.  ll_obs = (first input [n,22], scratch [n,22]); rnn = (state on entry [n,128], scratch [n,128]);

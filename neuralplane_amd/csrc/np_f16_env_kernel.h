@@ -198,7 +198,10 @@ void f16_env_kernel(const KArgs a) {
     }
     const bool flagged = fl_in != 0;
 
-    const bool frozen = INNER && flagged;  // planning_env.py:162-166: s[reset] = recent_s[reset]
+    // a.inner == 2 (INNER kernels only): F16Model.update(action) on its own (F16_model.py:51-67) — controls and state advance for EVERY row,
+    // nothing else of env.step happens: no hold, no step counter, flags handed through, no reward
+    const bool update_only = INNER && a.inner == 2;  // wave-uniform
+    const bool frozen = INNER && flagged && !update_only;  // planning_env.py:162-166: s[reset] = recent_s[reset]
     const bool tmo_prev = INNER && at_off(a.fin2, r32) != 0;
     // ---- self.reset(): re-initialise rows flagged by the previous step (env_base.py:83-95) ----
     if (flagged && !INNER) {
@@ -376,7 +379,7 @@ void f16_env_kernel(const KArgs a) {
             for (int k = 0; k < 12; k++) s[k] = frozen ? s[k] : y[k];
             NP_REREAD_ARGS(ap);
         }
-        sc += 1;  // env_base.py:102
+        sc += (INNER && ap->inner == 2) ? 0 : 1;  // env_base.py:102
     }
 
     // ---- observation at the new state (task.get_obs) ----
@@ -445,6 +448,10 @@ void f16_env_kernel(const KArgs a) {
             unsigned reasons = 0;
             float reward_task = 0.0f;
             done_and_reward<TASK>(ap->cfg, s, tgt, acc3, sc, done_prev, bad_prev, done, bad, reward, reasons, reward_task);
+            if (INNER && ap->inner == 2) {  // F16Model.update alone: the env's flags are not this call's business
+                done = done_prev;
+                bad = bad_prev;
+            }
             if (ap->reward_task && valid && part == STATE_WAVE) ap->reward_task[i] = reward_task;  // wave-uniform pointer test
             if (ap->term_reasons && valid && part == STATE_WAVE) {  // wave-uniform pointer test
                 // inner iterations of PlanningEnv.step: the bits accumulate like the flags they explain (the reset launch that opens
@@ -500,7 +507,7 @@ void f16_env_kernel(const KArgs a) {
         at_off(ap->fout0, iw) = done ? 1 : 0;
         at_off(ap->fout1, iw) = bad ? 1 : 0;
         at_off(ap->fout2, iw) = tmo_prev ? 1 : 0;
-        if (STEP) at_off(ap->reward, w4) = reward;
+        if (STEP && (!INNER || ap->reward)) at_off(ap->reward, w4) = reward;  // (no reward buffer: F16Model.update alone)
         if (STEP && ap->cache) {
             float *cache_w = ap->cache + ((long long)(iw >> 6) * NUM_CACHE_ROWS) * CACHE_TILE + (iw & (CACHE_TILE - 1));
 #pragma unroll

@@ -602,8 +602,11 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     if (io->ld < n) return fail("ld < n");
     if (io->ld >= (1ll << 30)) return fail("ld must be below 2^30 rows (32-bit byte offsets inside a row-indexed array)");
     if (!STEP && io->inner_step) return fail("inner_step applies to np_f16_step only");
-    if (STEP && (!io->action || !io->reward || io->act_stride < 4 || (!io->obs && !(io->inner_step && io->ll_obs))))
+    const bool update_only = STEP && io->inner_step == NP_INNER_UPDATE_ONLY;   // F16Model.update(action) alone
+    if (STEP && io->inner_step != 0 && io->inner_step != 1 && !update_only) return fail("inner_step: 0, 1 or NP_INNER_UPDATE_ONLY");
+    if (STEP && !update_only && (!io->action || !io->reward || io->act_stride < 4 || (!io->obs && !(io->inner_step && io->ll_obs))))
         return fail("step needs action (>=4 columns), obs and reward buffers (obs may be NULL only for an inner step that writes ll_obs)");
+    if (update_only && (!io->action || io->act_stride < 4)) return fail("update needs action (>=4 columns)");
     if (io->done_out == io->done_in || io->bad_out == io->bad_in || io->timeout_out == io->timeout_in)
         return fail("flag outputs may not alias flag inputs");
     DeviceGuard guard;
@@ -613,14 +616,14 @@ int launch_env(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, void *stream) {
     a.fin0 = io->done_in; a.fin1 = io->bad_in; a.fin2 = io->timeout_in;
     a.fout0 = io->done_out; a.fout1 = io->bad_out; a.fout2 = io->timeout_out;
     a.action = io->action; a.act_stride = io->act_stride; a.obs = io->obs; a.reward = io->reward;
-    a.inner = io->inner_step ? 1 : 0;
+    a.inner = update_only ? 2 : io->inner_step ? 1 : 0;
     a.rand_u = io->rand_u; a.noise = io->noise; a.cache = io->coef_cache; a.seed = io->seed; a.call_idx = io->call_idx;
     a.call_idx_base = io->call_idx_base;
-    a.term_counters = io->term_counters;
-    a.term_reasons = io->term_reasons;
-    a.reward_task = STEP ? io->reward_task : nullptr;
-    a.ll_tgt = (STEP && io->inner_step) ? io->ll_tgt : nullptr;
-    a.ll_obs = (STEP && io->inner_step) ? io->ll_obs : nullptr;
+    a.term_counters = update_only ? nullptr : io->term_counters;   // update alone evaluates no condition for anybody to see
+    a.term_reasons = update_only ? nullptr : io->term_reasons;
+    a.reward_task = (STEP && !update_only) ? io->reward_task : nullptr;
+    a.ll_tgt = (STEP && io->inner_step && !update_only) ? io->ll_tgt : nullptr;
+    a.ll_obs = (STEP && io->inner_step && !update_only) ? io->ll_obs : nullptr;
     if (a.ll_obs && !a.ll_tgt) return fail("ll_obs needs ll_tgt");
     a.row0 = io->row0; a.n = n; a.cfg = ctx->cfg;
     a.reset_coef = ctx->d_reset_coef;
@@ -1526,6 +1529,42 @@ int np_policy_act(const np_policy_step *q, int device, void *stream) {
         for (int j = 0; j < q->act_dim; j++)
             if (!(q->std[j] > 0.0f)) return fail("np_policy_act: std must be positive");
     if (q->n == 0) return 0;
+    {   // no input range may overlap an output range: actor and critic workgroups of the one launch run in any order (the one allowed
+        // in-place write is the collector's: zeroing the recurrent-state INPUT of an env that ended, prev_flags mode)
+        struct Range { const void *p; size_t bytes; };
+        const size_t n = (size_t)q->n, od = (size_t)(q->obs_dim ? q->obs_dim : 22);
+        Range in[8], out[8];
+        int ni = 0, no = 0;
+        in[ni++] = {q->obs, n * od * 4};
+        if (q->masks) in[ni++] = {q->masks, n * 4};
+        if (q->prev_flags) {
+            in[ni++] = {q->prev_flags, n * 3};
+            out[no++] = {q->masks_out, n * 4};
+            out[no++] = {q->bad_masks_out, n * 4};
+        }
+        if (actor) {
+            in[ni++] = {q->rnn_states_actor_in, n * 128 * 4};
+            if (!det) in[ni++] = {q->noise, n * (size_t)q->act_dim * 4};
+            out[no++] = {q->rnn_states_actor_out, n * 128 * 4};
+            out[no++] = {q->actions, n * (size_t)q->act_dim * 4};
+            out[no++] = {q->action_log_probs, n * 4};
+        }
+        if (critic) {
+            in[ni++] = {q->rnn_states_critic_in, n * 128 * 4};
+            out[no++] = {q->rnn_states_critic_out, n * 128 * 4};
+            out[no++] = {q->values, n * 4};
+        }
+        auto overlap = [](const Range &a, const Range &b) {
+            const uintptr_t a0 = (uintptr_t)a.p, b0 = (uintptr_t)b.p;
+            return a0 < b0 + b.bytes && b0 < a0 + a.bytes;
+        };
+        for (int i = 0; i < ni; i++)
+            for (int j = 0; j < no; j++)
+                if (overlap(in[i], out[j])) return fail("np_policy_act: an input buffer overlaps an output buffer");
+        for (int i = 0; i < no; i++)
+            for (int j = i + 1; j < no; j++)
+                if (overlap(out[i], out[j])) return fail("np_policy_act: two output buffers overlap");
+    }
     int ndev = 0;
     NP_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("no such HIP device (this library has no CPU fallback)");

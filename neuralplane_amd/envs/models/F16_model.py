@@ -49,10 +49,21 @@ class F16Model(BaseModel):
         self._b.u.copy_(torch.as_tensor(value, device=self._b.device).t())
 
     def reset(self, env):
-        raise RuntimeError('F16Model.reset is fused into BaseEnv.reset()/step() (one HIP kernel)')
+        """F16Model.reset(env) (reference F16_model.py:33-45): state and controls of the rows `env` has flagged (is_done | bad_done |
+        exceed_time_limit) are re-initialised — one launch of the reset kernel on the env's flags; targets, step counters and the flags
+        themselves stay (BaseEnv.reset() is the call that also runs task.reset and clears them, in the same single launch)."""
+        if env is not None and getattr(env, '_batch', None) is not self._b:
+            raise ValueError('F16Model.reset(env): env must be the env this model belongs to')
+        self._b.model_reset()
+        self.recent_s, self.recent_u = None, None      # (the reference copies s / u of the reset rows into recent_*: see update)
 
     def update(self, action):
-        raise RuntimeError('F16Model.update is fused into BaseEnv.step() (one HIP kernel)')
+        """F16Model.update(action) (reference F16_model.py:51-67): clamp, first-order control lag, one integrator step — ONE kernel launch
+        (np_f16_io.inner_step = NP_INNER_UPDATE_ONLY), for callers that drive the model directly as envs/planning_env.py:160 and
+        example/quick_start.ipynb do.  `recent_s` / `recent_u` hold the state / controls from before the call, as the reference's do
+        ([n, 12] / [n, 5] copies: the one thing here that is not free — BaseEnv.step does not keep them)."""
+        self.recent_s, self.recent_u = self.s.clone(), self.u.clone()
+        self._b.update(torch.as_tensor(action, device=self._b.device))
 
     def get_extended_state(self):
         """nlplant(hstack(s,u)) — reference returns [n,17] with zero control derivatives (F16_model.py:47-49)."""

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .actor import _LAYOUT, _SHAPES, HID, NUM_FLOATS, NUM_FLOATS_I8, OBS, pack_i8
+from .actor import _LAYOUT, _SHAPES, HID, NUM_FLOATS, NUM_FLOATS_I8, OBS, SUPPORTED, pack_i8, reject_deeper_networks
 
 MAX_ACT = 4
 _CRITIC_KEYS = {'act.mlp.fc.0': 'mlp.fc.0', 'act.mlp.fc.2': 'mlp.fc.2', 'act.mlp.fc.3': 'mlp.fc.3', 'act.mlp.fc.5': 'mlp.fc.5'}
@@ -45,6 +45,7 @@ def _pack(state_dict, key_of, head_w, head_b, what):
     k0 = key_of('base.feature_norm.weight')
     if k0 not in state_dict:
         raise ValueError(f'not a {what} state_dict of the supported architecture: missing {k0}')
+    reject_deeper_networks(state_dict, key_of)
     obs_dim = int(_np(state_dict[k0]).shape[0])
     if obs_dim not in OBS_DIMS:
         raise ValueError(f'{k0}: {obs_dim} observations; supported: {OBS_DIMS}')
@@ -60,7 +61,7 @@ def _pack(state_dict, key_of, head_w, head_b, what):
             v = _np(state_dict[k])
             want = {'base.feature_norm.weight': (obs_dim,), 'base.feature_norm.bias': (obs_dim,), 'base.mlp.fc.0.weight': (HID, obs_dim)}.get(key, _SHAPES.get(key))
             if want is not None and tuple(v.shape) != want:
-                raise ValueError(f'{k}: shape {tuple(v.shape)}, expected {want} (hidden 128 128, GRU 128 x 1, {obs_dim} observations)')
+                raise ValueError(f'{k}: shape {tuple(v.shape)}, expected {want} (supported: {SUPPORTED}; {obs_dim} observations)')
             if obs_dim != OBS and key in ('base.feature_norm.weight', 'base.feature_norm.bias', 'base.mlp.fc.0.weight'):
                 pad = np.zeros(v.shape[:-1] + (OBS,), np.float32)
                 pad[..., :obs_dim] = v
@@ -80,7 +81,7 @@ def pack_policy_actor(state_dict):
     w, b, log_std = _np(state_dict[_HEAD_W]), _np(state_dict[_HEAD_B]), _np(state_dict['act.action_out.log_std']).reshape(-1)
     A = w.shape[0]
     if not (1 <= A <= MAX_ACT) or w.shape != (A, HID) or b.shape != (A,) or log_std.shape != (A,):
-        raise ValueError(f'mu_net: {tuple(w.shape)} / {tuple(b.shape)} / log_std {tuple(log_std.shape)}; supported: 1..4 actions on 128 features')
+        raise ValueError(f'mu_net: {tuple(w.shape)} / {tuple(b.shape)} / log_std {tuple(log_std.shape)}; supported: 1..4 actions on 128 features ({SUPPORTED})')
     wp, bp = np.zeros((MAX_ACT, HID), np.float32), np.zeros(MAX_ACT, np.float32)
     wp[:A], bp[:A] = w, b
     w, _ = _pack(state_dict, lambda k: k, wp, bp, 'PPOActor')
@@ -95,7 +96,7 @@ def pack_policy_critic(state_dict):
             raise ValueError(f'not a PPOCritic state_dict: missing {k}')
     w, b = _np(state_dict['value_out.weight']), _np(state_dict['value_out.bias'])
     if w.shape != (1, HID) or b.shape != (1,):
-        raise ValueError(f'value_out: {tuple(w.shape)} / {tuple(b.shape)}, expected (1, 128) / (1,)')
+        raise ValueError(f'value_out: {tuple(w.shape)} / {tuple(b.shape)}, expected (1, 128) / (1,) (supported: {SUPPORTED})')
     wp, bp = np.zeros((MAX_ACT, HID), np.float32), np.zeros(MAX_ACT, np.float32)
     wp[0], bp[0] = w[0], b[0]
 
@@ -208,24 +209,34 @@ class FusedPolicy:
         q.n, q.flags = n, flags
         q.obs, q.masks, q.prev_flags = obs.data_ptr(), m.data_ptr(), None   # (prev_flags: the collector's mode, collect.py)
         out = {}
+        # every staged input stays referenced until the launch is enqueued: a copy made by _rows (numpy / non-contiguous input) that lost
+        # its last reference before then would go back to the caching allocator, and the torch.empty of an OUTPUT of the same launch could
+        # be handed its block (np_policy_act also rejects any input range that overlaps an output range)
+        keep = [obs, m]
         if flags & ACTOR:
-            h = self._rows(ha, n, HID)
-            out['actions'] = torch.empty((n, self.act_dim), dtype=torch.float32, device=d)
-            out['logp'] = torch.empty((n, 1), dtype=torch.float32, device=d)
-            out['ha'] = torch.empty((n, 1, HID), dtype=torch.float32, device=d)
+            h_a = self._rows(ha, n, HID)
+            keep.append(h_a)
             if not flags & DETERMINISTIC:
                 if noise is None:
                     noise = torch.randn((n, self.act_dim), dtype=torch.float32, device=d)
                 noise = self._rows(noise, n, self.act_dim)
+                keep.append(noise)
                 q.noise = noise.data_ptr()
-            q.rnn_states_actor_in, q.rnn_states_actor_out = h.data_ptr(), out['ha'].data_ptr()
+        if flags & CRITIC:
+            h_c = self._rows(hc, n, HID)
+            keep.append(h_c)
+        if flags & ACTOR:
+            out['actions'] = torch.empty((n, self.act_dim), dtype=torch.float32, device=d)
+            out['logp'] = torch.empty((n, 1), dtype=torch.float32, device=d)
+            out['ha'] = torch.empty((n, 1, HID), dtype=torch.float32, device=d)
+            q.rnn_states_actor_in, q.rnn_states_actor_out = h_a.data_ptr(), out['ha'].data_ptr()
             q.actions, q.action_log_probs = out['actions'].data_ptr(), out['logp'].data_ptr()
         if flags & CRITIC:
-            h = self._rows(hc, n, HID)
             out['values'] = torch.empty((n, 1), dtype=torch.float32, device=d)
             out['hc'] = torch.empty((n, 1, HID), dtype=torch.float32, device=d)
-            q.rnn_states_critic_in, q.rnn_states_critic_out, q.values = h.data_ptr(), out['hc'].data_ptr(), out['values'].data_ptr()
+            q.rnn_states_critic_in, q.rnn_states_critic_out, q.values = h_c.data_ptr(), out['hc'].data_ptr(), out['values'].data_ptr()
         _lib.check(self.lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(d)))
+        del keep   # enqueued: later allocations are ordered behind the kernel on this stream
         return out
 
     # ---- the reference's three inference calls (ppo_policy.py:26-57) ----

@@ -1001,6 +1001,29 @@ int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *
                      row0, obs, reward, 1);
 }
 
+/* F16Model.update(action) on its own — envs/models/F16_model.py:51-67 (called directly by envs/planning_env.py:160 and the reference's
+ * example/quick_start.ipynb): clamp, control lag, one integrator step for EVERY row; flags, counters and targets are not its business */
+int f16o_update(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, const float *action, int64_t act_stride) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) update_row(m, cfg, s + 12 * i, u + 5 * i, action + act_stride * i);
+    return 0;
+}
+
+/* F16Model.reset(env) on its own — envs/models/F16_model.py:33-45: state and controls of the rows the env has flagged are re-initialised
+ * (two uniform draws: altitude, vt); targets, step counters and the flags themselves stay (they are task.reset's / BaseEnv.reset's) */
+int f16o_model_reset(const f16o_cfg *cfg, int64_t n, float *s, float *u, const uint8_t *done, const uint8_t *bad, const uint8_t *timeout,
+                     const float *rand_u, uint64_t seed, uint64_t call_idx, int64_t row0) {
+    for (int64_t i = 0; i < n; i++) {
+        if (!(done[i] | bad[i] | timeout[i])) continue;
+        float ru[8], tgt[3];
+        int64_t sc;
+        if (rand_u) memcpy(ru, rand_u + 5 * i, 5 * sizeof(float));
+        else f16o_rng_uniforms(seed, call_idx, row0 + i, ru);
+        reset_row(cfg, s + 12 * i, u + 5 * i, tgt, &sc, ru); /* the model's part of it: s, u */
+    }
+    return 0;
+}
+
 /* per-condition termination bits at the given (post-step) state: bit 0 overload, 1 low_altitude, 2 high_speed, 3 low_speed,
  * 4 extreme_state, 5 unreach_* (bad), 6 target reached (done) — what the condition classes count and print */
 void f16o_termination_reasons(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u,

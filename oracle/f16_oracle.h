@@ -111,6 +111,10 @@ int f16o_step_inner(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *
                     int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *action,
                     int64_t act_stride, const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0,
                     float *obs, float *reward);
+/* F16Model.update(action) / F16Model.reset(env) on their own (envs/models/F16_model.py:51-67, :33-45) — see f16_oracle.c */
+int f16o_update(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, const float *action, int64_t act_stride);
+int f16o_model_reset(const f16o_cfg *cfg, int64_t n, float *s, float *u, const uint8_t *done, const uint8_t *bad, const uint8_t *timeout,
+                     const float *rand_u, uint64_t seed, uint64_t call_idx, int64_t row0);
 /* per-condition termination bits of the state (s, u, tgt, step_count) — see f16_oracle.c */
 void f16o_termination_reasons(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u,
                               const float *tgt, const int64_t *step_count, uint8_t *reasons);

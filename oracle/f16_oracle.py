@@ -265,6 +265,23 @@ class Oracle:
         assert rc == 0
         return obs, rew, st['done'].copy(), st['bad'].copy(), st['timeout'].copy()
 
+    def update(self, st, action):
+        """F16Model.update(action) alone (F16_model.py:51-67): clamp, control lag, one integrator step for every row."""
+        self._set_mode()
+        n = st['s'].shape[0]
+        a = _f32(action)
+        assert a.ndim == 2 and a.shape[0] == n and a.shape[1] >= 4
+        rc = self.lib.f16o_update(C.c_void_p(self.model), C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']), _p(a), C.c_int64(a.shape[1]))
+        assert rc == 0
+
+    def model_reset(self, st, rand_u=None, seed=0, call_idx=0, row0=0):
+        """F16Model.reset(env) alone (F16_model.py:33-45): s, u of the flagged rows; targets, counters and flags stay."""
+        n = st['s'].shape[0]
+        ru = None if rand_u is None else _f32(rand_u)
+        rc = self.lib.f16o_model_reset(C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']), _p(st['done'], C.c_uint8), _p(st['bad'], C.c_uint8),
+                                       _p(st['timeout'], C.c_uint8), _p(ru), C.c_uint64(seed), C.c_uint64(call_idx), C.c_int64(row0))
+        assert rc == 0
+
     def step(self, st, action, rand_u=None, noise=None, seed=0, call_idx=0, row0=0):
         self._set_mode()
         n = st['s'].shape[0]

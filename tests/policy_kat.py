@@ -43,3 +43,54 @@ def random_state_dicts(act_dim, seed, scale=1.0, obs_dim=22):
     actor['act.action_out.log_std'] = rng.uniform(-2.0, 0.5, act_dim)
     critic['value_out.weight'], critic['value_out.bias'] = 0.5 * rng.normal(size=(1, 128)), 0.3 * rng.normal(size=1)
     return ({k: np.asarray(v, np.float32) for k, v in actor.items()}, {k: np.asarray(v, np.float32) for k, v in critic.items()})
+
+
+LONG_N, LONG_STEPS, LONG_EVERY = 48, 200, 10
+
+
+def long_inputs(n=LONG_N, steps=LONG_STEPS, obs_dim=22, seed=4242):
+    """Inputs of tests/golden/policy_long_kat.npz (tools/gen_golden.py::gen_policy_long), regenerated instead of stored (numpy RandomState is
+    version-stable): observations that move like observations do — an AR(1) walk per row and column around per-column scales —
+    and masks with episode ends (2 % per row and step; `masks[t] = 0` makes get_actions restart that row's recurrent state,
+    algorithms/utils/gru.py; runner/F16sim_runner.py:131-154 builds them from done | bad_done | exceed_time_limit)."""
+    rng = np.random.RandomState(seed)
+    scale = rng.uniform(0.1, 3.0, (1, obs_dim))
+    x = rng.normal(0, 1, (n, obs_dim))
+    obs = np.empty((steps, n, obs_dim), np.float32)
+    for t in range(steps):
+        x = 0.97 * x + np.sqrt(1 - 0.97 ** 2) * rng.normal(0, 1, (n, obs_dim))
+        obs[t] = (x * scale).astype(np.float32)
+    masks = (rng.uniform(0, 1, (steps, n, 1)) > 0.02).astype(np.float32)
+    masks[0] = 1.0
+    return obs, masks
+
+
+def check_long_chain(g, run, what):
+    """`run(obs, ha, hc, masks, eps) -> values, actions, logp, ha, hc` chained for 200 steps on its OWN recurrent states against the
+    reference's recording (every LONG_EVERY-th step): the bounds of the 5-step fixture, at 200 steps.  Returns the worst errors."""
+    obs, masks = long_inputs()
+    n = obs.shape[1]
+    ha = hc = np.zeros((n, 128), np.float32)
+    worst = {k: 0.0 for k in TOL if k != 'means'}
+    rec = 0
+    for t in range(obs.shape[0]):
+        v, a, lp, ha, hc = run(obs[t], ha, hc, masks[t], g['eps'][t])
+        ha, hc = np.asarray(ha, np.float32).reshape(n, 128), np.asarray(hc, np.float32).reshape(n, 128)
+        if (t + 1) % LONG_EVERY == 0:
+            e = {'values': np.max(np.abs(np.asarray(v).reshape(-1) - g['values'][rec].reshape(-1))), 'actions': np.max(np.abs(np.asarray(a) - g['actions'][rec])),
+                 'logp': np.max(np.abs(np.asarray(lp).reshape(-1) - g['logp'][rec].reshape(-1))),
+                 'rnn': max(np.max(np.abs(ha - g['ha'][rec])), np.max(np.abs(hc - g['hc'][rec])))}
+            for k, x in e.items():
+                assert x < TOL[k], (what, t + 1, k, float(x))
+                worst[k] = max(worst[k], float(x))
+            rec += 1
+    assert rec == g['values'].shape[0] == LONG_STEPS // LONG_EVERY and int((masks == 0).sum()) > 50
+    return worst
+
+
+def load_long(golden_dir):
+    d = np.load(f'{golden_dir}/policy_long_kat.npz')
+    g = {k: d[k] for k in d.files if '::' not in k}
+    sa = {k[len('actor::'):]: d[k] for k in d.files if k.startswith('actor::')}
+    sc = {k[len('critic::'):]: d[k] for k in d.files if k.startswith('critic::')}
+    return g, sa, sc

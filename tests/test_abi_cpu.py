@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.np_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.np_abi_version() == _lib.ABI_VERSION == 16
 
 
 def _flat_fields(struct, prefix=''):

@@ -337,6 +337,43 @@ def test_planning_closed_loop_vs_the_reference_recording(golden_dir, mode, waves
     assert int((env.step_count == 150).sum()) >= 30
 
 
+@pytest.mark.parametrize('mode,numerics', [('auto', 'i8'), ('auto', 'fp32'), ('launches', 'i8'), ('launches', 'fp32'), ('eager', 'i8')])
+def test_planning_closed_loop_over_1000_inner_steps_vs_the_reference_and_the_oracle(golden_dir, mode, numerics):
+    """PlanningEnv(controller=FusedActor).step x 20 = 1 000 closed-loop inner steps against the REFERENCE's own
+    PlanningEnv.step x 20 on the same actor state_dict / high-level actions / reset draws (tests/golden/planning_closed_long_kat.npz;
+    reference envs/planning_env.py:144-177, algorithms/ppo/ppo_actor.py:38-64; 62 of 64 rows never terminate), for the default
+    block-fixed-point controller and the fp32 one: after EVERY macro-step masks and counters equal, states <= 1e-4 (SURVEY floors),
+    recurrent state <= 5e-5, observation <= 1e-4 — and bit-identical to the CPU oracle's closed loop all the way (persistent kernel and
+    launch-by-launch).  The per-numerics worst errors go to gpurun_out/parity_planning_long.json."""
+    import json
+    import os
+    from tests.planning_closed import OracleClosedLoop, compare_with_reference
+    g = np.load(f'{golden_dir}/planning_closed_long_kat.npz')
+    env, w = _closed_env(g, mode, 0, 0, numerics)
+    cl = OracleClosedLoop(g, w, numerics) if mode != 'eager' else None
+    worst = {}
+    for k in range(g['hi_actions'].shape[0]):
+        env._batch.reset(rand_u=g[f'rand_u_{k}'], want_obs=False)
+        got = _closed_result(env, env.step(torch.from_numpy(g['hi_actions'][k]).cuda()))
+        for q, v in compare_with_reference(got, g, k).items():
+            worst[q] = max(worst.get(q, 0.0), v)
+        if cl is not None:
+            want = cl.macro_step(k)
+            for q in ('flags', 'step_count', 's', 'u', 'tgt', 'rnn', 'obs', 'reward'):
+                assert _same(got[q], want[q]), f'macro-step {k}: {q} differs from the oracle'
+    assert int(got['step_count'][g['never_flagged']].min()) == 1000 and int(g['never_flagged'].sum()) >= 32
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        path = os.path.join(root, 'gpurun_out', 'parity_planning_long.json')
+        rep = json.load(open(path)) if os.path.exists(path) else {}
+        rep[f'{numerics}/{mode}'] = {'inner_steps': 1000, 'rows': int(g['hi_actions'].shape[1]), 'rows_never_terminated': int(g['never_flagged'].sum()),
+                                     'worst_over_20_macro_steps_vs_reference': worst, 'bit_identical_to_oracle_closed_loop': cl is not None}
+        json.dump(rep, open(path, 'w'), indent=1)
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize('mode,waves,block,numerics', CLOSED_CASES)
 def test_planning_macro_steps_equal_the_oracle_closed_loop_bit_for_bit(golden_dir, mode, waves, block, numerics):
     """DIRECT: whole macro-steps of the persistent kernel (each schedule; and the 2 x 50-launch call) against Oracle.reset / lowlevel_obs /

@@ -353,3 +353,68 @@ def test_obs_after_step_leaves_the_reason_bits_of_the_last_step_alone():
     assert seen, 'no condition fired: the test did not exercise anything'
     env.reset()
     assert int(env.termination_reasons().sum()) == 0, 'a real reset() clears the bits'
+
+
+@pytest.mark.parametrize('task,solver', [('heading', None), ('tracking', None), ('control', 'rk4')])
+@pytest.mark.parametrize('n', [300, 20_000, 150_000])      # latency family, latency2, pair variant
+def test_model_update_and_model_reset_as_callables_equal_the_oracle_and_mix_with_env_step(task, solver, n):
+    """`env.model.update(action)` / `env.model.reset(env)` (reference envs/models/F16_model.py:51-67, :33-45; called
+    directly by envs/planning_env.py:160 and example/quick_start.ipynb) are ONE launch each instead of a RuntimeError.  20 x update ==
+    the oracle's update bit for bit (state and controls advance for every row; step_count, flags, targets untouched; recent_s / recent_u
+    hold the previous state as the reference's do); then update and env.step MIXED — the cross-step coefficient cache is refreshed by
+    update as by any step, so the steps that follow read valid keys — and model.reset(env) on the flags a step left behind
+    (flagged rows get the re-initialised s / u, nothing else changes), all bit for bit against the oracle on the production RNG."""
+    from neuralplane_amd.envs.control_env import ControlEnv
+    seed = 11
+    env = ControlEnv(num_envs=n, config=task, model='F16', random_seed=seed, device='cuda:0', solver=solver)
+    o, st = Oracle(task, solver=solver), Oracle.new_state(n)
+    obs = env.reset()
+    assert _same(obs.cpu().numpy(), o.reset(st, seed=seed, call_idx=0))
+    call = 1
+    rng = np.random.RandomState(n % 1000)
+    nsteps = 20 if n <= 20_000 else 6
+
+    def state_equal(what):
+        b = env._batch
+        assert _same(b.s.cpu().numpy().T, st['s']), f'{what}: state'
+        assert _same(b.u.cpu().numpy().T, st['u']), f'{what}: controls'
+        assert _same(b.tgt.cpu().numpy().T, st['tgt']), f'{what}: targets'
+        assert np.array_equal(b.step_count.cpu().numpy(), st['step_count']), f'{what}: step_count'
+        f = b.flags.cpu().numpy()
+        assert np.array_equal(f[0], st['done']) and np.array_equal(f[1], st['bad']) and np.array_equal(f[2], st['timeout']), f'{what}: masks'
+
+    for t in range(nsteps):                                   # 20 x update
+        a = rng.uniform(-1.3, 1.3, (n, 4)).astype(np.float32)
+        prev_s, prev_u = env.model.s.clone(), env.model.u.clone()
+        env.model.update(torch.from_numpy(a).cuda())
+        o.update(st, a)
+        call += 1
+        state_equal(f'update {t}')
+        assert torch.equal(env.model.recent_s, prev_s) and torch.equal(env.model.recent_u, prev_u)
+    assert int(env.step_count.max()) == 0 and not bool(env._batch.flags.any())
+    flagged_total = 0
+    for t in range(nsteps):                                   # update and env.step mixed; model.reset on the flags a step left
+        a = rng.uniform(-1.3, 1.3, (n, 4)).astype(np.float32)
+        if t % 3 == 1:
+            env.model.update(torch.from_numpy(a).cuda())
+            o.update(st, a)
+            call += 1
+            state_equal(f'mixed update {t}')
+            continue
+        obs, rew, done, bad, tmo, _ = env.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _, _, _ = o.step(st, a, seed=seed, call_idx=call)
+        call += 1
+        state_equal(f'mixed step {t}')
+        assert _same(obs.cpu().numpy(), o_obs) and _same(rew.cpu().numpy(), o_rew), f'mixed step {t}: obs / reward'
+        if t % 3 == 2:
+            flagged = (st['done'] | st['bad'] | st['timeout']).astype(bool)
+            flagged_total += int(flagged.sum())
+            before = {k: v.copy() for k, v in st.items()}
+            env.model.reset(env)
+            o.model_reset(st, seed=seed, call_idx=call)
+            call += 1
+            state_equal(f'model.reset {t}')
+            assert np.array_equal(st['s'][~flagged], before['s'][~flagged]) and np.array_equal(st['tgt'], before['tgt'])
+            if flagged.any():
+                assert np.all(st['s'][flagged][:, [0, 1, 3, 4, 5, 7, 8, 9, 10, 11]] == 0) and np.all(st['u'][flagged, 1:] == 0)
+    assert flagged_total > 0 or n < 1000, 'no row was ever flagged: model.reset was not exercised'

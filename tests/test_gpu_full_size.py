@@ -177,18 +177,37 @@ def test_same_seed_same_trajectory_and_flagged_rows_are_reinitialised():
     assert bool(((alt0 > 18000) & (alt0 < 21000)).all())
 
 
-def _bench_json(args, timeout=300):
+def _bench_json(args, timeout=300, raw=False):
+    """Runs bench.py as a plain command.  stdout must END with the contract line (the only line that starts with '{', < 4 KB, the line the
+    driver parses) and hold one BENCH_DETAILS line before it; returns the details dict (a superset) after checking that every scalar
+    of the contract line equals the details' value."""
     import json
     import os
     import subprocess
     import sys
+    import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.perf_counter()
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    wall = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
-    return json.loads(lines[0])
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in out_lines if ln.startswith('{')]
+    assert len(lines) == 1 and out_lines[-1] == lines[0], r.stdout[-2000:]                     # rank 0 only, and LAST
+    assert len(lines[0]) < 4000, len(lines[0])
+    line = json.loads(lines[0])
+    det = [ln for ln in out_lines if ln.startswith('BENCH_DETAILS ')]
+    assert len(det) == 1
+    d = json.loads(det[0][len('BENCH_DETAILS '):])
+    for k, v in line.items():
+        if not isinstance(v, dict) and k != 'details':
+            assert d[k] == v, k
+    assert line['roofline']['frac'] == d['roofline']['frac'] and line['roofline']['kernel_avg_ms'] == d['roofline']['kernel_avg_ms']
+    assert line['ms_per_step'] * 1e-3 * line['steps'] < wall            # the timed region fits inside the run's own wall clock
+    if line.get('details'):
+        assert json.load(open(os.path.join(root, line['details'])))['value'] == line['value']
+    return (d, line, wall) if raw else d
 
 
 def test_bench_multi_rank_path_on_one_gpu():
@@ -217,6 +236,23 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert d['n_gpus'] == 1 and d['rccl_ranks'] == 0 and d['steps'] == 20 and d['warmup'] == 5
     assert d['world_size'] == 1 and d['backend'] is None and len(d['per_rank']['host_enqueue_us_per_step']) == 1
     assert d['expected_scaling']['host_keeps_gpu_fed'] in (True, False) and d['expected_scaling']['measured_at_world_size'] == 1
+
+
+def test_bench_driver_command_last_line_is_the_small_contract_line():
+    """The driver's own command (`bench.py --gpus 1 --steps 20 --warmup 5`, full size, CPU baselines included): the LAST stdout line is
+    the contract line and nothing else — < 4 KB (round 5's 28.8 KB line was not parsed), json.loads succeeds, it carries value,
+    ms_per_step, roofline.frac and cpu_baseline.value, K x ms_per_step fits inside the run's wall time, and the run stays under 60 s
+    (40 s is the target on a warm box; the first `import torch` of a fresh one takes longer)."""
+    d, line, wall = _bench_json(['--gpus', '1', '--steps', '20', '--warmup', '5'], raw=True)
+    assert set(line) >= {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                         'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
+    assert line['metric'].startswith('aircraft-steps/sec at N=1e6 F-16 Heading') and line['config']['aircraft_per_gpu'] == 1_000_000
+    assert line['value'] == pytest.approx(1_000_000 * 20 / (line['ms_per_step'] * 1e-3 * 20), rel=1e-6) and line['value'] > 1e9
+    r, c = line['roofline'], line['cpu_baseline']
+    assert 0.3 < r['frac'] < 1.0 and r['executed_frac'] < r['frac'] and r['kernel_avg_ms'] <= line['ms_per_step'] * 1.001
+    assert r['algorithmic_bytes_per_launch'] == 278.0 * 1_000_000 and (r['traffic'] is None or r['traffic'] >= r['algorithmic_bytes_per_launch'])
+    assert c['value'] > 0 and c['cores'] >= 1 and c['kind'] == 'port' and 'oracle/f16_oracle.c' in c['sample'] and c['torch_eager'] > 0
+    assert 'optional_modes' not in d and wall < 60, wall
 
 
 @pytest.mark.parametrize('task', ['tracking', 'combat'])

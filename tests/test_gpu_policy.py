@@ -446,3 +446,133 @@ def test_prev_flags_equal_insert_then_policy(numerics):
     assert torch.equal(ha, ha_ref) and torch.equal(hc, hc_ref)                 # zeroed in place where an env ended, untouched elsewhere
     q.masks_out = None
     assert _lib.load().np_policy_act(C.byref(q), 0, _lib.stream_ptr(torch.device(dev))) != 0      # prev_flags without somewhere to put the masks
+
+
+def test_collector_with_a_policy_of_another_shape_runs_its_torch_modules_on_the_device_loop():
+    """a policy built with --hidden-size "64 64" --recurrent-hidden-size 64 (the reference's command line allows it,
+    /root/reference/config.py:48-285) has no fused kernel: FusedPolicy raises a ValueError naming the supported shape, fuse_or_torch warns and
+    hands the policy back, and DeviceCollector keeps collecting with the policy's own torch get_actions — storage and flight state
+    bit-identical to the same steps spelled as policy.get_actions -> DeviceVecEnv.step -> DeviceReplayBuffer.insert_step (the FusedPolicy-free path)."""
+    import torch.nn as nn
+    from neuralplane_amd.buffer import DeviceReplayBuffer
+    from neuralplane_amd.collect import DeviceCollector, fuse_or_torch
+    from neuralplane_amd.envs.control_env import ControlEnv
+    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
+    from neuralplane_amd.policy import FusedPolicy
+    n, T, H = 500, 5, 64
+
+    class Tower(nn.Module):          # PPOActor / PPOCritic with the reference's state_dict key names, hidden 64
+        def __init__(self, out, critic):
+            super().__init__()
+            mlp = 'mlp' if critic else 'act_mlp'
+            self.mlp_name = mlp
+            self.ln0, self.l1, self.n1, self.l2, self.n2 = nn.LayerNorm(22), nn.Linear(22, H), nn.LayerNorm(H), nn.Linear(H, H), nn.LayerNorm(H)
+            self.gru, self.n3 = nn.GRU(H, H, num_layers=1), nn.LayerNorm(H)
+            self.a1, self.n4, self.a2, self.n5, self.head = nn.Linear(H, H), nn.LayerNorm(H), nn.Linear(H, H), nn.LayerNorm(H), nn.Linear(H, out)
+
+        def forward(self, obs, h, masks):            # h [n, 1, H] as the reference's runner passes it
+            x = self.n2(torch.relu(self.l2(self.n1(torch.relu(self.l1(self.ln0(obs)))))))
+            y, hn = self.gru(x.unsqueeze(0), (h * masks.unsqueeze(-1)).transpose(0, 1).contiguous())
+            x = self.n3(y.squeeze(0))
+            x = self.n5(torch.relu(self.a2(self.n4(torch.relu(self.a1(x))))))
+            return self.head(x), hn.transpose(0, 1)
+
+        def state_dict(self, *a, **k):
+            names = {'ln0': 'base.feature_norm', 'l1': 'base.mlp.fc.0', 'n1': 'base.mlp.fc.2', 'l2': 'base.mlp.fc.3', 'n2': 'base.mlp.fc.5', 'n3': 'rnn.norm',
+                     'a1': ('mlp' if self.mlp_name == 'mlp' else 'act.mlp') + '.fc.0', 'n4': ('mlp' if self.mlp_name == 'mlp' else 'act.mlp') + '.fc.2',
+                     'a2': ('mlp' if self.mlp_name == 'mlp' else 'act.mlp') + '.fc.3', 'n5': ('mlp' if self.mlp_name == 'mlp' else 'act.mlp') + '.fc.5',
+                     'head': 'value_out' if self.mlp_name == 'mlp' else 'act.action_out.mu_net.fc.0', 'gru': 'rnn.gru'}
+            return {names[k.split('.')[0]] + '.' + k.split('.', 1)[1]: v for k, v in super().state_dict().items()}
+
+    class Policy:                    # PPOPolicy's inference surface (algorithms/ppo/ppo_policy.py:26-57)
+        def __init__(self):
+            torch.manual_seed(3)
+            self.actor, self.critic = Tower(4, False).cuda(), Tower(1, True).cuda()
+            self.log_std = torch.zeros(4, device='cuda:0')
+            sd = self.actor.state_dict
+            self.actor.state_dict = lambda: {**sd(), 'act.action_out.log_std': self.log_std}
+
+        def get_actions(self, obs, ha, hc, masks):
+            mu, ha = self.actor(obs, ha, masks)
+            mu = torch.tanh(mu)
+            a = torch.randn_like(mu) * self.log_std.exp() + mu
+            lp = (-0.5 * (a - mu) ** 2 - 0.9189385).sum(-1, keepdim=True)
+            v, hc = self.critic(obs, hc, masks)
+            return v, a, lp, ha, hc
+
+        def get_values(self, obs, hc, masks):
+            return self.critic(obs, hc, masks)[0]
+
+    class Args:
+        buffer_size, n_rollout_threads = T, n
+        gamma, use_proper_time_limits, use_gae, gae_lambda = 0.99, True, True, 0.95
+        recurrent_hidden_size, recurrent_hidden_layers = H, 1
+
+    pol = Policy()
+    with pytest.raises(ValueError, match='128 128'):
+        FusedPolicy(pol, 'cuda:0')
+    with pytest.warns(RuntimeWarning, match='128 128'):
+        assert fuse_or_torch(pol, 'cuda:0') is pol
+
+    def make():
+        envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=5, device='cuda:0')])
+        buf = DeviceReplayBuffer(Args, 1, envs.observation_space, envs.action_space, device='cuda:0')
+        buf.obs[0].copy_(envs.reset())
+        return envs, buf
+
+    envs, buf = make()
+    torch.manual_seed(21)
+    with torch.no_grad():
+        for _ in range(T + 2):
+            s = buf.step
+            v, a, lp, ha, hc = pol.get_actions(buf.obs[s].reshape(n, -1), buf.rnn_states_actor[s].reshape(n, 1, H), buf.rnn_states_critic[s].reshape(n, 1, H),
+                                               buf.masks[s].reshape(n, 1))
+            obs, rew, d, bd, tm, _ = envs.step(a)
+            buf.insert_step(obs, a, rew, d, bd, tm, lp, v, ha, hc)
+        buf.compute_returns(pol.get_values(buf.obs[-1].reshape(n, -1), buf.rnn_states_critic[-1].reshape(n, 1, H), buf.masks[-1].reshape(n, 1)).reshape(n, 1, 1))
+    envs2, buf2 = make()
+    col = DeviceCollector(fuse_or_torch(pol, 'cuda:0') if False else pol, envs2, buf2)
+    assert col.fused is False and col.in_place is False
+    torch.manual_seed(21)
+    for _ in range(T + 2):
+        col.step()
+    col.finish()
+    col.compute_returns()
+    for k in buf._STORAGE + ('returns',):
+        assert torch.equal(getattr(buf, k), getattr(buf2, k)), k
+    assert torch.equal(envs.env.model.s, envs2.env.model.s) and float(buf2.actions.abs().sum()) > 0 and float(buf2.rnn_states_actor.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('numerics', ['i8', 'fp32'])
+def test_fused_policy_chained_over_200_steps_vs_the_reference_and_the_oracle(golden_dir, numerics):
+    """FusedPolicy.get_actions chained for 200 calls on its own recurrent states with episode ends through the masks,
+    against the REFERENCE's PPOPolicy.get_actions chained the same way (tests/golden/policy_long_kat.npz; ppo_policy.py:26-32): at every
+    10th step actions <= 2e-5, values <= 1e-4, log-probabilities <= 5e-5, recurrent states <= 5e-5 — for the default block-fixed-point
+    numerics and the fp32 one — and bit-identical to the CPU restatement chained the same way.  Worst errors -> gpurun_out/parity_policy_long.json."""
+    import json
+    import os
+    from neuralplane_amd.policy import FusedPolicy, pack_policy_actor, pack_policy_critic
+    from oracle.f16_oracle import PolicyOracle
+    from tests.policy_kat import check_long_chain, load_long
+    g, sa, sc = load_long(golden_dir)
+    pol = FusedPolicy((sa, sc), 'cuda:0', numerics=numerics)
+    wa, A, log_std = pack_policy_actor(sa)
+    o = PolicyOracle(wa, pack_policy_critic(sc), pol.std, pol.log_std, numerics, 22)
+    st = {'ha': np.zeros((48, 128), np.float32), 'hc': np.zeros((48, 128), np.float32)}
+
+    def run(obs, ha, hc, m, eps):
+        v, a, lp, ha2, hc2 = [x.cpu().numpy() for x in pol.get_actions(_t(obs), _t(ha), _t(hc), _t(m), noise=_t(eps))]
+        ov, oa, olp, oha, ohc = o.run(obs, st['ha'], st['hc'], m, noise=eps)
+        st['ha'], st['hc'] = oha, ohc
+        assert same(v, ov) and same(a, oa) and same(lp, olp) and same(ha2.reshape(-1, 128), oha) and same(hc2.reshape(-1, 128), ohc), 'HIP != oracle'
+        return v, a, lp, ha2, hc2
+    worst = check_long_chain(g, run, f'hip {numerics}')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        path = os.path.join(root, 'gpurun_out', 'parity_policy_long.json')
+        rep = json.load(open(path)) if os.path.exists(path) else {}
+        rep[numerics] = {'get_actions_calls_chained': 200, 'rows': 48, 'episode_ends': 172, 'worst_vs_reference_at_every_10th_step': worst, 'bit_identical_to_oracle': True}
+        json.dump(rep, open(path, 'w'), indent=1)
+    except OSError:
+        pass

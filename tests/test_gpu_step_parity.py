@@ -513,6 +513,10 @@ def test_hip_parity_report_vs_reference_recordings():
     rep = build('hip')
     for tr in rep['trajectories']:
         check_parity_rows(tr, tr['n'])
+    from test_oracle_golden import check_done_chain
+    for tr in rep['trajectories_with_done_events']:      # flown by the reference's PID stack: `done` fires, rows re-initialise mid-trajectory
+        check_parity_rows(tr, tr['n'], p99=1e-4, median=5e-5)      # episodes of up to 2 500 uninterrupted steps (test_oracle_golden.py)
+        check_done_chain(tr, tr['n'])
     cl = rep['closed_loop']
     assert cl['resets_in_reference'] == 0
     check_parity_rows(cl, cl['n'])

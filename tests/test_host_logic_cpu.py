@@ -349,3 +349,67 @@ def test_i8_weight_packer_agrees_with_the_oracles_quantiser(golden_dir):
     assert lnmax[0] == np.abs(w[0:22]).max() and lnmax[1] == np.abs(w[22:44]).max()
     tab = out[NUM_FLOATS: NUM_FLOATS + 4368]
     assert np.array_equal(tab[1280: 1280 + 128], w[44: 44 + 128]) and np.array_equal(tab[3840: 3840 + 512], w[NUM_FLOATS - 512:]) and np.array_equal(tab[4352: 4356], w[NUM_FLOATS - 516: NUM_FLOATS - 512])
+
+
+def _policy_state_dicts(hid=128, gru_layers=1, mlp_layers=2, act_dim=4, obs_dim=22):
+    """(actor, critic) state_dicts with the reference's PPOActor / PPOCritic keys for --hidden-size / --act-hidden-size "hid x mlp_layers",
+    --recurrent-hidden-size hid, --recurrent-hidden-layers gru_layers (algorithms/utils/mlp.py, gru.py; config.py:48-285)."""
+    rng = np.random.RandomState(0)
+
+    def trunk(mlp):
+        sd = {'base.feature_norm.weight': np.ones(obs_dim), 'base.feature_norm.bias': np.zeros(obs_dim)}
+        for stack, first in (('base.mlp', obs_dim), (mlp, hid)):
+            i = first
+            for layer in range(mlp_layers):
+                sd[f'{stack}.fc.{3 * layer}.weight'], sd[f'{stack}.fc.{3 * layer}.bias'] = rng.normal(size=(hid, i)), np.zeros(hid)
+                sd[f'{stack}.fc.{3 * layer + 2}.weight'], sd[f'{stack}.fc.{3 * layer + 2}.bias'] = np.ones(hid), np.zeros(hid)
+                i = hid
+        for layer in range(gru_layers):
+            for k in ('ih', 'hh'):
+                sd[f'rnn.gru.weight_{k}_l{layer}'], sd[f'rnn.gru.bias_{k}_l{layer}'] = rng.normal(size=(3 * hid, hid)), np.zeros(3 * hid)
+        sd['rnn.norm.weight'], sd['rnn.norm.bias'] = np.ones(hid), np.zeros(hid)
+        return sd
+    a, c = trunk('act.mlp'), trunk('mlp')
+    a['act.action_out.mu_net.fc.0.weight'], a['act.action_out.mu_net.fc.0.bias'], a['act.action_out.log_std'] = rng.normal(size=(act_dim, hid)), np.zeros(act_dim), np.zeros(act_dim)
+    c['value_out.weight'], c['value_out.bias'] = rng.normal(size=(1, hid)), np.zeros(1)
+    return ({k: np.asarray(v, np.float32) for k, v in a.items()}, {k: np.asarray(v, np.float32) for k, v in c.items()})
+
+
+@pytest.mark.parametrize('kw', [dict(hid=64), dict(hid=256), dict(gru_layers=2), dict(mlp_layers=3)])
+def test_fused_policy_packers_name_the_supported_shape_for_any_other(kw):
+    """the reference takes --hidden-size / --act-hidden-size / --recurrent-hidden-size / --recurrent-hidden-layers from the
+    command line (/root/reference/config.py:48-285); the fused kernels exist for one shape.  Any other must be a ValueError that names the
+    supported one (FusedPolicy / FusedActor construct through these packers), never a silently mis-packed network."""
+    from neuralplane_amd.actor import pack_ppo_actor
+    from neuralplane_amd.policy import pack_policy_actor, pack_policy_critic
+    sa, sc = _policy_state_dicts(**kw)
+    for pack, sd in ((pack_policy_actor, sa), (pack_policy_critic, sc), (pack_ppo_actor, sa)):
+        with pytest.raises(ValueError, match='128'):
+            pack(sd)
+    sa, sc = _policy_state_dicts()
+    assert pack_policy_actor(sa)[0].size == pack_policy_critic(sc).size == pack_ppo_actor(sa).size == 153392
+
+
+def test_bench_contract_line_is_small_and_complete():
+    """bench.py's LAST stdout line is what the driver parses: built from the full record by contract_line(), it must stay under 4 KB whatever
+    the details hold (round 5: one 28.8 KB line, `parsed: null`), carry the contract fields, and refuse to grow."""
+    import json
+    import bench
+    big = {'note': 'x' * 30000}
+    out = {'metric': bench.METRIC, 'value': 3.6e9, 'unit': 'aircraft-steps/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 0.27,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'F-16 heading, N=1000000', 'aircraft_per_gpu': 1000000, 'sharding': 'rows', 'other': big},
+           'roofline': {'bound': 'valu', 'achieved': 124.0, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': 0.79, 'executed_frac': 0.6, 'kernel': 'k',
+                        'kernel_avg_ms': 0.27, 'traffic': 4.0e8, 'traffic_source': 'profiles/x.json', 'algorithmic_bytes_per_launch': 2.78e8, 'note': 'y' * 5000},
+           'roofline_hbm': {'achieved': 1000.0, 'frac': 0.125},
+           'cpu_baseline': {'value': 1.1e6, 'unit': 'aircraft-steps/s', 'cores': 16, 'kind': 'port', 'sample': 's', 'torch_eager': {'value': 2e5, 'note': 'z' * 3000},
+                            'reference_context': big},
+           'optional_modes': big, 'cold_start': big, 'per_rank': big, 'expected_scaling': big, 'world_size': 1, 'backend': None, 'state_finite': True}
+    txt = bench.contract_line(out, 'gpurun_out/bench_details.json')
+    line = json.loads(txt)
+    assert len(txt) < 4000 and '\n' not in txt
+    assert line['value'] == 3.6e9 and line['roofline']['frac'] == 0.79 and line['cpu_baseline']['value'] == 1.1e6 and line['cpu_baseline']['torch_eager'] == 2e5
+    assert 'optional_modes' not in line and 'note' not in line['roofline'] and set(line['config']) == {'workload', 'aircraft_per_gpu', 'sharding'}
+    out['config']['workload'] = 'w' * 5000
+    with pytest.raises(SystemExit):
+        bench.contract_line(out)

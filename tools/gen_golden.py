@@ -489,6 +489,113 @@ def gen_traj_closed(n=256, T=1000):
     print(f'traj closed: done={int(flags[:, :, 0].sum())} bad={int(flags[:, :, 1].sum())} longest episode {int(env.step_count.max())}')
 
 
+ACTION_QUANTUM = 4096.0   # PID-driven fixtures store their actions as int16 multiples of 1 / 4096 (what the reference env was driven with)
+
+
+def _pid_loop(env, task, T, n, drive, rec_every=25, overrides=None, name=None):
+    """Free-running reference env with the reference's OWN PID stack in the loop (algorithms/pid/controller.py:69,140 — SURVEY §2 #21):
+    `drive(controller, env, t)` issues the outer-loop calls of renders/render_control.py:82-88, the controller's action is rounded to a
+    multiple of 1 / 4096 (so that the fixture can hold it exactly as int16) and THAT is what the reference env steps on.  Recorded: every
+    action, every mask, the reset draws, and (s, u, targets) every `rec_every` steps and at the step after every `done`."""
+    from algorithms.pid.controller import Controller
+    n_task = 0 if task == 'heading' else 3
+    with Recorder() as rec, quiet():      # the controller reads the env's state before the first step: reset first, its draws recorded too
+        env.reset()
+        log0 = rec.take()
+    rand_u_reset, _ = draws_to_arrays(log0, np.ones(n, bool), n, n_task, which_randn=0)
+    with quiet():
+        c = Controller(dt=env.model.dt, n=env.n, device='cpu')
+    acts = np.zeros((T, n, 4), np.int16)
+    flags = np.zeros((T, n, 3), np.uint8)
+    rand_u = np.zeros((T, n, 5), np.float32)
+    states, rec_steps, after_done = [], [], False
+    edit_t, edit_s = [], []
+    for t in range(T):
+        prev = (env.is_done | env.bad_done | env.exceed_time_limit).numpy().astype(bool)
+        s_before = env.model.s.clone()
+        with quiet():
+            drive(c, env, t)
+            c.stabilize(env)
+            a = torch.round(torch.clamp(c.get_action(), -2, 2) * ACTION_QUANTUM)
+        # The reference's TECS edits the env's state IN PLACE on its first call (the altitude it reads is a view of model.s; +83.33 ft): a quirk
+        # of the consumer, outside env.step — recorded as an external state write that the replay applies at the same point
+        if not torch.equal(s_before, env.model.s):
+            assert torch.equal(s_before[:, [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]], env.model.s[:, [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11]])
+            edit_t.append(t)
+            edit_s.append(env.model.s.numpy().copy())
+        with Recorder() as rec, quiet():
+            acts[t] = a.numpy().astype(np.int16)
+            obs, rew, done, bad, tmo, _ = env.step((a / ACTION_QUANTUM).to(torch.float32))
+            log = rec.take()
+        rand_u[t], _ = draws_to_arrays(log, prev, n, n_task, which_randn=1)
+        flags[t, :, 0], flags[t, :, 1], flags[t, :, 2] = done.numpy(), bad.numpy(), tmo.numpy()
+        if (t + 1) % rec_every == 0 or t < 3 or after_done or t + 1 == T:   # (after_done: this step re-initialised the rows that were done)
+            states.append(np.hstack([env.model.s.numpy(), env.model.u.numpy()[:, :4], get_tgt(env, task)]))
+            rec_steps.append(t)
+        after_done = bool(done.any())
+    return dict(actions_q=acts, action_quantum=np.float32(ACTION_QUANTUM), flags=flags, rand_u=rand_u, rand_u_reset=rand_u_reset,
+                state_edit_steps=np.array(edit_t, np.int64), state_edits=np.stack(edit_s).astype(np.float32) if edit_s else np.zeros((0, n, 12), np.float32), rec_steps=np.array(rec_steps, np.int64),
+                state=np.stack(states).astype(np.float32), step_count_final=env.step_count.numpy())
+
+
+def gen_traj_pid_heading(n=64, T=2600):
+    """a Heading trajectory in which `done` FIRES.  heading_task.py:56-67 always asks for +120 deg of heading and
+    +1000 ft; the reference's PID stack (heading hold from the first step) flies that turn in 1 700-2 600 steps depending on the bank limit —
+    set per aircraft here (Controller.roll_limit 0.70 ... 1.05 rad; the shipped 45 deg would need ~2 700 steps) so that the fast rows reach
+    the target (UnreachHeading.done: 300 <= step < 2 500, |d heading| < 5 deg, |d alt| < 100 ft, |d vt| < 20 ft/s, unreach_heading.py:38-53)
+    and the slow ones run into max_check_interval = 2 500 (bad).  After a `done` the whole chain is in the recording: BaseEnv.step's
+    self.reset() -> F16Model.reset (state re-drawn, F16_model.py:37-45) -> HeadingTask.reset (new targets) -> step_count = 0."""
+    env = make_env('heading', n, seed=0)
+    env.task.noise_scale = 0
+    limits = torch.linspace(0.70, 1.05, n).reshape(-1, 1)
+
+    def drive(c, env, t):
+        c.roll_limit = limits
+        if t % 5 == 0:
+            c.cal_pitch_throttle(env.task.target_altitude.reshape(-1, 1), env.task.target_vt.reshape(-1, 1), env)
+            c.update_heading_hold(env.task.target_heading.reshape(-1, 1), env)
+    d = _pid_loop(env, 'heading', T, n, drive)
+    fl = d['flags']
+    n_done, n_bad = int(fl[:, :, 0].sum()), int(fl[:, :, 1].sum())
+    t_done = np.nonzero(fl[:, :, 0].any(1))[0]
+    assert n_done >= 20, n_done
+    assert n_bad >= 1 and t_done.min() + 1 >= 300 and t_done.max() + 1 < 2500
+    # the re-initialisations that follow: the step after a done row's flag, its counter restarts at 1 (reset to 0, then += 1)
+    print(f'traj pid heading: done={n_done} (steps {t_done.min() + 1}..{t_done.max() + 1}) bad={n_bad} recorded states {len(d["rec_steps"])}')
+    np.savez_compressed(os.path.join(OUT, f'traj_pid_heading_N{n}_T{T}.npz'), **d)
+
+
+PID_CONTROL_OVERRIDES = {'max_pitch_increment': 0.15, 'max_heading_increment': 0.25, 'max_velocities_u_increment': 40.0}
+
+
+def gen_traj_pid_control(n=64, T=400):
+    """VERDICT r5 item 3, Control: target increments small enough (scenario keys max_pitch_increment / max_heading_increment /
+    max_velocities_u_increment = 0.15 rad / 0.25 rad / 40 ft/s instead of control.yaml's 3 / 3 / 300; stored in the fixture, both sides
+    read them) that UnreachPosture.done (|d pitch| < 5 deg — no wrap —, |d heading| < 5 deg, |d vt| < 20 ft/s, any step count below
+    max_check_interval: unreach_posture.py:40-55) fires within 300 steps with the reference's PID stack in the loop: pitch demand = the
+    task's target pitch, heading hold on its target heading, TECS throttle on its target vt."""
+    import json
+    env = make_env('control', n, seed=0)
+    env.task.noise_scale = 0
+    for k, v in PID_CONTROL_OVERRIDES.items():
+        assert hasattr(env.task, k), k
+        setattr(env.task, k, v)
+
+    def drive(c, env, t):
+        if t % 5 == 0:
+            alt = env.model.get_position()[2].reshape(-1, 1)
+            c.cal_pitch_throttle(alt, env.task.target_vt.reshape(-1, 1), env)
+            c.update_heading_hold(env.task.target_heading.reshape(-1, 1), env)
+        c.pitch_dem = env.task.target_pitch.reshape(-1, 1).clone()
+    d = _pid_loop(env, 'control', T, n, drive, rec_every=20)
+    fl = d['flags']
+    n_done = int(fl[:, :, 0].sum())
+    late = int(fl[20:, :, 0].sum())          # reached by flying there, not by a lucky draw at reset
+    assert n_done >= 20 and late >= 10, (n_done, late)
+    print(f'traj pid control: done={n_done} ({late} after step 20) bad={int(fl[:, :, 1].sum())} recorded states {len(d["rec_steps"])}')
+    np.savez_compressed(os.path.join(OUT, f'traj_pid_control_N{n}_T{T}.npz'), overrides=np.array(json.dumps(PID_CONTROL_OVERRIDES)), **d)
+
+
 def gen_recorded_episode():
     """Rows 0..426 of the authors' CUDA recording renders/result/*.npy (render_ppo.py:157-175)."""
     d = '/root/reference/renders/result'
@@ -589,18 +696,87 @@ def gen_planning(n=48, outer=3):
     np.savez_compressed(os.path.join(OUT, 'planning_kat.npz'), hi_actions=hi_actions, **data)
 
 
-def gen_planning_closed(n=80, outer=3, mu_scale=15.0):
+def teacher_lowlevel_action(obs):
+    """An attitude-hold law on PlanningEnv.low_level_obs (planning_env.py:60-142; the gains of tools/parity_report.py::closed_loop_action, which
+    keep 256 aircraft flying for 1000 steps): elevator on the pitch error + Q, aileron on roll towards a bank command proportional to the heading
+    error + P, yaw damper, throttle on the speed error.  Only the labels of cloned_actor() come from it."""
+    d_pitch, d_head, d_vt, sin_roll = obs[:, 0], obs[:, 1], obs[:, 2], obs[:, 4]
+    P, Q, R = obs[:, 13], obs[:, 14], obs[:, 15]
+    phi_cmd = torch.clamp(-1.0 * d_head, -0.4, 0.4)
+    a = torch.stack([0.3 - 3.0 * d_vt, 2.0 * d_pitch + 1.0 * Q, 1.0 * (sin_roll - phi_cmd) + 0.5 * P, 0.2 * R], 1)
+    a[:, 0] = torch.clamp(a[:, 0], 0.0, 1.0)
+    return torch.clamp(a, -0.97, 0.97)
+
+
+def cloned_actor(n=64, rounds=5, macro=6, epochs=300, hi_amp=0.5):
+    """A reference PPOActor that FLIES: seeded_actor()'s random initialisation fitted (plain regression, Adam, fixed seeds) to
+    teacher_lowlevel_action on the (observation, recurrent state) pairs its own closed loop visits in the reference's PlanningEnv
+    (DAgger: round 0 the teacher drives, afterwards the actor itself; the labels are always the teacher's).  Test-fixture tooling: nothing
+    of an RL algorithm — the result is a state_dict of the reference's own module whose closed loop keeps the aircraft in the air for
+    1 000 inner steps, which a random-init head does not (24 of 64 rows end in Overload per macro-step)."""
+    import envs.planning_env as pe
+    actor = seeded_actor(4.0, 0.0)
+    o_load = torch.load
+    torch.load = lambda f, *a, **k: {k_: v.clone() for k_, v in actor.state_dict().items()} if str(f).endswith('actor_latest.pt') else o_load(f, *a, **k)
+    try:
+        with quiet():
+            env = pe.PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=1, device='cpu')
+    finally:
+        torch.load = o_load
+    data_obs, data_h, data_y = [], [], []
+    state = {'student_drives': False}
+
+    def controller(obs, rnn, masks, deterministic=True):
+        with torch.no_grad():
+            a_s, _, h = actor(obs, rnn, masks, deterministic=True)
+        y = teacher_lowlevel_action(obs)
+        data_obs.append(obs.clone()); data_h.append(rnn.clone()); data_y.append(y)
+        return (a_s if state['student_drives'] else y), None, h
+    env.controller = controller
+    rng = np.random.RandomState(5)
+    opt = torch.optim.Adam(actor.parameters(), lr=2e-3)
+    for r in range(rounds):
+        state['student_drives'] = r > 0
+        with quiet():
+            env.is_done[:] = 1        # every round starts from freshly drawn states
+            env.ego_rnn_states = torch.zeros_like(env.ego_rnn_states)
+            bad_total = 0
+            for k in range(macro):
+                _, _, done, bad, tmo, _ = env.step(torch.from_numpy(rng.uniform(-hi_amp, hi_amp, (n, 3)).astype(np.float32)))
+                bad_total += int(bad.sum())
+        X, H, Y = torch.cat(data_obs), torch.cat(data_h), torch.cat(data_y)
+        ok = torch.isfinite(X).all(1) & torch.isfinite(Y).all(1)
+        X, H, Y = X[ok], H[ok], Y[ok]
+        actor.train()
+        g = torch.Generator().manual_seed(100 + r)
+        for e in range(epochs):
+            idx = torch.randint(0, X.shape[0], (4096,), generator=g)
+            a, _, _ = actor(X[idx], H[idx], torch.ones((idx.numel(), 1)), deterministic=True)
+            loss = ((a - Y[idx]) ** 2).mean()
+            opt.zero_grad(); loss.backward(); opt.step()
+        actor.eval()
+        print(f'cloned actor, round {r}: {X.shape[0]} samples, loss {float(loss):.5f}, rows that ended badly while {"the actor" if r > 0 else "the teacher"} flew: {bad_total}', flush=True)
+    return actor
+
+
+def gen_planning_closed(n=80, outer=3, mu_scale=15.0, name='planning_closed_kat.npz', long=False, hi_amp=1.2):
     """PlanningEnv.step CLOSED LOOP (envs/planning_env.py:144-177): the reference env constructs its own PPOActor
     (planning_env.py:41-43) and really loads a state_dict — the one of seeded_actor(), handed over where the reference reads its
     (unshipped) checkpoint file — then runs `outer` macro-steps = 50 x {low_level_obs -> controller -> model.update -> done / reward}
     each, with the recurrent state feeding back.  Recorded per macro-step: the reset draws, everything `step` returns, the env state
     (s, u, targets, step_count, flags, ego_rnn_states); per inner iteration (forward hook on the controller, outputs untouched): the
     controller's input observation, actions and recurrent state.  The actor's state_dict is stored (`sd::*`): consumers run their own
-    controller in the loop, nothing is replayed."""
+    controller in the loop, nothing is replayed.
+
+    long=True (`planning_closed_long_kat.npz`: n = 64, outer = 20): 1 000 closed-loop inner steps, the horizon north_star
+    names.  The per-iteration recordings are dropped (state / recurrent state / masks at the end of every macro-step = every 50th inner step
+    stay) and the generator asserts that >= 32 rows fly all 1 000 steps without a termination."""
     if not hasattr(np, 'product'):
         np.product = np.prod  # the reference targets numpy 1.x (algorithms/utils/flatten.py:83)
     import envs.planning_env as pe
-    actor = seeded_actor(mu_scale, 0.0)
+    actor = cloned_actor() if long else seeded_actor(mu_scale, 0.0)
+    if long:
+        hi_amp = 0.5
 
     def build(sd):
         o_load = torch.load
@@ -620,10 +796,11 @@ def gen_planning_closed(n=80, outer=3, mu_scale=15.0):
         probe.reset()
     z = torch.zeros(n)
     _, pitch, yaw = probe.model.get_posture()
-    with torch.no_grad():
-        a0, _, _ = actor(probe.low_level_obs(pitch + z, yaw + z, probe.model.get_vt() + z), torch.zeros((n, 1, 128)), torch.ones((n, 1)), deterministic=True)
-        actor.act.action_out.mu_net.fc[0].bias.sub_(a0.mean(0))
-    sd = {k: v.clone() for k, v in actor.state_dict().items()}
+    if not long:     # (the cloned actor needs no centring: it was fitted to fly)
+        with torch.no_grad():
+            a0, _, _ = actor(probe.low_level_obs(pitch + z, yaw + z, probe.model.get_vt() + z), torch.zeros((n, 1, 128)), torch.ones((n, 1)), deterministic=True)
+            actor.act.action_out.mu_net.fc[0].bias.sub_(a0.mean(0))
+    sd = {k: v.detach().clone() for k, v in actor.state_dict().items()}
     env = build(sd)
     for k, v in env.controller.state_dict().items():
         assert torch.equal(v, sd[k]), k            # the reference's own load_state_dict took every tensor
@@ -631,8 +808,9 @@ def gen_planning_closed(n=80, outer=3, mu_scale=15.0):
     env.controller.register_forward_hook(lambda mod, inp, out: log.append((inp[0].numpy().copy(), out[0].numpy().copy(), out[2].numpy().copy())))
     LL_OBS_AT = (0, 1, 9, 19, 29, 39, 49)
     rng = np.random.RandomState(77)
-    hi_actions = rng.uniform(-1.2, 1.2, (outer, n, 3)).astype(np.float32)
+    hi_actions = rng.uniform(-hi_amp, hi_amp, (outer, n, 3)).astype(np.float32)
     data = {}
+    ever_flagged = np.zeros(n, bool)
     for k in range(outer):
         del log[:]
         prev = (env.is_done | env.bad_done | env.exceed_time_limit).numpy().astype(bool)
@@ -645,9 +823,13 @@ def gen_planning_closed(n=80, outer=3, mu_scale=15.0):
         for c, x in enumerate(rand):
             rand_u[prev, c] = x
         data[f'rand_u_{k}'] = rand_u
-        data[f'll_obs_{k}'] = np.stack([log[i][0] for i in LL_OBS_AT])                # the controller's input at these inner iterations
-        data[f'll_act_{k}'] = np.stack([x[1] for x in log])
-        data[f'll_rnn_{k}'] = np.stack([x[2][:, 0] for x in log[9::10]])     # after inner iterations 10, 20, 30, 40, 50
+        if not long:
+            data[f'll_obs_{k}'] = np.stack([log[i][0] for i in LL_OBS_AT])                # the controller's input at these inner iterations
+            data[f'll_act_{k}'] = np.stack([x[1] for x in log])
+            data[f'll_rnn_{k}'] = np.stack([x[2][:, 0] for x in log[9::10]])     # after inner iterations 10, 20, 30, 40, 50
+        else:
+            data[f'll_act_last_{k}'] = log[-1][1]                                        # the 50th controller call of the macro-step
+        ever_flagged |= (done | bad | tmo).numpy().astype(bool)
         data[f's_{k}'] = env.model.s.numpy().copy()
         data[f'u_{k}'] = env.model.u.numpy().copy()
         data[f'tgt_{k}'] = get_tgt(env, 'tracking')
@@ -656,9 +838,13 @@ def gen_planning_closed(n=80, outer=3, mu_scale=15.0):
         data[f'obs_{k}'] = obs.numpy().copy()
         data[f'reward_{k}'] = rew.numpy().copy()
         data[f'flags_{k}'] = np.stack([done.numpy(), bad.numpy(), tmo.numpy()]).astype(np.uint8)
-        print('planning closed loop, outer', k, 'done', int(done.sum()), 'bad', int(bad.sum()), '|ll action| max', float(np.abs(data[f'll_act_{k}']).max()),
-              'rnn std', float(data[f'rnn_{k}'].std()))
-    np.savez_compressed(os.path.join(OUT, 'planning_closed_kat.npz'), hi_actions=hi_actions, ll_obs_at=np.array(LL_OBS_AT), **data,
+        print('planning closed loop, outer', k, 'done', int(done.sum()), 'bad', int(bad.sum()), '|ll action| max', float(np.abs(log[-1][1]).max()),
+              'rnn std', float(data[f'rnn_{k}'].std()), 'rows never flagged so far', int((~ever_flagged).sum()), flush=True)
+    data['never_flagged'] = ~ever_flagged
+    if long:
+        assert int((~ever_flagged).sum()) >= 32, int((~ever_flagged).sum())
+        assert int(env.step_count[~ever_flagged].min()) == 50 * outer
+    np.savez_compressed(os.path.join(OUT, name), hi_actions=hi_actions, ll_obs_at=np.array(LL_OBS_AT), **data,
                         **{'sd::' + k: v.numpy() for k, v in sd.items()})
 
 
@@ -1024,6 +1210,41 @@ def gen_policy(n=96, steps=5):
     np.savez_compressed(os.path.join(OUT, 'policy_kat.npz'), **out)
 
 
+def gen_policy_long():
+    """PPOPolicy.get_actions (algorithms/ppo/ppo_policy.py:26-32) x 200 CHAINED — both recurrent states fed back, episode
+    ends through the masks — for the heading policy (4 actions, 22 observations).  Inputs come from tests/policy_kat.py::long_inputs (a
+    seeded formula, not stored); stored: the normal draws behind every sample, the reference's values / actions / log-probabilities /
+    recurrent states at every 10th step, and the two state_dicts."""
+    sys.path.insert(0, REPO)
+    from tests.policy_kat import LONG_EVERY, long_inputs
+    pol = seeded_policy(4, 22)
+    obs, masks = long_inputs()
+    steps, n = obs.shape[:2]
+    ha, hc = torch.zeros((n, 1, 128)), torch.zeros((n, 1, 128))
+    std = pol.actor.act.action_out.log_std.detach().exp()
+    rec = {k: [] for k in ('values', 'actions', 'logp', 'ha', 'hc')}
+    eps_all = np.zeros((steps, n, 4), np.float32)
+    with torch.no_grad():
+        for t in range(steps):
+            o, m = torch.from_numpy(obs[t]), torch.from_numpy(masks[t])
+            mean, _ = pol.act(o, ha, m, deterministic=True)
+            torch.manual_seed(7000 + t)
+            eps = torch.empty(n, 4).normal_()
+            torch.manual_seed(7000 + t)
+            values, actions, logp, ha, hc = pol.get_actions(o, ha, hc, m)
+            assert torch.equal(actions, eps * std + mean), 'the sample is not fl(fl(eps * std) + mean)'
+            eps_all[t] = eps.numpy()
+            if (t + 1) % LONG_EVERY == 0:
+                for k, v in (('values', values), ('actions', actions), ('logp', logp), ('ha', ha[:, 0]), ('hc', hc[:, 0])):
+                    rec[k].append(v.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(eps=eps_all, std=std.numpy(), log_std=pol.actor.act.action_out.log_std.detach().numpy().copy())
+    out.update({'actor::' + k: v.numpy() for k, v in pol.actor.state_dict().items()})
+    out.update({'critic::' + k: v.numpy() for k, v in pol.critic.state_dict().items()})
+    print('policy long: steps', steps, 'rows', n, 'episode ends', int((masks == 0).sum()), '|ha| max', float(np.abs(out['ha']).max()), 'values', float(out['values'].min()), float(out['values'].max()))
+    np.savez_compressed(os.path.join(OUT, 'policy_long_kat.npz'), **out)
+
+
 def gen_combat_all():
     gen_geodesy()
     gen_pairwise()
@@ -1122,6 +1343,18 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'model_grid':
         gen_model_grid(make_env('heading', 4))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'traj_pid_heading':
+        gen_traj_pid_heading()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'traj_pid_control':
+        gen_traj_pid_control()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'planning_closed_long':
+        gen_planning_closed(n=64, outer=20, name='planning_closed_long_kat.npz', long=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'policy_long':
+        gen_policy_long()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'traj':
         gen_traj('heading', 256, 1000)     # BASELINE.json configs[0] / SURVEY.md App. D.3 #5: N = 256

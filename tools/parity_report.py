@@ -63,14 +63,23 @@ def closed_loop_action(s, th_cmd, phi_cmd, dither):
 class OracleEngine:
     name = 'oracle (oracle/f16_oracle.c, CPU)'
 
-    def __init__(self, task, n):
+    def __init__(self, task, n, overrides=None):
         from oracle.f16_oracle import Oracle
-        self.o = Oracle(task, overrides={'noise_scale': 0})
+        self.o = Oracle(task, overrides=dict(overrides or {}, noise_scale=0))
         self.st = Oracle.new_state(n)
 
     def step(self, action, rand_u):
         _, _, d, b, tm = self.o.step(self.st, action, rand_u=rand_u)
         return self.st['s'], np.stack([d, b, tm], 1).astype(bool)
+
+    def targets(self):
+        return self.st['tgt']
+
+    def reset(self, rand_u):
+        self.o.reset(self.st, rand_u=rand_u, want_obs=False)
+
+    def set_state(self, s):
+        self.st['s'][:] = s
 
     @staticmethod
     def xdot(s, u):
@@ -81,11 +90,13 @@ class OracleEngine:
 class HipEngine:
     name = 'hip (libneuralplane_hip.so on cuda:0)'
 
-    def __init__(self, task, n):
+    def __init__(self, task, n, overrides=None):
         import torch
         from neuralplane_amd.core import F16Batch
         from neuralplane_amd.envs.utils.utils import parse_config
         cfg = parse_config(task)
+        for k, v in (overrides or {}).items():
+            setattr(cfg, k, v)
         cfg.noise_scale = 0
         self.torch = torch
         self.b = F16Batch(n, cfg, task, 'cuda:0', seed=0)
@@ -93,6 +104,15 @@ class HipEngine:
     def step(self, action, rand_u):
         _, _, flags = self.b.step(self.torch.from_numpy(action).cuda(), rand_u=rand_u)
         return self.b.s.cpu().numpy().T, flags.cpu().numpy().astype(bool).T
+
+    def targets(self):
+        return self.b.tgt.cpu().numpy().T
+
+    def reset(self, rand_u):
+        self.b.reset(rand_u=rand_u, want_obs=False)
+
+    def set_state(self, s):
+        self.b.s.copy_(self.torch.from_numpy(np.ascontiguousarray(s.T)))   # a caller writing model.s between two steps (the cache keys notice)
 
     @staticmethod
     def xdot(s, u):
@@ -105,25 +125,59 @@ class HipEngine:
         return b.derived()[:12].cpu().numpy().T
 
 
-def trajectory_report(engine_cls, task, n, T, at):
-    g = np.load(os.path.join(GOLDEN, f'traj_{task}_N{n}_T{T}.npz'))
-    acts = traj_actions(T, n)
-    eng = engine_cls(task, n)
+PID_TRAJ = (('heading', 64, 2600, (1, 100, 1000, 1500, 2000, 2500, 2600)), ('control', 64, 400, (1, 20, 100, 200, 300, 400)))
+
+
+def trajectory_report(engine_cls, task, n, T, at, fixture=None):
+    """fixture = None: tests/golden/traj_<task>_N<n>_T<T>.npz, open-loop actions from traj_actions().  fixture = 'traj_pid_...': a trajectory
+    flown by the reference's own PID stack (tools/gen_golden.py::gen_traj_pid_*): the actions the reference env stepped on are in the fixture
+    (int16 multiples of 1 / action_quantum), as are the scenario keys it changed; in these `done` fires and rows are re-initialised with new
+    targets mid-trajectory (`done_events`, `first_steps_after_done_compared` count them)."""
+    g = np.load(os.path.join(GOLDEN, fixture or f'traj_{task}_N{n}_T{T}.npz'))
+    if 'actions_q' in g.files:
+        acts = (g['actions_q'].astype(np.float32) / np.float32(g['action_quantum'])).astype(np.float32)
+        overrides = json.loads(str(g['overrides'])) if 'overrides' in g.files else None
+        eng = engine_cls(task, n, overrides)
+        eng.reset(g['rand_u_reset'])     # the PID stack reads the env's state before the first step: the reference run began with env.reset()
+    else:
+        acts = traj_actions(T, n)
+        eng = engine_cls(task, n)
     rec = {int(t): i for i, t in enumerate(g['rec_steps'])}
     diverged = np.zeros(n, bool)
     first_mask_diff, rows = 0, []
+    done_events = after_done_compared = 0
+    after_done_worst = tgt_worst = 0.0
+    edits = {int(t): i for i, t in enumerate(g['state_edit_steps'])} if 'state_edit_steps' in g.files else {}
     for t in range(T):
+        if t in edits:     # the reference's TECS writes the altitude it read (a view of model.s) in place on its first call: replayed here
+            eng.set_state(g['state_edits'][edits[t]])
         s, f = eng.step(acts[t], g['rand_u'][t])
         diff = (f != g['flags'][t].astype(bool)).any(axis=1)
         first_mask_diff += int((diff & ~diverged).sum())
         diverged |= diff
+        if fixture and t > 0 and g['flags'][t - 1, :, 0].any() and t in rec:
+            # the step that re-initialised the rows whose `done` fired: whole state redrawn (F16_model.py:37-45), then one step flown
+            rows_d = g['flags'][t - 1, :, 0].astype(bool) & ~diverged
+            ref = g['state'][rec[t]][:, :12]
+            if rows_d.any():
+                after_done_compared += int(rows_d.sum())
+                after_done_worst = max(after_done_worst, float(np.nanmax(np.abs(s[rows_d] - ref[rows_d]) / np.maximum(np.abs(ref[rows_d]), STATE_FLOORS))))
+        done_events += int(g['flags'][t, :, 0].sum())
+        if fixture and t in rec and (~diverged).any():   # the task's targets (re-drawn by task.reset after every done / bad)
+            ref_t, got_t = g['state'][rec[t]][:, 16:19][~diverged], eng.targets()[~diverged]
+            tgt_worst = max(tgt_worst, float(np.max(np.abs(got_t - ref_t) / np.maximum(np.abs(ref_t), np.float32(1.0)))))
         if (t + 1) in at:
             ref = g['state'][rec[t]][:, :12]
             e = np.nanmax(np.abs(s - ref) / np.maximum(np.abs(ref), STATE_FLOORS), axis=1)[~diverged]
             rows.append({'t': t + 1, 'rows_compared': int(e.size), 'rows_diverged': int(diverged.sum()), 'median': float(np.median(e)),
                          'p90': float(np.percentile(e, 90)), 'p99': float(np.percentile(e, 99)), 'max': float(e.max())})
-    return {'task': task, 'n': n, 'T': T, 'first_mask_differences': first_mask_diff, 'rows_diverged_final': int(diverged.sum()),
-            'resets_in_reference': int(g['flags'].any(axis=2).sum()), 'at': rows}
+    out = {'task': task, 'n': n, 'T': T, 'first_mask_differences': first_mask_diff, 'rows_diverged_final': int(diverged.sum()),
+           'resets_in_reference': int(g['flags'].any(axis=2).sum()), 'at': rows}
+    if fixture:
+        out.update({'fixture': fixture, 'done_events_in_reference': done_events, 'bad_events_in_reference': int(g['flags'][:, :, 1].sum()),
+                    'first_steps_after_done_compared': after_done_compared, 'first_step_after_done_max_rel': after_done_worst,
+                    'targets_max_rel_at_recorded_steps': tgt_worst})
+    return out
 
 
 def closed_loop_report(engine_cls, n=256, T=1000, at=(1, 10, 100, 426, 1000)):
@@ -420,7 +474,9 @@ def build(engine):
     return {'engine': cls.name, 'reference': 'tests/golden/traj_*.npz: free-running trajectories of the imported reference (tools/gen_golden.py), '
                                              'reset draws injected, observation noise off',
             'metric': 'per aircraft max_k |x_k - ref_k| / max(|ref_k|, floor_k); aircraft that left the reference episode schedule excluded',
-            'trajectories': [trajectory_report(cls, *t) for t in TRAJ], 'closed_loop': closed_loop_report(cls), 'recorded_episode': recorded_episode_report(cls),
+            'trajectories': [trajectory_report(cls, *t) for t in TRAJ],
+            'trajectories_with_done_events': [trajectory_report(cls, *t, fixture=f'traj_pid_{t[0]}_N{t[1]}_T{t[2]}.npz') for t in PID_TRAJ],
+            'closed_loop': closed_loop_report(cls), 'recorded_episode': recorded_episode_report(cls),
             'planning_env': planning_report(engine), 'planning_env_closed_loop': planning_closed_report(engine), 'single_combat': combat_report(engine),
             'rollout_policy': policy_report(engine)}
 
