@@ -44,6 +44,24 @@ enum { NP_TASK_HEADING = 0, NP_TASK_CONTROL = 1, NP_TASK_TRACKING = 2 }; /* envs
 enum { NP_SOLVER_EULER = 0, NP_SOLVER_RK4 = 1 };                          /* envs/models/F16_model.py:16,64-67 */
 #define NP_INNER_UPDATE_ONLY 2 /* np_f16_io.inner_step: F16Model.update(action) on its own (envs/models/F16_model.py:51-67) */
 
+/* The airframe as data (ABI 16).  What the reference spells as literals inside F16Dynamics.nlplant / atmos and F16Model.update
+ * (envs/models/F16/F16_dynamics.py:22-35,61-76,114-116; envs/models/F16_model.py:52-62).  An ALL-ZERO block means "the F-16": every
+ * field then takes the reference's literal (np_f16_airframe_default() writes them out), and a context computes exactly what it computed
+ * when these were compile-time constants.  Together with a second weights blob of the same net topology (np_f16_ctx_create) this is how
+ * another aircraft is expressed — mass and inertias, reference areas and lengths, c.g. positions, engine angular momentum, control
+ * scalings, atmosphere constants, command scales.  Derived constants (xcgr - xcg, cbar / B, the inertia products, Jx Jz - Jxz^2,
+ * reciprocals of divisors) are folded in double on the host and rounded once, as the literal expressions were.
+ * PARITY of anything but the defaults is UNPINNED: the reference holds no second airframe; HIP == CPU oracle holds for any block. */
+typedef struct np_f16_airframe {
+    double g, mass, B, S, cbar, xcgr, xcg, Heng;  /* F16_dynamics.py:61-68: 32.17, 636.94, 30, 300, 11.32, 0.35, 0.30, 0 */
+    double Jy, Jxz, Jz, Jx;                        /* :71-74: 55814, 982, 63100, 9496 */
+    double ail_ref, rud_ref;                       /* :114-115: dail = ail / 21.5, drud = rud / 30 (dlef = 1 - lef / 25 with lef == 0) */
+    double atm_lapse, atm_exp, rho0;               /* atmos :22-35: tfac = 1 - 0.703e-5 alt, rho = 2.377e-3 tfac^4.14 */
+    double lag_keep, lag_new;                      /* F16_model.py:53-56: u' = 0.9 u + 0.1 a * scale */
+    double thrust_frac, thrust_max, thrust_unit;   /* :53: scale_T = 0.225 * 76300 / 0.3048 */
+    double surf_max[3];                            /* :54-56: 45, 45, 45 (el, ail, rud) */
+} np_f16_airframe;
+
 /* Scenario constants = the keys of envs/configs/{heading,control,tracking}.yaml, with the
  * defaults of the reference's getattr(config, key, default) calls.  Values are passed as Python
  * holds them (double / int); the library rounds them to fp32 where the reference's tensor
@@ -64,6 +82,7 @@ typedef struct np_f16_cfg {
      * differ from the default by ~1e-5 relative per coefficient, i.e. by the fp32 noise of the MLP itself. */
     int32_t aero_1d_tables;
     int32_t reserved_cfg_;
+    np_f16_airframe airframe;   /* all zero = the F-16 literals (see np_f16_airframe) */
 } np_f16_cfg;
 
 /* Buffers of one reset()/step() call.  n aircraft, global row index of local row i = row0 + i
@@ -138,6 +157,8 @@ typedef struct np_f16_io {
 typedef struct np_f16_ctx np_f16_ctx;
 
 int np_abi_version(void);
+/* the reference's literals (the values an all-zero np_f16_airframe stands for) */
+void np_f16_airframe_default(np_f16_airframe *out);
 /* number of floats np_f16_io.coef_cache must hold for n aircraft */
 int64_t np_f16_cache_floats(int64_t n);
 const char *np_last_error(void);
@@ -231,6 +252,7 @@ typedef struct np_f16_combat_cfg {
     double airspeed_min, airspeed_max; /* controller.py:15 */
     int32_t aero_1d_tables;            /* see np_f16_cfg.aero_1d_tables */
     int32_t reserved_cfg_;
+    np_f16_airframe airframe;          /* all zero = the F-16 literals */
 } np_f16_combat_cfg;
 
 typedef struct np_f16_combat_io {

@@ -35,6 +35,7 @@ struct CombatDevCfg {
     float roll_ff, gravity, scale_min, scale_max;
     int inner_steps;
     int aero_1d_tables;
+    Airframe af;   // np_f16_combat_cfg.airframe (defaults: the F-16 literals)
 };
 
 struct CombatArgs;
@@ -112,7 +113,7 @@ __device__ __forceinline__ void stabilize(const CFG &cfg, const float (&s)[12], 
     const float roll_rate = P + tt * (Q * tr.sphi + R * tr.cphi);   // F16_dynamics.py:136-138
     const float pitch_rate = Q * tr.cphi - R * tr.sphi;
     const float yaw_rate = (Q * tr.sphi + R * tr.cphi) / tr.ct;
-    const float eas2tas = eas2tas_of(s[2]);
+    const float eas2tas = eas2tas_of(cfg.af, s[2]);
     const float TAS = s[6] + cfg.airspeed * 1.0f;
     float scaler = (1.0f / (TAS + 1e-8f)) * 1000.0f;                // calc_speed_scaler :35-40
     scaler = clampf(scaler, cfg.scale_min, cfg.scale_max);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(WPT == 4 ? TILE * 4 : dual_waves(WPT) ? 64 * dual_w
             pid[PID_PITCH_DEM] = 0.9f * pid[PID_PITCH_DEM] + NP_DIVC((0.1f * act[2]) * PI_F, 12.0f);
             float el, ail, rud;
             stabilize(ap->cfg, s, tr, tt, pid, ap->pid_first != 0 && it == 0, el, ail, rud);
-            u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);  // :251
+            u[0] = ap->cfg.af.lag_keep * u[0] + np_divc(((ap->cfg.af.lag_new * act[0]) * ap->cfg.af.thrust_frac) * ap->cfg.af.thrust_max, ap->cfg.af.thrust_unit, ap->cfg.af.r_thrust_unit);  // :251
             u[1] = -el;                                                                 // :252-255, written straight to u
             u[2] = -ail;
             u[3] = -rud;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(WPT == 4 ? TILE * 4 : dual_waves(WPT) ? 64 * dual_w
             const bool tables1 = ap->cfg.aero_1d_tables != 0;
             if (SOLVER == 0) {
                 float k1[12];
-                nlplant<true, AB_REST, B, WPT>(wt1, s, u, tr, tt, spsi, cpsi, coef, tables1, k1, part);
+                nlplant<true, AB_REST, B, WPT>(wt1, airframe_via(ap), s, u, tr, tt, spsi, cpsi, coef, tables1, k1, part);
                 NP_REREAD_ARGS(ap);
                 const float dt = ap->cfg.dt;
 #pragma unroll
@@ -358,8 +359,8 @@ __global__ __launch_bounds__(WPT == 4 ? TILE * 4 : dual_waves(WPT) ? 64 * dual_w
 #pragma nounroll
                 for (int stage = 0; stage < 4; stage++) {
                     float kk[12];
-                    if (stage == 0) nlplant<true, AB_REST, B, WPT>(a.wt, y, u, tr, tt, spsi, cpsi, coef, tables, kk, part);
-                    else xdot_full<AB_ALL, B, WPT>(a.wt, y, u, coef, tables, kk, part);
+                    if (stage == 0) nlplant<true, AB_REST, B, WPT>(a.wt, airframe_via(ap), y, u, tr, tt, spsi, cpsi, coef, tables, kk, part);
+                    else xdot_full<AB_ALL, B, WPT>(a.wt, airframe_via(ap), y, u, coef, tables, kk, part);
                     if (stage == 0) {
 #pragma unroll
                         for (int k = 0; k < 12; k++) {
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(WPT == 4 ? TILE * 4 : dual_waves(WPT) ? 64 * dual_w
             float xd[12], acc3[3];
             {
                 const AeroWeights wt2 = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
-                nlplant<false, AB_FORCE, B, WPT>(wt2, s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, part);
+                nlplant<false, AB_FORCE, B, WPT>(wt2, airframe_via(ap), s, u, tr, 0.0f, 0.0f, 0.0f, coef, ap->cfg.aero_1d_tables != 0, xd, part);
             }
             NP_REREAD_ARGS(ap);
             body_acceleration(s, tr, xd, acc3);

@@ -28,6 +28,40 @@ struct AeroWeights {
     const float *pwl_unnorm;  // [NUM_PWL_TABLES * 2] or null
 };
 
+// The airframe as data (np_f16_airframe, ABI 16): what F16Dynamics.nlplant / atmos and F16Model.update spell as literals
+// (envs/models/F16/F16_dynamics.py:22-35,61-76,114-116; envs/models/F16_model.py:52-62), rounded to fp32 on the host exactly where the
+// literal expressions round (derived constants folded in double first: np_f16_kernels.hip::make_airframe).  r_* = RN(1 / x) of a divisor
+// (np_divc).  The defaults are the F-16 literals: a context built without an airframe block computes what the literals computed, bit for bit.
+struct Airframe {
+    float g, mass, r_mass, B, S, cbar, Heng;
+    float Jy, r_Jy, Jxz, Jz, Jx;
+    float xc, cbar_over_B, c1, c2, c3, c4, denom, r_denom;       // xcgr - xcg, cbar / B, the inertia products of the moment equations
+    float ail_ref, r_ail_ref, rud_ref, r_rud_ref;                 // dail = ail / 21.5, drud = rud / 30
+    float atm_lapse, atm_exp, rho0;                               // tfac = 1 - 0.703e-5 alt; rho = 2.377e-3 tfac^4.14
+    float lag_keep, lag_new, thrust_frac, thrust_max, thrust_unit, r_thrust_unit, surf_max[3];   // u' = 0.9 u + 0.1 a * scale
+    __device__ __forceinline__ const Airframe &get() const { return *this; }
+};
+// How nlplant reaches the airframe.  Inside the step kernels nothing scalar may stay live across the two MLP phases (asm statements that own
+// s4-s101), so the constants are (re-)read from the kernel-argument segment AFTER the phase, through the pointer the kernel already keeps
+// for that purpose (`ap`, NP_REREAD_ARGS): ~35 scalar loads per evaluation, no VALU work, no register held across the statement.
+// AirframeVia<AP>{ap}.get() = ap->cfg.af behind such a re-read; a plain `Airframe` (kernels off the hot path) is its own get().
+#ifndef NP_REREAD_ARGS
+#define NP_REREAD_ARGS(ap) asm volatile("" : "+s"(ap) : : "memory")
+#endif
+// (np_cfg_of: where an argument record keeps its DevCfg / CombatDevCfg — `ap->cfg` unless the record's own header says otherwise)
+template <class AP>
+__device__ __forceinline__ auto np_cfg_of(AP ap) -> decltype(&ap->cfg) { return &ap->cfg; }
+template <class AP>
+struct AirframeVia {
+    AP &ap;
+    __device__ __forceinline__ auto &get() const {
+        NP_REREAD_ARGS(ap);
+        return np_cfg_of(ap)->af;
+    }
+};
+template <class AP>
+__device__ __forceinline__ AirframeVia<AP> airframe_via(AP &ap) { return AirframeVia<AP>{ap}; }
+
 // Scenario constants, pre-rounded on the host exactly where the reference rounds them.
 struct DevCfg {
     float dt, airspeed, noise_scale;
@@ -38,6 +72,7 @@ struct DevCfg {
     float max_heading_increment, max_pitch_increment, max_velocities_u_increment;
     float dist_span, min_distance;
     int aero_1d_tables;  // single-input nets through their piecewise-linear tables instead of the MLP bodies
+    Airframe af;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -711,6 +746,16 @@ __device__ __forceinline__ void normalise_inputs(const AeroWeights &wt, float al
 // ---------------------------------------------------------------------------------------------
 // F16Dynamics.nlplant — envs/models/F16/F16_dynamics.py:37-228 (atmos :22-35)
 // ---------------------------------------------------------------------------------------------
+template <class A>  // Airframe, or Airframe in the constant address space
+__device__ __forceinline__ float atmos_pow(const A &af, float alt) {   // (1 - 0.703e-5 alt)^4.14 (F16_dynamics.py:22-35)
+    return np_pow(1.0f - af.atm_lapse * alt, af.atm_exp);
+}
+template <class A>
+__device__ __forceinline__ float eas2tas_of(const A &af, float alt) {
+    const float e = (1.0f / atmos_pow(af, alt)) * 1.0f;
+    return sqrtf(e);
+}
+
 struct Trig {  // sines/cosines of the attitude and flow angles of one state
     float sa, ca, sb, cb, st, ct, sphi, cphi;
 };
@@ -735,31 +780,25 @@ constexpr int NUM_SHARED_SCALARS = 12;
 // STAGE (SHARE only; the persistent PlanningEnv kernel splits an evaluation in time): 0 = everything; 1 = this wave's share of the state's
 // serial chains -> LDS and nothing else (no barrier: the caller publishes them); 2 = everything BUT the share computation (the set is
 // already in LDS and published).
-template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0, bool HAVE_POW = false, int STAGE = 0>
-__device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], StateScalars &sc,
+// AF: how the airframe constants are reached — AirframeVia<AP> (step kernels: re-read from the kernel arguments after the MLP phase) or Airframe
+template <bool FULL, int PART, int LD, int WPT = 1, bool SHARE = false, int SET = 0, bool HAVE_POW = false, int STAGE = 0, class AF>
+__device__ __forceinline__ void nlplant(const AeroWeights &wt, const AF &afv, const float (&s)[12], const float (&u)[4], StateScalars &sc,
                                         float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
     static_assert(!SHARE || WPT == 4 || WPT == 8 || WPT == WPT_LAT2, "shared state scalars belong to the latency variants");
     static_assert(STAGE == 0 || SHARE, "stages split the shared-scalar evaluation");
-    const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
-    const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
-    const float xc = (float)(0.35 - 0.30);
-    const float cbar_over_B = (float)(11.32 / 30.0);
     const float r2d = (float)(180.0 / 3.141592653589793);
-    const float c1 = (float)(63100.0 * (63100.0 - 55814.0) + 982.0 * 982.0);
-    const float c2 = (float)(982.0 * (9496.0 - 55814.0 + 63100.0));
-    const float c3 = (float)(63100.0 - 9496.0);
-    const float c4 = (float)(9496.0 * (9496.0 - 55814.0) + 982.0 * 982.0);
-    const float denom = (float)(9496.0 * 63100.0 - 982.0 * 982.0);
 
     const float alt = s[2];
     float vt = s[6];
     const float alpha = s[7] * r2d, beta = s[8] * r2d;
     const float P = s[9], Q = s[10], R = s[11];
     const float T = u[0], el = u[1], ail = u[2], rud = u[3];
-    const float tfac = 1.0f - 0.703e-5f * alt;
 
     if constexpr (SHARE && STAGE != 2) {  // this wave's share of the state's serial chains -> LDS (published by the barrier inside eval_nets)
         float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
+        // (before the MLP phase only the atmosphere's two constants are needed, by the wave that computes tfac^4.14)
+        const auto &a0 = afv.get();
+        const float tfac = 1.0f - a0.atm_lapse * alt, atm_exp = a0.atm_exp;
         if constexpr (WPT == WPT_LAT2) {  // two waves: wave 0 alpha, theta (+ tan), psi; wave 1 beta, phi, tfac^4.14
             float a_, b_, c_ = 0.0f;
             if (part == 0) {
@@ -783,7 +822,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
                 np_sincos(s[3], a_, b_);
                 shr[6 * LD] = a_;
                 shr[7 * LD] = b_;
-                shr[11 * LD] = np_pow(tfac, 4.14f);
+                shr[11 * LD] = np_pow(tfac, atm_exp);
             }
         } else if (part == 0 || (WPT == 8 && part == 4)) {  // four waves: wave 0 takes alpha and psi; eight: wave 4 takes psi
             float a_, b_;
@@ -802,7 +841,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
             np_sincos(s[8], a_, b_);
             shr[2 * LD] = a_;
             shr[3 * LD] = b_;
-            shr[11 * LD] = np_pow(tfac, 4.14f);
+            shr[11 * LD] = np_pow(tfac, atm_exp);
         } else if (part == 2) {
             float a_, b_, c_ = 0.0f;
             if (FULL || NUM_CACHED_TRIG > 0) np_sincostan(s[4], a_, b_, c_);   // tan(theta) of the new state travels in the cross-step cache
@@ -832,6 +871,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
 #define NPF16_NET(id) (coef[slot_of(id) * LD])
 #define NPF16_POISON(v) (ok ? (v) : qnan)
 
+    const auto &af = afv.get();   // the airframe constants: scalar loads issued here, behind the MLP phase
     if constexpr (SHARE) {
         const float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
         sc.tr.sa = shr[0 * LD]; sc.tr.ca = shr[1 * LD]; sc.tr.sb = shr[2 * LD]; sc.tr.cb = shr[3 * LD];
@@ -841,17 +881,20 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         sc.cpsi = FULL ? shr[10 * LD] : 0.0f;
         sc.powv = shr[11 * LD];
     } else if constexpr (!HAVE_POW) {  // HAVE_POW: the caller brought it (the cross-step cache: the previous step computed it for this state)
-        sc.powv = np_pow(tfac, 4.14f);
+        sc.powv = atmos_pow(af, alt);
     }
+    const float g = af.g, mass = af.mass, B = af.B, S = af.S, cbar = af.cbar, Heng = af.Heng;
+    const float Jy = af.Jy, Jxz = af.Jxz, Jz = af.Jz, Jx = af.Jx;
+    const float xc = af.xc, cbar_over_B = af.cbar_over_B, c1 = af.c1, c2 = af.c2, c3 = af.c3, c4 = af.c4, denom = af.denom;
     const Trig &tr = sc.tr;
     const float tt = sc.tt, spsi = sc.spsi, cpsi = sc.cpsi;
     const float sa = tr.sa, ca = tr.ca, sb = tr.sb, cb = tr.cb, st = tr.st, ct = tr.ct, sphi = tr.sphi, cphi = tr.cphi;
 
     vt = (vt <= 0.01f ? 1.0f : 0.0f) * 0.01f + (vt > 0.01f ? 1.0f : 0.0f) * vt;  // :104
 
-    const float dail = NP_DIVC(ail, 21.5f), drud = NP_DIVC(rud, 30.0f);  // lef == 0 -> dlef == 1 (exact)
+    const float dail = np_divc(ail, af.ail_ref, af.r_ail_ref), drud = np_divc(rud, af.rud_ref, af.r_rud_ref);  // lef == 0 -> dlef == 1 (exact)
 
-    const float rho = 2.377e-3f * sc.powv;
+    const float rho = af.rho0 * sc.powv;
     const float qbar = (0.5f * rho) * (vt * vt);
 
     const float U = (vt * ca) * cb, V = vt * sb, W = (vt * sa) * cb;
@@ -883,9 +926,10 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
     const float Cy_tot =
         NPF16_POISON(((((NPF16_NET(N_Cy) + NPF16_NET(N_dCy_lef)) + dYdail * dail) + NPF16_NET(N_dCy_r30) * drud) + dYdR * R) + dYdP * P);
 
-    const float Udot = (((R * V - Q * W) - g * st) + NP_DIVC((qbar * S) * Cx_tot, mass)) + NP_DIVC(T, mass);
-    const float Vdot = ((P * W - R * U) + (g * ct) * sphi) + NP_DIVC((qbar * S) * Cy_tot, mass);
-    const float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + NP_DIVC((qbar * S) * Cz_tot, mass);
+    const float r_mass = af.r_mass;
+    const float Udot = (((R * V - Q * W) - g * st) + np_divc((qbar * S) * Cx_tot, mass, r_mass)) + np_divc(T, mass, r_mass);
+    const float Vdot = ((P * W - R * U) + (g * ct) * sphi) + np_divc((qbar * S) * Cy_tot, mass, r_mass);
+    const float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + np_divc((qbar * S) * Cz_tot, mass, r_mass);
     xd[6] = ((U * Udot + V * Vdot) + W * Wdot) / vt;
     xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
     xd[8] = (Vdot * vt - V * xd[6]) / ((vt * vt) * cb);
@@ -912,24 +956,34 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[
         const float L_tot = ((Cl_tot * qbar) * S) * B;
         const float M_tot = ((Cm_tot * qbar) * S) * cbar;
         const float N_tot = ((Cn_tot * qbar) * S) * B;
-        xd[9] = NP_DIVC((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng, denom);
-        xd[10] = NP_DIVC(((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng, Jy);
-        xd[11] = NP_DIVC((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom);
+        xd[9] = np_divc((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng, denom, af.r_denom);
+        xd[10] = np_divc(((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng, Jy, af.r_Jy);
+        xd[11] = np_divc((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom, af.r_denom);
     }
 #undef NPF16_NET
 #undef NPF16_POISON
 }
 
 // the state's trigonometry computed by the caller (every variant but the latency one)
-template <bool FULL, int PART, int LD, int WPT = 1>
-__device__ __forceinline__ void nlplant(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
+template <bool FULL, int PART, int LD, int WPT = 1, class AF>
+__device__ __forceinline__ void nlplant(const AeroWeights &wt, const AF &afv, const float (&s)[12], const float (&u)[4], const Trig &tr, float tt, float spsi,
                                         float cpsi, float *__restrict__ coef, bool tables, float (&xd)[12], int part = 0) {
     StateScalars sc;
     sc.tr = tr;
     sc.tt = tt;
     sc.spsi = spsi;
     sc.cpsi = cpsi;
-    nlplant<FULL, PART, LD, WPT, false, 0>(wt, s, u, sc, coef, tables, xd, part);
+    nlplant<FULL, PART, LD, WPT, false, 0>(wt, afv, s, u, sc, coef, tables, xd, part);
+}
+
+// F16Model.update's first-order control lag (F16_model.py:52-62), left to right exactly as written:
+//   T' = 0.9 T + 0.1 a0 * 0.225 * 76300 / 0.3048;  el' = 0.9 el + 0.1 a1 * 45  (ail, rud alike)
+template <class A>  // Airframe, or Airframe in the constant address space
+__device__ __forceinline__ void control_lag(const A &af, const float (&act)[4], float (&u)[4]) {
+    u[0] = af.lag_keep * u[0] + np_divc(((af.lag_new * act[0]) * af.thrust_frac) * af.thrust_max, af.thrust_unit, af.r_thrust_unit);
+    u[1] = af.lag_keep * u[1] + (af.lag_new * act[1]) * af.surf_max[0];
+    u[2] = af.lag_keep * u[2] + (af.lag_new * act[2]) * af.surf_max[1];
+    u[3] = af.lag_keep * u[3] + (af.lag_new * act[3]) * af.surf_max[2];
 }
 
 __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &tt) {
@@ -940,14 +994,14 @@ __device__ __forceinline__ void trig_of(const float (&s)[12], Trig &tr, float &t
 }
 
 // full derivative at (s,u) including the heading terms
-template <int PART, int LD, int WPT = 1>
-__device__ __forceinline__ void xdot_full(const AeroWeights &wt, const float (&s)[12], const float (&u)[4], float *__restrict__ coef, bool tables,
+template <int PART, int LD, int WPT = 1, class AF>
+__device__ __forceinline__ void xdot_full(const AeroWeights &wt, const AF &afv, const float (&s)[12], const float (&u)[4], float *__restrict__ coef, bool tables,
                                           float (&xd)[12], int part = 0) {
     Trig tr;
     float tt, spsi, cpsi;
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
-    nlplant<true, PART, LD, WPT>(wt, s, u, tr, tt, spsi, cpsi, coef, tables, xd, part);
+    nlplant<true, PART, LD, WPT>(wt, afv, s, u, tr, tt, spsi, cpsi, coef, tables, xd, part);
 }
 // F16Model.get_acceleration — F16_model.py:132-148, from xdot[6..8] at (s,u)
 __device__ __forceinline__ void body_acceleration(const float (&s)[12], const Trig &tr, const float (&xd)[12], float (&a)[3]) {
@@ -962,12 +1016,6 @@ __device__ __forceinline__ void body_acceleration(const float (&s)[12], const Tr
     a[2] = (w_dot + s[9] * vel_v) - s[10] * vel_u;
 }
 
-// F16Model.get_EAS2TAS — F16_model.py:156-162
-__device__ __forceinline__ float eas2tas_of(float alt) {
-    const float tfac = 1.0f - 0.703e-5f * alt;
-    const float e = (1.0f / np_pow(tfac, 4.14f)) * 1.0f;
-    return sqrtf(e);
-}
 
 // ---------------------------------------------------------------------------------------------
 // reset of one flagged aircraft — F16_model.py:33-45 + task.reset + env_base.py:92
@@ -1015,7 +1063,7 @@ __device__ __forceinline__ void observe(const CFG &cfg, const float (&s)[12], co
                                         const Trig &tr, float (&o)[22], float powv = 0.0f) {
     const float alt = s[2], pitch = s[4], heading = s[5], vt = s[6];
     // F16Model.get_EAS2TAS (F16_model.py:156-162); powv = (1 - 0.703e-5 alt)^4.14 when the caller already has it (latency variant)
-    const float eas2tas = HAVE_POW ? sqrtf((1.0f / powv) * 1.0f) : eas2tas_of(alt);
+    const float eas2tas = HAVE_POW ? sqrtf((1.0f / powv) * 1.0f) : eas2tas_of(cfg.af, alt);
     const float TAS = vt + cfg.airspeed * 1.0f;
     const float EAS = TAS / eas2tas;
     if (TASK == 0) {

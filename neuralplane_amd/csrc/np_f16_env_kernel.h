@@ -261,12 +261,12 @@ void f16_env_kernel(const KArgs a) {
                 float xd_[12];
                 if constexpr (SHARED) {
                     StateScalars scx;
-                    nlplant<false, AB_FORCE, TILE, WPT, true, 1>(a.wt, s, u, scx, coef, tables, xd_, pw);
+                    nlplant<false, AB_FORCE, TILE, WPT, true, 1>(a.wt, airframe_via(ap), s, u, scx, coef, tables, xd_, pw);
                 } else {   // one wave on its own (the pair variant's two waves hold different rows and decide for themselves)
                     StateScalars scx;
                     trig_of(s, scx.tr, scx.tt);
                     scx.spsi = scx.cpsi = 0.0f;
-                    nlplant<false, AB_FORCE, TILE, 1, false, 0>(a.wt, s, u, scx, coef, tables, xd_, 0);
+                    nlplant<false, AB_FORCE, TILE, 1, false, 0>(a.wt, airframe_via(ap), s, u, scx, coef, tables, xd_, 0);
                 }
 #endif
             }
@@ -282,7 +282,7 @@ void f16_env_kernel(const KArgs a) {
             if (flagged && !INNER) {  // a re-initialised aircraft: every angle is 0 (F16_model.py:33-45); its altitude was just drawn
                 tv[0] = tv[2] = tv[4] = tv[6] = tv[8] = 0.0f;
                 tv[1] = tv[3] = tv[5] = tv[7] = 1.0f;
-                tv[9] = np_pow(1.0f - 0.703e-5f * s[2], 4.14f);
+                tv[9] = atmos_pow(ap->cfg.af, s[2]);
             }
             sc_old.tr.sa = tv[0]; sc_old.tr.ca = tv[1]; sc_old.tr.sb = tv[2]; sc_old.tr.cb = tv[3];
             sc_old.tr.st = tv[4]; sc_old.tr.ct = tv[5]; sc_old.tr.sphi = tv[6]; sc_old.tr.cphi = tv[7];
@@ -297,7 +297,7 @@ void f16_env_kernel(const KArgs a) {
         if constexpr (NUM_CACHED_TRIG > 0) {
 #pragma unroll
             for (int k = 0; k < 9; k++) cache_blk[(NUM_CACHED + k) * CACHE_TILE] = (k & 1) && k < 8 ? 1.0f : 0.0f;   // sin 0, cos 0 x 4, tan 0
-            cache_blk[(NUM_CACHED + 9) * CACHE_TILE] = np_pow(1.0f - 0.703e-5f * s[2], 4.14f);
+            cache_blk[(NUM_CACHED + 9) * CACHE_TILE] = atmos_pow(ap->cfg.af, s[2]);
         }
         cache_blk[CACHE_KEY0 * CACHE_TILE] = s[7];
         cache_blk[(CACHE_KEY0 + 1) * CACHE_TILE] = s[8];
@@ -313,23 +313,20 @@ void f16_env_kernel(const KArgs a) {
             v = v > 1.0f ? 1.0f : v;
             act[k] = v;
         }
-        u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);
-        u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
-        u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
-        u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
+        control_lag(ap->cfg.af, act, u);
         if (SOLVER == 0) {  // euler: y1 = y0 + dt*f(y0)
             float k1[12];
             NP_LT(1);
             if constexpr (SHARED) {
                 StateScalars sc0;
-                nlplant<true, (CACHED ? AB_REST : AB_ALL), TILE, WPT, true, 0>(a.wt, s, u, sc0, coef, tables, k1, pw);
+                nlplant<true, (CACHED ? AB_REST : AB_ALL), TILE, WPT, true, 0>(a.wt, airframe_via(ap), s, u, sc0, coef, tables, k1, pw);
                 NP_LT(2);
             } else if constexpr (TRIG_CACHED) {  // the state's trigonometry comes from the cache; only the heading's is evaluated here
                 np_sincos(s[5], sc_old.spsi, sc_old.cpsi);
-                nlplant<true, AB_REST, TILE, WPT, false, 0, true>(a.wt, s, u, sc_old, coef, tables, k1, pw);
+                nlplant<true, AB_REST, TILE, WPT, false, 0, true>(a.wt, airframe_via(ap), s, u, sc_old, coef, tables, k1, pw);
                 NP_LT(2);
             } else {
-                xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, s, u, coef, tables, k1, pw);
+                xdot_full<(CACHED ? AB_REST : AB_ALL), TILE, WPT>(a.wt, airframe_via(ap), s, u, coef, tables, k1, pw);
                 NP_LT(2);
             }
             NP_REREAD_ARGS(ap);
@@ -350,8 +347,8 @@ void f16_env_kernel(const KArgs a) {
                 NP_REREAD_ARGS(ap);
                 const AeroWeights wts = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
                 const bool tbs = ap->cfg.aero_1d_tables != 0;
-                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(wts, y, u, coef, tbs, kk, pw);  // y == s: cached coefficients apply
-                else xdot_full<AB_ALL, TILE, WPT>(wts, y, u, coef, tbs, kk, pw);
+                if (CACHED && stage == 0) xdot_full<AB_REST, TILE, WPT>(wts, airframe_via(ap), y, u, coef, tbs, kk, pw);  // y == s: cached coefficients apply
+                else xdot_full<AB_ALL, TILE, WPT>(wts, airframe_via(ap), y, u, coef, tbs, kk, pw);
                 if (stage == 0) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
@@ -423,7 +420,7 @@ void f16_env_kernel(const KArgs a) {
             const AeroWeights wt2 = {ap->wt.kblob, ap->wt.kblob_dual, ap->wt.pwl, ap->wt.pwl_unnorm};
             if constexpr (SHARED) {
                 NP_LT(3);
-                nlplant<false, AB_FORCE, TILE, WPT, true, 1>(wt2, s, u, sc1, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                nlplant<false, AB_FORCE, TILE, WPT, true, 1>(wt2, airframe_via(ap), s, u, sc1, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
                 NP_LT(4);
                 tr = sc1.tr;
                 tt_new = sc1.tt;
@@ -433,7 +430,7 @@ void f16_env_kernel(const KArgs a) {
                 StateScalars scn;
                 scn.tr = tr;
                 scn.tt = scn.spsi = scn.cpsi = 0.0f;
-                nlplant<false, AB_FORCE, TILE, WPT, false, 0>(wt2, s, u, scn, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
+                nlplant<false, AB_FORCE, TILE, WPT, false, 0>(wt2, airframe_via(ap), s, u, scn, coef, ap->cfg.aero_1d_tables != 0, xd, pw);
                 pow_new = scn.powv;
                 NP_LT(4);
             }

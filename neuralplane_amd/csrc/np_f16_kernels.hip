@@ -45,7 +45,7 @@ namespace npf16 {
 // F16Model getters that need the dynamics or the atmosphere (F16_model.py:47-49, 132-198): out[23][ld_out]
 __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restrict__ sp, const float *__restrict__ up,
                                                             long long ld, float *__restrict__ out, long long ld_out,
-                                                            long long n, float airspeed, int tables, AeroWeights wt) {
+                                                            long long n, float airspeed, int tables, AeroWeights wt, Airframe af) {
     __shared__ float lds[NUM_LDS_SLOTS * BLOCK];
     float *coef = lds + threadIdx.x;
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -61,20 +61,20 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     trig_of(s, tr, tt);
     np_sincos(s[5], spsi, cpsi);
     float xd[12];
-    nlplant<true, AB_ALL, BLOCK>(wt, s, u, tr, tt, spsi, cpsi, coef, tables != 0, xd);
+    nlplant<true, AB_ALL, BLOCK>(wt, af, s, u, tr, tt, spsi, cpsi, coef, tables != 0, xd);
     float a3[3];
     body_acceleration(s, tr, xd, a3);
     const float inv_grav = (float)(1.0 / 32.174), minv_grav = (float)(-1.0 / 32.174);  // F16_model.py:166,176-178
     const float nx = inv_grav * a3[0] + tr.st;
     const float ny = inv_grav * a3[1] - tr.ct * tr.sphi;
     const float nz = minv_grav * a3[2] + tr.ct * tr.cphi;
-    const float e2t = eas2tas_of(s[2]);
+    const float e2t = eas2tas_of(af, s[2]);
     const float eas = (s[6] + airspeed * 1.0f) / e2t;
     // F16Model.get_atmos (F16_model.py:183-198 == F16Dynamics.atmos, F16_dynamics.py:22-35): mach, qbar, ps
-    const float tfac = 1.0f - 0.703e-5f * s[2];
+    const float tfac = 1.0f - af.atm_lapse * s[2];
     float temp = 519.0f * tfac;
     temp = (s[2] >= 35000.0f ? 1.0f : 0.0f) * 390.0f + (s[2] < 35000.0f ? 1.0f : 0.0f) * temp;
-    const float rho = 2.377e-3f * np_pow(tfac, 4.14f);
+    const float rho = af.rho0 * np_pow(tfac, af.atm_exp);
     const float mach = s[6] / sqrtf((float)(1.4 * 1716.3) * temp);
     const float qbar = (0.5f * rho) * (s[6] * s[6]);
     float ps = (1715.0f * rho) * temp;
@@ -441,8 +441,63 @@ int pack_kblob(const void *blob, size_t nbytes, std::vector<float> &kb, std::vec
     return 0;
 }
 
+// np_f16_airframe -> the fp32 constants of the kernels.  Every value is rounded where the literal expression of the reference rounds it:
+// plain literals are Python doubles that enter fp32 tensor arithmetic (one rounding), derived constants are folded in double first
+// (F16_dynamics.py:221-227 evaluates e.g. Jz * (Jz - Jy) + Jxz ** 2 in Python before it meets a tensor).
+np_f16_airframe airframe_defaults() {
+    np_f16_airframe a = {};
+    a.g = 32.17; a.mass = 636.94; a.B = 30.0; a.S = 300.0; a.cbar = 11.32; a.xcgr = 0.35; a.xcg = 0.30; a.Heng = 0.0;
+    a.Jy = 55814.0; a.Jxz = 982.0; a.Jz = 63100.0; a.Jx = 9496.0;
+    a.ail_ref = 21.5; a.rud_ref = 30.0;
+    a.atm_lapse = 0.703e-5; a.atm_exp = 4.14; a.rho0 = 2.377e-3;
+    a.lag_keep = 0.9; a.lag_new = 0.1; a.thrust_frac = 0.225; a.thrust_max = 76300.0; a.thrust_unit = 0.3048;
+    a.surf_max[0] = a.surf_max[1] = a.surf_max[2] = 45.0;
+    return a;
+}
+
+bool airframe_is_zero(const np_f16_airframe &a) {
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&a);
+    for (size_t k = 0; k < sizeof(a); k++)
+        if (p[k]) return false;
+    return true;
+}
+
+const char *airframe_error(const np_f16_airframe &a) {
+    const double pos[] = {a.mass, a.B, a.S, a.cbar, a.Jy, a.Jz, a.Jx, a.ail_ref, a.rud_ref, a.rho0, a.thrust_unit};
+    for (double v : pos)
+        if (!(v > 0.0) || !std::isfinite(v)) return "airframe: mass, B, S, cbar, Jx, Jy, Jz, ail_ref, rud_ref, rho0 and thrust_unit must be positive and finite";
+    if (!(a.Jx * a.Jz - a.Jxz * a.Jxz > 0.0)) return "airframe: Jx Jz - Jxz^2 must be positive";
+    const double fin[] = {a.g, a.xcgr, a.xcg, a.Heng, a.Jxz, a.atm_lapse, a.atm_exp, a.lag_keep, a.lag_new, a.thrust_frac, a.thrust_max, a.surf_max[0], a.surf_max[1], a.surf_max[2]};
+    for (double v : fin)
+        if (!std::isfinite(v)) return "airframe: non-finite value";
+    return nullptr;
+}
+
+Airframe make_airframe(const np_f16_airframe &in) {
+    const np_f16_airframe a = airframe_is_zero(in) ? airframe_defaults() : in;
+    auto rcp = [](float c) { return (float)(1.0 / (double)c); };   // NP_RCP_CONST: RN(1 / c) of the fp32 divisor
+    Airframe d;
+    d.g = (float)a.g; d.mass = (float)a.mass; d.r_mass = rcp(d.mass); d.B = (float)a.B; d.S = (float)a.S; d.cbar = (float)a.cbar; d.Heng = (float)a.Heng;
+    d.Jy = (float)a.Jy; d.r_Jy = rcp(d.Jy); d.Jxz = (float)a.Jxz; d.Jz = (float)a.Jz; d.Jx = (float)a.Jx;
+    d.xc = (float)(a.xcgr - a.xcg);
+    d.cbar_over_B = (float)(a.cbar / a.B);
+    d.c1 = (float)(a.Jz * (a.Jz - a.Jy) + a.Jxz * a.Jxz);
+    d.c2 = (float)(a.Jxz * (a.Jx - a.Jy + a.Jz));
+    d.c3 = (float)(a.Jz - a.Jx);
+    d.c4 = (float)(a.Jx * (a.Jx - a.Jy) + a.Jxz * a.Jxz);
+    d.denom = (float)(a.Jx * a.Jz - a.Jxz * a.Jxz);
+    d.r_denom = rcp(d.denom);
+    d.ail_ref = (float)a.ail_ref; d.r_ail_ref = rcp(d.ail_ref); d.rud_ref = (float)a.rud_ref; d.r_rud_ref = rcp(d.rud_ref);
+    d.atm_lapse = (float)a.atm_lapse; d.atm_exp = (float)a.atm_exp; d.rho0 = (float)a.rho0;
+    d.lag_keep = (float)a.lag_keep; d.lag_new = (float)a.lag_new; d.thrust_frac = (float)a.thrust_frac; d.thrust_max = (float)a.thrust_max;
+    d.thrust_unit = (float)a.thrust_unit; d.r_thrust_unit = rcp(d.thrust_unit);
+    for (int k = 0; k < 3; k++) d.surf_max[k] = (float)a.surf_max[k];
+    return d;
+}
+
 DevCfg make_devcfg(const np_f16_cfg &c) {
     DevCfg d;
+    d.af = make_airframe(c.airframe);
     d.dt = (float)c.dt - 0.0f;  // t = tensor([0., dt]); dt = t1 - t0   (F16_model.py:66)
     d.airspeed = (float)c.airspeed;
     d.noise_scale = (float)c.noise_scale;
@@ -698,6 +753,7 @@ PidDev make_pid(const np_pid_gains &g, double dt) {
 
 CombatDevCfg make_combat_devcfg(const np_f16_combat_cfg &c) {
     CombatDevCfg d;
+    d.af = make_airframe(c.airframe);
     d.dt = (float)c.dt - 0.0f;
     d.dt_pid = (float)c.dt;
     d.airspeed = (float)c.airspeed;
@@ -806,6 +862,10 @@ extern "C" {
 
 int np_abi_version(void) { return NP_ABI_VERSION; }
 
+void np_f16_airframe_default(np_f16_airframe *out) {
+    if (out) *out = airframe_defaults();
+}
+
 int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, int32_t tables, int32_t variant, np_dispatch_info *out) {
     if (!out) return fail("null argument");
     if (n <= 0 || num_cus <= 0) return fail("np_dispatch_plan: n and num_cus must be positive");
@@ -896,6 +956,8 @@ int np_f16_ctx_create(const void *weights_blob, size_t nbytes, const np_f16_cfg 
     *out = nullptr;
     if (cfg->task < 0 || cfg->task > 2) return fail("cfg.task must be NP_TASK_HEADING/CONTROL/TRACKING");
     if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
+    if (!airframe_is_zero(cfg->airframe))
+        if (const char *e = airframe_error(cfg->airframe)) return fail(e);
     if (ctx_create_common(weights_blob, nbytes, cfg->aero_1d_tables, device, out)) return 1;
     (*out)->task = cfg->task;
     (*out)->solver = cfg->solver;
@@ -910,6 +972,8 @@ int np_f16_combat_ctx_create(const void *weights_blob, size_t nbytes, const np_f
     if (cfg->solver < 0 || cfg->solver > 1) return fail("cfg.solver must be NP_SOLVER_EULER/RK4");
     if (cfg->inner_steps < 1 || cfg->inner_steps > 16) return fail("cfg.inner_steps must be in 1..16");
     if (!(cfg->dt > 0.0)) return fail("cfg.dt must be positive");
+    if (!airframe_is_zero(cfg->airframe))
+        if (const char *e = airframe_error(cfg->airframe)) return fail(e);
     if (ctx_create_common(weights_blob, nbytes, cfg->aero_1d_tables, device, out)) return 1;
     (*out)->solver = cfg->solver;
     (*out)->combat = true;
@@ -976,7 +1040,7 @@ int np_f16_derived(np_f16_ctx *ctx, int64_t n, const float *s, const float *u, i
     NP_HIP(guard.enter(ctx->device));
     const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipLaunchKernelGGL(f16_derived_kernel, grid, block, 0, (hipStream_t)stream, s, u, (long long)ld, out, (long long)ld_out,
-                       (long long)n, ctx->cfg.airspeed, ctx->cfg.aero_1d_tables, ctx->wt);
+                       (long long)n, ctx->cfg.airspeed, ctx->cfg.aero_1d_tables, ctx->wt, ctx->combat ? ctx->ccfg.af : ctx->cfg.af);
     NP_HIP(hipGetLastError());
     return 0;
 }

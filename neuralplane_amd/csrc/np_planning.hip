@@ -64,6 +64,7 @@
 namespace npf16 {
 
 typedef const PlanArgs __attribute__((address_space(4))) *PlanArgsC;
+__device__ __forceinline__ auto np_cfg_of(PlanArgsC ap) -> decltype(&ap->k.cfg) { return &ap->k.cfg; }   // (AirframeVia: the env record is member `k`)
 
 #if NP_PLAN_TRACE
 __device__ unsigned long long np_plan_trace_buf[8 * 16];   // [wave][stamp]
@@ -280,16 +281,13 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
         v = v > 1.0f ? 1.0f : v;
         act[k] = v;
     }
-    u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);
-    u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
-    u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
-    u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
+    control_lag(ap->k.cfg.af, act, u);
     NP_PSTAMP(4);
     {
         float k1[12];
         StateScalars sc0;
         const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
-        nlplant<true, AB_REST, TILE, W, true, 0>(wt1, s, u, sc0, coef, tables, k1, part);
+        nlplant<true, AB_REST, TILE, W, true, 0>(wt1, airframe_via(ap), s, u, sc0, coef, tables, k1, part);
         NP_REREAD_ARGS(ap);
         const float dt = ap->k.cfg.dt;
 #pragma unroll
@@ -303,7 +301,7 @@ __device__ __forceinline__ void plan_fdm_step(PlanArgsC &ap, float *lds_fdm, flo
     float xd[12];
     {
         const AeroWeights wt2 = {ap->k.wt.kblob, ap->k.wt.kblob_dual, ap->k.wt.pwl, ap->k.wt.pwl_unnorm};
-        nlplant<false, AB_FORCE, TILE, W, true, 1>(wt2, s, u, sc1, coef, tables, xd, part);
+        nlplant<false, AB_FORCE, TILE, W, true, 1>(wt2, airframe_via(ap), s, u, sc1, coef, tables, xd, part);
     }
     const Trig tr = sc1.tr;
     NP_REREAD_ARGS(ap);
@@ -444,10 +442,7 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
         v = v > 1.0f ? 1.0f : v;
         act[k] = v;
     }
-    u[0] = 0.9f * u[0] + NP_DIVC(((0.1f * act[0]) * 0.225f) * 76300.0f, 0.3048f);
-    u[1] = 0.9f * u[1] + (0.1f * act[1]) * 45.0f;
-    u[2] = 0.9f * u[2] + (0.1f * act[2]) * 45.0f;
-    u[3] = 0.9f * u[3] + (0.1f * act[3]) * 45.0f;
+    control_lag(ap->k.cfg.af, act, u);
     NP_PSTAMP(4);
     {
         float k1[12];
@@ -456,7 +451,7 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
         // WIN (static schedule): all 36 alpha/beta-only coefficients of this state are in the columns (the previous step's back and its
         // window nets, or the import): only the six el-dependent nets — the ones that see this step's action — are evaluated on the
         // critical path, one per wave; otherwise the 22 moment-side nets are evaluated here too (the cache carries the 14 force-side ones)
-        nlplant<true, WIN ? AB_EL : AB_REST, TILE, W, true, 0>(wt1, s, u, sc0, coef, false, k1, part);
+        nlplant<true, WIN ? AB_EL : AB_REST, TILE, W, true, 0>(wt1, airframe_via(ap), s, u, sc0, coef, false, k1, part);
         NP_REREAD_ARGS(ap);
         const float dt = ap->k.cfg.dt;
 #pragma unroll
@@ -468,7 +463,7 @@ __device__ __forceinline__ void plan_fdm_front(PlanArgsC &ap, float *lds_fdm, fl
         StateScalars scx;
         float xd[12];
         const AeroWeights wt2 = {ap->k.wt.kblob, ap->k.wt.kblob_dual, ap->k.wt.pwl, ap->k.wt.pwl_unnorm};
-        nlplant<false, WIN ? AB_ABALL : AB_FORCE, TILE, 4, true, 1, false, 1>(wt2, s, u, scx, coef, false, xd, part - 4);
+        nlplant<false, WIN ? AB_ABALL : AB_FORCE, TILE, 4, true, 1, false, 1>(wt2, airframe_via(ap), s, u, scx, coef, false, xd, part - 4);
     }
     if (part == 4 + PLAN_STATE_WAVE && t < PLAN_ROWS) {   // the state the back (and the next front) start from
         float *sw = ctx + CTX_ST + r;
@@ -523,7 +518,7 @@ __device__ __forceinline__ void plan_fdm_back(PlanArgsC &ap, float *lds_fdm, flo
         const AeroWeights wt2 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
         // force-side build-up for the Overload check; WIN: 10 of the 22 moment-side nets (what the next front finds) ride along, the other
         // 12 are evaluated in the call's three short windows (plan_window_nets)
-        nlplant<false, WIN ? AB_GRU : AB_FORCE, TILE, 4, true, 1, false, 2>(wt2, s, u, sc1, coef, false, xd, part4);   // two barriers inside (eval_nets)
+        nlplant<false, WIN ? AB_GRU : AB_FORCE, TILE, 4, true, 1, false, 2>(wt2, airframe_via(ap), s, u, sc1, coef, false, xd, part4);   // two barriers inside (eval_nets)
     }
     NP_REREAD_ARGS(ap);
     if (part4 == PLAN_STATE_WAVE) {
@@ -572,7 +567,7 @@ __device__ __forceinline__ void plan_fill_cache(PlanArgsC &ap, float *lds_fdm, c
     StateScalars sc1;
     float xd[12];
     const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
-    nlplant<false, AB_FORCE, TILE, W, true, 1>(wt1, s, u, sc1, coef, false, xd, part);
+    nlplant<false, AB_FORCE, TILE, W, true, 1>(wt1, airframe_via(ap), s, u, sc1, coef, false, xd, part);
     NP_REREAD_ARGS(ap);
 }
 
@@ -621,7 +616,7 @@ __device__ __forceinline__ void plan_fill_ab(PlanArgsC &ap, float *lds_fdm, cons
     StateScalars sc1;
     float xd[12];
     const AeroWeights wt1 = {a->k.wt.kblob, a->k.wt.kblob_dual, a->k.wt.pwl, a->k.wt.pwl_unnorm};
-    nlplant<false, AB_ABALL, TILE, 4, true, 1>(wt1, s, u, sc1, coef, false, xd, part - 4);
+    nlplant<false, AB_ABALL, TILE, 4, true, 1>(wt1, airframe_via(ap), s, u, sc1, coef, false, xd, part - 4);
     NP_REREAD_ARGS(ap);
 }
 
