@@ -17,6 +17,37 @@ ABI_VERSION = 16
 INNER_UPDATE_ONLY = 2   # np_f16_io.inner_step: F16Model.update(action) on its own (NP_INNER_UPDATE_ONLY)
 
 
+class NpF16Airframe(C.Structure):
+    """include/neuralplane_amd.h: np_f16_airframe.  All zero = the F-16 literals of the reference (F16_dynamics.py:22-35,61-76,114-116,
+    F16_model.py:52-62); `airframe(**overrides)` below builds a block from the defaults."""
+    _fields_ = [(k, C.c_double) for k in ('g', 'mass', 'B', 'S', 'cbar', 'xcgr', 'xcg', 'Heng', 'Jy', 'Jxz', 'Jz', 'Jx', 'ail_ref', 'rud_ref',
+                                          'atm_lapse', 'atm_exp', 'rho0', 'lag_keep', 'lag_new', 'thrust_frac', 'thrust_max', 'thrust_unit')] + [('surf_max', C.c_double * 3)]
+
+
+AIRFRAME_KEYS = tuple(k for k, _ in NpF16Airframe._fields_)
+
+
+def airframe(overrides=None):
+    """np_f16_airframe with the reference's F-16 values (np_f16_airframe_default) and `overrides` ({field: value}; surf_max: three values) on top.
+    None / {} -> the all-zero block, which the library reads as "the F-16"."""
+    a = NpF16Airframe()
+    if not overrides:
+        return a
+    lib = load()
+    lib.np_f16_airframe_default.argtypes = [C.POINTER(NpF16Airframe)]
+    lib.np_f16_airframe_default.restype = None
+    lib.np_f16_airframe_default(C.byref(a))
+    for k, v in dict(overrides).items():
+        if k not in AIRFRAME_KEYS:
+            raise ValueError(f'airframe: unknown field {k!r} (fields: {", ".join(AIRFRAME_KEYS)})')
+        if k == 'surf_max':
+            for j, x in enumerate(v):
+                a.surf_max[j] = float(x)
+        else:
+            setattr(a, k, float(v))
+    return a
+
+
 class NpF16Cfg(C.Structure):
     _fields_ = [('task', C.c_int32), ('solver', C.c_int32),
                 ('dt', C.c_double), ('airspeed', C.c_double), ('noise_scale', C.c_double),
@@ -30,7 +61,7 @@ class NpF16Cfg(C.Structure):
                 ('max_heading_increment', C.c_double), ('max_pitch_increment', C.c_double),
                 ('max_velocities_u_increment', C.c_double),
                 ('max_distance', C.c_double), ('min_distance', C.c_double),
-                ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32)]
+                ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32), ('airframe', NpF16Airframe)]
 
 
 class NpF16Io(C.Structure):
@@ -61,7 +92,7 @@ class NpF16CombatCfg(C.Structure):
                 ('max_epos', C.c_double), ('min_epos', C.c_double),
                 ('roll', NpPidGains), ('pitch', NpPidGains), ('yaw', NpPidGains),
                 ('roll_ff', C.c_double), ('gravity', C.c_double), ('airspeed_min', C.c_double), ('airspeed_max', C.c_double),
-                ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32)]
+                ('aero_1d_tables', C.c_int32), ('reserved_cfg_', C.c_int32), ('airframe', NpF16Airframe)]
 
 
 class NpPlanningLoop(C.Structure):
@@ -95,7 +126,7 @@ def dispatch_plan(n, num_cus, step=True, solver=0, tables=False, variant=0):
     return {k: getattr(info, k) for k, _ in NpDispatchInfo._fields_ if k != 'reserved_'}
 
 
-EXPORTS = ('np_abi_version', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
+EXPORTS = ('np_abi_version', 'np_f16_airframe_default', 'np_f16_cache_floats', 'np_last_error', 'np_f16_ctx_create', 'np_f16_ctx_destroy', 'np_f16_reset',
            'np_f16_step', 'np_f16_derived', 'np_f16_aero_coefficients', 'np_f16_lowlevel_obs', 'np_f16_set_timing', 'np_f16_get_timing', 'np_f16_get_timing_samples', 'np_f16_set_trace', 'np_selfcheck_divc',
            'np_f16_combat_ctx_create', 'np_f16_combat_reset', 'np_f16_combat_step', 'np_f16_set_kernel_variant', 'np_actor_forward', 'np_rollout_returns', 'np_planning_inner_loop', 'np_planning_check', 'np_actor_pack_i8', 'np_rollout_insert', 'np_policy_act', 'np_planning_targets_obs', 'np_dispatch_plan')
 KERNEL_VARIANTS = {'auto': 0, 'latency': 1, 'throughput': 2, 'pair': 3, 'latency8': 4, 'latency2': 5, 'latency4w': 6, 'dual8': 7, 'dual4': 8}

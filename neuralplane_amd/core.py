@@ -55,6 +55,9 @@ def cfg_from_config(config, task, solver=None, aero_1d_tables=None):
     if aero_1d_tables is None:
         aero_1d_tables = g('aero_1d_tables', int(os.environ.get('NPF16_AERO_1D_TABLES', '0')))
     c.aero_1d_tables = 1 if aero_1d_tables else 0
+    # the airframe as data (not a reference key: the reference spells these as literals, F16_dynamics.py:61-76): scenario key `airframe`, a
+    # mapping of np_f16_airframe fields that differ from the F-16's, e.g. {mass: 700, Jy: 60000}; absent / empty = the F-16
+    c.airframe = _lib.airframe(g('airframe', None))
     return c
 
 
@@ -520,6 +523,7 @@ def combat_cfg_from_config(config, solver=None, aero_1d_tables=None, pid_dir=PID
         if name == 'pitch':
             c.roll_ff, c.gravity = p['roll_ff'], p['gravity']
     c.airspeed_min, c.airspeed_max = 100, 2300                 # controller.py:15
+    c.airframe = _lib.airframe(g('airframe', None))             # see cfg_from_config
     if aero_1d_tables is None:
         aero_1d_tables = g('aero_1d_tables', int(os.environ.get('NPF16_AERO_1D_TABLES', '0')))
     c.aero_1d_tables = 1 if aero_1d_tables else 0

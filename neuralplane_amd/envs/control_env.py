@@ -10,9 +10,9 @@ class ControlEnv(BaseEnv):
     """Fly-control env: one F-16 per agent, tasks heading / control / tracking."""
 
     def __init__(self, num_envs=1, config='heading', model='F16', random_seed=None, device='cuda:0', row0=0,
-                 aero_1d_tables=None, solver=None, weights=None):
+                 aero_1d_tables=None, solver=None, weights=None, airframe=None):
         super().__init__(num_envs, config, model, random_seed, device, row0=row0, aero_1d_tables=aero_1d_tables, solver=solver,
-                         weights=weights)
+                         weights=weights, airframe=airframe)
 
     def load(self, random_seed, config, model):
         if model != 'F16':

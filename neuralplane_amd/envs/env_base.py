@@ -14,9 +14,15 @@ from .utils.utils import parse_config
 
 class BaseEnv(Env):
     def __init__(self, num_envs=10, config='heading', model='F16', random_seed=None, device='cuda:0', row0=0,
-                 aero_1d_tables=None, solver=None, weights=None):
+                 aero_1d_tables=None, solver=None, weights=None, airframe=None):
+        """airframe (not a reference argument): {np_f16_airframe field: value} for every constant that differs from the F-16's — mass, Jx,
+        Jy, Jz, Jxz, S, B, cbar, xcg, xcgr, Heng, g, ail_ref, rud_ref, the atmosphere and command scales (include/neuralplane_amd.h) —,
+        or the scenario YAML's `airframe:` mapping; together with `weights` (another NPF16MLP blob of the same topology) that is another
+        aircraft on the same kernels.  Parity of a non-F-16 airframe is unpinned: the reference has none."""
         super().__init__()
         self.config = parse_config(config)
+        if airframe is not None:
+            self.config.airframe = dict(airframe)
         self.num_envs = num_envs
         self.num_agents = getattr(self.config, 'num_agents', 100)
         self.n = self.num_agents * self.num_envs

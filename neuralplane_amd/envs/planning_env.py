@@ -52,8 +52,8 @@ class Args(_ActorArgs):  # the reference's name for the same object (planning_en
 
 class PlanningEnv(BaseEnv):
     def __init__(self, num_envs=1, config='tracking', model='F16', random_seed=None, device='cuda:0', controller=None,
-                 controller_checkpoint=None, row0=0, aero_1d_tables=None, controller_numerics='i8'):
-        super().__init__(num_envs, config, model, random_seed, device, row0=row0, aero_1d_tables=aero_1d_tables)
+                 controller_checkpoint=None, row0=0, aero_1d_tables=None, controller_numerics='i8', weights=None, airframe=None):
+        super().__init__(num_envs, config, model, random_seed, device, row0=row0, aero_1d_tables=aero_1d_tables, weights=weights, airframe=airframe)
         self.low_level_action_space = Box(low=-np.inf, high=np.inf, shape=(4,))
         if isinstance(controller, str):
             if controller != 'fused':

@@ -19,9 +19,11 @@ from .utils.utils import parse_config
 
 
 class SingleCombatEnv(Env):
-    def __init__(self, num_envs=1, config='selfplay', random_seed=None, device='cuda:0', env0=0, aero_1d_tables=None):
+    def __init__(self, num_envs=1, config='selfplay', random_seed=None, device='cuda:0', env0=0, aero_1d_tables=None, airframe=None):
         super().__init__()
         self.config = parse_config(config)
+        if airframe is not None:        # {np_f16_airframe field: value}: see BaseEnv
+            self.config.airframe = dict(airframe)
         self.num_envs = num_envs
         self.num_agents = getattr(self.config, 'num_agents', 100)
         if self.num_agents != 2:

@@ -54,10 +54,23 @@ typedef struct {
     const float *pwl; /* NULL, or t[64], a[64], x0[64], c[64] (blob PWL section) */
 } net_t;
 
+/* The airframe as data (f16o_airframe; device twin: csrc/np_f16_device.h::Airframe, built by np_f16_kernels.hip::make_airframe): the
+ * reference's literals (F16_dynamics.py:22-35,61-76,114-116; F16_model.py:52-62) rounded to fp32 where the literal expressions round —
+ * derived constants folded in double first.  r_* = RN(1 / x) of a divisor. */
+typedef struct af_t {
+    float g, mass, r_mass, B, S, cbar, Heng;
+    float Jy, r_Jy, Jxz, Jz, Jx;
+    float xc, cbar_over_B, c1, c2, c3, c4, denom, r_denom;
+    float ail_ref, r_ail_ref, rud_ref, r_rud_ref;
+    float atm_lapse, atm_exp, rho0;
+    float lag_keep, lag_new, thrust_frac, thrust_max, thrust_unit, r_thrust_unit, surf_max[3];
+} af_t;
+
 struct f16o_model {
     net_t net[F16O_NUM_NETS];
     float *params;
     float *scaled;
+    af_t af; /* the F-16 unless f16o_model_set_airframe said otherwise */
 };
 
 /* Numerics spec, "ReLU": hidden activations are carried divided by 2^ACT_SHIFT and the ReLU saturates at 1 there, i.e. at
@@ -84,6 +97,45 @@ static inline float divc_rc(float x, float c, float rc) {
 }
 #define DIVC(x, c) divc_rc((x), (c), (float)(1.0 / (double)(c)))
 float f16o_divc(float x, float c) { return DIVC(x, c); }
+
+void f16o_airframe_default(f16o_airframe *a) {
+    memset(a, 0, sizeof(*a));
+    a->g = 32.17; a->mass = 636.94; a->B = 30.0; a->S = 300.0; a->cbar = 11.32; a->xcgr = 0.35; a->xcg = 0.30; a->Heng = 0.0; /* :61-68 */
+    a->Jy = 55814.0; a->Jxz = 982.0; a->Jz = 63100.0; a->Jx = 9496.0;                                                   /* :71-74 */
+    a->ail_ref = 21.5; a->rud_ref = 30.0;                                                                                /* :114-115 */
+    a->atm_lapse = 0.703e-5; a->atm_exp = 4.14; a->rho0 = 2.377e-3;                                                       /* :22-35 */
+    a->lag_keep = 0.9; a->lag_new = 0.1; a->thrust_frac = 0.225; a->thrust_max = 76300.0; a->thrust_unit = 0.3048;        /* F16_model.py:53 */
+    a->surf_max[0] = a->surf_max[1] = a->surf_max[2] = 45.0;                                                              /* :54-56 */
+}
+
+static float rcp_f(float c) { return (float)(1.0 / (double)c); }
+
+void f16o_model_set_airframe(f16o_model *m, const f16o_airframe *in) {
+    f16o_airframe a;
+    int zero = 1;
+    if (in)
+        for (size_t k = 0; k < sizeof(*in); k++)
+            if (((const unsigned char *)in)[k]) zero = 0;
+    if (zero) f16o_airframe_default(&a);
+    else a = *in;
+    af_t *d = &m->af;
+    d->g = (float)a.g; d->mass = (float)a.mass; d->r_mass = rcp_f(d->mass); d->B = (float)a.B; d->S = (float)a.S; d->cbar = (float)a.cbar;
+    d->Heng = (float)a.Heng;
+    d->Jy = (float)a.Jy; d->r_Jy = rcp_f(d->Jy); d->Jxz = (float)a.Jxz; d->Jz = (float)a.Jz; d->Jx = (float)a.Jx;
+    d->xc = (float)(a.xcgr - a.xcg);                               /* (xcgr - xcg)      :204 */
+    d->cbar_over_B = (float)(a.cbar / a.B);                        /* (cbar / B)        :212 */
+    d->c1 = (float)(a.Jz * (a.Jz - a.Jy) + a.Jxz * a.Jxz);         /* Jz*(Jz-Jy)+Jxz^2  :225 */
+    d->c2 = (float)(a.Jxz * (a.Jx - a.Jy + a.Jz));                 /* Jxz*(Jx-Jy+Jz)         */
+    d->c3 = (float)(a.Jz - a.Jx);                                  /* (Jz - Jx)         :226 */
+    d->c4 = (float)(a.Jx * (a.Jx - a.Jy) + a.Jxz * a.Jxz);         /* Jx*(Jx-Jy)+Jxz^2  :227 */
+    d->denom = (float)(a.Jx * a.Jz - a.Jxz * a.Jxz);               /* :224 */
+    d->r_denom = rcp_f(d->denom);
+    d->ail_ref = (float)a.ail_ref; d->r_ail_ref = rcp_f(d->ail_ref); d->rud_ref = (float)a.rud_ref; d->r_rud_ref = rcp_f(d->rud_ref);
+    d->atm_lapse = (float)a.atm_lapse; d->atm_exp = (float)a.atm_exp; d->rho0 = (float)a.rho0;
+    d->lag_keep = (float)a.lag_keep; d->lag_new = (float)a.lag_new; d->thrust_frac = (float)a.thrust_frac; d->thrust_max = (float)a.thrust_max;
+    d->thrust_unit = (float)a.thrust_unit; d->r_thrust_unit = rcp_f(d->thrust_unit);
+    for (int k = 0; k < 3; k++) d->surf_max[k] = (float)a.surf_max[k];
+}
 
 long f16o_divc_check(float c) {
     const float rc = (float)(1.0 / (double)c);
@@ -184,6 +236,7 @@ f16o_model *f16o_model_load(const void *blob, size_t nbytes) {
             q += 8 + 4 * 64 * 4;
         }
     }
+    f16o_model_set_airframe(m, NULL); /* the F-16 literals */
     return m;
 bad:
     f16o_model_free(m);
@@ -568,18 +621,14 @@ enum {
 /* ------------------------------------------------------------------------------------------ */
 
 static void nlplant_row(const f16o_model *m, const float x[17], float xd[12]) {
-    /* constants :61-76; Python-double expressions are folded in double and rounded once,
-     * exactly where the reference multiplies them into a tensor. */
-    const float g = 32.17f, mass = 636.94f, B = 30.0f, S = 300.0f, cbar = 11.32f, Heng = 0.0f;
-    const float Jy = 55814.0f, Jxz = 982.0f, Jz = 63100.0f, Jx = 9496.0f;
-    const float xc = (float)(0.35 - 0.30);                             /* (xcgr - xcg)      :204 */
-    const float cbar_over_B = (float)(11.32 / 30.0);                   /* (cbar / B)        :212 */
+    /* constants :61-76 (m->af: the airframe as data; Python-double expressions were folded in double and rounded once, exactly where the
+     * reference multiplies them into a tensor — f16o_model_set_airframe) */
+    const af_t *af = &m->af;
+    const float g = af->g, mass = af->mass, B = af->B, S = af->S, cbar = af->cbar, Heng = af->Heng;
+    const float Jy = af->Jy, Jxz = af->Jxz, Jz = af->Jz, Jx = af->Jx;
+    const float xc = af->xc, cbar_over_B = af->cbar_over_B;
     const float r2d = (float)(180.0 / 3.141592653589793);              /* :76 */
-    const float c1 = (float)(63100.0 * (63100.0 - 55814.0) + 982.0 * 982.0); /* Jz*(Jz-Jy)+Jxz^2 :225 */
-    const float c2 = (float)(982.0 * (9496.0 - 55814.0 + 63100.0));    /* Jxz*(Jx-Jy+Jz)          */
-    const float c3 = (float)(63100.0 - 9496.0);                        /* (Jz - Jx)         :226 */
-    const float c4 = (float)(9496.0 * (9496.0 - 55814.0) + 982.0 * 982.0); /* Jx*(Jx-Jy)+Jxz^2 :227 */
-    const float denom = (float)(9496.0 * 63100.0 - 982.0 * 982.0);     /* :224 */
+    const float c1 = af->c1, c2 = af->c2, c3 = af->c3, c4 = af->c4, denom = af->denom;
 
     float alt = x[2], phi = x[3], theta = x[4], psi = x[5];
     float vt = x[6];
@@ -597,11 +646,11 @@ static void nlplant_row(const f16o_model *m, const float x[17], float xd[12]) {
 
     float T = x[12], el = x[13], ail = x[14], rud = x[15];
     /* lef = x[16] is identically 0 (F16_model.py:57): dlef = 1 - lef/25 = 1 and `* dlef` is exact */
-    float dail = DIVC(ail, 21.5f), drud = DIVC(rud, 30.0f); /* :114-115 */
+    float dail = divc_rc(ail, af->ail_ref, af->r_ail_ref), drud = divc_rc(rud, af->rud_ref, af->r_rud_ref); /* :114-115 */
 
     /* atmos :22-35 (mach, ps are dead) */
-    float tfac = 1.0f - 0.703e-5f * alt;
-    float rho = 2.377e-3f * f16o_pow(tfac, 4.14f);
+    float tfac = 1.0f - af->atm_lapse * alt;
+    float rho = af->rho0 * f16o_pow(tfac, af->atm_exp);
     float qbar = (0.5f * rho) * (vt * vt);
 
     float U = (vt * ca) * cb, V = vt * sb, W = (vt * sa) * cb; /* :129-131 */
@@ -641,18 +690,18 @@ static void nlplant_row(const f16o_model *m, const float x[17], float xd[12]) {
     float Cl_tot = (((((c[N_Cl] + c[N_dCl_lef]) + dLdail * dail) + c[N_dCl_r30] * drud) + dLdR * R) + dLdP * P) +
                    c[N_dClbeta] * beta;
 
-    float Udot = (((R * V - Q * W) - g * st) + DIVC((qbar * S) * Cx_tot, mass)) + DIVC(T, mass);
-    float Vdot = ((P * W - R * U) + (g * ct) * sphi) + DIVC((qbar * S) * Cy_tot, mass);
-    float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + DIVC((qbar * S) * Cz_tot, mass);
+    float Udot = (((R * V - Q * W) - g * st) + divc_rc((qbar * S) * Cx_tot, mass, af->r_mass)) + divc_rc(T, mass, af->r_mass);
+    float Vdot = ((P * W - R * U) + (g * ct) * sphi) + divc_rc((qbar * S) * Cy_tot, mass, af->r_mass);
+    float Wdot = ((Q * U - P * V) + (g * ct) * cphi) + divc_rc((qbar * S) * Cz_tot, mass, af->r_mass);
     xd[6] = ((U * Udot + V * Vdot) + W * Wdot) / vt;
     xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
     xd[8] = (Vdot * vt - V * xd[6]) / ((vt * vt) * cb);
     float L_tot = ((Cl_tot * qbar) * S) * B;
     float M_tot = ((Cm_tot * qbar) * S) * cbar;
     float N_tot = ((Cn_tot * qbar) * S) * B;
-    xd[9] = DIVC((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng, denom);
-    xd[10] = DIVC(((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng, Jy);
-    xd[11] = DIVC((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom);
+    xd[9] = divc_rc((((Jz * L_tot + Jxz * N_tot) - (c1 * Q) * R) + (c2 * P) * Q) + (Jxz * Q) * Heng, denom, af->r_denom);
+    xd[10] = divc_rc(((M_tot + (c3 * P) * R) - Jxz * (P * P - R * R)) - R * Heng, Jy, af->r_Jy);
+    xd[11] = divc_rc((((Jx * N_tot + Jxz * L_tot) + (c4 * P) * Q) - (c2 * Q) * R) + (Jx * Q) * Heng, denom, af->r_denom);
 }
 
 void f16o_nlplant(const f16o_model *m, int64_t n, const float *x17, float *xdot12) {
@@ -706,27 +755,28 @@ void f16o_get_accels(const f16o_model *m, int64_t n, const float *s, const float
 }
 
 /* F16Model.get_EAS2TAS — envs/models/F16_model.py:156-162 */
-static float eas2tas_row(float alt) {
-    float tfac = 1.0f - 0.703e-5f * alt;
-    float e = (1.0f / f16o_pow(tfac, 4.14f)) * 1.0f; /* 1 / t == t.reciprocal() * 1 */
+static float eas2tas_row(const af_t *af, float alt) {
+    float tfac = 1.0f - af->atm_lapse * alt;
+    float e = (1.0f / f16o_pow(tfac, af->atm_exp)) * 1.0f; /* 1 / t == t.reciprocal() * 1 */
     return sqrtf(e);
 }
 
-void f16o_get_eas2tas(int64_t n, const float *s, float *out) {
-    for (int64_t i = 0; i < n; i++) out[i] = eas2tas_row(s[12 * i + 2]);
+void f16o_get_eas2tas(const f16o_model *m, int64_t n, const float *s, float *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = eas2tas_row(&m->af, s[12 * i + 2]);
 }
 
 /* F16Model.get_atmos — envs/models/F16_model.py:183-198 (the same arithmetic as F16Dynamics.atmos, F16_dynamics.py:22-35):
  * (mach, qbar, ps) from altitude and airspeed.  `(alt >= 35000.0) * 390 + (alt < 35000.0) * temp` selects; `1.4 * 1716.3` is a
  * Python double product rounded to fp32 when it meets the tensor; pow(vt, 2) is vt * vt in ATen. */
-void f16o_get_atmos(int64_t n, const float *s, float *out3) {
+void f16o_get_atmos(const f16o_model *m, int64_t n, const float *s, float *out3) {
     const float c_gas = (float)(1.4 * 1716.3);
+    const af_t *af = &m->af;
     for (int64_t i = 0; i < n; i++) {
         float alt = s[12 * i + 2], vt = s[12 * i + 6];
-        float tfac = 1.0f - 0.703e-5f * alt;
+        float tfac = 1.0f - af->atm_lapse * alt;
         float temp = 519.0f * tfac;
         temp = (float)(alt >= 35000.0f) * 390.0f + (float)(alt < 35000.0f) * temp;
-        float rho = 2.377e-3f * f16o_pow(tfac, 4.14f);
+        float rho = af->rho0 * f16o_pow(tfac, af->atm_exp);
         float mach = vt / sqrtf(c_gas * temp);
         float qbar = (0.5f * rho) * (vt * vt);
         float ps = (1715.0f * rho) * temp;
@@ -775,9 +825,9 @@ static void reset_row(const f16o_cfg *cfg, float *s, float *u, float *tgt, int64
 
 /* 22-float observation before noise: heading_task.py:71-152, control_task.py:70-152,
  * tracking_task.py:73-155 (identical except slots 0..2) */
-static void obs_row(const f16o_cfg *cfg, const float *s, const float *u, const float *tgt, float *o) {
+static void obs_row(const af_t *af, const f16o_cfg *cfg, const float *s, const float *u, const float *tgt, float *o) {
     float alt = s[2], roll = s[3], pitch = s[4], heading = s[5], vt = s[6];
-    float eas2tas = eas2tas_row(alt);
+    float eas2tas = eas2tas_row(af, alt);
     float TAS = vt + (float)cfg->airspeed * 1.0f; /* get_TAS :96-97 */
     float EAS = TAS / eas2tas;                    /* get_EAS :99-103 */
     if (cfg->task == F16O_TASK_HEADING) {
@@ -823,7 +873,6 @@ static void add_noise(const f16o_cfg *cfg, float *o, const float *noise_row, uin
 int f16o_reset(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, float *u, float *tgt,
                int64_t *step_count, uint8_t *done, uint8_t *bad, uint8_t *timeout, const float *rand_u,
                const float *noise, uint64_t seed, uint64_t call_idx, int64_t row0, float *obs) {
-    (void)m;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) {
         if (done[i] | bad[i] | timeout[i]) {
@@ -834,7 +883,7 @@ int f16o_reset(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float *s, fl
         }
         done[i] = bad[i] = timeout[i] = 0; /* env_base.py:93-95 */
         if (obs) {
-            obs_row(cfg, s + 12 * i, u + 5 * i, tgt + 3 * i, obs + F16O_NOBS * i);
+            obs_row(&m->af, cfg, s + 12 * i, u + 5 * i, tgt + 3 * i, obs + F16O_NOBS * i);
             add_noise(cfg, obs + F16O_NOBS * i, noise ? noise + F16O_NOBS * i : NULL, seed, call_idx, row0 + i);
         }
     }
@@ -873,10 +922,11 @@ static void update_row(const f16o_model *m, const f16o_cfg *cfg, float *s, float
     }
     float x[17];
     memcpy(x, s, 12 * sizeof(float));
-    x[12] = 0.9f * u[0] + DIVC(((0.1f * a[0]) * 0.225f) * 76300.0f, 0.3048f);
-    x[13] = 0.9f * u[1] + (0.1f * a[1]) * 45.0f;
-    x[14] = 0.9f * u[2] + (0.1f * a[2]) * 45.0f;
-    x[15] = 0.9f * u[3] + (0.1f * a[3]) * 45.0f;
+    const af_t *af = &m->af; /* F16_model.py:52-56: T' = 0.9 T + 0.1 a0 * 0.225 * 76300 / 0.3048; el' = 0.9 el + 0.1 a1 * 45 ... */
+    x[12] = af->lag_keep * u[0] + divc_rc(((af->lag_new * a[0]) * af->thrust_frac) * af->thrust_max, af->thrust_unit, af->r_thrust_unit);
+    x[13] = af->lag_keep * u[1] + (af->lag_new * a[1]) * af->surf_max[0];
+    x[14] = af->lag_keep * u[2] + (af->lag_new * a[2]) * af->surf_max[1];
+    x[15] = af->lag_keep * u[3] + (af->lag_new * a[3]) * af->surf_max[2];
     x[16] = 0.0f;
     integrate_x(m, cfg->solver, cfg->dt, x, s);
     for (int k = 0; k < 5; k++) u[k] = x[12 + k];
@@ -977,7 +1027,7 @@ static int step_impl(const f16o_model *m, const f16o_cfg *cfg, int64_t n, float 
         update_row(m, cfg, si, ui, action + act_stride * i); /* :101 */
         if (inner && flagged) memcpy(si, keep, sizeof(keep)); /* planning_env.py:162-166: s[reset] = recent_s[reset] */
         step_count[i] += 1;                                  /* :102 */
-        obs_row(cfg, si, ui, ti, obs + F16O_NOBS * i);       /* :103 */
+        obs_row(&m->af, cfg, si, ui, ti, obs + F16O_NOBS * i); /* :103 */
         add_noise(cfg, obs + F16O_NOBS * i, noise ? noise + F16O_NOBS * i : NULL, seed, call_idx, row0 + i);
         done_reward_row(m, cfg, si, ui, ti, step_count[i], dp, bp, tp, done + i, bad + i, timeout + i, reward + i, NULL); /* :105-106 */
     }
@@ -1036,10 +1086,10 @@ void f16o_termination_reasons(const f16o_model *m, const f16o_cfg *cfg, int64_t 
 }
 
 /* PlanningEnv.low_level_obs — envs/planning_env.py:60-142: ControlTask-style observation, caller's targets, no noise */
-void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs) {
+void f16o_lowlevel_obs(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs) {
     f16o_cfg c = *cfg;
     c.task = F16O_TASK_CONTROL;
-    for (int64_t i = 0; i < n; i++) obs_row(&c, s + 12 * i, u + 5 * i, tgt3 + 3 * i, obs + F16O_NOBS * i);
+    for (int64_t i = 0; i < n; i++) obs_row(&m->af, &c, s + 12 * i, u + 5 * i, tgt3 + 3 * i, obs + F16O_NOBS * i);
 }
 
 void f16o_set_threads(int n) {

@@ -48,6 +48,17 @@ typedef struct f16o_cfg {
 
 typedef struct f16o_model f16o_model;
 
+/* The airframe as data (device twin: include/neuralplane_amd.h::np_f16_airframe, same fields): the literals of F16Dynamics.nlplant / atmos
+ * (envs/models/F16/F16_dynamics.py:22-35,61-76,114-116) and of F16Model.update (envs/models/F16_model.py:52-62).  All zero / NULL = the
+ * F-16.  A model carries one (f16o_model_set_airframe); every function that evaluates the dynamics reads it from there.  Anything but
+ * the defaults is parity-UNPINNED: the reference has no second aircraft. */
+typedef struct f16o_airframe {
+    double g, mass, B, S, cbar, xcgr, xcg, Heng, Jy, Jxz, Jz, Jx, ail_ref, rud_ref, atm_lapse, atm_exp, rho0;
+    double lag_keep, lag_new, thrust_frac, thrust_max, thrust_unit, surf_max[3];
+} f16o_airframe;
+void f16o_airframe_default(f16o_airframe *a);
+void f16o_model_set_airframe(f16o_model *m, const f16o_airframe *a);
+
 /* Parse the NPF16MLP v1 blob (tools/export_weights.py).  Returns NULL on malformed input. */
 f16o_model *f16o_model_load(const void *blob, size_t nbytes);
 void f16o_model_free(f16o_model *m);
@@ -70,8 +81,8 @@ void f16o_nlplant(const f16o_model *m, int64_t n, const float *x17, float *xdot1
 /* getters of F16Model that need the dynamics (s[n][12], u[n][5]) */
 void f16o_get_acceleration(const f16o_model *m, int64_t n, const float *s, const float *u, float *a3);
 void f16o_get_accels(const f16o_model *m, int64_t n, const float *s, const float *u, float *n3);
-void f16o_get_eas2tas(int64_t n, const float *s, float *out);
-void f16o_get_atmos(int64_t n, const float *s, float *out3); /* (mach, qbar, ps) per row */
+void f16o_get_eas2tas(const f16o_model *m, int64_t n, const float *s, float *out);
+void f16o_get_atmos(const f16o_model *m, int64_t n, const float *s, float *out3); /* (mach, qbar, ps) per row */
 
 /* Elementary functions of the numerics spec, exposed for unit tests. */
 void f16o_sincos(float x, float *s, float *c);
@@ -119,7 +130,7 @@ int f16o_model_reset(const f16o_cfg *cfg, int64_t n, float *s, float *u, const u
 void f16o_termination_reasons(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u,
                               const float *tgt, const int64_t *step_count, uint8_t *reasons);
 /* PlanningEnv.low_level_obs (envs/planning_env.py:60-142); tgt3[n][3] = (target_pitch, target_heading, target_vt) */
-void f16o_lowlevel_obs(const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs);
+void f16o_lowlevel_obs(const f16o_model *m, const f16o_cfg *cfg, int64_t n, const float *s, const float *u, const float *tgt3, float *obs);
 
 /* ------------------------------------------------------------------------------------------ */
 /* SingleCombat 1v1 restatement (f16_combat.inc) — envs/singlecombat_env.py + algorithms/pid/  */
@@ -157,7 +168,7 @@ float f16o_exp(float x);
 void f16o_pairwise(int64_t n, const float *ego_pos, const float *enm_pos, const float *ego_vel, const float *enm_vel,
                    float target_dist, float *out11);
 /* Controller.stabilize for n aircraft (s[n][12], pid[n][F16O_NPID] in/out); out3 = (el, ail, rud) outputs */
-void f16o_stabilize(const f16o_combat_cfg *cfg, int64_t n, const float *s, float *pid, int first, float *out3);
+void f16o_stabilize(const f16o_model *m, const f16o_combat_cfg *cfg, int64_t n, const float *s, float *pid, int first, float *out3);
 /* Pairwise reset: both aircraft of an env in which any flag is set are re-initialised (rand_u[n][5] =
  * U_npos, U_epos, U_alt, U_yaw, U_vt or NULL -> counter RNG keyed by global aircraft row 2*env0+i), then all
  * flags are cleared; obs[n][15] may be NULL. */

@@ -40,6 +40,28 @@ class Cfg(C.Structure):
                 ('max_distance', C.c_double), ('min_distance', C.c_double)]
 
 
+class Airframe(C.Structure):
+    """f16o_airframe (f16_oracle.h); all zero = the F-16."""
+    _fields_ = [(k, C.c_double) for k in ('g', 'mass', 'B', 'S', 'cbar', 'xcgr', 'xcg', 'Heng', 'Jy', 'Jxz', 'Jz', 'Jx', 'ail_ref', 'rud_ref',
+                                          'atm_lapse', 'atm_exp', 'rho0', 'lag_keep', 'lag_new', 'thrust_frac', 'thrust_max', 'thrust_unit')] + [('surf_max', C.c_double * 3)]
+
+
+def make_airframe(lib, overrides):
+    """The F-16 defaults with {field: value} on top (None / {} -> None = keep the model's defaults)."""
+    if not overrides:
+        return None
+    a = Airframe()
+    lib.f16o_airframe_default(C.byref(a))
+    for k, v in dict(overrides).items():
+        if k == 'surf_max':
+            for j, x in enumerate(v):
+                a.surf_max[j] = float(x)
+        else:
+            assert hasattr(a, k), k
+            setattr(a, k, float(v))
+    return a
+
+
 def build(force=False):
     """Compile oracle/_build/libf16oracle.so with gcc (Makefile)."""
     src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('f16_oracle.c', 'f16_combat.inc', 'f16_actor.inc', 'f16_actor_i8.inc', 'f16_rollout.inc', 'f16_oracle.h', 'Makefile'))
@@ -111,6 +133,10 @@ class Oracle:
         if not self.model:
             raise RuntimeError('f16o_model_load failed')
         self.task = task
+        overrides = dict(overrides or {})
+        af = make_airframe(L, overrides.pop('airframe', None))    # scenario key `airframe`: {np_f16_airframe field: value}
+        if af is not None:
+            L.f16o_model_set_airframe(C.c_void_p(self.model), C.byref(af))
         self.cfg = load_cfg(task, solver, overrides)
         self.mode = mode
         if threads:
@@ -199,7 +225,7 @@ class Oracle:
         self._set_mode()
         s = _f32(s)
         out = np.empty(s.shape[0], dtype=np.float32)
-        self.lib.f16o_get_eas2tas(C.c_int64(s.shape[0]), _p(s), _p(out))
+        self.lib.f16o_get_eas2tas(C.c_void_p(self.model), C.c_int64(s.shape[0]), _p(s), _p(out))
         return out
 
     def get_atmos(self, s):
@@ -207,7 +233,7 @@ class Oracle:
         self._set_mode()
         s = _f32(s)
         out = np.empty((s.shape[0], 3), dtype=np.float32)
-        self.lib.f16o_get_atmos(C.c_int64(s.shape[0]), _p(s), _p(out))
+        self.lib.f16o_get_atmos(C.c_void_p(self.model), C.c_int64(s.shape[0]), _p(s), _p(out))
         return out
 
     # ---- env level -----------------------------------------------------------------------
@@ -247,7 +273,7 @@ class Oracle:
         t = _f32(tgt3)
         n = st['s'].shape[0]
         obs = np.empty((n, 22), np.float32)
-        self.lib.f16o_lowlevel_obs(C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']), _p(t), _p(obs))
+        self.lib.f16o_lowlevel_obs(C.c_void_p(self.model), C.byref(self.cfg), C.c_int64(n), _p(st['s']), _p(st['u']), _p(t), _p(obs))
         return obs
 
     def step_inner(self, st, action, noise=None, seed=0, call_idx=0, row0=0):
@@ -356,7 +382,8 @@ class CombatOracle(Oracle):
     """1v1 combat macro-step on top of the same model blob.  Rows 2k / 2k+1 = ego / enemy of env k."""
 
     def __init__(self, config='selfplay', solver=None, overrides=None, blob_path=DEFAULT_BLOB, mode=0, threads=None):
-        super().__init__('heading', None, None, blob_path, mode, threads)
+        overrides = dict(overrides or {})
+        super().__init__('heading', None, {'airframe': overrides.pop('airframe', None)}, blob_path, mode, threads)
         self.ccfg = load_combat_cfg(config, solver, overrides)
         for fn in ('f16o_acos', 'f16o_atanh', 'f16o_exp'):
             getattr(self.lib, fn).restype = C.c_float
@@ -385,7 +412,7 @@ class CombatOracle(Oracle):
         self._set_mode()
         s = _f32(s)
         out = np.empty((s.shape[0], 3), np.float32)
-        self.lib.f16o_stabilize(C.byref(self.ccfg), C.c_int64(s.shape[0]), _p(s), _p(pid), C.c_int(int(first)), _p(out))
+        self.lib.f16o_stabilize(C.c_void_p(self.model), C.byref(self.ccfg), C.c_int64(s.shape[0]), _p(s), _p(pid), C.c_int(int(first)), _p(out))
         return out
 
     def combat_reset(self, st, rand_u=None, seed=0, call_idx=0, env0=0):

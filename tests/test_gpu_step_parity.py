@@ -607,6 +607,103 @@ def test_two_aircraft_types_coexist_on_one_device(tmp_path, tables):
     assert not np.array_equal(sts[0]['s'], sts[1]['s'])
 
 
+# another aircraft: every field of np_f16_airframe moved off the F-16's value (mass + 25 %, other inertias incl. a non-zero engine angular
+# momentum, smaller wing, c.g. further aft, other control / command scales and atmosphere constants) — physically plausible enough to fly
+SECOND_AIRFRAME = dict(g=32.174, mass=800.0, B=34.5, S=345.0, cbar=10.1, xcgr=0.33, xcg=0.27, Heng=160.0, Jy=61000.0, Jxz=1100.0, Jz=70500.0,
+                       Jx=11000.0, ail_ref=20.0, rud_ref=28.0, atm_lapse=0.69e-5, atm_exp=4.2, rho0=2.4e-3, lag_keep=0.88, lag_new=0.12,
+                       thrust_frac=0.2, thrust_max=90000.0, thrust_unit=0.3, surf_max=(40.0, 42.0, 47.0))
+
+
+@pytest.mark.parametrize('task,solver,variant,n', [('heading', None, 'latency8', 300), ('heading', None, 'latency', 700), ('control', None, 'latency2', 900),
+                                                   ('tracking', None, 'throughput', 500), ('heading', None, 'pair', 150_000), ('control', 'rk4', 'pair', 600),
+                                                   ('heading', None, 'latency4w', 1000)])
+def test_a_second_airframe_is_data_and_runs_hip_equal_to_the_oracle(tmp_path, task, solver, variant, n):
+    """the airframe is DATA (np_f16_cfg.airframe, ABI 16) — mass, inertias, S, B, cbar, c.g., H_eng, g, control and command
+    scales, atmosphere constants — not literals in the kernel.  (a) A context whose block spells out the F-16 values is bit-identical to the
+    all-zero block (= what the kernels computed when these were compile-time literals: every pinned fixture and parity test of this suite runs
+    through the same loads).  (b) A context built from ANOTHER blob and ANOTHER airframe block runs HIP == oracle bit for bit — state, controls,
+    targets, masks, observation, reward, the derived getters — on every kernel variant, and differs from the F-16.  Parity of a non-F-16
+    aircraft against the reference is unpinned by construction: the reference has none."""
+    from neuralplane_amd.core import F16Batch
+    from neuralplane_amd.envs.utils.utils import parse_config
+    other = _second_aircraft_blob(str(tmp_path / 'second_aero_set.bin'))
+    seed = 8
+    f16_spelled = dict(g=32.17, mass=636.94, B=30.0, S=300.0, cbar=11.32, xcgr=0.35, xcg=0.30, Heng=0.0, Jy=55814.0, Jxz=982.0, Jz=63100.0, Jx=9496.0)
+
+    def mk(airframe, blob=None):
+        cfg = parse_config(task)
+        if airframe:
+            cfg.airframe = airframe
+        b = F16Batch(n, cfg, task, 'cuda:0', seed=seed, solver=solver, **({'blob_path': blob} if blob else {}))
+        b.set_kernel_variant(variant)
+        return b
+    bs = [mk(None), mk(f16_spelled), mk(SECOND_AIRFRAME, other)]
+    o2 = Oracle(task, solver=solver, overrides={'airframe': SECOND_AIRFRAME}, blob_path=other)
+    o1 = Oracle(task, solver=solver)
+    st1, st2 = Oracle.new_state(n), Oracle.new_state(n)
+    rng = np.random.RandomState(2)
+    steps = 25 if n < 10_000 else 6
+    for t in range(steps):
+        a = rng.uniform(-1.2, 1.2, (n, 4)).astype(np.float32)
+        outs = [b.step(torch.from_numpy(a).cuda()) for b in bs]
+        o_obs, o_rew, _, _, _ = o1.step(st1, a, seed=seed, call_idx=t)
+        _check_equal(bs[0], *outs[0], st1, o_obs, o_rew, f'F-16 step {t}')
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y), f'step {t}: the spelled-out F-16 block differs from the all-zero block'
+        assert torch.equal(bs[0].s, bs[1].s) and torch.equal(bs[0].u, bs[1].u)
+        o_obs, o_rew, _, _, _ = o2.step(st2, a, seed=seed, call_idx=t)
+        _check_equal(bs[2], *outs[2], st2, o_obs, o_rew, f'second aircraft step {t}')
+    assert not np.array_equal(st1['s'], st2['s'])
+    d = bs[2].derived().cpu().numpy()                       # the getters that need the dynamics / atmosphere read the same block
+    x = np.hstack([st2['s'], st2['u']]).astype(np.float32)
+    assert _same(d[:12].T, o2.nlplant(x)) and _same(d[18], o2.get_eas2tas(st2['s'])) and _same(d[20:23].T, o2.get_atmos(st2['s']))
+
+
+def test_a_second_airframe_in_single_combat_and_planning_env_hip_equals_the_oracle(tmp_path):
+    """The same block through the other two kernels that integrate the FDM: SingleCombatEnv (np_f16_combat_cfg.airframe) and PlanningEnv's
+    persistent kernel (the env record's cfg) — HIP == oracle bit for bit with the second airframe."""
+    from neuralplane_amd.actor import NUM_FLOATS, FusedActor
+    from neuralplane_amd.envs.planning_env import PlanningEnv
+    from neuralplane_amd.envs.singlecombat_env import SingleCombatEnv
+    from oracle.f16_oracle import ActorOracle, CombatOracle
+    seed, E = 4, 300
+    cenv = SingleCombatEnv(num_envs=E, config='selfplay', random_seed=seed, device='cuda:0', airframe=SECOND_AIRFRAME)
+    co = CombatOracle(overrides={'airframe': SECOND_AIRFRAME})
+    cst = co.new_state(E)
+    assert _same(cenv.reset().cpu().numpy(), co.combat_reset(cst, seed=seed, call_idx=0))
+    rng = np.random.RandomState(1)
+    for t in range(6):
+        a = rng.uniform(-1, 1, (2 * E, 4)).astype(np.float32)
+        obs, rew, done, bad, tmo, _ = cenv.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _, o_bad, _ = co.combat_step(cst, a, pid_first=(t == 0), seed=seed, call_idx=t + 1)
+        assert _same(cenv.s.cpu().numpy(), cst['s']) and _same(obs.cpu().numpy(), o_obs) and _same(rew.cpu().numpy(), o_rew), f'combat step {t}'
+    ref = CombatOracle()
+    rst = ref.new_state(E)
+    ref.combat_reset(rst, seed=seed, call_idx=0)
+    ref.combat_step(rst, np.zeros((2 * E, 4), np.float32), pid_first=True, seed=seed, call_idx=1)
+    P = 70
+    w = np.random.RandomState(3).normal(0, 0.08, NUM_FLOATS).astype(np.float32)
+    for numerics in ('i8', 'fp32'):
+        penv = PlanningEnv(num_envs=P, config='tracking', model='F16', random_seed=seed, device='cuda:0', controller=FusedActor(w, 'cuda:0', numerics=numerics),
+                           airframe=SECOND_AIRFRAME)
+        po, pa, pst, ph = Oracle('tracking', overrides={'airframe': SECOND_AIRFRAME}), ActorOracle(w, numerics), Oracle.new_state(P), np.zeros((P, 128), np.float32)
+        for k in range(2):
+            ru = rng.uniform(0, 1, (P, 5)).astype(np.float32)
+            hi = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+            penv._batch.reset(rand_u=ru, want_obs=False)
+            obs, rew, done, bad, tmo, _ = penv.step(torch.from_numpy(hi).cuda())
+            po.reset(pst, rand_u=ru, want_obs=False)
+            ac = np.clip(hi, -1, 1).astype(np.float32)
+            s = pst['s']
+            tgt3 = np.stack([s[:, 4] + ac[:, 0] * np.float32(0.3), s[:, 5] + ac[:, 1] * np.float32(0.3), s[:, 6] + ac[:, 2] * np.float32(30)], 1).astype(np.float32)
+            ones = np.ones(P, np.float32)
+            for i in range(50):
+                act, ph = pa.forward(po.lowlevel_obs(pst, tgt3), ph, ones)
+                o_obs, o_rew, d, b_, t_ = po.step_inner(pst, act)
+            assert _same(penv.model.s.cpu().numpy(), pst['s']) and _same(obs.cpu().numpy(), o_obs) and _same(rew.cpu().numpy(), o_rew), f'planning {numerics} macro-step {k}'
+            assert np.array_equal(bad.cpu().numpy(), b_.astype(bool))
+
+
 def test_c_abi_from_a_plain_cpp_host_matches_the_python_surface(tmp_path):
     """examples/c_abi_demo.cpp: a C++ program with no Python and no PyTorch links libneuralplane_hip.so, allocates with
     hipMalloc, and drives np_f16_ctx_create / np_f16_reset / np_f16_step through the public header.  Its final state must be

@@ -782,3 +782,23 @@ def test_policy_numerics_against_a_float64_evaluation_of_the_same_networks():
             e = (np.abs(a - np.tanh(mu)).max(), np.abs(v - v64).max(), np.abs(ha - hn).max())
             print('policy vs float64', scale, numerics, [float(x) for x in e])
             assert e[0] < b_mean and e[1] < b_val and e[2] < b_rnn, (scale, numerics, e)
+
+
+def test_airframe_block_defaults_are_the_reference_literals_and_a_second_airframe_changes_the_dynamics():
+    """The airframe as data in the oracle (f16o_airframe, the CPU twin of np_f16_airframe): a model given the F-16 values spelled out
+    computes bit for bit what the default model computes (the defaults ARE the literals of F16_dynamics.py:61-76 — the golden fixtures above
+    pin them against the reference), and another block changes nlplant, the atmosphere getters and the control lag."""
+    f16 = dict(g=32.17, mass=636.94, B=30.0, S=300.0, cbar=11.32, xcgr=0.35, xcg=0.30, Heng=0.0, Jy=55814.0, Jxz=982.0, Jz=63100.0, Jx=9496.0,
+               ail_ref=21.5, rud_ref=30.0, atm_lapse=0.703e-5, atm_exp=4.14, rho0=2.377e-3, lag_keep=0.9, lag_new=0.1, thrust_frac=0.225,
+               thrust_max=76300.0, thrust_unit=0.3048, surf_max=(45.0, 45.0, 45.0))
+    other = dict(f16, mass=800.0, Jy=61000.0, Heng=160.0, S=345.0, xcg=0.27, atm_exp=4.2, thrust_max=90000.0, surf_max=(40.0, 42.0, 47.0))
+    o0, o1, o2 = Oracle('heading'), Oracle('heading', overrides={'airframe': f16}), Oracle('heading', overrides={'airframe': other})
+    n = 200
+    sts = [Oracle.new_state(n) for _ in range(3)]
+    rng = np.random.RandomState(0)
+    for t in range(15):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        outs = [o.step(st, a, seed=3, call_idx=t) for o, st in zip((o0, o1, o2), sts)]
+        assert same(sts[0]['s'], sts[1]['s']) and same(sts[0]['u'], sts[1]['u']) and same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1])
+    assert not np.array_equal(sts[0]['s'], sts[2]['s']) and not np.array_equal(sts[0]['u'], sts[2]['u'])
+    assert same(o0.get_eas2tas(sts[0]['s']), o1.get_eas2tas(sts[0]['s'])) and not np.array_equal(o0.get_eas2tas(sts[0]['s']), o2.get_eas2tas(sts[0]['s']))

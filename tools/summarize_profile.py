@@ -39,7 +39,15 @@ def main(tag):
                     w.writerow([c[:100] for c in r])
     for extra in ('wg_timeline_n1e6.json', 'bench_driver_cmd.json', 'cold_start.json', 'n_sweep.json', 'bench_combat_e12500.json', 'bench_combat_e1e5.json', 'bench_tracking.json', 'bench_control.json'):
         if os.path.exists(os.path.join(src, extra)):
-            shutil.copy(os.path.join(src, extra), os.path.join(dst, f'{tag}_{extra}'))
+            lines = open(os.path.join(src, extra)).read().splitlines()
+            contract = [ln for ln in lines if ln.startswith('{')]
+            details = [ln[len('BENCH_DETAILS '):] for ln in lines if ln.startswith('BENCH_DETAILS ')]
+            if extra.startswith('bench') and contract:      # bench.py: the contract line (last) + everything measured on the BENCH_DETAILS line
+                open(os.path.join(dst, f'{tag}_{extra}'), 'w').write(contract[-1] + '\n')
+                if details:
+                    json.dump(json.loads(details[-1]), open(os.path.join(dst, f'{tag}_{extra[:-5]}_details.json'), 'w'), indent=1)
+            else:
+                shutil.copy(os.path.join(src, extra), os.path.join(dst, f'{tag}_{extra}'))
     # PlanningEnv: kernel stats per controller numerics, and the PMC passes over the persistent kernel
     for sub in ('stats_planning_i8', 'stats_planning_fp32', 'stats_planning_i8_n1e4'):
         ks = find(os.path.join(src, sub, '**', '*kernel_stats.csv'))
