@@ -33,11 +33,12 @@ struct AeroWeights {
 // literal expressions round (derived constants folded in double first: np_f16_kernels.hip::make_airframe).  r_* = RN(1 / x) of a divisor
 // (np_divc).  The defaults are the F-16 literals: a context built without an airframe block computes what the literals computed, bit for bit.
 struct Airframe {
-    float g, mass, r_mass, B, S, cbar, Heng;
+    float g, mass, r_mass, B, S, cbar, Heng, pad_;
     float Jy, r_Jy, Jxz, Jz, Jx;
     float xc, cbar_over_B, c1, c2, c3, c4, denom, r_denom;       // xcgr - xcg, cbar / B, the inertia products of the moment equations
     float ail_ref, r_ail_ref, rud_ref, r_rud_ref;                 // dail = ail / 21.5, drud = rud / 30
-    float atm_lapse, atm_exp, rho0;                               // tfac = 1 - 0.703e-5 alt; rho = 2.377e-3 tfac^4.14
+    float atm_lapse, rho0;                                        // tfac = 1 - 0.703e-5 alt; rho = 2.377e-3 tfac^4.14
+    double atm_exp;                                               // (double)(float)4.14: the double np_pow computes in; > 0 (host check)
     float lag_keep, lag_new, thrust_frac, thrust_max, thrust_unit, r_thrust_unit, surf_max[3];   // u' = 0.9 u + 0.1 a * scale
     __device__ __forceinline__ const Airframe &get() const { return *this; }
 };
@@ -748,7 +749,7 @@ __device__ __forceinline__ void normalise_inputs(const AeroWeights &wt, float al
 // ---------------------------------------------------------------------------------------------
 template <class A>  // Airframe, or Airframe in the constant address space
 __device__ __forceinline__ float atmos_pow(const A &af, float alt) {   // (1 - 0.703e-5 alt)^4.14 (F16_dynamics.py:22-35)
-    return np_pow(1.0f - af.atm_lapse * alt, af.atm_exp);
+    return np_pow_posexp(1.0f - af.atm_lapse * alt, af.atm_exp);
 }
 template <class A>
 __device__ __forceinline__ float eas2tas_of(const A &af, float alt) {
@@ -798,7 +799,8 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const AF &afv, co
         float *shr = coef + (NUM_LDS_SLOTS + NUM_SHARED_SCALARS * SET) * LD;
         // (before the MLP phase only the atmosphere's two constants are needed, by the wave that computes tfac^4.14)
         const auto &a0 = afv.get();
-        const float tfac = 1.0f - a0.atm_lapse * alt, atm_exp = a0.atm_exp;
+        const float tfac = 1.0f - a0.atm_lapse * alt;
+        const double atm_exp = a0.atm_exp;
         if constexpr (WPT == WPT_LAT2) {  // two waves: wave 0 alpha, theta (+ tan), psi; wave 1 beta, phi, tfac^4.14
             float a_, b_, c_ = 0.0f;
             if (part == 0) {
@@ -822,7 +824,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const AF &afv, co
                 np_sincos(s[3], a_, b_);
                 shr[6 * LD] = a_;
                 shr[7 * LD] = b_;
-                shr[11 * LD] = np_pow(tfac, atm_exp);
+                shr[11 * LD] = np_pow_posexp(tfac, atm_exp);
             }
         } else if (part == 0 || (WPT == 8 && part == 4)) {  // four waves: wave 0 takes alpha and psi; eight: wave 4 takes psi
             float a_, b_;
@@ -841,7 +843,7 @@ __device__ __forceinline__ void nlplant(const AeroWeights &wt, const AF &afv, co
             np_sincos(s[8], a_, b_);
             shr[2 * LD] = a_;
             shr[3 * LD] = b_;
-            shr[11 * LD] = np_pow(tfac, atm_exp);
+            shr[11 * LD] = np_pow_posexp(tfac, atm_exp);
         } else if (part == 2) {
             float a_, b_, c_ = 0.0f;
             if (FULL || NUM_CACHED_TRIG > 0) np_sincostan(s[4], a_, b_, c_);   // tan(theta) of the new state travels in the cross-step cache

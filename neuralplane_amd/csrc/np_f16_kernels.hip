@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void f16_derived_kernel(const float *__restr
     const float tfac = 1.0f - af.atm_lapse * s[2];
     float temp = 519.0f * tfac;
     temp = (s[2] >= 35000.0f ? 1.0f : 0.0f) * 390.0f + (s[2] < 35000.0f ? 1.0f : 0.0f) * temp;
-    const float rho = af.rho0 * np_pow(tfac, af.atm_exp);
+    const float rho = af.rho0 * np_pow_posexp(tfac, af.atm_exp);
     const float mach = s[6] / sqrtf((float)(1.4 * 1716.3) * temp);
     const float qbar = (0.5f * rho) * (s[6] * s[6]);
     float ps = (1715.0f * rho) * temp;
@@ -463,9 +463,9 @@ bool airframe_is_zero(const np_f16_airframe &a) {
 }
 
 const char *airframe_error(const np_f16_airframe &a) {
-    const double pos[] = {a.mass, a.B, a.S, a.cbar, a.Jy, a.Jz, a.Jx, a.ail_ref, a.rud_ref, a.rho0, a.thrust_unit};
+    const double pos[] = {a.mass, a.B, a.S, a.cbar, a.Jy, a.Jz, a.Jx, a.ail_ref, a.rud_ref, a.rho0, a.thrust_unit, a.atm_exp};
     for (double v : pos)
-        if (!(v > 0.0) || !std::isfinite(v)) return "airframe: mass, B, S, cbar, Jx, Jy, Jz, ail_ref, rud_ref, rho0 and thrust_unit must be positive and finite";
+        if (!(v > 0.0) || !std::isfinite(v)) return "airframe: mass, B, S, cbar, Jx, Jy, Jz, ail_ref, rud_ref, rho0, thrust_unit and atm_exp must be positive and finite";
     if (!(a.Jx * a.Jz - a.Jxz * a.Jxz > 0.0)) return "airframe: Jx Jz - Jxz^2 must be positive";
     const double fin[] = {a.g, a.xcgr, a.xcg, a.Heng, a.Jxz, a.atm_lapse, a.atm_exp, a.lag_keep, a.lag_new, a.thrust_frac, a.thrust_max, a.surf_max[0], a.surf_max[1], a.surf_max[2]};
     for (double v : fin)
@@ -488,7 +488,7 @@ Airframe make_airframe(const np_f16_airframe &in) {
     d.denom = (float)(a.Jx * a.Jz - a.Jxz * a.Jxz);
     d.r_denom = rcp(d.denom);
     d.ail_ref = (float)a.ail_ref; d.r_ail_ref = rcp(d.ail_ref); d.rud_ref = (float)a.rud_ref; d.r_rud_ref = rcp(d.rud_ref);
-    d.atm_lapse = (float)a.atm_lapse; d.atm_exp = (float)a.atm_exp; d.rho0 = (float)a.rho0;
+    d.atm_lapse = (float)a.atm_lapse; d.atm_exp = (double)(float)a.atm_exp; d.rho0 = (float)a.rho0; d.pad_ = 0.0f;
     d.lag_keep = (float)a.lag_keep; d.lag_new = (float)a.lag_new; d.thrust_frac = (float)a.thrust_frac; d.thrust_max = (float)a.thrust_max;
     d.thrust_unit = (float)a.thrust_unit; d.r_thrust_unit = rcp(d.thrust_unit);
     for (int k = 0; k < 3; k++) d.surf_max[k] = (float)a.surf_max[k];

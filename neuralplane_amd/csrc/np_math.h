@@ -189,6 +189,20 @@ __device__ __forceinline__ float np_pow(float xf, float yf) {
     return (float)exp2_d(y * log2_d(x));
 }
 
+// the same for an exponent known to be positive and finite (the atmosphere's 4.14: np_f16_airframe.atm_exp, checked on the host), handed over as the
+// double the sequence works in — np_pow(x, (float)y) without the run-time tests on y and without its conversion
+__device__ __forceinline__ float np_pow_posexp(float xf, double y) {
+#if defined(NPF16_EXP) && (NPF16_EXP & 8)
+    return __powf(xf, (float)y);
+#endif
+    const double x = (double)xf;
+    if (x != x) return __builtin_nanf("");
+    if (x < 0.0) return __builtin_nanf("");
+    if (x == 0.0) return 0.0f;
+    if (x == (double)__builtin_inff()) return __builtin_inff();
+    return (float)exp2_d(y * log2_d(x));
+}
+
 // ---- pairwise geometry / reward functions of the combat envs (envs/utils/utils.py:156-249) ----
 #define NPM_PS0 (1.66666666666666657415e-01)
 #define NPM_PS1 (-3.25565818622400915405e-01)
@@ -262,8 +276,11 @@ __device__ __forceinline__ float np_wrap_pi(float x) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&out)[4]) {
+#ifndef NPF16_PHILOX_ROUNDS
+#define NPF16_PHILOX_ROUNDS 10   // the spec's ten rounds; other values are TIMING EXPERIMENTS only (tools/microbench/ab_libs.py: HIP != oracle)
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < NPF16_PHILOX_ROUNDS; r++) {
         // one v_mad_u64_u32 per 32x32->64 product (separate mul_hi / mul_lo would be two quarter-rate instructions)
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;

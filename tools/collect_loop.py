@@ -412,7 +412,9 @@ def collect_loop_report(n, T, dev):
            'numpy_contract': run_numpy(n, T, dev)}
     # the same loop with the policy's inference step as ONE launch (neuralplane_amd.policy.FusedPolicy, np_policy_act)
     rep['device_fused_policy'] = run_device(n, T, dev, fused_policy=True)
-    rep['device_fused_policy_graph'] = run_device(n, T, dev, graph=True, fused_policy=True)
+    # (round 5 also replayed {fused policy, env.step} from a HIP graph: 80.9 vs 68.4 us eager at 3 000 envs, 145 vs 124 at 10^4 — with the policy
+    # ONE launch a graph has nothing left to amortise, and its four staging copies + the replay cost more than the two launches they replace.
+    # Removed in round 6; `device_graph` above stays: with the ~110-kernel torch policy the graph halves the step.)
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
     rep['device_collector_i8_noise_block16'] = run_collector(n, T, dev, noise_block=16)   # the normal draws of 16 steps from one randn
     rep['device_collector_i8'] = run_collector(n, T, dev)   # the same three launches behind neuralplane_amd.collect.DeviceCollector (addresses pre-bound)
