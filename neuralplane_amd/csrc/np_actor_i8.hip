@@ -184,7 +184,9 @@ void pack_layer(const float *wt, int n_in, int ld, int j0, int blocks, int ks_co
 
 extern "C" int np_actor_pack_i8(const float *packed_fp32, float *out) {
     using namespace npact8;
-    if (!packed_fp32 || !out) return 1;
+    if (!packed_fp32 || !out) return np_internal_fail("np_actor_pack_i8: null argument");
+    for (int k = 0; k < TOTAL; k++)   // a NaN / infinite weight has no fixed-point image ((int32_t)nearbyint(...) of it is undefined behaviour)
+        if (!std::isfinite(packed_fp32[k])) return np_internal_fail("np_actor_pack_i8: non-finite weight (the block-fixed-point numerics need finite parameters; numerics='fp32' carries them)");
     std::memcpy(out, packed_fp32, sizeof(float) * TOTAL);
     std::memset(out + TOTAL, 0, sizeof(float) * (size_t)(TOTAL_I8 - TOTAL));
     unsigned char *frag = reinterpret_cast<unsigned char *>(out + FRAG);

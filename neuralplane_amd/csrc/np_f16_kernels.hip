@@ -886,6 +886,9 @@ int np_dispatch_plan(int64_t n, int32_t num_cus, int32_t step, int32_t solver, i
 }
 int64_t np_f16_cache_floats(int64_t n) { return n <= 0 ? 0 : ((n + BLOCK - 1) / BLOCK) * (int64_t)BLOCK * NUM_CACHE_ROWS; }
 const char *np_last_error(void) { return g_err.c_str(); }
+}  // extern "C"
+int np_internal_fail(const char *msg) { return fail(msg ? msg : "unknown error"); }
+extern "C" {
 
 static int ctx_create_common(const void *weights_blob, size_t nbytes, int tables, int device, np_f16_ctx **out) {
     std::vector<float> kb, kbd, pwl, pwl_unnorm;
@@ -1288,7 +1291,7 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
     unsigned grid = (unsigned)pa.tiles;
     if (mode == NP_PLANNING_PERSISTENT_GUESTS) {
         // tiles beyond the resident workgroups are guests: cut into as many blocks as there are hosts to go round (np_planning.hip)
-        const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves);
+        const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves, i8);
         if (per_cu <= 0) return fail("np_planning_inner_loop (persistent): occupancy query failed");
         const int64_t resident = (int64_t)per_cu * ctx->num_cus;
         const int64_t guests = pa.tiles - resident;
@@ -1307,7 +1310,7 @@ static int planning_persistent(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, 
         }
     }
     if (mode == NP_PLANNING_PERSISTENT_QUEUE || mode == NP_PLANNING_PERSISTENT_GUESTS) {
-        const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves);
+        const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, waves, i8);
         if (per_cu <= 0) return fail("np_planning_inner_loop (persistent): occupancy query failed");
         const int64_t resident = (int64_t)per_cu * ctx->num_cus;
         if (pa.tiles * (int64_t)lp->iterations >= (1ll << 31)) return fail("np_planning_inner_loop (queue): too many items");
@@ -1461,7 +1464,7 @@ int np_planning_inner_loop(np_f16_ctx *ctx, int64_t n, const np_f16_io *io, cons
             // step: n = 16 384 3.39 -> 3.21); beyond that the launches, whose 64-row controller tiles and row groups fill the chip better
             mode = NP_PLANNING_LAUNCHES;
             if (eligible && !stream_is_capturing(st)) {
-                const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, 8);
+                const int per_cu = planning_persistent_workgroups_per_cu(ctx->task, 8, lp->actor_weights_floats == NP_ACTOR_I8_NUM_FLOATS);
                 static_assert(NP_PLANNING_LAUNCHES == npdispatch::PL_LAUNCHES && NP_PLANNING_PERSISTENT == npdispatch::PL_PERSISTENT &&
                                   NP_PLANNING_PERSISTENT_GUESTS == npdispatch::PL_GUESTS && NP_PLANNING_PERSISTENT_DUAL == npdispatch::PL_DUAL && NP_PLANNING_PERSISTENT_QUEUE == npdispatch::PL_QUEUE && PLAN_ROWS == 32,
                               "np_dispatch.h mirrors the NP_PLANNING_* numbers");

@@ -51,6 +51,6 @@ hipError_t launch_planning_dual(int task, const PlanArgs &args, unsigned grid, h
 // are the persistent kernels of this task (0 heading, 1 control, 2 tracking) part of the build?  (tracking: the reference's PlanningEnv task)
 bool planning_persistent_built(int task);
 // how many workgroups of that shape fit one CU / the device (occupancy query)
-int planning_persistent_workgroups_per_cu(int task, int waves);
+int planning_persistent_workgroups_per_cu(int task, int waves, bool i8);   // i8: the block-fixed-point controller's instantiation (its own dynamic LDS)
 
 }  // namespace npf16

@@ -989,19 +989,22 @@ hipError_t launch_dual(const PlanArgs &args, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((planning_persistent_kernel<TASK, 8, false, true>), dim3(grid), dim3(512), bytes, st, args);
     return hipGetLastError();
 }
-template <int TASK, int W>
+template <int TASK, int W, bool I8>
 int occupancy_of() {
-    // the kernel the guest / queue schedules launch, with the dynamic LDS they launch it with (the hosts' parking area: ADVICE r4 — a query
-    // with 0 bytes would over-count once the registers allow two workgroups per CU; grid = resident and B = resident / guests rest on it)
-    constexpr size_t dyn = W == 8 ? sizeof(float) * PARK_LDS_FLOATS : 0;
+    // the kernel the guest / queue schedules launch — the instantiation of the controller numerics at hand (the block-fixed-point
+    // build is another kernel with more dynamic LDS) — with the dynamic LDS launch_one gives it (the hosts' parking area, the i8 controller's GRU
+    // parking area and staged tables: ADVICE r4 — a query with fewer bytes would over-count once the registers allow two workgroups per CU;
+    // grid = resident and B = resident / guests rest on it)
+    constexpr size_t dyn = sizeof(float) * ((W == 8 ? PARK_LDS_FLOATS : 0) + (I8 ? npact8::ACTOR8_PARK_FLOATS + npact8::TAB_FLOATS : 0));
+    const auto kernel = planning_persistent_kernel<TASK, W, true, false, I8>;
     if constexpr (dyn != 0) {
-        if (hipFuncSetAttribute((const void *)planning_persistent_kernel<TASK, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
     }
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, planning_persistent_kernel<TASK, W, true>, 64 * W, dyn) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 64 * W, dyn) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
@@ -1041,20 +1044,20 @@ hipError_t launch_planning_persistent(int task, int waves, bool i8, const PlanAr
 
 bool planning_persistent_built(int task) { return task >= 0 && task <= 2 && ((NP_PLAN_TASKS >> task) & 1) != 0; }
 
-static int workgroups_per_cu_uncached(int task, int waves);
-int planning_persistent_workgroups_per_cu(int task, int waves) {
-    static int cached[64][3][2] = {};   // the occupancy query costs a driver call; its answer belongs to the code object and the device
+static int workgroups_per_cu_uncached(int task, int waves, bool i8);
+int planning_persistent_workgroups_per_cu(int task, int waves, bool i8) {
+    static int cached[64][3][2][2] = {};   // the occupancy query costs a driver call; its answer belongs to the code object (per numerics) and the device
     if (task < 0 || task > 2) return 0;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return workgroups_per_cu_uncached(task, waves);
-    int &c = cached[dev][task][waves == 8];
-    if (c == 0) c = workgroups_per_cu_uncached(task, waves);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return workgroups_per_cu_uncached(task, waves, i8);
+    int &c = cached[dev][task][waves == 8][i8 ? 1 : 0];
+    if (c == 0) c = workgroups_per_cu_uncached(task, waves, i8);
     return c;
 }
-static int workgroups_per_cu_uncached(int task, int waves) {
+static int workgroups_per_cu_uncached(int task, int waves, bool i8) {
 #define NP_PLAN_CASE(T)                                                       \
     if constexpr (((NP_PLAN_TASKS >> T) & 1) != 0) {                        \
-        if (task == T) return waves == 8 ? occupancy_of<T, 8>() : 0; \
+        if (task == T) return waves != 8 ? 0 : i8 ? occupancy_of<T, 8, true>() : occupancy_of<T, 8, false>(); \
     }
     NP_PLAN_CASE(0)
     NP_PLAN_CASE(1)

@@ -25,3 +25,6 @@ hipError_t launch_policy_act(const ActArgs &a, hipStream_t stream);
 namespace npact8 {
 hipError_t launch_policy_act_i8(const nppol::ActArgs &a, hipStream_t stream);   // np_actor_i8.hip: both networks in the block-fixed-point numerics
 }
+
+// the library's thread-local error string (np_last_error), for the entry points that live outside np_f16_kernels.hip; returns 1
+int np_internal_fail(const char *msg);

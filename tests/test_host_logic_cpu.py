@@ -413,3 +413,51 @@ def test_bench_contract_line_is_small_and_complete():
     out['config']['workload'] = 'w' * 5000
     with pytest.raises(SystemExit):
         bench.contract_line(out)
+
+
+def test_i8_weight_packer_reports_its_errors_through_the_library():
+    """np_actor_pack_i8 used to return 1 without setting the error string (a stale message surfaced) and pushed NaN / infinite
+    weights through (int32_t)nearbyint(...): undefined behaviour.  Both are library errors with their own message now."""
+    from neuralplane_amd.actor import NUM_FLOATS, pack_i8
+    w = np.random.RandomState(0).normal(0, 0.05, NUM_FLOATS).astype(np.float32)
+    assert pack_i8(w).size == 309312
+    for bad in (np.nan, np.inf):
+        w2 = w.copy()
+        w2[1234] = bad
+        with pytest.raises(RuntimeError, match='non-finite weight'):
+            pack_i8(w2)
+
+
+def test_airframe_block_defaults_and_validation():
+    """np_f16_airframe (ABI 16): np_f16_airframe_default() writes the reference's literals (F16_dynamics.py:61-76,114-116, 22-35; F16_model.py:52-62);
+    `_lib.airframe({})` is the all-zero block (= the F-16); unknown fields are refused on the Python side."""
+    from neuralplane_amd import _lib
+    a = _lib.airframe({'mass': 700.0})
+    assert (a.g, a.mass, a.B, a.S, a.cbar, a.xcgr, a.xcg, a.Heng) == (32.17, 700.0, 30.0, 300.0, 11.32, 0.35, 0.30, 0.0)
+    assert (a.Jy, a.Jxz, a.Jz, a.Jx, a.ail_ref, a.rud_ref) == (55814.0, 982.0, 63100.0, 9496.0, 21.5, 30.0)
+    assert (a.atm_lapse, a.atm_exp, a.rho0, a.lag_keep, a.lag_new, a.thrust_frac, a.thrust_max, a.thrust_unit) == (0.703e-5, 4.14, 2.377e-3, 0.9, 0.1, 0.225, 76300.0, 0.3048)
+    assert list(a.surf_max) == [45.0, 45.0, 45.0]
+    z = _lib.airframe(None)
+    assert bytes(z) == bytes(len(bytes(z)))
+    with pytest.raises(ValueError, match='unknown field'):
+        _lib.airframe({'wingspan': 30})
+    cfg = parse_config('heading')
+    cfg.airframe = {'Jy': 60000.0}
+    c = cfg_from_config(cfg, 'heading')
+    assert c.airframe.Jy == 60000.0 and c.airframe.mass == 636.94
+    assert bytes(cfg_from_config(parse_config('heading'), 'heading').airframe) == bytes(z)
+
+
+def test_ctx_create_refuses_an_unphysical_airframe_before_it_touches_a_device():
+    import ctypes as C
+    from neuralplane_amd import _lib
+    from neuralplane_amd.core import ASSET_BLOB
+    lib = _lib.load()
+    blob = open(ASSET_BLOB, 'rb').read()
+    for bad, msg in (({'mass': -1.0}, 'positive'), ({'Jxz': 1e6}, 'Jx Jz - Jxz'), ({'atm_exp': 0.0}, 'positive'), ({'g': float('nan')}, 'non-finite')):
+        cfg = parse_config('heading')
+        cfg.airframe = bad
+        c = cfg_from_config(cfg, 'heading')
+        ctx = C.c_void_p()
+        assert lib.np_f16_ctx_create(blob, len(blob), C.byref(c), 0, C.byref(ctx)) != 0 and not ctx.value
+        assert msg in lib.np_last_error().decode(), lib.np_last_error()

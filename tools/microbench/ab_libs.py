@@ -38,7 +38,8 @@ def main():
             cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--headline-only', '--steps', str(args.steps), '--warmup', '5', '--n', str(args.n),
                    '--task', args.task] + args.extra.split()
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            # bench.py prints everything it measured on the BENCH_DETAILS line and the small contract line last (round 6)
+            line = [ln[len('BENCH_DETAILS '):] for ln in r.stdout.splitlines() if ln.startswith('BENCH_DETAILS ')] or [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             if r.returncode != 0 or not line:
                 res[n].append(None)
                 print(n, 'FAILED', r.stderr[-400:], flush=True)
