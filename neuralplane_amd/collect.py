@@ -40,16 +40,10 @@ class DeviceCollector:
     """collector = DeviceCollector(policy, envs, buffer); `collector.step()` = one collect step at `buffer.step` (which it advances);
     `collector.compute_returns()` = the runner's `compute` (:112-121).  Single-agent envs (ControlEnv, PlanningEnv under DeviceVecEnv)."""
 
-    def __init__(self, policy, envs, buffer, in_place=True, noise_block=1, overlap_critic=None):
+    def __init__(self, policy, envs, buffer, in_place=True, noise_block=1):
         """in_place: for ControlEnv, skip the insert launch (see below); False keeps the three launches per step.
         noise_block = K > 1: the normal draws of K consecutive steps come from ONE torch.randn((K, n, A)) (the same generator, one launch per K
-        steps instead of one per step; the draws are then not the ones K separate calls would have produced).
-        overlap_critic (in_place mode): the critic's half of get_actions as its OWN launch on a side stream.  Nothing in a collect step waits for the
-        critic — env.step needs the actions, the next policy step the next observation; values and the critic's recurrent state are read by the next
-        critic call and by compute_returns — so its workgroups run beside env.step and the next actor call instead of in front of them.  That pays
-        when one launch of both networks does not fit the chip in one round (two 4-wave workgroups per CU: more than 8 192 envs on 256 CUs —
-        at 10^4 envs the 626 workgroups of a call take two rounds, 49 us, of which env.step waits for 22); None = exactly then.  Same kernels on the
-        same inputs: results bit-identical to the single launch."""
+        steps instead of one per step; the draws are then not the ones K separate calls would have produced)."""
         if not isinstance(buffer, DeviceReplayBuffer):
             raise TypeError('DeviceCollector(policy, envs: DeviceVecEnv, buffer: DeviceReplayBuffer)')
         env = getattr(envs, 'env', envs)
@@ -90,15 +84,6 @@ class DeviceCollector:
         self.in_place = bool(in_place) and self._plain and policy.obs_dim == 22
         self._flag_bufs = [torch.zeros((3, n), dtype=torch.uint8, device=d) for _ in range(2)]
         self._pending = None       # (flags tensor, slot) of the env step whose insert rule has not been applied yet
-        if overlap_critic is None:
-            cus = torch.cuda.get_device_properties(d).multi_processor_count
-            overlap_critic = (n + 31) // 32 > cus            # both networks of one call: 2 x tiles workgroups on 2 x CUs slots
-        self.overlap_critic = bool(overlap_critic) and self.in_place
-        if self.overlap_critic:
-            self._side = torch.cuda.Stream(device=d)
-            self._ev_env = torch.cuda.Event()                # env.step t enqueued on the caller's stream: obs / flags of slot t + 1 exist
-            self._ev_critic = [torch.cuda.Event(), torch.cuda.Event()]   # critic launch of step t (alternating)
-            self._critic_steps = 0
 
     def _bind(self):
         """Base addresses of the storage (re-read when the buffer re-allocated or somebody replaced a tensor)."""
@@ -132,7 +117,6 @@ class DeviceCollector:
         Between two in_place steps slot step + 1 is UNFINISHED (stale masks / bad_masks, recurrent states of ended envs not yet zeroed): call
         finish() before reading the storage directly mid-rollout (a checkpoint, buffer.compute_returns, policy.get_values on the newest slot).
         compute_returns() here and the wrap of the buffer call it themselves."""
-        self._join_critic()
         if self._pending is None:
             return
         flags, slot = self._pending              # slot = step index of that env step: its results live in slot (actions …) and slot + 1 (obs …)
@@ -148,11 +132,6 @@ class DeviceCollector:
         _lib.check(self._lib.np_rollout_insert(C.byref(qi), self.device.index, _lib.stream_ptr(self.device)))
         qi.rnn_states_actor_in, qi.rnn_states_critic_in = self.ha.data_ptr(), self.hc.data_ptr()
         self._pending = None
-
-    def _join_critic(self):
-        """overlap_critic: the caller's stream waits for the newest critic launch (before anything reads values / the critic's recurrent states)."""
-        if getattr(self, 'overlap_critic', False) and self._critic_steps:
-            torch.cuda.current_stream(self.device).wait_event(self._ev_critic[(self._critic_steps - 1) & 1])
 
     def _step_in_place(self):
         p, b, n = self.policy, self.buffer, self.n
@@ -175,30 +154,12 @@ class DeviceCollector:
         q.rnn_states_actor_out, q.rnn_states_critic_out = base['rnn_states_actor'] + (s + 1) * f4 * HID, base['rnn_states_critic'] + (s + 1) * f4 * HID
         q.values, q.actions, q.action_log_probs = base['value_preds'] + s * f4, base['actions'] + s * f4 * ad, base['action_log_probs'] + s * f4
         try:
-            if self.overlap_critic:
-                main = torch.cuda.current_stream(self.device)
-                if self._pending is None:                # first step / first step after finish(): whatever prepared this slot (reset, the runner's
-                    self._ev_env.record(main)            # after_update copies) is on the caller's stream, behind the last recorded env.step
-                self._side.wait_event(self._ev_env)       # the critic reads obs / flags of the env step before this one
-                q.flags = CRITIC
-                _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, C.c_void_p(self._side.cuda_stream)))
-                self._ev_critic[self._critic_steps & 1].record(self._side)
-                q.flags = ACTOR
-                _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(self.device)))
-                # env.step below overwrites the flag buffer the PREVIOUS critic launch read (two buffers alternate): that launch has long finished
-                # (it ran beside the previous actor call); the wait makes it a guarantee and bounds the critic's lag to one step
-                if self._critic_steps:
-                    main.wait_event(self._ev_critic[(self._critic_steps - 1) & 1])
-                self._critic_steps += 1
-            else:
-                _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(self.device)))
+            _lib.check(self._lib.np_policy_act(C.byref(q), self.device.index, _lib.stream_ptr(self.device)))
         finally:
             q.prev_flags = None    # the struct is the policy's own: a failed launch must not leave the collector's mode set in it
         flags = self._flag_bufs[0] if self.env._batch.flags.data_ptr() != self._flag_bufs[0].data_ptr() else self._flag_bufs[1]
         out = (b.obs[s + 1].view(n, od), b.rewards[s].view(n), flags)
         self.env._batch.step(b.actions[s].view(n, ad), out=out)
-        if self.overlap_critic:
-            self._ev_env.record(torch.cuda.current_stream(self.device))
         self._pending = (flags, s)
         b.step = (s + 1) % b.buffer_size
         if b.step == 0:
@@ -267,7 +228,6 @@ class DeviceCollector:
     def compute_returns(self):
         """F16SimRunner.compute (:112-121): next values from the critic on the last slot, then ReplayBuffer.compute_returns."""
         self.finish()
-        self._join_critic()
         b, n = self.buffer, self.n
         if self.fused:
             nv = self.policy.get_values(b.obs[-1].reshape(n, -1), b.rnn_states_critic[-1].reshape(n, HID), b.masks[-1].reshape(n, 1))

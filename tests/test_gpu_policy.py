@@ -576,47 +576,3 @@ def test_fused_policy_chained_over_200_steps_vs_the_reference_and_the_oracle(gol
         json.dump(rep, open(path, 'w'), indent=1)
     except OSError:
         pass
-
-
-@pytest.mark.parametrize('n,overlap', [(700, True), (9_000, None), (20_000, None)])
-def test_collector_with_the_critic_on_a_side_stream_equals_the_single_launch(n, overlap):
-    """Round 6 (the part that needs no new kernel): nothing in a collect step waits for the critic, so DeviceCollector may run
-    the critic's half of get_actions as its own launch on a side stream, beside env.step and the next actor call (automatic above 8 192 envs,
-    where both networks of one call no longer fit the chip in one round).  Same kernels on the same inputs: every storage array, the
-    returns and the flight state are bit-identical to the single-launch collector over a rollout that wraps the buffer, episode ends included."""
-    from neuralplane_amd.buffer import DeviceReplayBuffer
-    from neuralplane_amd.collect import DeviceCollector
-    from neuralplane_amd.envs.control_env import ControlEnv
-    from neuralplane_amd.envs.env_wrappers import DeviceVecEnv
-    from neuralplane_amd.policy import FusedPolicy
-    from tests.policy_kat import random_state_dicts
-    T = 7
-
-    class Args:
-        buffer_size, n_rollout_threads = T, n
-        gamma, use_proper_time_limits, use_gae, gae_lambda = 0.99, True, True, 0.95
-        recurrent_hidden_size, recurrent_hidden_layers = 128, 1
-    sds = random_state_dicts(4, 3)
-
-    def run(ov):
-        envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config='heading', model='F16', random_seed=5, device='cuda:0')])
-        buf = DeviceReplayBuffer(Args, 1, envs.observation_space, envs.action_space, device='cuda:0')
-        buf.obs[0].copy_(envs.reset())
-        col = DeviceCollector(FusedPolicy(sds, 'cuda:0'), envs, buf, overlap_critic=ov)
-        torch.manual_seed(21)
-        for k in range(2 * T + 3):                  # wraps twice; the reference's after_update between rollouts
-            col.step()
-            if buf.step == 0:
-                col.compute_returns()
-                buf.after_update()
-        col.finish()
-        col.compute_returns()
-        torch.cuda.synchronize()
-        return col, envs, buf
-    c0, e0, b0 = run(False)
-    c1, e1, b1 = run(overlap)
-    assert c0.overlap_critic is False and c1.overlap_critic is True
-    for k in b0._STORAGE + ('returns',):
-        assert torch.equal(getattr(b0, k), getattr(b1, k)), k
-    assert torch.equal(e0.env.model.s, e1.env.model.s) and b0.step == b1.step
-    assert float(b1.value_preds.abs().sum()) > 0 and float((b1.masks == 0).sum()) > 0      # values were written, episodes ended

@@ -242,7 +242,7 @@ def run_device(n, T, dev, graph=False, task='heading', fused_policy=False, polic
     return out
 
 
-def run_collector(n, T, dev, task='heading', policy_numerics='i8', noise_block=1, overlap_critic=None):
+def run_collector(n, T, dev, task='heading', policy_numerics='i8', noise_block=1):
     """The device loop through neuralplane_amd.collect.DeviceCollector: FusedPolicy writing into the buffer's slot in place, env.step, insert."""
     from neuralplane_amd.buffer import DeviceReplayBuffer
     from neuralplane_amd.collect import DeviceCollector
@@ -254,7 +254,7 @@ def run_collector(n, T, dev, task='heading', policy_numerics='i8', noise_block=1
     envs = DeviceVecEnv([lambda: ControlEnv(num_envs=n, config=task, model='F16', random_seed=0, device=str(dev))])
     buf = DeviceReplayBuffer(_Args(n, T), 1, envs.observation_space, envs.action_space, device=dev)
     buf.obs[0].copy_(envs.reset())
-    col = DeviceCollector(policy, envs, buf, noise_block=noise_block, overlap_critic=overlap_critic)
+    col = DeviceCollector(policy, envs, buf, noise_block=noise_block)
     for _ in range(T):
         col.step()
     torch.cuda.synchronize(dev)
@@ -272,7 +272,7 @@ def run_collector(n, T, dev, task='heading', policy_numerics='i8', noise_block=1
     col.compute_returns()
     torch.cuda.synchronize(dev)
     return {'us_per_step_wall': wall_us, 'host_enqueue_us_per_step': host_us, 'compute_returns_ms': 1e3 * (time.perf_counter() - t0), 'steps': T,
-            'env_steps_per_s': n * 1e6 / wall_us, 'critic_on_side_stream': bool(col.overlap_critic)}
+            'env_steps_per_s': n * 1e6 / wall_us}
 
 
 def run_selfplay(E, T, dev, fused_policy=False, policy_numerics='i8'):
@@ -418,10 +418,6 @@ def collect_loop_report(n, T, dev):
     rep['device_fused_policy']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy']['us_per_step_wall']
     rep['device_collector_i8_noise_block16'] = run_collector(n, T, dev, noise_block=16)   # the normal draws of 16 steps from one randn
     rep['device_collector_i8'] = run_collector(n, T, dev)   # the same three launches behind neuralplane_amd.collect.DeviceCollector (addresses pre-bound)
-    # round 6: the critic's half of get_actions as its own launch on a side stream (automatic above 8 192 envs): A/B of both settings at this size
-    rep['device_collector_i8_critic_side_stream'] = run_collector(n, T, dev, overlap_critic=True)
-    rep['device_collector_i8_single_policy_launch'] = run_collector(n, T, dev, overlap_critic=False)
-    rep['device_collector_i8_critic_side_stream_noise_block16'] = run_collector(n, T, dev, overlap_critic=True, noise_block=16)
     rep['device_fused_policy_i8'] = run_device(n, T, dev, fused_policy=True, policy_numerics='i8')   # both networks in the block-fixed-point numerics
     rep['device_fused_policy_i8']['speedup_vs_torch_policy'] = rep['device']['us_per_step_wall'] / rep['device_fused_policy_i8']['us_per_step_wall']
     if n == 3000:
@@ -456,12 +452,7 @@ if __name__ == '__main__':
     if args.only == 'selfplay':
         rep = {'selfplay_e12500': {'torch_policies': run_selfplay(12500, args.steps, 'cuda:0'), 'fused_policies': run_selfplay(12500, args.steps, 'cuda:0', fused_policy=True)}}
     elif args.only == 'collector':
-        rep = {f'collect_loop_n{n}': {'device_collector_i8': run_collector(n, args.steps, 'cuda:0'),
-                                      'device_collector_i8_single_policy_launch': run_collector(n, args.steps, 'cuda:0', overlap_critic=False),
-                                      'device_collector_i8_critic_side_stream': run_collector(n, args.steps, 'cuda:0', overlap_critic=True),
-                                      'device_collector_i8_critic_side_stream_noise_block16': run_collector(n, args.steps, 'cuda:0', overlap_critic=True, noise_block=16),
-                                      'device_collector_i8_noise_block16': run_collector(n, args.steps, 'cuda:0', noise_block=16, overlap_critic=False),
-                                      'device_fused_policy_i8': run_device(n, args.steps, 'cuda:0', fused_policy=True, policy_numerics='i8')} for n in args.n}
+        rep = {f'collect_loop_n{n}': {'device_collector_i8': run_collector(n, args.steps, 'cuda:0'), 'device_collector_i8_noise_block16': run_collector(n, args.steps, 'cuda:0', noise_block=16), 'device_fused_policy_i8': run_device(n, args.steps, 'cuda:0', fused_policy=True, policy_numerics='i8')} for n in args.n}
     elif args.only:
         rep = {f'collect_loop_n{n}': {'device_fused_policy' if args.only == 'fused' else 'device': run_device(n, args.steps, 'cuda:0', fused_policy=args.only == 'fused')}
                for n in args.n}
