@@ -14,6 +14,8 @@ cases = sys.argv[2:] or ['auto:4000', 'auto:8192', 'auto:8193', 'auto:9001', 'au
 w = np.random.RandomState(0).normal(0, 0.08, NUM_FLOATS).astype(np.float32)
 for case in cases:
     mode, n = case.split(':'); n = int(n)
+    if mode == 'dual' and os.environ.get('NUMERICS', 'i8') == 'i8':
+        continue   # the dual workgroups serve the fp32 controller only (NUMERICS=fp32 runs this case)
     envs = [PlanningEnv(num_envs=n, config='tracking', model='F16', random_seed=3, device='cuda:0', controller=FusedActor(w, 'cuda:0', numerics=os.environ.get('NUMERICS', 'i8'))) for _ in range(2)]
     envs[0].loop_mode = 'launches'
     envs[1].loop_mode = mode
