@@ -21,7 +21,8 @@
 #include "np_actor.h"
 
 #ifndef NPACT8_EXP
-#define NPACT8_EXP 0   // timing-only experiment switches (tools/microbench/i8_actor_phases.hip: wrong results); 0 in every shipped build
+#define NPACT8_EXP 0   // timing-only experiment switches (tools/microbench/i8_actor_phases.hip: wrong results: 1 no matrix instructions, 2 no weight stream,
+                       // 4 no LayerNorm exchange, 8 no quantiser arithmetic, 16 one-instruction epilogue); 0 in every shipped build
 #endif
 
 namespace npact8 {
@@ -76,6 +77,16 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned
 // the 16 values of this lane -> limb bytes: P = (q + 0x808080) ^ 0x808080 with q = round-half-even(x * 2^(22 - ex)); the three limb planes
 // as B-operand dwords (dword g = the limb of registers 4 g .. 4 g + 3) -> LDS fragment `ks` of `frags`
 __device__ __forceinline__ void quantise_store(const float (&y)[16], int ex, float *frags, int ks, int lane) {
+#if NPACT8_EXP & 8   // timing only: no quantiser arithmetic (the raw bits go to the fragment slots: same LDS traffic)
+    {
+        i32x4 *dst = reinterpret_cast<i32x4 *>(frags) + (ks * 3) * 64 + lane;
+        (void)ex;
+        dst[0] = i32x4{(int)__float_as_uint(y[0]), (int)__float_as_uint(y[1]), (int)__float_as_uint(y[2]), (int)__float_as_uint(y[3])};
+        dst[64] = i32x4{(int)__float_as_uint(y[4]), (int)__float_as_uint(y[5]), (int)__float_as_uint(y[6]), (int)__float_as_uint(y[7])};
+        dst[128] = i32x4{(int)__float_as_uint(y[8]), (int)__float_as_uint(y[9]), (int)__float_as_uint(y[10]), (int)__float_as_uint(y[11])};
+        return;
+    }
+#endif
     const float scale = pow2f(XBITS - ex), magic = __uint_as_float(MAGIC_BITS);
     unsigned p[16];
 #pragma unroll
@@ -107,6 +118,33 @@ __device__ __forceinline__ void quantise_store(const float (&y)[16], int ex, flo
 template <bool EXTRA, int T>
 __device__ __forceinline__ void layernorm_acc(const float (&v)[T][16], const float *gp, const float *bp, float gmax, float bmax, float *lds, int blk, int a,
                                               int fbase, float (&y)[T][16], int (&ex)[T], const float (&extra_in)[T], float (&extra_out)[T]) {
+#if NPACT8_EXP & 4   // timing only: no LayerNorm exchange (no LDS round trips, no barriers: the lane's own 16 values stand in for the row's 128)
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        float s = 0.0f, q = 0.0f, m = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s = s + v[t][r];
+        const float mean = s * (1.0f / 16.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float d = v[t][r] - mean;
+            q = fmaf(d, d, q);
+            m = fmaxf(m, fabsf(d));
+            y[t][r] = d;
+        }
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 16.0f) + 1e-5f);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 qg = *reinterpret_cast<const float4 *>(gp + fbase + 8 * g), qb = *reinterpret_cast<const float4 *>(bp + fbase + 8 * g);
+            y[t][4 * g] = fmaf(y[t][4 * g] * rstd, qg.x, qb.x); y[t][4 * g + 1] = fmaf(y[t][4 * g + 1] * rstd, qg.y, qb.y);
+            y[t][4 * g + 2] = fmaf(y[t][4 * g + 2] * rstd, qg.z, qb.z); y[t][4 * g + 3] = fmaf(y[t][4 * g + 3] * rstd, qg.w, qb.w);
+        }
+        ex[t] = exponent_of(fmaf(m * rstd, gmax, bmax) * 1.000001f);
+        if constexpr (EXTRA) extra_out[t] = extra_in[t];
+    }
+    (void)lds; (void)blk; (void)a;
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < T; t++) {
         float s = 0.0f;

@@ -5,6 +5,7 @@
 // kernel are not (a stamp orders the memory operations around it).  tools/microbench/i8_actor_phases.sh builds and runs the set.
 #include "../../neuralplane_amd/csrc/np_actor_i8.hip"
 #include <cstdio>
+int np_internal_fail(const char *msg) { fprintf(stderr, "%s\n", msg); return 1; }   // (the library's error string lives in np_f16_kernels.hip)
 #include <random>
 #include <vector>
 #ifndef TILES
