@@ -70,6 +70,16 @@ def _check_numerics_spec(sd):
                       'trajectories will differ in the last bits from a run recorded under the old spec', RuntimeWarning, stacklevel=3)
 
 
+def _check_airframe(sd, airframe):
+    """A checkpoint written with another np_f16_airframe block would continue on a different aircraft: refuse it (checkpoints from before
+    round 6 carry no block: they were the F-16, i.e. the all-zero block)."""
+    def key(b):      # the all-zero block and the spelled-out F-16 defaults are the same aircraft
+        b = bytes(b)
+        return bytes(_lib.airframe({'Heng': 0.0})) if not any(b) else b
+    if key(sd.get('airframe', bytes(len(bytes(airframe))))) != key(airframe):
+        raise ValueError('checkpoint was written with a different airframe block (np_f16_airframe) than this env was built with')
+
+
 class F16Batch:
     """N aircraft on one GPU.  `row0` is the global index of local row 0 (sharded batches)."""
 
@@ -411,12 +421,14 @@ class F16Batch:
         left by the last step and the RNG counter (the RNG is counter-based: no generator state)."""
         return {'s': self.s.clone(), 'u': self.u.clone(), 'tgt': self.tgt.clone(), 'step_count': self.step_count.clone(),
                 'flags': self.flags.clone(), 'call_idx': int(self.call_idx), 'seed': int(self.seed), 'row0': int(self.row0),
-                'task': self.task, 'n': self.n, 'numerics_spec': NUMERICS_SPEC, 'abi_version': _lib.ABI_VERSION}
+                'task': self.task, 'n': self.n, 'numerics_spec': NUMERICS_SPEC, 'abi_version': _lib.ABI_VERSION,
+                'airframe': bytes(self.cfg.airframe)}   # np_f16_airframe as built (all zero = the F-16): a resumed run must fly the same aircraft
 
     def load_state_dict(self, sd):
         if sd['n'] != self.n or sd['task'] != self.task:
             raise ValueError(f"checkpoint is for n={sd['n']}, task={sd['task']}; this batch is n={self.n}, task={self.task}")
         _check_numerics_spec(sd)
+        _check_airframe(sd, self.cfg.airframe)
         for k in ('s', 'u', 'tgt', 'step_count'):
             getattr(self, k).copy_(sd[k].to(self.device))
         self.flags = sd['flags'].to(self.device).clone()
@@ -695,12 +707,13 @@ class F16CombatBatch:
         return {'s': self.s.clone(), 'u': self.u.clone(), 'pid': self.pid.clone(), 'blood': self.blood.clone(),
                 'step_count': self.step_count.clone(), 'flags': self.flags.clone(), 'pid_first': bool(self.pid_first),
                 'call_idx': int(self.call_idx), 'seed': int(self.seed), 'env0': int(self.env0), 'num_envs': self.num_envs,
-                'numerics_spec': NUMERICS_SPEC, 'abi_version': _lib.ABI_VERSION}
+                'numerics_spec': NUMERICS_SPEC, 'abi_version': _lib.ABI_VERSION, 'airframe': bytes(self.cfg.airframe)}
 
     def load_state_dict(self, sd):
         if sd['num_envs'] != self.num_envs:
             raise ValueError(f"checkpoint is for num_envs={sd['num_envs']}; this batch has {self.num_envs}")
         _check_numerics_spec(sd)
+        _check_airframe(sd, self.cfg.airframe)
         for k in ('s', 'u', 'pid', 'blood', 'step_count'):
             getattr(self, k).copy_(sd[k].to(self.device))
         self.flags = sd['flags'].to(self.device).clone()

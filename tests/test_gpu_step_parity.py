@@ -654,6 +654,9 @@ def test_a_second_airframe_is_data_and_runs_hip_equal_to_the_oracle(tmp_path, ta
         o_obs, o_rew, _, _, _ = o2.step(st2, a, seed=seed, call_idx=t)
         _check_equal(bs[2], *outs[2], st2, o_obs, o_rew, f'second aircraft step {t}')
     assert not np.array_equal(st1['s'], st2['s'])
+    with pytest.raises(ValueError, match='airframe'):        # a checkpoint continues on the aircraft it was written with
+        bs[0].load_state_dict(bs[2].state_dict())
+    bs[0].load_state_dict(bs[1].state_dict())                # (the all-zero block and the spelled-out F-16 values are the same aircraft)
     d = bs[2].derived().cpu().numpy()                       # the getters that need the dynamics / atmosphere read the same block
     x = np.hstack([st2['s'], st2['u']]).astype(np.float32)
     assert _same(d[:12].T, o2.nlplant(x)) and _same(d[18], o2.get_eas2tas(st2['s'])) and _same(d[20:23].T, o2.get_atmos(st2['s']))
