@@ -567,6 +567,22 @@ static float net_eval(const net_t *t, const float in3[3]) {
         }
         return (float)xd[0] * t->out_std + t->out_mean; /* unnormalize :36-37 */
     }
+    if (g_mode & F16O_MODE_BIAS_LAST) { /* EXPERIMENT, not the spec (tools/parity_report.py --engine oracle-bias-last): every Linear layer as
+                                         * acc = 0; acc = fma(W[j][k], x[k], acc), k ascending; acc + bias — the order of a GEMM with a bias
+                                         * epilogue; unscaled parameters, plain ReLU */
+        for (int l = 0; l < t->n_linear; l++) {
+            int in = t->dims[l], out = t->dims[l + 1];
+            for (int j = 0; j < out; j++) {
+                float acc = 0.0f;
+                for (int k = 0; k < in; k++) acc = fmaf(t->w[l][j * in + k], x[k], acc);
+                acc = acc + t->b[l][j];
+                if (l + 1 < t->n_linear) acc = acc > 0.0f ? acc : 0.0f;
+                y[j] = acc;
+            }
+            for (int j = 0; j < out; j++) x[j] = y[j];
+        }
+        return x[0] * t->out_std + t->out_mean;
+    }
     for (int l = 0; l + 1 < t->n_linear; l++) { /* hidden layers: acc = bias; acc = fma(W[j][k], x[k], acc), k ascending (spec) */
         int in = t->dims[l], out = t->dims[l + 1];
         for (int j = 0; j < out; j++) {

@@ -69,6 +69,8 @@ void f16o_model_free(f16o_model *m);
 #define F16O_MODE_PWL 4      /* single-input nets through their exact piecewise-linear tables (blob PWL section) */
 #define F16O_MODE_DIV_IEEE 8 /* divisions by constants as plain IEEE `x / c` (the reference's operator) instead of the spec's
                               * Markstein sequence f16o_divc — identical results wherever f16o_divc_check holds (tests run both) */
+#define F16O_MODE_BIAS_LAST 16 /* EXPERIMENT (never the spec, never compared with the kernels): the aero MLPs' Linear layers as acc = 0; fmaf chain;
+                               * + bias — the order of a GEMM with a bias epilogue (profiles/r06h_mlp_order_probe.log) */
 void f16o_set_mode(int mode);
 int f16o_get_mode(void);
 

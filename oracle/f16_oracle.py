@@ -22,6 +22,7 @@ SOLVERS = {'euler': 0, 'rk4': 1}
 MODE_MLP_F64 = 1
 MODE_LIBM = 2
 MODE_PWL = 4
+MODE_BIAS_LAST = 16   # EXPERIMENT, never the spec: the aero MLPs with the bias added last (f16_oracle.h)
 MODE_DIV_IEEE = 8   # constant divisions as plain IEEE x / c instead of the Markstein sequence (identical results; tests run both)
 
 
