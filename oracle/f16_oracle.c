@@ -570,12 +570,20 @@ static float net_eval(const net_t *t, const float in3[3]) {
     if (g_mode & F16O_MODE_BIAS_LAST) { /* EXPERIMENT, not the spec (tools/parity_report.py --engine oracle-bias-last): every Linear layer as
                                          * acc = 0; acc = fma(W[j][k], x[k], acc), k ascending; acc + bias — the order of a GEMM with a bias
                                          * epilogue; unscaled parameters, plain ReLU */
+        /* F16O_BIAS_LAST_LAYERS (experiments): bit 0 = the first hidden layer, bit 1 = the other hidden layers, bit 2 = the output layer take the bias
+         * last; the rest keep acc = bias first.  Unset = all three. */
+        static int layers = -1;
+        if (layers < 0) {
+            const char *e = getenv("F16O_BIAS_LAST_LAYERS");
+            layers = e ? atoi(e) : 7;
+        }
         for (int l = 0; l < t->n_linear; l++) {
             int in = t->dims[l], out = t->dims[l + 1];
+            const int cls = (l + 1 == t->n_linear) ? 4 : (l == 0 ? 1 : 2);
             for (int j = 0; j < out; j++) {
-                float acc = 0.0f;
+                float acc = (layers & cls) ? 0.0f : t->b[l][j];
                 for (int k = 0; k < in; k++) acc = fmaf(t->w[l][j * in + k], x[k], acc);
-                acc = acc + t->b[l][j];
+                if (layers & cls) acc = acc + t->b[l][j];
                 if (l + 1 < t->n_linear) acc = acc > 0.0f ? acc : 0.0f;
                 y[j] = acc;
             }
