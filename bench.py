@@ -380,6 +380,10 @@ def run_env(args, rank, local_rank, world, dev, dist):
                      'executed_flop_per_aircraft_step': EXEC_FLOP if exe_tflops is not None else None,
                      'executed': exe_tflops, 'executed_frac': exe_tflops / PEAK_FP32_TFLOPS if exe_tflops is not None else None,
                      'kernel': 'f16_env_kernel<task,solver,STEP>', **st, 'effective_shader_mhz': mhz,
+                     # the clock the governor settles at differs between boxes of the pool (2.15 - 2.37 GHz seen in round 6) while the kernel's CYCLES
+                     # per launch do not (6.3 - 6.5e5): the same fraction against the peak AT THE MEASURED CLOCK (157.3 TFLOP/s is quoted at 2.4 GHz)
+                     'kernel_shader_kcycles': st['kernel_avg_ms'] * mhz if mhz else None,
+                     'frac_at_measured_clock': (ach_tflops / (PEAK_FP32_TFLOPS * mhz / 2400.0)) if mhz else None,
                      'note': 'fp32 VECTOR (VALU) roof: 157.3 TFLOP/s is both the fp32 vector peak and the f32-input MFMA peak on '
                              'gfx950; the kernel issues no MFMA.  achieved = algorithmic FLOP x N / average launch duration (HIP '
                              'events on the launch stream: one pair around the K timed launches; per-dispatch pairs on the launches before them for the median); executed = the FLOP the kernel '
@@ -776,7 +780,7 @@ def contract_line(out, details_path=None):
     r = out['roofline']
     keep_r = ('bound', 'achieved', 'peak', 'unit', 'frac', 'executed_frac', 'kernel', 'kernel_avg_ms', 'kernel_median_ms', 'launches_timed',
               'traffic', 'traffic_source', 'algorithmic_bytes_per_launch', 'algorithmic_flop_per_aircraft_step', 'executed_flop_per_aircraft_step',
-              'algorithmic_flop_per_engagement_step', 'effective_shader_mhz')
+              'algorithmic_flop_per_engagement_step', 'effective_shader_mhz', 'kernel_shader_kcycles', 'frac_at_measured_clock')
     line = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                                 'vs_baseline', 'dtype', 'data')}
     line['config'] = {k: v for k, v in out['config'].items() if k in ('workload', 'aircraft_per_gpu', 'engagements_total', 'sharding')}
